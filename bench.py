@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py -- 256x256 images/sec of the Local-Hints forward pass on MI355X (+ p50 click latency).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path (pack_input -> 29 implicit-GEMM conv/deconv launches -> tanh
+head, i.e. SIGGRAPHGenerator.forward, models/pytorch/model.py:134-175) over one batch of 32
+synthetic 256x256 inputs per GPU, bf16 MFMA path -- BASELINE.json configs[2] ("Batch 32 random
+256x256 L-channels with random sparse hint masks, 1x MI355X bf16"), the configuration the
+images/sec target is quoted on.  Inputs and outputs are resident in HBM during the timed region.
+With N ranks every rank runs its own 32 images (weak scaling, no data-path collective); the
+weights are packed on rank 0 and broadcast once over RCCL before the timed region.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      : the conv stack (kernel family conv_igemm<bf16>) against the dense bf16 MFMA peak,
+                  from per-layer HIP events recorded on the engine's stream inside the timed region;
+  cpu_baseline  : the torch-CPU oracle (same ATen kernels as the reference's PyTorch backend)
+                  timed on this box's host cores on a bounded sample (rank 0, N=1 only);
+  latency       : p50 per-click recolor latency, BASELINE.json configs[1] (one 256x256 image,
+                  5 hint points), fp32 and bf16, kernel-only and through the blocking C-ABI call.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+FLOP_PER_IMAGE_256 = 150.391e9          # 75.1955 GMAC, conv/deconv MACs x 2
+PEAK_BF16_DENSE_TFLOPS = 2500.0         # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+PEAK_FP32_MFMA_TFLOPS = 157.3
+PER_GPU_BATCH = 32
+H = W = 256
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="images per GPU per step")
+    return ap.parse_args()
+
+
+def seeded_weights():
+    """Random-init weights of the reference architecture (no checkpoint ships / no network):
+    numpy-seeded, reference state_dict key set."""
+    from oracle import weights           # weight GENERATION only; nothing of the oracle is measured here
+    return weights.make_state_dict(0, "he")
+
+
+def cpu_baseline(sd, reps=3):
+    """The reference path on the host cores: torch-CPU oracle, N=1, fp32, all cores."""
+    import torch
+    from interactive_deep_colorization_amd import workloads
+    from oracle import siggraph_torch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    L, ab, m = workloads.random_batch(1, H, seed=0)
+    siggraph_torch.forward(sd, L, ab, m, 0.0)                       # warm-up
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        siggraph_torch.forward(sd, L, ab, m, 0.0)
+        ts.append(time.perf_counter() - t0)
+    p50 = statistics.median(ts)
+    return {"value": round(1.0 / p50, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "%d x one 256x256 image (N=1, fp32, torch CPU oracle = the reference's ATen kernels), p50 %.3f s"
+                      % (reps, p50)}
+
+
+def measure_latency(sd, device):
+    """BASELINE configs[1]: single 256x256 image, 5 hint points; p50 over 200 calls after 20 warm-ups."""
+    import torch
+    from interactive_deep_colorization_amd import engine, workloads
+    out = {}
+    rgb_free_L = workloads.random_batch(1, H, seed=7)[0]
+    hab, hm = workloads.hints_config2(256, 5, 3, 0)
+    L = rgb_free_L.astype(np.float32); ab = hab[None].astype(np.float32); m = hm[None].astype(np.float32)
+    for prec in ("fp32", "bf16"):
+        e = engine.HipColorizer(H, W, max_batch=1, precision=prec, device=device)
+        e.load_state_dict(sd)
+        dev = torch.device("cuda", device)
+        dL, dab, dm = (torch.from_numpy(x).to(dev) for x in (L, ab, m))
+        dout = torch.empty((1, 2, H, W), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize(dev)
+        for _ in range(20):
+            e.forward_device(1, dL, dab, dm, dout, 0.0, sync=True)
+        tk = []
+        for _ in range(200):
+            t0 = time.perf_counter()
+            e.forward_device(1, dL, dab, dm, dout, 0.0, sync=True)
+            tk.append(time.perf_counter() - t0)
+        th = []
+        for _ in range(100):
+            t0 = time.perf_counter()
+            e.forward(L, ab, m, 0.0)
+            th.append(time.perf_counter() - t0)
+        out[prec] = {"device_resident_p50_ms": round(statistics.median(tk) * 1e3, 4),
+                     "c_abi_host_call_p50_ms": round(statistics.median(th) * 1e3, 4)}
+        e.close()
+    return out
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    from interactive_deep_colorization_amd import engine, sharded, workloads
+
+    rank, local_rank, world = sharded.init_process_group()
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run for N>1"
+                  % (args.gpus, world), file=sys.stderr)
+        if world == 1 and args.gpus != 1:
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible -- the HIP path has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    nb = args.batch
+
+    # ---- engine + weights (rank 0 packs, RCCL broadcast of the packed blob) --------------------------
+    e = engine.HipColorizer(H, W, max_batch=nb, precision=args.precision, device=local_rank)
+    sc = sharded.ShardedColorizer(e, rank=rank, world_size=world)
+    sd = seeded_weights() if rank == 0 else None
+    blob = engine.pack_weights(sd, args.precision) if rank == 0 else None
+    sc.broadcast_weights(blob)
+
+    # ---- synthetic inputs, resident in HBM (each rank owns its own contiguous shard of the job) -----
+    Lh, abh, mh = workloads.random_batch(nb, H, seed=0, start=rank * nb)
+    dL, dab, dm = (torch.from_numpy(x).to(dev) for x in (Lh, abh, mh))
+    dout = torch.empty((nb, 2, H, W), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        e.forward_device(nb, dL, dab, dm, dout, 0.0, sync=False)
+    e.sync()
+    e.set_profiling(True)                       # per-layer hipEvents on the engine's stream
+    barrier(); torch.cuda.synchronize(dev); e.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        e.forward_device(nb, dL, dab, dm, dout, 0.0, sync=False)
+    e.sync(); torch.cuda.synchronize(dev); barrier()
+    elapsed = time.perf_counter() - t0
+    layer_ms = e.layer_times_ms()
+    e.set_profiling(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+        return
+
+    # ---- accounting -------------------------------------------------------------------------------------
+    table = e.layer_table()
+    conv_rows = [(r, float(layer_ms[r["index"]])) for r in table if r["kernel"].startswith("conv_igemm")]
+    conv_ms = sum(ms for _, ms in conv_rows)
+    conv_flops = sum(r["flops"] for r, _ in conv_rows) * nb                 # algorithmic, per launch-set
+    other_ms = float(sum(layer_ms)) - conv_ms
+    achieved_tflops = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    peak = PEAK_BF16_DENSE_TFLOPS if args.precision == "bf16" else PEAK_FP32_MFMA_TFLOPS
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * nb * args.steps / elapsed
+    worst = sorted(conv_rows, key=lambda x: -x[1])[:6]
+    result = {
+        "metric": "256x256 images/sec",
+        "value": round(value, 2),
+        "unit": "images/sec",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": args.precision,
+        "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[2]: batch %d random 256x256 L-channels + random sparse ab "
+                               "hint masks per GPU, %s MFMA conv path, Local-Hints SIGGRAPHGenerator forward "
+                               "(dist=False), seeded random-init weights" % (nb, args.precision),
+                   "global_batch": world * nb, "per_gpu_batch": nb, "height": H, "width": W,
+                   "parallelism": "independent images sharded over %d GPU(s); one RCCL weight broadcast" % world,
+                   "weights_broadcast_ms": sc.weights_broadcast_ms},
+        "roofline": {"bound": "mfma", "achieved": round(achieved_tflops, 2), "peak": peak, "unit": "TFLOP/s",
+                     "frac": round(achieved_tflops / peak, 4), "traffic": _pmc_traffic(),
+                     "kernel": "conv_igemm<%s> (29 launches per forward)" % args.precision,
+                     "algorithmic_flop_per_forward": conv_flops,
+                     "conv_ms_per_forward": round(conv_ms, 4), "other_kernels_ms_per_forward": round(other_ms, 4),
+                     "slowest_layers_ms": {r["name"]: round(ms, 4) for r, ms in worst},
+                     "whole_forward_frac": round(FLOP_PER_IMAGE_256 * nb / (ms_per_step * 1e-3) / 1e12 / peak, 4)},
+        "layers_ms": {r["name"]: round(float(layer_ms[r["index"]]), 4) for r in table},
+    }
+    e.close()
+    if world == 1 and not args.no_latency:
+        result["latency"] = measure_latency(sd, local_rank)
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(sd)
+    elif world == 1:
+        result["cpu_baseline"] = None
+    print(json.dumps(result))
+    sys.stdout.flush()
+    if world > 1:
+        dist.barrier()
+
+
+def _pmc_traffic():
+    """HBM bytes per forward from the rocprofv3 PMC passes, if a summary was committed
+    (profiles/pmc_traffic.json, produced by tools/pmc_traffic.py); else null."""
+    p = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get("hbm_bytes_per_forward")
+    except Exception:
+        return None
+
+
+if __name__ == "__main__":
+    main()

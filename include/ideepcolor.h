@@ -1,0 +1,156 @@
+/*
+ * ideepcolor.h -- C ABI of libideepcolor_hip.so: the MI355X (gfx950) implementation of the
+ * Local-Hints colorization forward pass.
+ *
+ * The reference has NO FFI/plugin interface for this path: the boundary is the
+ * duck-typed Python class in data/colorize_image.py whose net_forward() calls
+ *     self.net.forward(self.img_l_mc, self.input_ab_mc, self.input_mask_mult, self.mask_cent)
+ * at data/colorize_image.py:263 (torch backend) / :427-428 (caffe backend).  Everything below
+ * replaces exactly that call and the module it lands in, models/pytorch/model.py:134-175
+ * (SIGGRAPHGenerator.forward).  Each entry point cites what it stands in for.
+ *
+ * Conventions: extern "C", plain pointers and sizes, no torch/C++ types.  Every function returns
+ * IDC_OK (0) or a negative idc_status; idc_last_error() gives the text.  Host tensors are NCHW
+ * fp32, C-contiguous, caller-owned (the layout of the reference's torch tensors).  A handle owns
+ * one device, one stream, all device memory; it is not thread-safe; distinct handles are
+ * independent.  There is no CPU fallback: without a gfx950 device idc_create fails.
+ */
+#ifndef IDEEPCOLOR_H
+#define IDEEPCOLOR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IDC_VERSION 1
+
+typedef struct idc_context* idc_handle;
+
+typedef enum idc_status {
+    IDC_OK = 0,
+    IDC_ERR_INVALID_ARG = -1,
+    IDC_ERR_NO_DEVICE = -2,     /* no HIP device / not gfx950 */
+    IDC_ERR_HIP = -3,           /* a HIP runtime call failed */
+    IDC_ERR_NO_WEIGHTS = -4,    /* forward before weights (reference: "I need to have a net!", colorize_image.py:88-90) */
+    IDC_ERR_MISSING_KEY = -5,   /* a state_dict key of SURVEY.md Appendix B is absent or mis-shaped */
+    IDC_ERR_BATCH = -6,         /* n > max_batch or n <= 0 */
+    IDC_ERR_UNSUPPORTED = -7
+} idc_status;
+
+/* Arithmetic type of the conv stack.  BF16: bf16 activations+weights, fp32 MFMA accumulation,
+ * fp32 bias/BN/shortcut sums.  FP32: exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) end to end.      */
+typedef enum idc_precision { IDC_FP32 = 0, IDC_BF16 = 1 } idc_precision;
+
+/* idc_create flags */
+#define IDC_FLAG_DIST_HEAD   0x1u  /* also build model_class (529-bin) head: SIGGRAPHGenerator(dist=True), model.py:105,159-160 */
+#define IDC_FLAG_HIP_GRAPH   0x2u  /* replay the forward as one hipGraph (batch-1 click latency path) */
+
+/* ---- library ------------------------------------------------------------------------------- */
+int idc_version(void);
+/* Number of visible HIP devices (0 when none; never fails). */
+int idc_device_count(void);
+/* Text of the last error on this handle (h may be NULL: last error of a failed idc_create or of a
+ * handle-less call on the calling thread). */
+const char* idc_last_error(idc_handle h);
+
+/* ---- lifetime: replaces SIGGRAPHGenerator.__init__ (model.py:6-132) + net.eval()/.cuda()
+ *      in ColorizeImageTorch.prep_net (colorize_image.py:216-233) ---------------------------- */
+int idc_create(int device_id, int height, int width, int max_batch, int precision, unsigned flags,
+               idc_handle* out);
+int idc_destroy(idc_handle h);
+
+/* Input/output scaling: {l_div, ab_div, mask_mul, out_mul}.  Default = torch backend
+ * {100, 110, 1, 110} (model.py:148,175).  The Caffe twin feeds raw values and scales by 100:
+ * {1, 1, 1, 100} (colorize_image.py:379-383,425; deploy_nodist.prototxt:812-821).              */
+int idc_set_io_scales(idc_handle h, float l_div, float ab_div, float mask_mul, float out_mul);
+
+/* ---- weights: replaces torch.load + load_state_dict (colorize_image.py:222-229) ------------ *
+ * Tensors are given under the reference state_dict key names in torch
+ * layouts: Conv2d (Cout,Cin,kh,kw); ConvTranspose2d (Cin,Cout,4,4); BatchNorm weight/bias/
+ * running_mean/running_var.  Unknown keys (num_batches_tracked, model_class.* without the dist
+ * flag) are ignored; a missing key is IDC_ERR_MISSING_KEY.                                      */
+typedef struct idc_tensor_desc {
+    const char* name;      /* e.g. "model1.0.weight" */
+    const float* data;     /* host fp32, C-contiguous */
+    int ndim;
+    int64_t dims[4];
+} idc_tensor_desc;
+
+/* Size of the packed, device-ready weight blob (MFMA-tiled, LDS-swizzled). */
+size_t idc_weights_blob_bytes(int precision, unsigned flags);
+/* Host-only: pack a state_dict into `blob` (no device needed; used by rank 0 before the RCCL
+ * broadcast and by the CPU-side tests). */
+int idc_pack_weights(int precision, unsigned flags, const idc_tensor_desc* tensors, int n_tensors,
+                     void* blob, size_t blob_bytes);
+/* Upload a packed blob from host memory (H2D copy into handle-owned memory). */
+int idc_set_weights_host(idc_handle h, const void* blob, size_t blob_bytes);
+/* Use a packed blob that already lives in device memory (e.g. a torch uint8 tensor that just
+ * received the RCCL broadcast).  copy=0 adopts the pointer (caller keeps it alive), copy=1 does
+ * a D2D copy into handle-owned memory. */
+int idc_set_weights_device(idc_handle h, const void* dev_blob, size_t blob_bytes, int copy);
+/* Convenience = idc_pack_weights + idc_set_weights_host. */
+int idc_load_weights(idc_handle h, const idc_tensor_desc* tensors, int n_tensors);
+/* Device pointer of the blob in use (NULL before weights are set). */
+const void* idc_weights_device_ptr(idc_handle h);
+
+/* ---- forward: replaces SIGGRAPHGenerator.forward (model.py:134-175) ------------------------ *
+ * L_mc [n,1,H,W] = L-50; ab [n,2,H,W] raw Lab ab hints (0 where none); mask [n,1,H,W] in {0,1};
+ * maskcent = the mask_cent argument (0 or .5, colorize_image.py:210,263).
+ * out_ab [n,2,H,W] = 110*tanh(.) -- the tensor the reference returns at colorize_image.py:263.
+ * Host-pointer form: blocking; returns when out_ab is valid.                                    */
+int idc_forward(idc_handle h, int n, const float* L_mc, const float* ab, const float* mask,
+                float maskcent, float* out_ab);
+/* Device-pointer form (same layouts, device memory); enqueued on the handle's stream.
+ * sync!=0 waits for completion. */
+int idc_forward_device(idc_handle h, int n, const float* d_L_mc, const float* d_ab,
+                       const float* d_mask, float maskcent, float* d_out_ab, int sync);
+/* dist=True variant (needs IDC_FLAG_DIST_HEAD): additionally writes the 529-bin distribution
+ * softmax(0.2*logits) at quarter resolution, dist_q [n,529,H/4,W/4] (the reference's out_cl is
+ * its nearest x4 upsample, model.py:160: out_cl[:, :, y, x] == dist_q[:, :, y/4, x/4]).         */
+int idc_forward_dist(idc_handle h, int n, const float* L_mc, const float* ab, const float* mask,
+                     float maskcent, float* out_ab, float* dist_q);
+int idc_sync(idc_handle h);
+/* The hipStream_t all work of this handle is enqueued on (as void*). */
+void* idc_stream(idc_handle h);
+
+/* ---- introspection for parity tests and roofline accounting -------------------------------- */
+int idc_num_layers(idc_handle h);
+typedef struct idc_layer_info {
+    char name[32];        /* caffe-style layer name: conv1_1 ... conv10_2, conv3_3_short, head ... */
+    char kernel[48];      /* kernel family launched */
+    double flops;         /* ALGORITHMIC flops per image (2*MACs), 0 for non-conv */
+    double min_bytes;     /* algorithmic HBM bytes per image: input + output + residual (+weights once) */
+    int launches;         /* kernel launches per forward */
+} idc_layer_info;
+int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out);
+/* Per-layer timing with hipEvents on the handle's stream.  While on, every forward records an
+ * event pair around each layer (kept for the last 32 forwards); idc_layer_times_ms() syncs and
+ * returns, for layers [0, idc_num_layers), the mean duration (ms) over the forwards recorded
+ * since profiling was switched on (at most the last 32). */
+int idc_set_profiling(idc_handle h, int on);
+int idc_layer_times_ms(idc_handle h, float* ms, int capacity);
+/* Copy an intermediate activation of the LAST forward to the host as NCHW fp32.
+ * name = idc_layer_info.name; out must hold n*C*H*W floats; *C,*H,*W are returned.            */
+int idc_get_activation(idc_handle h, const char* name, int n, float* out, size_t capacity_floats,
+                       int* C, int* H, int* W);
+
+/* ---- single operators (parity tests drive the same kernels the network uses) --------------- *
+ * x NCHW fp32 [n,cin,h,w]; w/b in torch layouts; optional post-activation affine (eval-BN):
+ * y = act(conv(x)+b [+ resid]) * bn_scale + bn_shift.  act: 0 none, 1 ReLU, 2 LeakyReLU(0.2).
+ * in_stride=2 reads x[:, :, ::2, ::2] (model.py:149-151).  Output NCHW fp32.                  */
+int idc_op_conv2d(int device_id, int precision, int n, int cin, int h, int w, const float* x,
+                  int cout, int ksize, int dilation, int in_stride, const float* weight,
+                  const float* bias, int act, const float* bn_scale, const float* bn_shift,
+                  const float* resid, float* y);
+/* ConvTranspose2d(k=4, s=2, p=1) (+ residual) (+act): weight (cin,cout,4,4); y [n,cout,2h,2w].  */
+int idc_op_deconv4x4s2(int device_id, int precision, int n, int cin, int h, int w, const float* x,
+                       int cout, const float* weight, const float* bias, int act,
+                       const float* resid, float* y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IDEEPCOLOR_H */

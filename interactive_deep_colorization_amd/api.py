@@ -1,0 +1,331 @@
+"""The reference's model-wrapper API, re-implemented on top of the HIP engine.
+
+Callers of the reference (``ideepcolor.py:60-74``, ``ui/gui_draw.py:109-113,250-286``, the two
+notebooks) construct ``ColorizeImageTorch`` / ``ColorizeImageTorchDist`` / ``ColorizeImageCaffe``
+objects from ``data/colorize_image.py`` and use: ``prep_net``, ``load_image``, ``set_image``,
+``net_forward``, the ``get_*`` getters, ``get_ab_reccs`` and a handful of attributes
+(SURVEY.md 8b).  This module provides classes with those names and that observable behaviour
+-- including ``net_forward`` returning ``-1`` after printing a message when the image or the
+net is missing (``data/colorize_image.py:85-90``) -- while ``self.net`` is a
+:class:`~interactive_deep_colorization_amd.engine.HipColorizer`: hand-written gfx950 kernels
+behind the C ABI of ``include/ideepcolor.h``.
+
+    reference (CPU torch / caffe)                      here
+    ColorizeImageTorch.prep_net     :216-233    torch.load -> idc_load_weights
+    ColorizeImageTorch.net_forward  :249-268    idc_forward, then the same Lab->RGB post step
+    ColorizeImageTorchDist          :279-372    idc_forward_dist (529-bin head on device)
+    ColorizeImageCaffe              :375-442    same graph with Caffe i/o scaling
+
+No CPU fallback exists: without the built library and a gfx950 device ``prep_net`` raises.
+"""
+from __future__ import print_function
+
+import os
+
+import numpy as np
+from scipy.ndimage import zoom
+
+from . import colorspace
+from .colorspace import lab2rgb_transpose, rgb2lab_transpose  # same helper names as the reference
+from .engine import HipColorizer
+from .workloads import put_point  # noqa: F401  notebook helper (DemoInteractiveColorization.ipynb:131-139)
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+
+
+def create_temp_directory(path_template, N=1e8):
+    """Make a fresh ``path_template % random_int`` directory (reference helper, ``:10-17``)."""
+    print(path_template)
+    while True:
+        candidate = path_template % np.random.randint(0, N)
+        if not os.path.exists(candidate):
+            break
+    print('Creating directory: %s' % candidate)
+    os.mkdir(candidate)
+    return candidate
+
+
+def read_state_dict(path):
+    """Weights file -> dict.  ``.pth`` goes through ``torch.load`` exactly like the reference
+    (``:222-224``, including dropping ``_metadata``); ``.npz`` is accepted for torch-free use.
+    The reference's InstanceNorm key patch (``:235-246``) has nothing to patch in this network."""
+    if str(path).endswith(".npz"):
+        with np.load(path) as z:
+            return dict((k, z[k]) for k in z.files)
+    import torch
+    sd = torch.load(path, map_location="cpu")
+    if hasattr(sd, "_metadata"):
+        del sd._metadata
+    return sd
+
+
+class ColorizeImageBase(object):
+    """Image state + getters shared by every backend (reference ``:39-198``).
+
+    Backend classes define the five normalisation constants ``l_norm, ab_norm, l_mean,
+    ab_mean, mask_mult`` before any image is set."""
+
+    def __init__(self, Xd=256, Xfullres_max=10000):
+        self.Xd = Xd
+        self.Xfullres_max = Xfullres_max      # cap on the larger side of the full-res copy
+        self.img_l_set = False
+        self.net_set = False
+        self.img_just_set = False
+
+    def prep_net(self):
+        raise Exception("Should be implemented by base class")
+
+    # ------------------------------------------------------------------ image ingestion
+    def _ingest(self, rgb_fullres, rgb_net):
+        """Common tail of load_image / set_image: full-res Lab, net-res Lab, mean-centred L."""
+        big = rgb_fullres
+        longest = max(big.shape[0], big.shape[1])
+        if longest > self.Xfullres_max:
+            f = 1. * self.Xfullres_max / longest
+            big = zoom(big, (f, f, 1), order=1)
+        self.img_rgb_fullres = big
+        self.img_lab_fullres = colorspace.rgb2lab(big).transpose((2, 0, 1))
+        self.img_l_fullres = self.img_lab_fullres[[0]]
+        self.img_ab_fullres = self.img_lab_fullres[1:]
+
+        self.img_rgb = rgb_net
+        self.img_lab = colorspace.rgb2lab(rgb_net).transpose((2, 0, 1))
+        self.img_l = self.img_lab[[0]]
+        self.img_ab = self.img_lab[1:]
+
+        scale = np.array((self.l_norm, self.ab_norm, self.ab_norm))[:, None, None]
+        shift = np.array((self.l_mean, self.ab_mean, self.ab_mean))[:, None, None] / scale
+        self.img_lab_mc = self.img_lab / scale - shift
+        self.img_l_mc = self.img_lab_mc[[0]]          # = L - 50 for every shipped backend
+        self.img_l_set = True
+
+    def load_image(self, input_path):
+        """Read a file, keep the full-res copy, bilinear-resize to Xd x Xd (``:52-66``)."""
+        full = colorspace.imread_rgb(input_path)
+        small = colorspace.resize_bilinear_u8(full, self.Xd, self.Xd)
+        self._ingest(full.copy(), small)
+
+    def set_image(self, input_image):
+        """Take an already Xd x Xd RGB uint8 array; like the reference it is NOT resized (``:68-77``)."""
+        self._ingest(input_image.copy(), input_image)
+
+    # ------------------------------------------------------------------ forward bookkeeping
+    def net_forward(self, input_ab, input_mask):
+        """Guards + input bookkeeping (``:79-96``).  ab 2xXxX raw Lab units, mask 1xXxX (float or bool)."""
+        for ready, complaint in ((self.img_l_set, 'I need to have an image!'),
+                                 (self.net_set, 'I need to have a net!')):
+            if not ready:
+                print(complaint)
+                return -1
+        self.input_ab = input_ab
+        self.input_mask = input_mask
+        self.input_ab_mc = (input_ab - self.ab_mean) / self.ab_norm
+        self.input_mask_mult = input_mask * self.mask_mult
+        return 0
+
+    def _finish_forward(self, raw_ab):
+        """Lab->RGB of the prediction, then refresh ``output_ab`` from the uint8 result -- the
+        reference does this round trip too (``:264-267,196-198``), so ``output_ab`` is the
+        quantised map while ``output_ab_raw`` (extra) is the net's own output."""
+        self.output_ab_raw = raw_ab
+        self.output_rgb = lab2rgb_transpose(self.img_l, raw_ab)
+        self._set_out_ab_()
+        return self.output_rgb
+
+    def _set_out_ab_(self):
+        self.output_lab = rgb2lab_transpose(self.output_rgb)
+        self.output_ab = self.output_lab[1:]
+
+    # ------------------------------------------------------------------ getters (``:98-158``)
+    def _zeros_ab(self, like):
+        return np.zeros((2,) + tuple(like.shape[1:]))
+
+    def _up(self, arr, order):
+        """Zoom a CxXdxXd map to the full-res image size (bilinear order=1 / nearest order=0)."""
+        fh = 1. * self.img_l_fullres.shape[1] / arr.shape[1]
+        fw = 1. * self.img_l_fullres.shape[2] / arr.shape[2]
+        return zoom(arr, (1, fh, fw), order=order)
+
+    def get_result_PSNR(self, result=-1, return_SE_map=False):
+        cur = self.get_img_forward() if np.array(result).flatten()[0] == -1 else result.copy()
+        se = (1. * self.img_rgb - cur) ** 2
+        psnr = 20 * np.log10(255. / np.sqrt(np.mean(se)))
+        return (psnr, se) if return_SE_map else psnr
+
+    def get_img_forward(self):
+        return self.output_rgb
+
+    def get_img_gray(self):
+        return lab2rgb_transpose(self.img_l, self._zeros_ab(self.img_l))
+
+    def get_img_gray_fullres(self):
+        return lab2rgb_transpose(self.img_l_fullres, self._zeros_ab(self.img_l_fullres))
+
+    def get_img_fullres(self):
+        return lab2rgb_transpose(self.img_l_fullres, self._up(self.output_ab, 1))
+
+    def get_input_img_fullres(self):
+        return lab2rgb_transpose(self.img_l_fullres, self._up(self.input_ab, 1))
+
+    def get_input_img(self):
+        return lab2rgb_transpose(self.img_l, self.input_ab)
+
+    def get_img_mask(self):
+        return lab2rgb_transpose(100. * (1 - self.input_mask), self._zeros_ab(self.img_l))
+
+    def get_img_mask_fullres(self):
+        m = self._up(self.input_mask, 0)
+        return lab2rgb_transpose(100. * (1 - m), self._zeros_ab(m))
+
+    def get_sup_img(self):
+        return lab2rgb_transpose(50 * self.input_mask, self.input_ab)
+
+    def get_sup_fullres(self):
+        return lab2rgb_transpose(50 * self._up(self.input_mask, 0), self._up(self.input_ab, 0))
+
+
+def _grid_529():
+    """23x23 ab grid in the torch class's bin order (a varies fastest), ``:213,283``."""
+    axis = np.arange(-110, 120, 10)
+    return np.array(np.meshgrid(axis, axis)).reshape((2, 529)).T
+
+
+class ColorizeImageTorch(ColorizeImageBase):
+    """PyTorch-backend wrapper (``:201-276``) with the network on the MI355X.
+
+    ``precision`` (not in the reference): ``'fp32'`` = exact-fp32 MFMA, the parity path (default);
+    ``'bf16'`` = bf16 MFMA with fp32 accumulation, the throughput path."""
+
+    def __init__(self, Xd=256, maskcent=False, precision='fp32'):
+        print('ColorizeImageTorch instantiated')
+        ColorizeImageBase.__init__(self, Xd)
+        self.l_norm, self.ab_norm = 1., 1.
+        self.l_mean, self.ab_mean = 50., 0.
+        self.mask_mult = 1.
+        self.mask_cent = .5 if maskcent else 0
+        self.precision = precision
+        self.pts_in_hull = _grid_529()
+
+    def prep_net(self, gpu_id=None, path='', dist=False, state_dict=None):
+        """``gpu_id=None`` selects device 0 (the reference's torch backend stayed on the CPU:
+        ``ideepcolor.py:68-72``).  ``state_dict`` may replace ``path``."""
+        print('path = %s' % path)
+        print('Model set! dist mode? ', dist)
+        sd = read_state_dict(path) if state_dict is None else state_dict
+        self.net = HipColorizer(H=self.Xd, W=self.Xd, max_batch=1, precision=self.precision,
+                                device=0 if gpu_id is None else int(gpu_id), dist=dist)
+        self.net.load_state_dict(sd)
+        self.net_set = True
+
+    def net_forward(self, input_ab, input_mask):
+        if ColorizeImageBase.net_forward(self, input_ab, input_mask) == -1:
+            return -1
+        # the device boundary -- stands for self.net.forward(...)[0].cpu().data.numpy() at :263
+        raw = self.net.forward(self.img_l_mc, self.input_ab_mc, self.input_mask_mult, self.mask_cent)[0]
+        return self._finish_forward(raw)
+
+
+class ColorizeImageTorchDist(ColorizeImageTorch):
+    """Regression + 529-bin colour distribution and colour suggestions (``:279-372``)."""
+
+    def __init__(self, Xd=256, maskcent=False, precision='fp32'):
+        ColorizeImageTorch.__init__(self, Xd, precision=precision)
+        self.dist_ab_set = False
+        self.pts_grid = _grid_529()
+        self.in_hull = np.ones(529, dtype=bool)
+        self.AB = 529
+        self.A = self.B = 23
+        self.dist_ab_full = np.zeros((self.AB, Xd, Xd))
+        self.dist_ab_grid = np.zeros((self.A, self.B, Xd, Xd))
+        self.dist_entropy = np.zeros((Xd, Xd))
+        self.mask_cent = .5 if maskcent else 0
+
+    def prep_net(self, gpu_id=None, path='', dist=True, S=.2, state_dict=None):
+        ColorizeImageTorch.prep_net(self, gpu_id=gpu_id, path=path, dist=dist, state_dict=state_dict)
+
+    def net_forward(self, input_ab, input_mask):
+        if ColorizeImageBase.net_forward(self, input_ab, input_mask) == -1:
+            return -1
+        out_ab, dist_q = self.net.forward_dist(self.img_l_mc, self.input_ab_mc, self.input_mask_mult, self.mask_cent)
+        # device returns softmax(0.2*logits) at X/4; the reference's out_cl is its nearest x4
+        # upsample (models/pytorch/model.py:131,160)
+        self.dist_ab = np.repeat(np.repeat(dist_q[0], 4, axis=1), 4, axis=2)
+        self.dist_ab_set = True
+        self.dist_ab_full[self.in_hull] = self.dist_ab
+        self.dist_ab_grid = self.dist_ab_full.reshape((self.A, self.B, self.Xd, self.Xd))
+        # the reference returns out_reg*110*110 here (model.py:166-168), a value nothing reads;
+        # this returns the ab map itself
+        return out_ab[0]
+
+    def get_ab_reccs(self, h, w, K=5, N=25000, return_conf=False):
+        """K suggested colours at pixel (h,w): sample N points from the predicted pdf, k-means them,
+        order by cluster occupancy (``:322-354``)."""
+        if not self.dist_ab_set:
+            print('Need to set prediction first')
+            return 0
+        from sklearn.cluster import KMeans
+        cmf = np.cumsum(self.dist_ab[:, h, w])
+        cmf = cmf / cmf[-1]
+        draws = np.random.uniform(low=0, high=1.0, size=N)
+        samples = self.pts_in_hull[np.digitize(draws, bins=cmf), :]
+        km = KMeans(n_clusters=K).fit(samples)
+        counts = np.histogram(km.labels_, np.arange(0, K + 1))[0]
+        order = np.argsort(counts, axis=0)[::-1]
+        centers = km.cluster_centers_[order, :]
+        if return_conf:
+            return centers, 1. * counts[order] / N
+        return centers
+
+    def compute_entropy(self):
+        self.dist_entropy = np.sum(self.dist_ab * np.log(self.dist_ab), axis=0)
+
+    def plot_dist_grid(self, h, w):
+        import matplotlib.pyplot as plt
+        plt.figure()
+        plt.imshow(self.dist_ab_grid[:, :, h, w], extent=[-110, 110, 110, -110], interpolation='nearest')
+        plt.colorbar(); plt.ylabel('a'); plt.xlabel('b')
+
+    def plot_dist_entropy(self):
+        import matplotlib.pyplot as plt
+        plt.figure()
+        plt.imshow(-self.dist_entropy, interpolation='nearest')
+        plt.colorbar()
+
+
+class ColorizeImageCaffe(ColorizeImageBase):
+    """Caffe-backend wrapper (``:375-442``) on the same kernels.
+
+    The Caffe net (``models/reference_model/deploy_nodist.prototxt``) is the same graph with the
+    input normalisation folded into its trained weights: it is fed raw ``L-50``, raw ab and
+    ``mask*110`` (``:379-383,425``) and ends in ``TanH -> Scale 100`` (prototxt ``:812-821``).
+    Caffe cannot be installed here, so ``prep_net`` takes the weights as a ``state_dict`` under
+    the torch key names (e.g. the reference's converted ``caffemodel.pth``),
+    passed as ``caffemodel_path`` or ``state_dict``; ``prototxt_path`` is accepted and ignored."""
+
+    def __init__(self, Xd=256, precision='fp32'):
+        print('ColorizeImageCaffe instantiated')
+        ColorizeImageBase.__init__(self, Xd)
+        self.l_norm, self.ab_norm = 1., 1.
+        self.l_mean, self.ab_mean = 50., 0.
+        self.mask_mult = 110.
+        self.precision = precision
+        self.pred_ab_layer = 'pred_ab'
+        self.pts_in_hull_path = os.path.join(_PKG_DIR, 'color_bins', 'pts_in_hull.npy')
+        self.pts_in_hull = np.load(self.pts_in_hull_path) if os.path.exists(self.pts_in_hull_path) else None
+
+    def prep_net(self, gpu_id, prototxt_path='', caffemodel_path='', state_dict=None):
+        print('gpu_id = %d, net_path = %s, model_path = %s' % (gpu_id, prototxt_path, caffemodel_path))
+        if gpu_id == -1:
+            raise RuntimeError('cpu mode is not available: this backend runs on gfx950 only')
+        sd = read_state_dict(caffemodel_path) if state_dict is None else state_dict
+        self.gpu_id = gpu_id
+        self.net = HipColorizer(H=self.Xd, W=self.Xd, max_batch=1, precision=self.precision, device=int(gpu_id))
+        self.net.set_io_scales(l_div=1., ab_div=1., mask_mul=1., out_mul=100.)
+        self.net.load_state_dict(sd)
+        self.net_set = True
+
+    def net_forward(self, input_ab, input_mask):
+        if ColorizeImageBase.net_forward(self, input_ab, input_mask) == -1:
+            return -1
+        raw = self.net.forward(self.img_l_mc, self.input_ab_mc, self.input_mask_mult, 0.0)[0]
+        return self._finish_forward(raw)

@@ -1,0 +1,841 @@
+// idc_engine.hip -- host side of libideepcolor_hip.so: weight packer, static-schedule executor of
+// the SIGGRAPHGenerator graph, and the C ABI declared in include/ideepcolor.h.
+//
+// Replaces: SIGGRAPHGenerator.__init__/forward (models/pytorch/model.py:6-175) and the
+// load_state_dict/eval part of ColorizeImageTorch.prep_net (data/colorize_image.py:216-233).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ideepcolor.h"
+#include "idc_kernels.h"
+#include "idc_layout.h"
+#include "idc_net.h"
+
+namespace idc {
+
+static thread_local std::string g_last_error;
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+BlobPlan make_blob_plan(int precision, unsigned flags) {
+    BlobPlan p;
+    p.precision = precision;
+    p.flags = flags & IDC_FLAG_DIST_HEAD;
+    const auto& specs = layer_specs();
+    size_t off = sizeof(BlobHeader);
+    const int kc = kc_elems(precision);
+    for (int i = 0; i < (int)specs.size(); ++i) {
+        const LayerSpec& s = specs[i];
+        if (s.dist_only && !(flags & IDC_FLAG_DIST_HEAD)) continue;
+        LayerBlob lb;
+        const int kch = k_channels(s);
+        lb.nkc = (s.kind == kConvIm2col) ? (64 / kc) : (kch + kc - 1) / kc;   // conv1_1 operand is 64 wide
+        lb.ncg = cout_pad(s.cout) / kCoutGroup;
+        lb.w_bytes = (size_t)weight_taps(s.kind) * lb.nkc * lb.ncg * kWBlockBytes;
+        off = align_up(off, 256); lb.w_off = off; off += lb.w_bytes;
+        off = align_up(off, 256); lb.bias_off = off; off += (size_t)cout_pad(s.cout) * 4;
+        if (s.bnkey) {
+            off = align_up(off, 256); lb.bn_scale_off = off; off += (size_t)cout_pad(s.cout) * 4;
+            off = align_up(off, 256); lb.bn_shift_off = off; off += (size_t)cout_pad(s.cout) * 4;
+        } else {
+            lb.bn_scale_off = lb.bn_shift_off = (size_t)-1;
+        }
+        p.layers.push_back(lb);
+        p.active.push_back(i);
+    }
+    off = align_up(off, 256); p.head_w_off = off; off += 2 * 128 * 4;
+    off = align_up(off, 256); p.head_b_off = off; off += 2 * 4;
+    p.total_bytes = align_up(off, 256);
+    return p;
+}
+
+static uint64_t fnv1a(const uint8_t* p, size_t n) {
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+struct TensorView {
+    const float* data = nullptr;
+    int ndim = 0;
+    int64_t dims[4] = {0, 0, 0, 0};
+};
+
+static bool dims_are(const TensorView& t, std::initializer_list<int64_t> d) {
+    if (t.ndim != (int)d.size()) return false;
+    int i = 0;
+    for (int64_t v : d) if (t.dims[i++] != v) return false;
+    return true;
+}
+
+// Write one element of the packed weight image.
+static inline void put_w(uint8_t* wimg, int precision, int nkc, int ncg, int tw, int co, int k, float v) {
+    const int kc_e = kc_elems(precision), eb = elem_bytes(precision), eps = kSlotBytes / eb;
+    const int kc = k / kc_e, kin = k % kc_e;
+    const int s = kin / eps, e = kin % eps;
+    const int cg = co / kCoutGroup, col = co % kCoutGroup;
+    // inverse of cg_row_to_cout: col = g*16 + ci*4 + reg  ->  lam = ci*16 + g*4 + reg
+    const int gq = col >> 4, ci = (col >> 2) & 3, reg = col & 3;
+    const int lam = ci * 16 + gq * 4 + reg;
+    const int sig = s ^ swz(lam);
+    const size_t off = ((size_t)(tw * nkc + kc) * ncg + cg) * kWBlockBytes + (size_t)lam * kRowBytes +
+                       (size_t)sig * kSlotBytes + (size_t)e * eb;
+    if (precision == IDC_BF16) {
+        const uint16_t b = f32_to_bf16_rne(v);
+        memcpy(wimg + off, &b, 2);
+    } else {
+        memcpy(wimg + off, &v, 4);
+    }
+}
+
+// Pack one conv-like layer: weights in torch layout -> MFMA-tiled, swizzled image.
+static void pack_layer_weights(uint8_t* wimg, int precision, const LayerSpec& s, const LayerBlob& lb,
+                               const float* w) {
+    memset(wimg, 0, lb.w_bytes);
+    const int cin = s.cin, cout = s.cout;
+    if (s.kind == kConv3x3) {
+        for (int co = 0; co < cout; ++co)
+            for (int ci = 0; ci < cin; ++ci)
+                for (int t = 0; t < 9; ++t)
+                    put_w(wimg, precision, lb.nkc, lb.ncg, t, co, ci, w[((size_t)co * cin + ci) * 9 + t]);
+    } else if (s.kind == kConvIm2col) {          // K index = tap*4 + c  (pack_input_kernel order)
+        for (int co = 0; co < cout; ++co)
+            for (int ci = 0; ci < cin; ++ci)
+                for (int t = 0; t < 9; ++t)
+                    put_w(wimg, precision, lb.nkc, lb.ncg, 0, co, t * 4 + ci, w[((size_t)co * cin + ci) * 9 + t]);
+    } else if (s.kind == kConv1x1) {
+        for (int co = 0; co < cout; ++co)
+            for (int ci = 0; ci < cin; ++ci)
+                put_w(wimg, precision, lb.nkc, lb.ncg, 0, co, ci, w[(size_t)co * cin + ci]);
+    } else {                                      // ConvTranspose2d weight is (Cin, Cout, 4, 4)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int co = 0; co < cout; ++co)
+                for (int t = 0; t < 16; ++t)
+                    put_w(wimg, precision, lb.nkc, lb.ncg, t, co, ci, w[((size_t)ci * cout + co) * 16 + t]);
+    }
+}
+
+static int fail(std::string* err, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    if (err) *err = buf;
+    return code;
+}
+
+static int pack_weights_impl(int precision, unsigned flags, const idc_tensor_desc* tensors, int n_tensors,
+                             void* blob, size_t blob_bytes, std::string* err) {
+    if (precision != IDC_FP32 && precision != IDC_BF16) return fail(err, IDC_ERR_INVALID_ARG, "bad precision %d", precision);
+    if (!tensors || n_tensors <= 0 || !blob) return fail(err, IDC_ERR_INVALID_ARG, "null tensors/blob");
+    const BlobPlan plan = make_blob_plan(precision, flags);
+    if (blob_bytes < plan.total_bytes)
+        return fail(err, IDC_ERR_INVALID_ARG, "blob too small: %zu < %zu", blob_bytes, plan.total_bytes);
+    std::map<std::string, TensorView> sd;
+    for (int i = 0; i < n_tensors; ++i) {
+        if (!tensors[i].name || !tensors[i].data) return fail(err, IDC_ERR_INVALID_ARG, "tensor %d has null name/data", i);
+        TensorView v;
+        v.data = tensors[i].data;
+        v.ndim = tensors[i].ndim;
+        for (int d = 0; d < 4 && d < v.ndim; ++d) v.dims[d] = tensors[i].dims[d];
+        sd[tensors[i].name] = v;
+    }
+    auto need = [&](const std::string& key, const TensorView** out) -> bool {
+        auto it = sd.find(key);
+        if (it == sd.end()) return false;
+        *out = &it->second;
+        return true;
+    };
+    uint8_t* base = (uint8_t*)blob;
+    memset(base, 0, plan.total_bytes);
+    const auto& specs = layer_specs();
+    for (size_t li = 0; li < plan.active.size(); ++li) {
+        const LayerSpec& s = specs[plan.active[li]];
+        const LayerBlob& lb = plan.layers[li];
+        const TensorView *w = nullptr, *b = nullptr;
+        const std::string wk = std::string(s.wkey) + ".weight", bk = std::string(s.wkey) + ".bias";
+        if (!need(wk, &w)) return fail(err, IDC_ERR_MISSING_KEY, "missing state_dict key '%s'", wk.c_str());
+        if (!need(bk, &b)) return fail(err, IDC_ERR_MISSING_KEY, "missing state_dict key '%s'", bk.c_str());
+        bool ok;
+        if (s.kind == kDeconv4x4) ok = dims_are(*w, {s.cin, s.cout, 4, 4});
+        else if (s.kind == kConv1x1) ok = dims_are(*w, {s.cout, s.cin, 1, 1});
+        else ok = dims_are(*w, {s.cout, s.cin, 3, 3});
+        if (!ok) return fail(err, IDC_ERR_MISSING_KEY, "key '%s' has the wrong shape", wk.c_str());
+        if (!dims_are(*b, {s.cout})) return fail(err, IDC_ERR_MISSING_KEY, "key '%s' has the wrong shape", bk.c_str());
+        pack_layer_weights(base + lb.w_off, precision, s, lb, w->data);
+        float* bias = (float*)(base + lb.bias_off);
+        for (int c = 0; c < s.cout; ++c) bias[c] = b->data[c];
+        if (s.bnkey) {
+            const TensorView *g = nullptr, *be = nullptr, *mu = nullptr, *var = nullptr;
+            const std::string p = s.bnkey;
+            if (!need(p + ".weight", &g) || !need(p + ".bias", &be) || !need(p + ".running_mean", &mu) ||
+                !need(p + ".running_var", &var))
+                return fail(err, IDC_ERR_MISSING_KEY, "missing BatchNorm keys under '%s'", s.bnkey);
+            if (!dims_are(*g, {s.cout}) || !dims_are(*be, {s.cout}) || !dims_are(*mu, {s.cout}) || !dims_are(*var, {s.cout}))
+                return fail(err, IDC_ERR_MISSING_KEY, "BatchNorm '%s' has the wrong shape", s.bnkey);
+            float* sc = (float*)(base + lb.bn_scale_off);
+            float* sh = (float*)(base + lb.bn_shift_off);
+            for (int c = 0; c < cout_pad(s.cout); ++c) { sc[c] = 1.f; sh[c] = 0.f; }
+            for (int c = 0; c < s.cout; ++c) {      // eval-BN folded in fp64: y = x*s + t  (eps 1e-5)
+                const double sd_ = (double)g->data[c] / sqrt((double)var->data[c] + 1e-5);
+                sc[c] = (float)sd_;
+                sh[c] = (float)((double)be->data[c] - (double)mu->data[c] * sd_);
+            }
+        }
+    }
+    {
+        const TensorView *w = nullptr, *b = nullptr;
+        if (!need("model_out.0.weight", &w) || !dims_are(*w, {2, 128, 1, 1}))
+            return fail(err, IDC_ERR_MISSING_KEY, "missing or mis-shaped key 'model_out.0.weight'");
+        if (!need("model_out.0.bias", &b) || !dims_are(*b, {2}))
+            return fail(err, IDC_ERR_MISSING_KEY, "missing or mis-shaped key 'model_out.0.bias'");
+        memcpy(base + plan.head_w_off, w->data, 2 * 128 * 4);
+        memcpy(base + plan.head_b_off, b->data, 2 * 4);
+    }
+    BlobHeader h;
+    memset(&h, 0, sizeof(h));
+    h.magic = kBlobMagic; h.version = IDC_VERSION; h.precision = (uint32_t)precision; h.flags = plan.flags;
+    h.total_bytes = plan.total_bytes;
+    h.checksum = fnv1a(base + sizeof(BlobHeader), plan.total_bytes - sizeof(BlobHeader));
+    memcpy(base, &h, sizeof(h));
+    return IDC_OK;
+}
+
+// ================================================================================================
+struct Tensor {
+    std::string name;
+    void* ptr = nullptr;
+    int C = 0, Cpad = 0, H = 0, W = 0;
+    int is_f32 = 0;                      // fp32 storage (else the context's element type)
+    size_t bytes = 0;
+};
+
+struct Layer {
+    const LayerSpec* spec = nullptr;
+    LayerBlob blob;
+    int src = -1, dst = -1, resid = -1;
+    int halo = 0;
+    ConvConfig cfg{2, 2};
+    ConvArgs args;                       // pointers patched per forward where they depend on weights
+    double flops = 0, min_bytes = 0;
+};
+
+}  // namespace idc
+
+using namespace idc;
+
+struct idc_context {
+    int device = 0, H = 0, W = 0, max_batch = 0, precision = 0;
+    unsigned flags = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    float l_div = 100.f, ab_div = 110.f, mask_mul = 1.f, out_mul = 110.f;
+    BlobPlan plan;
+    uint8_t* d_blob = nullptr;
+    bool own_blob = false, weights_set = false;
+    std::vector<Tensor> tensors;
+    std::vector<Layer> layers;
+    int t_input = -1, t_conv10_2 = -1, t_logits = -1;
+    // staging for the host-pointer forward
+    float *h_in = nullptr, *h_out = nullptr, *h_dist = nullptr;
+    float *d_L = nullptr, *d_ab = nullptr, *d_mask = nullptr, *d_out = nullptr, *d_dist = nullptr;
+    float* d_scratch = nullptr; size_t scratch_bytes = 0;
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;          // kProfRing slots x 2 per timed step: [pack, layers..., head, softmax]
+    int n_timed = 0;
+    long long prof_count = 0;            // forwards recorded since profiling was switched on
+    int last_n = 0;
+};
+
+#define HIPCHK(ctx, expr)                                                                                  \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return fail((ctx) ? &(ctx)->err : nullptr, IDC_ERR_HIP, "%s failed: %s (%s:%d)", #expr,        \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                        \
+    } while (0)
+
+static constexpr int kProfRing = 32;    // per-layer event pairs are kept for the last 32 forwards
+
+static int find_tensor(idc_context* c, const char* name) {
+    for (size_t i = 0; i < c->tensors.size(); ++i)
+        if (c->tensors[i].name == name) return (int)i;
+    return -1;
+}
+
+// Tile-shape choice (speed only).  cout<=64 layers can only use one 64-wide cout group per wave
+// column; otherwise prefer 128 couts x 128 pixels and fall back to smaller pixel tiles when the
+// launch would not fill the 256 CUs.
+static ConvConfig choose_config(int n, int Hs, int Ws, int coutpad, int nphase) {
+    const int wm = coutpad >= 128 ? 2 : 1;
+    const int cand_wp[3] = {wm == 1 ? 4 : 2, 2, 1};
+    ConvConfig best{wm, cand_wp[0]};
+    for (int i = 0; i < 3; ++i) {
+        const int wp = cand_wp[i];
+        const long long tiles = (long long)((Ws + 15) / 16) * ((Hs + 4 * wp - 1) / (4 * wp)) * n * (coutpad / (64 * wm)) * nphase;
+        best = ConvConfig{wm, wp};
+        if (tiles >= 512) break;
+    }
+    return best;
+}
+
+static void fill_taps(Layer& L) {
+    ConvArgs& a = L.args;
+    const LayerSpec& s = *L.spec;
+    memset(a.dy, 0, sizeof(a.dy)); memset(a.dx, 0, sizeof(a.dx)); memset(a.tw, 0, sizeof(a.tw));
+    memset(a.ro, 0, sizeof(a.ro)); memset(a.co, 0, sizeof(a.co));
+    if (s.kind == kConv3x3) {
+        a.nphase = 1; a.ntaps = 9; a.so = 1; a.si = s.in_stride;
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) {
+                const int t = ky * 3 + kx;
+                a.dy[t] = (ky - 1) * s.dilation; a.dx[t] = (kx - 1) * s.dilation; a.tw[t] = t;
+            }
+        L.halo = s.dilation;
+    } else if (s.kind == kDeconv4x4) {
+        // out[co,2m+r,2n+s] = b + sum over (ky,dy) in T(r), (kx,dx) in T(s) of in[m+dy,n+dx]*W[ci,co,ky,kx]
+        // T(0) = {(1,0),(3,-1)}, T(1) = {(0,+1),(2,0)}     
+        static const int T_k[2][2] = {{1, 3}, {0, 2}};
+        static const int T_d[2][2] = {{0, -1}, {1, 0}};
+        a.nphase = 4; a.ntaps = 4; a.so = 2; a.si = 1;
+        for (int r = 0; r < 2; ++r)
+            for (int c = 0; c < 2; ++c) {
+                const int ph = r * 2 + c;
+                a.ro[ph] = r; a.co[ph] = c;
+                for (int i = 0; i < 2; ++i)
+                    for (int j = 0; j < 2; ++j) {
+                        const int t = ph * 9 + i * 2 + j;
+                        a.dy[t] = T_d[r][i]; a.dx[t] = T_d[c][j];
+                        a.tw[t] = T_k[r][i] * 4 + T_k[c][j];
+                    }
+            }
+        L.halo = 1;
+    } else {
+        a.nphase = 1; a.ntaps = 1; a.so = 1; a.si = 1;
+        L.halo = 0;
+    }
+}
+
+static void set_geometry(Layer& L, int n, int Hs, int Ws) {
+    ConvArgs& a = L.args;
+    a.N = n; a.Hs = Hs; a.Ws = Ws;
+    a.nkc = L.blob.nkc; a.ncg = L.blob.ncg;
+    L.cfg = choose_config(n, Hs, Ws, L.blob.ncg * kCoutGroup, a.nphase);
+    a.tiles_x = (Ws + 15) / 16;
+    a.tiles_y = (Hs + 4 * L.cfg.wp - 1) / (4 * L.cfg.wp);
+    a.act = L.spec->act;
+    a.out_f32 = L.spec->out_f32;
+}
+
+static double layer_flops(const LayerSpec& s, int H, int W) {       // per image, SURVEY.md Appendix A
+    const double ho = (double)(H / s.level), wo = (double)(W / s.level);
+    switch (s.kind) {
+        case kConv3x3: case kConvIm2col: return 2.0 * s.cin * s.cout * 9.0 * ho * wo;
+        case kConv1x1: return 2.0 * s.cin * s.cout * ho * wo;
+        case kDeconv4x4: return 2.0 * s.cin * s.cout * 4.0 * ho * wo;   // 4 taps per OUTPUT pixel
+    }
+    return 0;
+}
+
+static int build_graph(idc_context* c) {
+    const auto& specs = layer_specs();
+    const int eb = elem_bytes(c->precision);
+    auto add_tensor = [&](const char* name, int C, int Cpad, int level, int f32) -> int {
+        Tensor t;
+        t.name = name; t.C = C; t.Cpad = Cpad; t.H = c->H / level; t.W = c->W / level; t.is_f32 = f32;
+        t.bytes = (size_t)c->max_batch * t.H * t.W * Cpad * (f32 ? 4 : eb);
+        c->tensors.push_back(t);
+        return (int)c->tensors.size() - 1;
+    };
+    c->t_input = add_tensor("data_l_ab_mask", 36, 64, 1, 0);
+    for (size_t li = 0; li < c->plan.active.size(); ++li) {
+        const LayerSpec& s = specs[c->plan.active[li]];
+        Layer L;
+        L.spec = &s; L.blob = c->plan.layers[li];
+        L.src = find_tensor(c, s.src);
+        if (L.src < 0) return fail(&c->err, IDC_ERR_INVALID_ARG, "graph: unknown source '%s'", s.src);
+        if (s.resid) {
+            L.resid = find_tensor(c, s.resid);
+            if (L.resid < 0) return fail(&c->err, IDC_ERR_INVALID_ARG, "graph: unknown residual '%s'", s.resid);
+        }
+        L.dst = add_tensor(s.name, s.cout, cout_pad(s.cout), s.level, s.out_f32 || c->precision == IDC_FP32);
+        fill_taps(L);
+        L.flops = layer_flops(s, c->H, c->W);
+        const Tensor& ti = c->tensors[L.src];
+        const Tensor& to = c->tensors[L.dst];
+        const double in_px = (double)(ti.H / s.in_stride) * (ti.W / s.in_stride);
+        L.min_bytes = in_px * ti.Cpad * (ti.is_f32 ? 4 : eb) + (double)to.H * to.W * to.Cpad * (to.is_f32 ? 4 : eb) +
+                      (L.resid >= 0 ? (double)to.H * to.W * to.Cpad * 4 : 0.0);
+        c->layers.push_back(L);
+    }
+    c->t_conv10_2 = find_tensor(c, "conv10_2");
+    c->t_logits = find_tensor(c, "class_logits");
+    return IDC_OK;
+}
+
+static int alloc_graph(idc_context* c) {
+    for (auto& t : c->tensors) {
+        HIPCHK(c, hipMalloc(&t.ptr, t.bytes));
+    }
+    const size_t hw = (size_t)c->H * c->W, nb = (size_t)c->max_batch;
+    HIPCHK(c, hipMalloc((void**)&c->d_L, nb * hw * 4));
+    HIPCHK(c, hipMalloc((void**)&c->d_ab, nb * hw * 2 * 4));
+    HIPCHK(c, hipMalloc((void**)&c->d_mask, nb * hw * 4));
+    HIPCHK(c, hipMalloc((void**)&c->d_out, nb * hw * 2 * 4));
+    HIPCHK(c, hipHostMalloc((void**)&c->h_in, nb * hw * 4 * 4, hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc((void**)&c->h_out, nb * hw * 2 * 4, hipHostMallocDefault));
+    if (c->flags & IDC_FLAG_DIST_HEAD) {
+        const size_t dq = nb * 529 * (hw / 16) * 4;
+        HIPCHK(c, hipMalloc((void**)&c->d_dist, dq));
+        HIPCHK(c, hipHostMalloc((void**)&c->h_dist, dq, hipHostMallocDefault));
+    }
+    c->n_timed = (int)c->layers.size() + 3;
+    c->ev.resize((size_t)c->n_timed * 2 * kProfRing);
+    for (auto& e : c->ev) HIPCHK(c, hipEventCreate(&e));
+    return IDC_OK;
+}
+
+static int run_graph(idc_context* c, int n, const float* dL, const float* dab, const float* dmask, float maskcent,
+                     float* dout, float* ddist) {
+    hipStream_t s = c->stream;
+    int step = 0;
+    const size_t ring = (size_t)(c->prof_count % kProfRing) * c->n_timed * 2;
+    auto tic = [&]() { if (c->profiling) (void)hipEventRecord(c->ev[ring + step * 2], s); };
+    auto toc = [&]() { if (c->profiling) (void)hipEventRecord(c->ev[ring + step * 2 + 1], s); ++step; };
+    tic();
+    HIPCHK(c, launch_pack_input(c->precision, dL, dab, dmask, c->tensors[c->t_input].ptr, n, c->H, c->W, c->l_div,
+                                c->ab_div, c->mask_mul, maskcent, s));
+    toc();
+    for (auto& L : c->layers) {
+        const Tensor& ti = c->tensors[L.src];
+        const Tensor& to = c->tensors[L.dst];
+        const int Hs = L.spec->kind == kDeconv4x4 ? ti.H : to.H;
+        const int Ws = L.spec->kind == kDeconv4x4 ? ti.W : to.W;
+        set_geometry(L, n, Hs, Ws);
+        ConvArgs& a = L.args;
+        a.in = ti.ptr; a.out = to.ptr;
+        a.resid = L.resid >= 0 ? (const float*)c->tensors[L.resid].ptr : nullptr;
+        a.wgt = c->d_blob + L.blob.w_off;
+        a.bias = (const float*)(c->d_blob + L.blob.bias_off);
+        a.bn_scale = L.blob.bn_scale_off != (size_t)-1 ? (const float*)(c->d_blob + L.blob.bn_scale_off) : nullptr;
+        a.bn_shift = L.blob.bn_shift_off != (size_t)-1 ? (const float*)(c->d_blob + L.blob.bn_shift_off) : nullptr;
+        tic();
+        HIPCHK(c, launch_conv(c->precision, L.cfg, L.halo, a, s));
+        toc();
+    }
+    tic();
+    HIPCHK(c, launch_head(c->precision, c->tensors[c->t_conv10_2].ptr, (const float*)(c->d_blob + c->plan.head_w_off),
+                          (const float*)(c->d_blob + c->plan.head_b_off), dout, n, c->H, c->W, c->out_mul, s));
+    toc();
+    tic();
+    if (ddist) {
+        const Tensor& tl = c->tensors[c->t_logits];
+        HIPCHK(c, launch_softmax_nchw((const float*)tl.ptr, ddist, n, tl.H, tl.W, 529, tl.Cpad, 0.2f, s));
+    }
+    toc();
+    c->last_n = n;
+    if (c->profiling) ++c->prof_count;
+    return IDC_OK;
+}
+
+static int check_forward_args(idc_context* c, int n) {
+    if (!c) return fail(nullptr, IDC_ERR_INVALID_ARG, "null handle");
+    if (!c->weights_set) return fail(&c->err, IDC_ERR_NO_WEIGHTS, "I need to have a net! (no weights loaded)");
+    if (n <= 0 || n > c->max_batch) return fail(&c->err, IDC_ERR_BATCH, "batch %d outside 1..%d", n, c->max_batch);
+    return IDC_OK;
+}
+
+static int forward_host(idc_context* c, int n, const float* L_mc, const float* ab, const float* mask, float maskcent,
+                        float* out_ab, float* dist_q) {
+    int rc = check_forward_args(c, n);
+    if (rc) return rc;
+    if (!L_mc || !ab || !mask || !out_ab) return fail(&c->err, IDC_ERR_INVALID_ARG, "null tensor pointer");
+    if (dist_q && !(c->flags & IDC_FLAG_DIST_HEAD))
+        return fail(&c->err, IDC_ERR_UNSUPPORTED, "handle was created without IDC_FLAG_DIST_HEAD");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t hw = (size_t)c->H * c->W;
+    float* hL = c->h_in; float* hab = hL + (size_t)n * hw; float* hm = hab + (size_t)n * hw * 2;
+    memcpy(hL, L_mc, (size_t)n * hw * 4);
+    memcpy(hab, ab, (size_t)n * hw * 2 * 4);
+    memcpy(hm, mask, (size_t)n * hw * 4);
+    HIPCHK(c, hipMemcpyAsync(c->d_L, hL, (size_t)n * hw * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_ab, hab, (size_t)n * hw * 2 * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_mask, hm, (size_t)n * hw * 4, hipMemcpyHostToDevice, c->stream));
+    rc = run_graph(c, n, c->d_L, c->d_ab, c->d_mask, maskcent, c->d_out, dist_q ? c->d_dist : nullptr);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, (size_t)n * hw * 2 * 4, hipMemcpyDeviceToHost, c->stream));
+    const size_t dq = (size_t)n * 529 * (hw / 16) * 4;
+    if (dist_q) HIPCHK(c, hipMemcpyAsync(c->h_dist, c->d_dist, dq, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(out_ab, c->h_out, (size_t)n * hw * 2 * 4);
+    if (dist_q) memcpy(dist_q, c->h_dist, dq);
+    return IDC_OK;
+}
+
+static void destroy_ctx(idc_context* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& t : c->tensors) if (t.ptr) (void)hipFree(t.ptr);
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->own_blob && c->d_blob) (void)hipFree(c->d_blob);
+    void* dev[] = {c->d_L, c->d_ab, c->d_mask, c->d_out, c->d_dist, c->d_scratch};
+    for (void* p : dev) if (p) (void)hipFree(p);
+    void* host[] = {c->h_in, c->h_out, c->h_dist};
+    for (void* p : host) if (p) (void)hipHostFree(p);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static int check_device(int device_id, std::string* err) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(err, IDC_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    if (device_id < 0 || device_id >= count) return fail(err, IDC_ERR_NO_DEVICE, "device %d not in 0..%d", device_id, count - 1);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return fail(err, IDC_ERR_HIP, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(err, IDC_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
+    return IDC_OK;
+}
+
+// ================================================================================================
+extern "C" {
+
+int idc_version(void) { return IDC_VERSION; }
+
+int idc_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+
+const char* idc_last_error(idc_handle h) { return h ? h->err.c_str() : g_last_error.c_str(); }
+
+int idc_create(int device_id, int height, int width, int max_batch, int precision, unsigned flags, idc_handle* out) {
+    if (!out) return fail(nullptr, IDC_ERR_INVALID_ARG, "null out handle");
+    *out = nullptr;
+    if (height <= 0 || width <= 0 || height % 8 || width % 8)
+        return fail(nullptr, IDC_ERR_INVALID_ARG, "H and W must be positive multiples of 8 (got %dx%d)", height, width);
+    if (max_batch <= 0) return fail(nullptr, IDC_ERR_INVALID_ARG, "max_batch must be positive");
+    if (precision != IDC_FP32 && precision != IDC_BF16) return fail(nullptr, IDC_ERR_INVALID_ARG, "bad precision %d", precision);
+    int rc = check_device(device_id, nullptr);
+    if (rc) return rc;
+    if (hipSetDevice(device_id) != hipSuccess) return fail(nullptr, IDC_ERR_HIP, "hipSetDevice(%d) failed", device_id);
+    idc_context* c = new idc_context();
+    c->device = device_id; c->H = height; c->W = width; c->max_batch = max_batch; c->precision = precision; c->flags = flags;
+    c->plan = make_blob_plan(precision, flags);
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = init_kernels();
+    if (e != hipSuccess) {
+        rc = fail(nullptr, IDC_ERR_HIP, "stream/kernel init failed: %s", hipGetErrorString(e));
+        destroy_ctx(c);
+        return rc;
+    }
+    rc = build_graph(c);
+    if (rc == IDC_OK) rc = alloc_graph(c);
+    if (rc != IDC_OK) { g_last_error = c->err; destroy_ctx(c); return rc; }
+    *out = c;
+    return IDC_OK;
+}
+
+int idc_destroy(idc_handle h) {
+    if (!h) return fail(nullptr, IDC_ERR_INVALID_ARG, "null handle");
+    destroy_ctx(h);
+    return IDC_OK;
+}
+
+int idc_set_io_scales(idc_handle h, float l_div, float ab_div, float mask_mul, float out_mul) {
+    if (!h) return fail(nullptr, IDC_ERR_INVALID_ARG, "null handle");
+    if (l_div == 0.f || ab_div == 0.f) return fail(&h->err, IDC_ERR_INVALID_ARG, "zero divisor");
+    h->l_div = l_div; h->ab_div = ab_div; h->mask_mul = mask_mul; h->out_mul = out_mul;
+    return IDC_OK;
+}
+
+size_t idc_weights_blob_bytes(int precision, unsigned flags) {
+    if (precision != IDC_FP32 && precision != IDC_BF16) return 0;
+    return make_blob_plan(precision, flags).total_bytes;
+}
+
+int idc_pack_weights(int precision, unsigned flags, const idc_tensor_desc* tensors, int n_tensors, void* blob,
+                     size_t blob_bytes) {
+    return pack_weights_impl(precision, flags, tensors, n_tensors, blob, blob_bytes, nullptr);
+}
+
+static int validate_header(idc_context* h, const BlobHeader& hd, size_t blob_bytes) {
+    if (hd.magic != kBlobMagic || hd.version != IDC_VERSION)
+        return fail(&h->err, IDC_ERR_INVALID_ARG, "not an ideepcolor weight blob (bad magic/version)");
+    if ((int)hd.precision != h->precision || hd.flags != h->plan.flags)
+        return fail(&h->err, IDC_ERR_INVALID_ARG, "blob was packed for precision %u flags %u, handle needs %d/%u",
+                    hd.precision, hd.flags, h->precision, h->plan.flags);
+    if (hd.total_bytes != h->plan.total_bytes || blob_bytes < h->plan.total_bytes)
+        return fail(&h->err, IDC_ERR_INVALID_ARG, "blob size mismatch");
+    return IDC_OK;
+}
+
+int idc_set_weights_host(idc_handle h, const void* blob, size_t blob_bytes) {
+    if (!h || !blob) return fail(h ? &h->err : nullptr, IDC_ERR_INVALID_ARG, "null handle/blob");
+    BlobHeader hd;
+    if (blob_bytes < sizeof(hd)) return fail(&h->err, IDC_ERR_INVALID_ARG, "blob too small");
+    memcpy(&hd, blob, sizeof(hd));
+    int rc = validate_header(h, hd, blob_bytes);
+    if (rc) return rc;
+    if (fnv1a((const uint8_t*)blob + sizeof(hd), h->plan.total_bytes - sizeof(hd)) != hd.checksum)
+        return fail(&h->err, IDC_ERR_INVALID_ARG, "blob checksum mismatch");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->own_blob || !h->d_blob) {
+        h->d_blob = nullptr;
+        HIPCHK(h, hipMalloc((void**)&h->d_blob, h->plan.total_bytes));
+        h->own_blob = true;
+    }
+    HIPCHK(h, hipMemcpy(h->d_blob, blob, h->plan.total_bytes, hipMemcpyHostToDevice));
+    h->weights_set = true;
+    return IDC_OK;
+}
+
+int idc_set_weights_device(idc_handle h, const void* dev_blob, size_t blob_bytes, int copy) {
+    if (!h || !dev_blob) return fail(h ? &h->err : nullptr, IDC_ERR_INVALID_ARG, "null handle/blob");
+    HIPCHK(h, hipSetDevice(h->device));
+    BlobHeader hd;
+    if (blob_bytes < sizeof(hd)) return fail(&h->err, IDC_ERR_INVALID_ARG, "blob too small");
+    HIPCHK(h, hipMemcpy(&hd, dev_blob, sizeof(hd), hipMemcpyDeviceToHost));
+    int rc = validate_header(h, hd, blob_bytes);
+    if (rc) return rc;
+    if (copy) {
+        if (!h->own_blob || !h->d_blob) {
+            h->d_blob = nullptr;
+            HIPCHK(h, hipMalloc((void**)&h->d_blob, h->plan.total_bytes));
+            h->own_blob = true;
+        }
+        HIPCHK(h, hipMemcpy(h->d_blob, dev_blob, h->plan.total_bytes, hipMemcpyDeviceToDevice));
+    } else {
+        if (h->own_blob && h->d_blob) (void)hipFree(h->d_blob);
+        h->d_blob = (uint8_t*)dev_blob;
+        h->own_blob = false;
+    }
+    h->weights_set = true;
+    return IDC_OK;
+}
+
+int idc_load_weights(idc_handle h, const idc_tensor_desc* tensors, int n_tensors) {
+    if (!h) return fail(nullptr, IDC_ERR_INVALID_ARG, "null handle");
+    std::vector<uint8_t> blob(h->plan.total_bytes);
+    int rc = pack_weights_impl(h->precision, h->flags, tensors, n_tensors, blob.data(), blob.size(), &h->err);
+    if (rc) return rc;
+    return idc_set_weights_host(h, blob.data(), blob.size());
+}
+
+const void* idc_weights_device_ptr(idc_handle h) { return (h && h->weights_set) ? h->d_blob : nullptr; }
+
+int idc_forward(idc_handle h, int n, const float* L_mc, const float* ab, const float* mask, float maskcent,
+                float* out_ab) {
+    return forward_host(h, n, L_mc, ab, mask, maskcent, out_ab, nullptr);
+}
+
+int idc_forward_dist(idc_handle h, int n, const float* L_mc, const float* ab, const float* mask, float maskcent,
+                     float* out_ab, float* dist_q) {
+    if (!dist_q) return fail(h ? &h->err : nullptr, IDC_ERR_INVALID_ARG, "null dist_q");
+    return forward_host(h, n, L_mc, ab, mask, maskcent, out_ab, dist_q);
+}
+
+int idc_forward_device(idc_handle h, int n, const float* d_L_mc, const float* d_ab, const float* d_mask, float maskcent,
+                       float* d_out_ab, int sync) {
+    int rc = check_forward_args(h, n);
+    if (rc) return rc;
+    if (!d_L_mc || !d_ab || !d_mask || !d_out_ab) return fail(&h->err, IDC_ERR_INVALID_ARG, "null tensor pointer");
+    HIPCHK(h, hipSetDevice(h->device));
+    rc = run_graph(h, n, d_L_mc, d_ab, d_mask, maskcent, d_out_ab, (h->flags & IDC_FLAG_DIST_HEAD) ? h->d_dist : nullptr);
+    if (rc) return rc;
+    if (sync) HIPCHK(h, hipStreamSynchronize(h->stream));
+    return IDC_OK;
+}
+
+int idc_sync(idc_handle h) {
+    if (!h) return fail(nullptr, IDC_ERR_INVALID_ARG, "null handle");
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return IDC_OK;
+}
+
+void* idc_stream(idc_handle h) { return h ? (void*)h->stream : nullptr; }
+
+int idc_num_layers(idc_handle h) { return h ? h->n_timed : 0; }
+
+int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
+    if (!h || !out) return fail(h ? &h->err : nullptr, IDC_ERR_INVALID_ARG, "null argument");
+    if (layer < 0 || layer >= h->n_timed) return fail(&h->err, IDC_ERR_INVALID_ARG, "layer %d out of range", layer);
+    memset(out, 0, sizeof(*out));
+    const int nl = (int)h->layers.size();
+    const double hw = (double)h->H * h->W;
+    const int eb = elem_bytes(h->precision);
+    if (layer == 0) {
+        snprintf(out->name, sizeof(out->name), "pack_input");
+        snprintf(out->kernel, sizeof(out->kernel), "pack_input_kernel");
+        out->min_bytes = hw * 4 * 4 + hw * 64 * eb; out->launches = 1;
+    } else if (layer <= nl) {
+        const Layer& L = h->layers[layer - 1];
+        snprintf(out->name, sizeof(out->name), "%s", L.spec->name);
+        snprintf(out->kernel, sizeof(out->kernel), "conv_igemm<%s>", h->precision == IDC_BF16 ? "bf16" : "f32");
+        out->flops = L.flops; out->min_bytes = L.min_bytes; out->launches = 1;
+    } else if (layer == nl + 1) {
+        snprintf(out->name, sizeof(out->name), "head");
+        snprintf(out->kernel, sizeof(out->kernel), "head_kernel");
+        out->flops = 2.0 * 128 * 2 * hw; out->min_bytes = hw * 128 * eb + hw * 2 * 4; out->launches = 1;
+    } else {
+        snprintf(out->name, sizeof(out->name), "dist_softmax");
+        snprintf(out->kernel, sizeof(out->kernel), "softmax_nchw_kernel");
+        out->launches = (h->flags & IDC_FLAG_DIST_HEAD) ? 1 : 0;
+        out->min_bytes = out->launches ? (hw / 16) * (640 + 529) * 4 : 0;
+    }
+    return IDC_OK;
+}
+
+int idc_set_profiling(idc_handle h, int on) {
+    if (!h) return fail(nullptr, IDC_ERR_INVALID_ARG, "null handle");
+    h->profiling = on != 0;
+    h->prof_count = 0;
+    return IDC_OK;
+}
+
+int idc_layer_times_ms(idc_handle h, float* ms, int capacity) {
+    if (!h || !ms) return fail(h ? &h->err : nullptr, IDC_ERR_INVALID_ARG, "null argument");
+    if (capacity < h->n_timed) return fail(&h->err, IDC_ERR_INVALID_ARG, "capacity %d < %d", capacity, h->n_timed);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int slots = (int)(h->prof_count < kProfRing ? h->prof_count : kProfRing);
+    if (slots == 0) return fail(&h->err, IDC_ERR_INVALID_ARG, "no forward was recorded with profiling on");
+    for (int i = 0; i < h->n_timed; ++i) {
+        double sum = 0;
+        for (int sl = 0; sl < slots; ++sl) {
+            float t = 0.f;
+            const size_t base = (size_t)sl * h->n_timed * 2;
+            if (hipEventElapsedTime(&t, h->ev[base + i * 2], h->ev[base + i * 2 + 1]) != hipSuccess) t = 0.f;
+            sum += t;
+        }
+        ms[i] = (float)(sum / slots);
+    }
+    return IDC_OK;
+}
+
+int idc_get_activation(idc_handle h, const char* name, int n, float* out, size_t capacity_floats, int* C, int* H,
+                       int* W) {
+    if (!h || !name || !out) return fail(h ? &h->err : nullptr, IDC_ERR_INVALID_ARG, "null argument");
+    const int ti = find_tensor(h, name);
+    if (ti < 0) return fail(&h->err, IDC_ERR_INVALID_ARG, "no activation named '%s'", name);
+    const Tensor& t = h->tensors[ti];
+    if (n <= 0 || n > h->max_batch) return fail(&h->err, IDC_ERR_BATCH, "bad n");
+    const size_t need = (size_t)n * t.C * t.H * t.W;
+    if (capacity_floats < need) return fail(&h->err, IDC_ERR_INVALID_ARG, "need %zu floats", need);
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->scratch_bytes < need * 4) {
+        if (h->d_scratch) (void)hipFree(h->d_scratch);
+        h->d_scratch = nullptr; h->scratch_bytes = 0;
+        HIPCHK(h, hipMalloc((void**)&h->d_scratch, need * 4));
+        h->scratch_bytes = need * 4;
+    }
+    const int src_bf16 = (!t.is_f32 && h->precision == IDC_BF16) ? 1 : 0;
+    HIPCHK(h, launch_nhwc_to_nchw(src_bf16, t.ptr, h->d_scratch, n, t.C, t.H, t.W, t.Cpad, h->stream));
+    HIPCHK(h, hipMemcpyAsync(out, h->d_scratch, need * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (C) *C = t.C;
+    if (H) *H = t.H;
+    if (W) *W = t.W;
+    return IDC_OK;
+}
+
+// ---- single operators -----------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
+};
+
+static int run_single_op(int device_id, int precision, LayerSpec spec, int n, int h, int w, const float* x,
+                         const float* weight, const float* bias, const float* bn_scale, const float* bn_shift,
+                         const float* resid, float* y) {
+    int rc = check_device(device_id, nullptr);
+    if (rc) return rc;
+    if (precision != IDC_FP32 && precision != IDC_BF16) return fail(nullptr, IDC_ERR_INVALID_ARG, "bad precision");
+    if (!x || !weight || !bias || !y || n <= 0 || h <= 0 || w <= 0) return fail(nullptr, IDC_ERR_INVALID_ARG, "bad argument");
+    const int kc = kc_elems(precision), eb = elem_bytes(precision);
+    if (spec.cin % kc) return fail(nullptr, IDC_ERR_UNSUPPORTED, "cin must be a multiple of %d in this precision", kc);
+    if (spec.in_stride != 1 && spec.in_stride != 2) return fail(nullptr, IDC_ERR_INVALID_ARG, "in_stride must be 1 or 2");
+    if (h % spec.in_stride || w % spec.in_stride) return fail(nullptr, IDC_ERR_INVALID_ARG, "H, W must divide by in_stride");
+    idc_context* nullctx = nullptr;
+    HIPCHK(nullctx, hipSetDevice(device_id));
+    HIPCHK(nullctx, init_kernels());
+    Layer L;
+    L.spec = &spec;
+    L.blob.nkc = spec.cin / kc; L.blob.ncg = cout_pad(spec.cout) / kCoutGroup;
+    L.blob.w_bytes = (size_t)weight_taps(spec.kind) * L.blob.nkc * L.blob.ncg * kWBlockBytes;
+    const int cpad = cout_pad(spec.cout);
+    std::vector<uint8_t> wimg(L.blob.w_bytes);
+    pack_layer_weights(wimg.data(), precision, spec, L.blob, weight);
+    std::vector<float> hb(cpad, 0.f), hs(cpad, 1.f), ht(cpad, 0.f);
+    for (int c = 0; c < spec.cout; ++c) {
+        hb[c] = bias[c];
+        if (bn_scale) { hs[c] = bn_scale[c]; ht[c] = bn_shift ? bn_shift[c] : 0.f; }
+    }
+    const int Hs = h / spec.in_stride, Ws = w / spec.in_stride;
+    const int so = spec.kind == kDeconv4x4 ? 2 : 1;
+    const int Ho = Hs * so, Wo = Ws * so;
+    DevBuf d_x, d_xn, d_w, d_b, d_s, d_t, d_r, d_rn, d_yn, d_y;
+    const size_t xin = (size_t)n * spec.cin * h * w, yout = (size_t)n * spec.cout * Ho * Wo;
+    HIPCHK(nullctx, d_x.alloc(xin * 4));
+    HIPCHK(nullctx, d_xn.alloc(xin * eb));
+    HIPCHK(nullctx, d_w.alloc(L.blob.w_bytes));
+    HIPCHK(nullctx, d_b.alloc(cpad * 4)); HIPCHK(nullctx, d_s.alloc(cpad * 4)); HIPCHK(nullctx, d_t.alloc(cpad * 4));
+    HIPCHK(nullctx, d_yn.alloc((size_t)n * Ho * Wo * cpad * 4));
+    HIPCHK(nullctx, d_y.alloc(yout * 4));
+    HIPCHK(nullctx, hipMemcpy(d_x.p, x, xin * 4, hipMemcpyHostToDevice));
+    HIPCHK(nullctx, hipMemcpy(d_w.p, wimg.data(), L.blob.w_bytes, hipMemcpyHostToDevice));
+    HIPCHK(nullctx, hipMemcpy(d_b.p, hb.data(), cpad * 4, hipMemcpyHostToDevice));
+    HIPCHK(nullctx, hipMemcpy(d_s.p, hs.data(), cpad * 4, hipMemcpyHostToDevice));
+    HIPCHK(nullctx, hipMemcpy(d_t.p, ht.data(), cpad * 4, hipMemcpyHostToDevice));
+    HIPCHK(nullctx, launch_nchw_to_nhwc(precision, (const float*)d_x.p, d_xn.p, n, spec.cin, h, w, spec.cin, nullptr));
+    if (resid) {
+        HIPCHK(nullctx, d_r.alloc(yout * 4));
+        HIPCHK(nullctx, d_rn.alloc((size_t)n * Ho * Wo * cpad * 4));
+        HIPCHK(nullctx, hipMemcpy(d_r.p, resid, yout * 4, hipMemcpyHostToDevice));
+        HIPCHK(nullctx, launch_nchw_to_nhwc(0, (const float*)d_r.p, d_rn.p, n, spec.cout, Ho, Wo, cpad, nullptr));
+    }
+    fill_taps(L);
+    set_geometry(L, n, Hs, Ws);
+    ConvArgs& a = L.args;
+    a.in = d_xn.p; a.out = d_yn.p; a.wgt = d_w.p; a.bias = (const float*)d_b.p;
+    a.bn_scale = bn_scale ? (const float*)d_s.p : nullptr;
+    a.bn_shift = bn_scale ? (const float*)d_t.p : nullptr;
+    a.resid = resid ? (const float*)d_rn.p : nullptr;
+    a.out_f32 = 1;
+    HIPCHK(nullctx, launch_conv(precision, L.cfg, L.halo, a, nullptr));
+    HIPCHK(nullctx, launch_nhwc_to_nchw(0, d_yn.p, (float*)d_y.p, n, spec.cout, Ho, Wo, cpad, nullptr));
+    HIPCHK(nullctx, hipMemcpy(y, d_y.p, yout * 4, hipMemcpyDeviceToHost));
+    HIPCHK(nullctx, hipDeviceSynchronize());
+    return IDC_OK;
+}
+
+int idc_op_conv2d(int device_id, int precision, int n, int cin, int h, int w, const float* x, int cout, int ksize,
+                  int dilation, int in_stride, const float* weight, const float* bias, int act, const float* bn_scale,
+                  const float* bn_shift, const float* resid, float* y) {
+    if (ksize != 3 && ksize != 1) return fail(nullptr, IDC_ERR_UNSUPPORTED, "ksize must be 1 or 3");
+    if (dilation != 1 && dilation != 2) return fail(nullptr, IDC_ERR_UNSUPPORTED, "dilation must be 1 or 2");
+    if (ksize == 1 && (dilation != 1 || in_stride != 1)) return fail(nullptr, IDC_ERR_UNSUPPORTED, "1x1 conv: d=1, stride 1 only");
+    LayerSpec s{"op", "op", nullptr, ksize == 3 ? kConv3x3 : kConv1x1, cin, cout, dilation, in_stride, act,
+                "x", nullptr, 1, 1, 0};
+    return run_single_op(device_id, precision, s, n, h, w, x, weight, bias, bn_scale, bn_shift, resid, y);
+}
+
+int idc_op_deconv4x4s2(int device_id, int precision, int n, int cin, int h, int w, const float* x, int cout,
+                       const float* weight, const float* bias, int act, const float* resid, float* y) {
+    LayerSpec s{"op", "op", nullptr, kDeconv4x4, cin, cout, 1, 1, act, "x", nullptr, 1, 1, 0};
+    return run_single_op(device_id, precision, s, n, h, w, x, weight, bias, nullptr, nullptr, resid, y);
+}
+
+}  // extern "C"

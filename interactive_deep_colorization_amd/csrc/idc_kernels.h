@@ -1,0 +1,62 @@
+// idc_kernels.h -- launch interface of the gfx950 kernels (internal; the public ABI is
+// include/ideepcolor.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace idc {
+
+// One implicit-GEMM convolution launch.  The output is computed over a grid of "sites":
+// site (sy,sx) reads input pixels (sy*si + tap offsets) and writes output pixel
+// (sy*so + ro[phase], sx*so + co[phase]).
+//   conv3x3 (dilation d, reading x[::si, ::si]) : so=1, 1 phase, 9 taps, dy,dx in {-d,0,d}
+//   ConvTranspose 4x4 s2 p1                     : si=1, so=2, 4 phases x 4 taps (2x2)
+//   1x1 conv                                    : 1 tap, halo 0
+struct ConvArgs {
+    const void* in;         // NHWC [N][Hs*si][Ws*si][Cin]          (T)
+    const void* wgt;        // packed [tap][kc][cout group][64][128B] (T), see idc_layout.h
+    void* out;              // NHWC [N][Hs*so][Ws*so][CoutPad]       (T, or fp32 if out_f32)
+    const float* resid;     // optional NHWC fp32, geometry of `out`: added before the activation
+    const float* bias;      // [CoutPad]
+    const float* bn_scale;  // optional [CoutPad]: y = act(.)*scale + shift  (eval-BN after ReLU)
+    const float* bn_shift;
+    int N, Hs, Ws;
+    int si, so;
+    int nkc;                // Cin / KC   (KC = 128 B of channels)
+    int ncg;                // CoutPad / 64
+    int nphase, ntaps;
+    int tiles_x, tiles_y;   // tiles per image
+    int act;                // 0 none, 1 ReLU, 2 LeakyReLU(0.2)
+    int out_f32;
+    int dy[36], dx[36], tw[36];   // [phase*9 + t]: tap offset in sites, packed-weight tap index
+    int ro[4], co[4];
+};
+
+struct ConvConfig { int wm, wp; };     // waves along cout (x64) and along pixel rows (x4 rows of 16)
+
+// precision: 0 fp32, 1 bf16.  halo: 0,1,2.  Returns hipSuccess or the launch error.
+hipError_t launch_conv(int precision, ConvConfig cfg, int halo, const ConvArgs& a, hipStream_t s);
+// One-time: raise the dynamic-LDS limit of every conv instantiation.
+hipError_t init_kernels();
+size_t conv_lds_bytes(ConvConfig cfg, int halo);
+
+// L/ab/mask planes (NCHW fp32) -> im2col'd conv1_1 operand [N][H][W][64]: channel tap*4+c holds
+// normalised input c of the 3x3 neighbour `tap` (zero outside the image, zero for k >= 36).
+hipError_t launch_pack_input(int precision, const float* L, const float* ab, const float* mask,
+                             void* out, int N, int H, int W, float l_div, float ab_div,
+                             float mask_mul, float maskcent, hipStream_t s);
+// conv1x1(128->2) + tanh + *out_mul, NHWC (T) -> NCHW fp32
+hipError_t launch_head(int precision, const void* x, const float* w, const float* b, float* out,
+                       int N, int H, int W, float out_mul, hipStream_t s);
+// softmax over the first `nclass` of `cstride` fp32 logits per pixel, * temperature first;
+// NHWC fp32 logits [npix][cstride] -> NCHW fp32 probabilities [N][nclass][H][W]
+hipError_t launch_softmax_nchw(const float* logits, float* out, int N, int H, int W, int nclass,
+                               int cstride, float temperature, hipStream_t s);
+// layout converters for the single-operator test entry points and idc_get_activation
+hipError_t launch_nchw_to_nhwc(int precision, const float* src, void* dst, int N, int C, int H, int W,
+                               int Cpad, hipStream_t s);
+hipError_t launch_nhwc_to_nchw(int src_is_bf16, const void* src, float* dst, int N, int C, int H,
+                               int W, int Cstride, hipStream_t s);
+
+}  // namespace idc

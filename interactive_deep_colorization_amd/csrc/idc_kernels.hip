@@ -1,0 +1,548 @@
+// idc_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the Local-Hints forward pass.
+//
+// conv_igemm<T, WM, WP, HALO>: im2col-free implicit GEMM for every conv / deconv of
+// models/pytorch/model.py:13-109, D[cout][pixel] += W_tap[cout][cin] * X[pixel + tap][cin].
+//   * one workgroup = (16 x 4*WP) output sites of ONE image x 64*WM output channels;
+//     one wave = 64 couts x 4 spatial rows of 16 pixels = 4x4 MFMA 16x16 accumulator tiles;
+//   * the input tile WITH ITS HALO is staged once per 128-byte channel chunk into LDS and reused
+//     by all taps (9x fewer L2->LDS bytes than per-tap gathers; zero padding = zero-filled rows);
+//   * weights arrive as pre-swizzled 8 KiB LDS images (idc_layout.h): a straight 16-B/lane copy,
+//     register-prefetched one tap ahead (issue-early / write-late) into a 2-deep LDS ring,
+//     one barrier per tap;
+//   * MFMA operands are 16-byte ds_read_b128 fragments, conflict-free under the row&7 XOR
+//     swizzle; bf16 uses v_mfma_f32_16x16x32_bf16, fp32 uses 4x v_mfma_f32_16x16x4_f32 (exact
+//     fp32 = an fmaf chain) on the same 16-byte fragments;
+//   * fused epilogue: +bias, +fp32 shortcut sum, ReLU/LeakyReLU, eval-BN affine AFTER the
+//     activation (model.py:13-17 order), 32/64-byte stores of 16 consecutive channels per lane.
+#include "idc_kernels.h"
+
+#include "idc_layout.h"
+
+namespace idc {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // 16-byte slot held in registers
+
+// ------------------------------------------------------------------------------------------------
+// MFMA wrappers on 16-byte fragments.  A lane (row/col = lane&15, group g = lane>>4) holds the
+// 16-byte slot (ks*4+g) of its row; the K index it stands for is the same permutation for both
+// operands, so the contraction is exact whatever the order.
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct Mma;
+template <> struct Mma<__bf16> {
+    static __device__ __forceinline__ void run(f32x4& acc, const u32x4& w, const u32x4& x) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w),
+                                                      __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static __device__ __forceinline__ void run(f32x4& acc, const u32x4& w, const u32x4& x) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.x), __uint_as_float(x.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.y), __uint_as_float(x.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.z), __uint_as_float(x.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.w), __uint_as_float(x.w), acc, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    const __bf16 a = (__bf16)lo, b = (__bf16)hi;                 // v_cvt_pk_bf16_f32, RNE
+    return (unsigned)__builtin_bit_cast(unsigned short, a) |
+           ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+// XCD-aware, bijective block remap: hardware places block b on XCD b%8; give each XCD a
+// contiguous range of the logical order so neighbouring tiles (same weights, shared halo) share
+// one L2.  Speed only -- any placement is correct.
+__device__ __forceinline__ int xcd_remap(int b, int nb) {
+    const int xcd = b & 7, q = nb >> 3, r = nb & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (b >> 3);
+}
+
+template <typename T, int WM, int WP, int HALO>
+__global__ __launch_bounds__(WM* WP * 64) void conv_igemm(const ConvArgs a) {
+    constexpr int NT = WM * WP * 64;
+    constexpr int TW = 16, TH = 4 * WP;
+    constexpr int HWP = TW + 2 * HALO, HHP = TH + 2 * HALO, HROWS = HWP * HHP;
+    constexpr int BN = 64 * WM;
+    constexpr int W_BYTES = BN * kRowBytes;
+    constexpr int N_HITEMS = (HROWS * kSlots + NT - 1) / NT;
+    constexpr int HALO_BYTES = N_HITEMS * NT * kSlotBytes;       // >= HROWS*128: every thread always writes
+    constexpr int N_WITEMS = (W_BYTES / kSlotBytes) / NT;        // = 8 / WP
+    static_assert((W_BYTES / kSlotBytes) % NT == 0, "weight tile must split evenly");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const halo = smem;
+    char* const wbuf = smem + HALO_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wp = wave / WM;
+    const int px = lane & 15, g = lane >> 4;
+
+    // ---- which tile -------------------------------------------------------------------------
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int nct = a.ncg / WM;
+    const int txi = b % a.tiles_x; b /= a.tiles_x;
+    const int tyi = b % a.tiles_y; b /= a.tiles_y;
+    const int n = b % a.N; b /= a.N;
+    const int ct = b % nct;
+    const int phase = b / nct;
+    const int ty0 = tyi * TH, tx0 = txi * TW;
+    const int Hs = a.Hs, Ws = a.Ws, si = a.si;
+    const int Win = Ws * si;
+    const int pix_bytes = a.nkc * kRowBytes;                      // Cin * sizeof(T)
+    const char* const in_img = (const char*)a.in + (size_t)n * (size_t)(Hs * si) * Win * pix_bytes;
+
+    // ---- halo staging plan: item = (halo row, physical slot); fixed for the whole K loop -----
+    int hoff[N_HITEMS];
+#pragma unroll
+    for (int j = 0; j < N_HITEMS; ++j) {
+        const int item = tid + j * NT;
+        const int hr = item >> 3, sig = item & 7;
+        const int hy = hr / HWP, hx = hr - hy * HWP;
+        const int sy = ty0 - HALO + hy, sx = tx0 - HALO + hx;
+        const bool inside = (unsigned)sy < (unsigned)Hs && (unsigned)sx < (unsigned)Ws;
+        const int s = sig ^ swz(hr);                              // logical slot stored at `sig`
+        // rows past the tile (item >= HROWS*8) land in the padding of the LDS halo area: store zeros
+        hoff[j] = (inside && item < HROWS * kSlots) ? ((sy * si) * Win + sx * si) * pix_bytes + s * kSlotBytes : -1;
+    }
+
+    // ---- weight tile source ------------------------------------------------------------------
+    const char* const wbase = (const char*)a.wgt + (size_t)(ct * WM) * kWBlockBytes + (size_t)tid * kSlotBytes;
+    const size_t w_kc_stride = (size_t)a.ncg * kWBlockBytes;      // next cin chunk
+    const size_t w_tap_stride = w_kc_stride * a.nkc;              // next tap
+    const int* const tap_dy = a.dy + phase * 9;
+    const int* const tap_dx = a.dx + phase * 9;
+    const int* const tap_tw = a.tw + phase * 9;
+    const int ntaps = a.ntaps, nkc = a.nkc;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 wreg[N_WITEMS];
+    {
+        const char* src = wbase + (size_t)tap_tw[0] * w_tap_stride;
+#pragma unroll
+        for (int j = 0; j < N_WITEMS; ++j) wreg[j] = *(const u32x4*)(src + (size_t)j * NT * kSlotBytes);
+    }
+
+    const int wrow_byte = (wm * 64 + px) * kRowBytes;             // + ci*16 rows
+    const int wsw = px & 7;                                       // swz of rows wm*64+ci*16+px
+    int cur = 0;
+
+    // Halo rows of chunk 0 go to registers now; chunk kc+1 is fetched under the last tap of chunk kc
+    // (issue-early / write-late), so HBM/L2 latency hides behind 32 MFMAs per wave.
+    u32x4 hreg[N_HITEMS];
+    auto load_halo = [&](int kc) {
+#pragma unroll
+        for (int j = 0; j < N_HITEMS; ++j) {
+            const int off = hoff[j];
+            const u32x4 v = *(const u32x4*)(in_img + (off >= 0 ? off : 0) + kc * kRowBytes);
+            hreg[j] = off >= 0 ? v : u32x4{0u, 0u, 0u, 0u};      // zero padding / rows past the tile
+        }
+    };
+    load_halo(0);
+
+    for (int kc = 0; kc < nkc; ++kc) {
+        __syncthreads();                       // every wave is done reading the previous halo
+#pragma unroll
+        for (int j = 0; j < N_HITEMS; ++j) *(u32x4*)(halo + (tid + j * NT) * kSlotBytes) = hreg[j];
+        for (int t = 0; t < ntaps; ++t) {
+            char* const wcur = wbuf + cur * W_BYTES;
+#pragma unroll
+            for (int j = 0; j < N_WITEMS; ++j)
+                *(u32x4*)(wcur + (tid + j * NT) * kSlotBytes) = wreg[j];
+            __syncthreads();
+            // prefetch the next (tap, chunk) weight tile; it lands in registers under the MFMAs
+            {
+                int t2 = t + 1, kc2 = kc;
+                if (t2 == ntaps) { t2 = 0; kc2 = kc + 1; }
+                if (kc2 == nkc) { t2 = t; kc2 = kc; }     // last step: harmless reload, keeps the loop branch-free
+                const char* src = wbase + (size_t)tap_tw[t2] * w_tap_stride + (size_t)kc2 * w_kc_stride;
+#pragma unroll
+                for (int j = 0; j < N_WITEMS; ++j)
+                    wreg[j] = *(const u32x4*)(src + (size_t)j * NT * kSlotBytes);
+            }
+            if (t == ntaps - 1 && kc + 1 < nkc) load_halo(kc + 1);
+            // keep the prefetch loads ABOVE the MFMA cluster (hipcc otherwise sinks them below it to
+            // save registers, which exposes the L2 latency at the next ds_write)
+            __builtin_amdgcn_sched_barrier(0);
+            const int dy = tap_dy[t], dx = tap_dx[t];
+            int xrow[4];
+#pragma unroll
+            for (int pj = 0; pj < 4; ++pj)
+                xrow[pj] = (wp * 4 + pj + HALO + dy) * HWP + (px + HALO + dx);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int slot = ks * 4 + g;
+                u32x4 wf[4], xf[4];
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci)
+                    wf[ci] = *(const u32x4*)(wcur + wrow_byte + ci * 16 * kRowBytes + ((slot ^ wsw) * kSlotBytes));
+#pragma unroll
+                for (int pj = 0; pj < 4; ++pj)
+                    xf[pj] = *(const u32x4*)(halo + xrow[pj] * kRowBytes + ((slot ^ swz(xrow[pj])) * kSlotBytes));
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+                    for (int pj = 0; pj < 4; ++pj) Mma<T>::run(acc[ci][pj], wf[ci], xf[pj]);
+            }
+            cur ^= 1;
+        }
+    }
+
+    // ---- epilogue: lane owns couts co0..co0+15 of pixel px in each of its 4 rows ----------------
+    const int CoutPad = a.ncg * kCoutGroup;
+    const int co0 = (ct * WM + wm) * kCoutGroup + g * 16;
+    float bias[16], bsc[16], bsh[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = *(const float4*)(a.bias + co0 + q * 4);
+        bias[q * 4 + 0] = v.x; bias[q * 4 + 1] = v.y; bias[q * 4 + 2] = v.z; bias[q * 4 + 3] = v.w;
+    }
+    const bool has_bn = a.bn_scale != nullptr;
+    if (has_bn) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 s4 = *(const float4*)(a.bn_scale + co0 + q * 4);
+            const float4 h4 = *(const float4*)(a.bn_shift + co0 + q * 4);
+            bsc[q * 4 + 0] = s4.x; bsc[q * 4 + 1] = s4.y; bsc[q * 4 + 2] = s4.z; bsc[q * 4 + 3] = s4.w;
+            bsh[q * 4 + 0] = h4.x; bsh[q * 4 + 1] = h4.y; bsh[q * 4 + 2] = h4.z; bsh[q * 4 + 3] = h4.w;
+        }
+    }
+    const int so = a.so, Wout = Ws * so, Hout = Hs * so;
+    const int ro = a.ro[phase], cof = a.co[phase];
+    const int act = a.act;
+#pragma unroll
+    for (int pj = 0; pj < 4; ++pj) {
+        const int sy = ty0 + wp * 4 + pj, sx = tx0 + px;
+        if (sy < Hs && sx < Ws) {
+            const size_t opix = ((size_t)n * Hout + (sy * so + ro)) * Wout + (sx * so + cof);
+            const size_t oidx = opix * CoutPad + co0;
+            float v[16];
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[ci * 4 + r] = acc[ci][pj][r] + bias[ci * 4 + r];
+            if (a.resid != nullptr) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 rv = *(const float4*)(a.resid + oidx + q * 4);
+                    v[q * 4 + 0] += rv.x; v[q * 4 + 1] += rv.y; v[q * 4 + 2] += rv.z; v[q * 4 + 3] += rv.w;
+                }
+            }
+            if (act == 1) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
+            } else if (act == 2) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = v[i] > 0.f ? v[i] : 0.2f * v[i];
+            }
+            if (has_bn) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = fmaf(v[i], bsc[i], bsh[i]);
+            }
+            if (a.out_f32 || sizeof(T) == 4) {
+                float* o = (float*)a.out + oidx;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *(float4*)(o + q * 4) = float4{v[q * 4 + 0], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]};
+            } else {
+                unsigned short* o = (unsigned short*)a.out + oidx;
+                uint4 p0, p1;
+                p0.x = pack_bf16x2(v[0], v[1]);   p0.y = pack_bf16x2(v[2], v[3]);
+                p0.z = pack_bf16x2(v[4], v[5]);   p0.w = pack_bf16x2(v[6], v[7]);
+                p1.x = pack_bf16x2(v[8], v[9]);   p1.y = pack_bf16x2(v[10], v[11]);
+                p1.z = pack_bf16x2(v[12], v[13]); p1.w = pack_bf16x2(v[14], v[15]);
+                *(uint4*)(o) = p0;
+                *(uint4*)(o + 8) = p1;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+static constexpr size_t conv_lds_bytes_c(int wm, int wp, int halo) {
+    const int nt = wm * wp * 64;
+    const int hrows = (16 + 2 * halo) * (4 * wp + 2 * halo);
+    const int items = (hrows * kSlots + nt - 1) / nt;
+    return (size_t)items * nt * kSlotBytes + 2 * (size_t)(64 * wm) * kRowBytes;
+}
+
+template <typename T, int WM, int WP, int HALO>
+static hipError_t launch_conv_t(const ConvArgs& a, hipStream_t s) {
+    constexpr int NT = WM * WP * 64;
+    constexpr size_t lds = conv_lds_bytes_c(WM, WP, HALO);
+    const int nct = a.ncg / WM;
+    const long long blocks = (long long)a.tiles_x * a.tiles_y * a.N * nct * a.nphase;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((conv_igemm<T, WM, WP, HALO>), dim3((unsigned)blocks), dim3(NT), lds, s, a);
+    return hipGetLastError();
+}
+
+template <typename T, int WM, int WP, int HALO>
+static hipError_t set_lds_attr() {
+    constexpr size_t lds = conv_lds_bytes_c(WM, WP, HALO);
+    return hipFuncSetAttribute((const void*)conv_igemm<T, WM, WP, HALO>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+size_t conv_lds_bytes(ConvConfig cfg, int halo) { return conv_lds_bytes_c(cfg.wm, cfg.wp, halo); }
+
+#define IDC_FOR_EACH_CONV(X)                                                             \
+    X(2, 2, 0) X(2, 2, 1) X(2, 2, 2) X(1, 4, 0) X(1, 4, 1) X(1, 4, 2) X(2, 4, 0) X(2, 4, 1) \
+    X(2, 4, 2) X(1, 2, 0) X(1, 2, 1) X(1, 2, 2) X(1, 1, 0) X(1, 1, 1) X(1, 1, 2)
+
+hipError_t init_kernels() {
+    hipError_t e;
+#define X(WM, WP, HL)                                              \
+    e = set_lds_attr<float, WM, WP, HL>();  if (e != hipSuccess) return e; \
+    e = set_lds_attr<__bf16, WM, WP, HL>(); if (e != hipSuccess) return e;
+    IDC_FOR_EACH_CONV(X)
+#undef X
+    return hipSuccess;
+}
+
+hipError_t launch_conv(int precision, ConvConfig cfg, int halo, const ConvArgs& a, hipStream_t s) {
+#define X(WM, WP, HL)                                                                   \
+    if (cfg.wm == WM && cfg.wp == WP && halo == HL)                                     \
+        return precision == 1 ? launch_conv_t<__bf16, WM, WP, HL>(a, s) : launch_conv_t<float, WM, WP, HL>(a, s);
+    IDC_FOR_EACH_CONV(X)
+#undef X
+    return hipErrorInvalidConfiguration;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pack_input: models/pytorch/model.py:139-148 (cast, mask - maskcent, cat(L/100, ab/110, mask))
+// fused with the im2col of conv1_1 so that the 4->64 conv is a K=64 GEMM on the MFMA.
+// One thread = one (pixel, 16-byte/32-byte slot of 8 channels = taps 2q, 2q+1).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ L, const float* __restrict__ ab,
+                                                         const float* __restrict__ mask, T* __restrict__ out,
+                                                         int N, int H, int W, float l_div, float ab_div,
+                                                         float mask_mul, float maskcent) {
+    const long long total = (long long)N * H * W * 8;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(i & 7);
+        const long long pix = i >> 3;
+        const int x = (int)(pix % W);
+        const int y = (int)((pix / W) % H);
+        const int n = (int)(pix / ((long long)W * H));
+        float v[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int tap = q * 2 + h;
+            float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+            if (tap < 9) {
+                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+                    const size_t p = (size_t)yy * W + xx;
+                    const size_t hw = (size_t)H * W;
+                    c0 = L[(size_t)n * hw + p] / l_div;
+                    c1 = ab[((size_t)n * 2 + 0) * hw + p] / ab_div;
+                    c2 = ab[((size_t)n * 2 + 1) * hw + p] / ab_div;
+                    c3 = mask[(size_t)n * hw + p] * mask_mul - maskcent;
+                }
+            }
+            v[h * 4 + 0] = c0; v[h * 4 + 1] = c1; v[h * 4 + 2] = c2; v[h * 4 + 3] = c3;
+        }
+        if (sizeof(T) == 4) {
+            float4* o = (float4*)((float*)out + pix * 64 + q * 8);
+            o[0] = float4{v[0], v[1], v[2], v[3]};
+            o[1] = float4{v[4], v[5], v[6], v[7]};
+        } else {
+            uint4 p;
+            p.x = pack_bf16x2(v[0], v[1]); p.y = pack_bf16x2(v[2], v[3]);
+            p.z = pack_bf16x2(v[4], v[5]); p.w = pack_bf16x2(v[6], v[7]);
+            *(uint4*)((unsigned short*)out + pix * 64 + q * 8) = p;
+        }
+    }
+}
+
+hipError_t launch_pack_input(int precision, const float* L, const float* ab, const float* mask, void* out,
+                             int N, int H, int W, float l_div, float ab_div, float mask_mul, float maskcent,
+                             hipStream_t s) {
+    const long long total = (long long)N * H * W * 8;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (precision == 1)
+        hipLaunchKernelGGL(pack_input_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, L, ab, mask, (__bf16*)out, N, H, W,
+                           l_div, ab_div, mask_mul, maskcent);
+    else
+        hipLaunchKernelGGL(pack_input_kernel<float>, dim3(blocks), dim3(256), 0, s, L, ab, mask, (float*)out, N, H, W,
+                           l_div, ab_div, mask_mul, maskcent);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// head: model_out = Conv1x1(128->2) -> Tanh, then *110 (model.py:108-109,174-175).
+// 16 lanes per pixel, 8 channels each, xor-shuffle reduction inside the 16-lane group.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void head_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                   const float* __restrict__ b, float* __restrict__ out,
+                                                   long long npix, int HW, float out_mul) {
+    const int sub = threadIdx.x & 15;
+    float w0[8], w1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { w0[i] = w[sub * 8 + i]; w1[i] = w[128 + sub * 8 + i]; }
+    const float b0 = b[0], b1 = b[1];
+    const long long stride = (long long)gridDim.x * (blockDim.x >> 4);
+    for (long long p = (long long)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4); p < npix; p += stride) {
+        float xv[8];
+        if (sizeof(T) == 4) {
+            const float4* xp = (const float4*)((const float*)x + p * 128 + sub * 8);
+            const float4 a0 = xp[0], a1 = xp[1];
+            xv[0] = a0.x; xv[1] = a0.y; xv[2] = a0.z; xv[3] = a0.w;
+            xv[4] = a1.x; xv[5] = a1.y; xv[6] = a1.z; xv[7] = a1.w;
+        } else {
+            const uint4 u = *(const uint4*)((const unsigned short*)x + p * 128 + sub * 8);
+            const unsigned uu[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xv[2 * i] = __uint_as_float(uu[i] << 16);
+                xv[2 * i + 1] = __uint_as_float(uu[i] & 0xffff0000u);
+            }
+        }
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s0 = fmaf(xv[i], w0[i], s0); s1 = fmaf(xv[i], w1[i], s1); }
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) {
+            s0 += __shfl_xor(s0, m, 16);
+            s1 += __shfl_xor(s1, m, 16);
+        }
+        if (sub == 0) {
+            const long long n = p / HW, r = p - n * HW;
+            out[(n * 2 + 0) * HW + r] = tanhf(s0 + b0) * out_mul;
+            out[(n * 2 + 1) * HW + r] = tanhf(s1 + b1) * out_mul;
+        }
+    }
+}
+
+hipError_t launch_head(int precision, const void* x, const float* w, const float* b, float* out, int N, int H, int W,
+                       float out_mul, hipStream_t s) {
+    const long long npix = (long long)N * H * W;
+    const long long want = (npix + 15) / 16;
+    const int blocks = (int)(want < 8192 ? want : 8192);
+    if (precision == 1)
+        hipLaunchKernelGGL(head_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, (const __bf16*)x, w, b, out, npix, H * W, out_mul);
+    else
+        hipLaunchKernelGGL(head_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, w, b, out, npix, H * W, out_mul);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// softmax over channels (model.py:160: softmax(model_class(conv8_3) * .2)), one wave per pixel,
+// 64-lane shuffle reductions; writes NCHW.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_nchw_kernel(const float* __restrict__ logits, float* __restrict__ out,
+                                                           long long npix, int HW, int nclass, int cstride,
+                                                           float temperature) {
+    const int lane = threadIdx.x & 63;
+    const long long stride = (long long)gridDim.x * (blockDim.x >> 6);
+    for (long long p = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); p < npix; p += stride) {
+        const float* row = logits + p * cstride;
+        float v[16];
+        float m = -3.0e38f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = lane + i * 64;
+            v[i] = c < nclass ? row[c] * temperature : -3.0e38f;
+            m = fmaxf(m, v[i]);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = lane + i * 64;
+            v[i] = c < nclass ? expf(v[i] - m) : 0.f;
+            sum += v[i];
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        const float inv = 1.0f / sum;
+        const long long n = p / HW, r = p - n * HW;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = lane + i * 64;
+            if (c < nclass) out[(n * nclass + c) * HW + r] = v[i] * inv;
+        }
+    }
+}
+
+hipError_t launch_softmax_nchw(const float* logits, float* out, int N, int H, int W, int nclass, int cstride,
+                               float temperature, hipStream_t s) {
+    if (nclass > 1024) return hipErrorInvalidValue;
+    const long long npix = (long long)N * H * W;
+    const long long want = (npix + 3) / 4;
+    const int blocks = (int)(want < 8192 ? want : 8192);
+    hipLaunchKernelGGL(softmax_nchw_kernel, dim3(blocks), dim3(256), 0, s, logits, out, npix, H * W, nclass, cstride,
+                       temperature);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout converters (test entry points / activation dumps only -- not on the hot path)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int N, int C, int H, int W,
+                                    int Cpad) {
+    const long long total = (long long)N * H * W * Cpad;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cpad);
+        const long long pix = i / Cpad;
+        const long long hw = (long long)H * W;
+        const long long n = pix / hw, r = pix - n * hw;
+        const float v = c < C ? src[(n * C + c) * hw + r] : 0.f;
+        if (sizeof(T) == 4) ((float*)dst)[i] = v;
+        else ((__bf16*)dst)[i] = (__bf16)v;
+    }
+}
+
+__global__ void nhwc_to_nchw_kernel(const void* __restrict__ src, float* __restrict__ dst, int N, int C, int H, int W,
+                                    int Cstride, int src_is_bf16) {
+    const long long total = (long long)N * C * H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long hw = (long long)H * W;
+        const long long r = i % hw;
+        const int c = (int)((i / hw) % C);
+        const long long n = i / (hw * C);
+        const long long sidx = (n * hw + r) * Cstride + c;
+        float v;
+        if (src_is_bf16) v = __uint_as_float((unsigned)((const unsigned short*)src)[sidx] << 16);
+        else v = ((const float*)src)[sidx];
+        dst[i] = v;
+    }
+}
+
+hipError_t launch_nchw_to_nhwc(int precision, const float* src, void* dst, int N, int C, int H, int W, int Cpad,
+                               hipStream_t s) {
+    const long long total = (long long)N * H * W * Cpad;
+    const int blocks = (int)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
+    if (precision == 1)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, src, (__bf16*)dst, N, C, H, W, Cpad);
+    else
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(blocks), dim3(256), 0, s, src, (float*)dst, N, C, H, W, Cpad);
+    return hipGetLastError();
+}
+
+hipError_t launch_nhwc_to_nchw(int src_is_bf16, const void* src, float* dst, int N, int C, int H, int W, int Cstride,
+                               hipStream_t s) {
+    const long long total = (long long)N * C * H * W;
+    const int blocks = (int)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(blocks), dim3(256), 0, s, src, dst, N, C, H, W, Cstride, src_is_bf16);
+    return hipGetLastError();
+}
+
+}  // namespace idc

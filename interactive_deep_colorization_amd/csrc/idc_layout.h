@@ -1,0 +1,52 @@
+// idc_layout.h -- data layout shared by the host-side weight packer and the gfx950 kernels.
+//
+// Everything on the hot path moves in 16-byte slots and 128-byte rows:
+//   * activations are NHWC; one pixel's channels are cut into 128-byte chunks
+//     (64 bf16 or 32 fp32 channels = "KC" channels), i.e. one chunk of one pixel = one row;
+//   * weights are packed per layer as [tap][cin-chunk][cout-group of 64][row 0..63][slot 0..7]:
+//     one 8 KiB block is the exact LDS image a workgroup needs for (tap, chunk, 64 couts), so
+//     staging it is a straight coalesced copy;
+//   * inside a row the eight 16-byte slots are XOR-swizzled by swz(row) = row&7, so that the
+//     16 consecutive rows one MFMA operand fragment touches land on 16 different 16-byte bank
+//     groups of the 256-byte LDS bank row (conflict-free ds_read_b128);
+//   * the 64 rows of a cout group are permuted (cg_row_to_cout) so that after the MFMA each lane
+//     owns 16 CONSECUTIVE output channels of one pixel -> 32-byte (bf16) / 64-byte (fp32) stores
+//     and one full 128-byte line per pixel per wave.
+#pragma once
+#include <stdint.h>
+
+namespace idc {
+
+constexpr int kRowBytes = 128;
+constexpr int kSlotBytes = 16;
+constexpr int kSlots = 8;
+constexpr int kCoutGroup = 64;                               // MFMA rows owned by one wave
+constexpr int kWBlockBytes = kCoutGroup * kRowBytes;         // 8192
+constexpr int kMaxTaps = 9;
+constexpr int kMaxPhases = 4;
+
+// swizzle: physical slot = logical slot ^ swz(row)
+__host__ __device__ inline int swz(int row) { return row & 7; }
+
+// Row `lam` (0..63) of a cout-group block holds this output channel (relative to the group):
+// fragment ci = lam>>4 (MFMA row block), r = lam&15 (MFMA row).  D-layout of the 16x16 MFMA puts
+// row r = 4*g + reg in lane group g, register reg; choosing cout = g*16 + ci*4 + reg makes the
+// 16 accumulators (ci, reg) of a lane consecutive channels.
+__host__ __device__ inline int cg_row_to_cout(int lam) {
+    const int ci = lam >> 4, r = lam & 15;
+    return (r >> 2) * 16 + ci * 4 + (r & 3);
+}
+
+inline int elem_bytes(int precision) { return precision == 1 ? 2 : 4; }       // IDC_BF16 == 1
+inline int kc_elems(int precision) { return kRowBytes / elem_bytes(precision); }  // 64 or 32
+
+// fp32 -> bf16, round to nearest even (matches v_cvt_pk_bf16_f32 for finite values)
+inline uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u;
+    __builtin_memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+}  // namespace idc

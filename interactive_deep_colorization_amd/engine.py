@@ -1,0 +1,222 @@
+"""HipColorizer -- thin Python owner of one ``idc_handle`` (one GPU, one stream).
+
+Stands where ``SIGGRAPHGenerator`` (``models/pytorch/model.py:5-175``) stands in
+the reference: ``forward(L_mc, ab, mask, maskcent)`` returns the raw ab map the
+reference returns at ``data/colorize_image.py:263``.  All arithmetic happens in
+the HIP library behind the C ABI (``include/ideepcolor.h``); this file only
+marshals numpy arrays and weight dictionaries.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _native as N
+
+_PREC = {"fp32": N.IDC_FP32, "f32": N.IDC_FP32, "float32": N.IDC_FP32, 0: N.IDC_FP32,
+         "bf16": N.IDC_BF16, "bfloat16": N.IDC_BF16, 1: N.IDC_BF16}
+
+
+def _fptr(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def _f32c(a, shape=None):
+    """float32, C-contiguous view/copy (bool masks and f64 GUI arrays accepted)."""
+    out = np.ascontiguousarray(np.asarray(a), dtype=np.float32)
+    if shape is not None and tuple(out.shape) != tuple(shape):
+        raise ValueError("expected shape %s, got %s" % (tuple(shape), out.shape))
+    return out
+
+
+def state_dict_to_numpy(sd):
+    """Accept a torch ``state_dict`` (tensors) or a dict of arrays; return {name: f32 ndarray}."""
+    out = {}
+    for k, v in sd.items():
+        if k.endswith("num_batches_tracked"):
+            continue
+        if hasattr(v, "detach"):
+            v = v.detach().cpu().numpy()
+        out[k] = np.ascontiguousarray(np.asarray(v), dtype=np.float32)
+    return out
+
+
+def _tensor_descs(sd):
+    sd = state_dict_to_numpy(sd)
+    names = sorted(sd)
+    arr = (N.TensorDesc * len(names))()
+    keep = []
+    for i, k in enumerate(names):
+        a = sd[k]
+        if a.ndim > 4:
+            raise ValueError("tensor %s has %d dims" % (k, a.ndim))
+        kb = k.encode()
+        keep.append((kb, a))
+        arr[i].name = kb
+        arr[i].data = _fptr(a)
+        arr[i].ndim = a.ndim
+        for d in range(a.ndim):
+            arr[i].dims[d] = a.shape[d]
+    return arr, len(names), keep
+
+
+def pack_weights(sd, precision="bf16", dist=False):
+    """Host-only: reference ``state_dict`` -> packed device-ready blob (uint8 ndarray).
+    Needs no GPU (used by rank 0 before the RCCL broadcast)."""
+    lib = N.load()
+    prec = _PREC[precision]
+    flags = N.IDC_FLAG_DIST_HEAD if dist else 0
+    nbytes = lib.idc_weights_blob_bytes(prec, flags)
+    blob = np.zeros(nbytes, dtype=np.uint8)
+    arr, n, keep = _tensor_descs(sd)
+    N.check(lib.idc_pack_weights(prec, flags, arr, n, blob.ctypes.data_as(ctypes.c_void_p), nbytes))
+    del keep
+    return blob
+
+
+class HipColorizer(object):
+    def __init__(self, H=256, W=None, max_batch=1, precision="bf16", device=0, dist=False):
+        self.lib = N.load()
+        self.H, self.W = int(H), int(H if W is None else W)
+        self.max_batch = int(max_batch)
+        self.precision = precision
+        self._prec = _PREC[precision]
+        self.dist = bool(dist)
+        self.device = int(device)
+        self._flags = N.IDC_FLAG_DIST_HEAD if dist else 0
+        self._h = ctypes.c_void_p()
+        N.check(self.lib.idc_create(self.device, self.H, self.W, self.max_batch, self._prec, self._flags,
+                                    ctypes.byref(self._h)))
+        self._blob_keepalive = None
+
+    # ---- lifetime -------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.idc_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, status):
+        return N.check(status, self._h)
+
+    # ---- weights --------------------------------------------------------------------------
+    def load_state_dict(self, sd):
+        arr, n, keep = _tensor_descs(sd)
+        self._chk(self.lib.idc_load_weights(self._h, arr, n))
+        del keep
+
+    def blob_bytes(self):
+        return int(self.lib.idc_weights_blob_bytes(self._prec, self._flags))
+
+    def set_weights_blob(self, blob):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        self._chk(self.lib.idc_set_weights_host(self._h, blob.ctypes.data_as(ctypes.c_void_p), blob.size))
+
+    def set_weights_device(self, dev_ptr, nbytes, copy=False, keepalive=None):
+        """Adopt (or copy) a packed blob already in device memory, e.g. the torch uint8 tensor that
+        received the RCCL broadcast; ``keepalive`` is held so the memory outlives the handle."""
+        self._chk(self.lib.idc_set_weights_device(self._h, ctypes.c_void_p(int(dev_ptr)), int(nbytes), 1 if copy else 0))
+        self._blob_keepalive = None if copy else keepalive
+
+    def set_io_scales(self, l_div=100., ab_div=110., mask_mul=1., out_mul=110.):
+        self._chk(self.lib.idc_set_io_scales(self._h, l_div, ab_div, mask_mul, out_mul))
+
+    # ---- forward --------------------------------------------------------------------------
+    def _prep(self, L_mc, ab, mask):
+        L_mc = np.asarray(L_mc)
+        if L_mc.ndim == 3:                      # reference call shape: (1,X,X),(2,X,X),(1,X,X)
+            L_mc, ab, mask = L_mc[None], np.asarray(ab)[None], np.asarray(mask)[None]
+        n = L_mc.shape[0]
+        L = _f32c(L_mc, (n, 1, self.H, self.W))
+        A = _f32c(ab, (n, 2, self.H, self.W))
+        M = _f32c(mask, (n, 1, self.H, self.W))
+        return n, L, A, M
+
+    def forward(self, L_mc, ab, mask, maskcent=0.0):
+        """(N,1,H,W),(N,2,H,W),(N,1,H,W) -> (N,2,H,W) float32 ab.  3-D inputs = one image."""
+        n, L, A, M = self._prep(L_mc, ab, mask)
+        out = np.empty((n, 2, self.H, self.W), np.float32)
+        self._chk(self.lib.idc_forward(self._h, n, _fptr(L), _fptr(A), _fptr(M), float(maskcent), _fptr(out)))
+        return out
+
+    def forward_dist(self, L_mc, ab, mask, maskcent=0.0):
+        """Also returns the 529-bin distribution at quarter resolution (N,529,H/4,W/4)."""
+        n, L, A, M = self._prep(L_mc, ab, mask)
+        out = np.empty((n, 2, self.H, self.W), np.float32)
+        dq = np.empty((n, 529, self.H // 4, self.W // 4), np.float32)
+        self._chk(self.lib.idc_forward_dist(self._h, n, _fptr(L), _fptr(A), _fptr(M), float(maskcent),
+                                            _fptr(out), _fptr(dq)))
+        return out, dq
+
+    def forward_device(self, n, d_L, d_ab, d_mask, d_out, maskcent=0.0, sync=False):
+        """Device-pointer form (ints / objects with ``data_ptr()``); enqueued on the handle stream."""
+        def p(x):
+            return ctypes.c_void_p(int(x.data_ptr()) if hasattr(x, "data_ptr") else int(x))
+        self._chk(self.lib.idc_forward_device(self._h, int(n), p(d_L), p(d_ab), p(d_mask), float(maskcent),
+                                              p(d_out), 1 if sync else 0))
+
+    def sync(self):
+        self._chk(self.lib.idc_sync(self._h))
+
+    @property
+    def stream(self):
+        return self.lib.idc_stream(self._h)
+
+    # ---- introspection ----------------------------------------------------------------------
+    def layer_table(self):
+        rows = []
+        for i in range(self.lib.idc_num_layers(self._h)):
+            info = N.LayerInfo()
+            self._chk(self.lib.idc_layer_info_get(self._h, i, ctypes.byref(info)))
+            rows.append(dict(index=i, name=info.name.decode(), kernel=info.kernel.decode(), flops=info.flops,
+                             min_bytes=info.min_bytes, launches=info.launches))
+        return rows
+
+    def set_profiling(self, on):
+        self._chk(self.lib.idc_set_profiling(self._h, 1 if on else 0))
+
+    def layer_times_ms(self):
+        n = self.lib.idc_num_layers(self._h)
+        ms = np.zeros(n, np.float32)
+        self._chk(self.lib.idc_layer_times_ms(self._h, _fptr(ms), n))
+        return ms
+
+    def activation(self, name, n=1):
+        """NCHW fp32 copy of an intermediate tensor of the last forward (parity tests)."""
+        cap = int(n) * 640 * self.H * self.W
+        buf = np.empty(cap, np.float32)
+        C, H, W = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        self._chk(self.lib.idc_get_activation(self._h, name.encode(), int(n), _fptr(buf), cap,
+                                              ctypes.byref(C), ctypes.byref(H), ctypes.byref(W)))
+        return buf[: n * C.value * H.value * W.value].reshape(n, C.value, H.value, W.value).copy()
+
+
+# ---- single operators through the same kernels (used by the parity tests) ---------------------
+def op_conv2d(x, weight, bias, dilation=1, in_stride=1, act=0, bn_scale=None, bn_shift=None, resid=None,
+              precision="fp32", device=0):
+    lib = N.load()
+    x = _f32c(x); weight = _f32c(weight); bias = _f32c(bias)
+    n, cin, h, w = x.shape
+    cout, ksize = weight.shape[0], weight.shape[2]
+    y = np.empty((n, cout, h // in_stride, w // in_stride), np.float32)
+    opt = lambda a: _fptr(_f32c(a)) if a is not None else None
+    keep = [opt(bn_scale), opt(bn_shift), opt(resid)]
+    N.check(lib.idc_op_conv2d(device, _PREC[precision], n, cin, h, w, _fptr(x), cout, ksize, dilation, in_stride,
+                              _fptr(weight), _fptr(bias), act, keep[0], keep[1], keep[2], _fptr(y)))
+    return y
+
+
+def op_deconv4x4s2(x, weight, bias, act=0, resid=None, precision="fp32", device=0):
+    lib = N.load()
+    x = _f32c(x); weight = _f32c(weight); bias = _f32c(bias)
+    n, cin, h, w = x.shape
+    cout = weight.shape[1]
+    y = np.empty((n, cout, 2 * h, 2 * w), np.float32)
+    r = _f32c(resid) if resid is not None else None
+    N.check(lib.idc_op_deconv4x4s2(device, _PREC[precision], n, cin, h, w, _fptr(x), cout, _fptr(weight),
+                                   _fptr(bias), act, _fptr(r) if r is not None else None, _fptr(y)))
+    return y

@@ -1,0 +1,130 @@
+"""Batched path across the GPUs of one node: one process per GPU, independent images.
+
+The reference has no multi-device code at all; the path shards trivially because
+eval-mode BatchNorm uses fixed statistics (``data/colorize_image.py:232``) and no op mixes images.
+So:
+
+* images are split into contiguous shards, one per rank -- no data-path collective;
+* the ONLY collective is a one-time broadcast of the packed weight blob (68 MB bf16 / 136 MB
+  fp32) from rank 0: RCCL over xGMI when the process group is ``nccl``, ``gloo`` in the CPU tests.
+  Rank 0 packs once on the host; every other rank receives device-ready bytes straight into the
+  memory its engine then adopts (no re-packing, no host copy on the receivers);
+* results stay on the rank that produced them unless ``gather_to_rank0`` is asked for.
+
+torch / torch.distributed are plumbing here (device memory for the blob, the process group);
+the arithmetic is the HIP engine's.
+"""
+import os
+
+import numpy as np
+
+from .workloads import shard_bounds
+
+
+def dist_env():
+    """(rank, local_rank, world_size) from the torchrun environment (1-process defaults)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_process_group(backend=None):
+    """Join the job's process group (idempotent).  ``nccl`` (= RCCL on ROCm) when a GPU is visible,
+    else ``gloo``.  Rendezvous comes from MASTER_ADDR/MASTER_PORT (use 127.0.0.1 on one node)."""
+    import torch
+    import torch.distributed as dist
+    rank, local_rank, world = dist_env()
+    if world == 1 and not dist.is_initialized():
+        return rank, local_rank, world
+    if not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+class ShardedColorizer(object):
+    """Per-rank engine + shard bookkeeping.
+
+    ``engine`` is a :class:`~interactive_deep_colorization_amd.engine.HipColorizer` in production.
+    The CPU (gloo) tests inject a stand-in with the same four methods (``blob_bytes``,
+    ``set_weights_blob``, ``set_weights_device``, ``forward``) to exercise the sharding and the
+    broadcast without a GPU; nothing in this module computes anything itself.
+    """
+
+    def __init__(self, engine, rank=None, world_size=None):
+        env_rank, _, env_world = dist_env()
+        self.engine = engine
+        self.rank = env_rank if rank is None else int(rank)
+        self.world_size = env_world if world_size is None else int(world_size)
+        self.weights_broadcast_ms = None
+
+    # ---- the one collective -------------------------------------------------------------------
+    def broadcast_weights(self, packed_blob=None, src=0):
+        """Rank ``src`` passes the packed blob (uint8 ndarray from ``engine.pack_weights``); the
+        others pass None.  After the call every rank's engine holds the weights."""
+        import time
+
+        import torch
+        import torch.distributed as dist
+        nbytes = int(self.engine.blob_bytes())
+        if self.world_size == 1 or not dist.is_initialized():
+            if packed_blob is None:
+                raise ValueError("single process: the packed blob must be given")
+            self.engine.set_weights_blob(packed_blob)
+            self.weights_broadcast_ms = 0.0
+            return
+        on_gpu = dist.get_backend() == "nccl"
+        if self.rank == src:
+            if packed_blob is None or int(packed_blob.size) != nbytes:
+                raise ValueError("rank %d must provide a %d-byte packed blob" % (src, nbytes))
+            t = torch.from_numpy(np.ascontiguousarray(packed_blob, dtype=np.uint8))
+            if on_gpu:
+                t = t.cuda(non_blocking=False)
+        else:
+            t = torch.empty(nbytes, dtype=torch.uint8, device="cuda" if on_gpu else "cpu")
+        if on_gpu:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dist.broadcast(t, src=src)
+        if on_gpu:
+            torch.cuda.synchronize()
+        self.weights_broadcast_ms = (time.perf_counter() - t0) * 1e3
+        if on_gpu:
+            # adopt the device memory the broadcast landed in; the tensor is kept alive by the engine
+            self.engine.set_weights_device(t.data_ptr(), nbytes, copy=False, keepalive=t)
+        else:
+            self.engine.set_weights_blob(t.numpy())
+
+    # ---- sharding -----------------------------------------------------------------------------
+    def my_bounds(self, n_images):
+        return shard_bounds(n_images, self.world_size, self.rank)
+
+    def forward_shard(self, L_mc, ab, mask, maskcent=0.0, global_batch=True):
+        """Run this rank's images.  With ``global_batch`` the arrays hold the WHOLE batch and the
+        rank slices its contiguous shard; otherwise they are already the local shard.
+        Returns (start, stop, ab_out[stop-start, 2, H, W])."""
+        n = L_mc.shape[0]
+        lo, hi = self.my_bounds(n) if global_batch else (0, n)
+        if hi <= lo:
+            return lo, hi, np.zeros((0, 2) + tuple(L_mc.shape[2:]), np.float32)
+        out = self.engine.forward(L_mc[lo:hi], ab[lo:hi], mask[lo:hi], maskcent)
+        return lo, hi, out
+
+    def gather_to_rank0(self, n_images, lo, hi, local_out):
+        """Optional: collect every shard on rank 0 (host gather; the path itself needs no exchange)."""
+        import torch.distributed as dist
+        if self.world_size == 1 or not dist.is_initialized():
+            return local_out
+        parts = [None] * self.world_size
+        dist.all_gather_object(parts, (lo, hi, local_out if hi > lo else None))
+        if self.rank != 0:
+            return None
+        full = np.zeros((n_images,) + tuple(local_out.shape[1:]), np.float32)
+        for plo, phi, arr in parts:
+            if phi > plo:
+                full[plo:phi] = arr
+        return full

@@ -1,0 +1,198 @@
+"""GPU parity of the whole forward pass through the C ABI (idc_forward) against
+(a) the reference-generated golden vectors in tests/golden/ and (b) the oracle re-run here.
+
+Stated tolerances (max-abs on the ab output, range +-110):
+  fp32 path, torch-default-style weights (|ab| <~ 25):   1e-3   <- the BASELINE.json target
+  fp32 path, he-style weights (full tanh range):          3e-3   = the reference's own fp32 noise floor
+        (its output moves 4.8e-4 between oneDNN blockings at 64x64 -- golden field
+         batched_vs_single_f32 -- and the fp32-vs-fp64 gap is 3.7e-4)
+  bf16 path: max-abs <= 6.0 and mean-abs <= 0.6 (he-style), max-abs <= 0.6 (torch-style)
+Per-layer activations are compared too, so a failure names the first bad layer.
+"""
+import numpy as np
+import pytest
+import torch
+
+from interactive_deep_colorization_amd import api, engine, workloads
+from oracle import siggraph_torch
+
+pytestmark = pytest.mark.gpu
+
+FP32_TOL = {"he": 3e-3, "torch": 1e-3}
+BF16_MAX = {"he": 6.0, "torch": 0.6}
+BF16_MEAN = {"he": 0.6, "torch": 0.06}
+ACT_NAMES = ["conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3", "conv4_1", "conv4_2",
+             "conv4_3", "conv5_1", "conv5_2", "conv5_3", "conv6_1", "conv6_2", "conv6_3", "conv7_1", "conv7_2",
+             "conv7_3", "conv3_3_short", "conv8_1", "conv8_2", "conv8_3", "conv2_2_short", "conv9_1", "conv9_2",
+             "conv1_2_short", "conv10_1", "conv10_2"]
+
+_ENGINES = {}
+
+
+def get_engine(H, W, max_batch, precision, seed, style, dist=False, make_sd=None):
+    key = (H, W, max_batch, precision, seed, style, dist)
+    if key not in _ENGINES:
+        e = engine.HipColorizer(H, W, max_batch=max_batch, precision=precision, dist=dist)
+        e.load_state_dict(make_sd(seed, style))
+        _ENGINES[key] = e
+    return _ENGINES[key]
+
+
+@pytest.mark.parametrize("name", ["net64_he_s0_mc05", "net64_torch_s1_mc0", "net32x48_he_s2"])
+def test_fp32_matches_reference_golden_layer_by_layer(golden, make_sd, name):
+    g = golden(name)
+    style, seed = str(g["weight_style"]), int(g["weight_seed"])
+    n, _, H, W = g["L_mc"].shape
+    e = get_engine(H, W, n, "fp32", seed, style, make_sd=make_sd)
+    out = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
+    _, _, acts = siggraph_torch.forward(make_sd(seed, style), g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]),
+                                        return_acts=True, dtype=torch.float64)
+    for k in ACT_NAMES:                                   # first failing layer is reported
+        got = e.activation(k, n)
+        ref = acts[k]
+        assert got.shape == ref.shape, k
+        err = np.abs(got - ref).max()
+        assert err <= 2e-4 * (1 + np.abs(ref).max()), "layer %s: max-abs err %.3e" % (k, err)
+    err = np.abs(out - g["out_ab"]).max()
+    assert err <= FP32_TOL[style], "fp32 vs reference golden: %.3e > %.1e" % (err, FP32_TOL[style])
+    # both fp32 implementations sit at the same distance from the float64 truth
+    e64_ref = float(g["noise_floor_f32_vs_f64"])
+    e64_hip = np.abs(out - g["out_ab_f64"]).max()
+    assert e64_hip <= 4 * e64_ref + 1e-4, "HIP fp32 is %.2e from fp64, the reference %.2e" % (e64_hip, e64_ref)
+
+
+@pytest.mark.parametrize("name", ["net64_he_s0_mc05", "net64_torch_s1_mc0", "net32x48_he_s2"])
+def test_bf16_within_stated_tolerance(golden, make_sd, name):
+    g = golden(name)
+    style, seed = str(g["weight_style"]), int(g["weight_seed"])
+    n, _, H, W = g["L_mc"].shape
+    e = get_engine(H, W, n, "bf16", seed, style, make_sd=make_sd)
+    out = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
+    d = np.abs(out - g["out_ab"])
+    assert np.isfinite(out).all() and np.abs(out).max() <= 110.0
+    assert d.max() <= BF16_MAX[style] and d.mean() <= BF16_MEAN[style], "bf16: max %.3f mean %.4f" % (d.max(), d.mean())
+
+
+@pytest.mark.parametrize("name,precision", [("config1_mortar_zero_hints", "fp32"), ("config2_mortar_5hints", "fp32"),
+                                            ("config2_mortar_5hints_torchinit", "fp32"),
+                                            ("config2_mortar_5hints", "bf16")])
+def test_baseline_configs_1_and_2(golden, make_sd, name, precision):
+    """BASELINE.json configs[0]/[1]: mortar_pestle.jpg at 256x256, zero hints / 5 hint points."""
+    g = golden(name)
+    style, seed = str(g["weight_style"]), int(g["weight_seed"])
+    e = get_engine(256, 256, 1, precision, seed, style, make_sd=make_sd)
+    out = e.forward(g["L_mc"][0], g["ab"][0], g["mask"][0], float(g["maskcent"]))     # 3-D call shape of the reference
+    d = np.abs(out - g["out_ab"])
+    if precision == "fp32":
+        assert d.max() <= FP32_TOL[style], "max-abs %.3e" % d.max()
+    else:
+        assert d.max() <= BF16_MAX[style] and d.mean() <= BF16_MEAN[style], "bf16: max %.3f mean %.4f" % (d.max(), d.mean())
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_batching_is_exactly_per_image(make_sd, precision):
+    """No op mixes images (eval-BN): a batch equals its images run alone, bit for bit, and a
+    2-way shard of the batch equals the whole batch (the multi-GPU equivalence)."""
+    L, ab, m = workloads.random_batch(5, 64, seed=21)
+    e = get_engine(64, 64, 5, precision, 0, "he", make_sd=make_sd)
+    full = e.forward(L, ab, m, 0.0)
+    for i in (0, 3, 4):
+        np.testing.assert_array_equal(e.forward(L[i:i + 1], ab[i:i + 1], m[i:i + 1], 0.0)[0], full[i])
+    parts = [e.forward(L[lo:hi], ab[lo:hi], m[lo:hi], 0.0) for lo, hi in
+             (workloads.shard_bounds(5, 2, r) for r in range(2))]
+    np.testing.assert_array_equal(np.concatenate(parts), full)
+    np.testing.assert_array_equal(e.forward(L, ab, m, 0.0), full)         # run-to-run deterministic
+    # hints matter, masks accepted as bool (GUI passes bool: ui/gui_draw.py:274-275)
+    out_b = e.forward(L[:1], ab[:1], m[:1].astype(bool), 0.0)
+    np.testing.assert_array_equal(out_b[0], full[0])
+
+
+def test_config3_full_size_properties(make_sd):
+    """BASELINE.json configs[2]: N=32 random 256x256, bf16 -- size-independent properties only
+    (the oracle needs ~10 s per image here): finite, bounded by 110*tanh, deterministic, and
+    image 7 of the batch equals image 7 run alone."""
+    L, ab, m = workloads.random_batch(32, 256, seed=0)
+    e = get_engine(256, 256, 32, "bf16", 0, "he", make_sd=make_sd)
+    out = e.forward(L, ab, m, 0.0)
+    assert out.shape == (32, 2, 256, 256) and np.isfinite(out).all() and np.abs(out).max() <= 110.0
+    assert out.std() > 1.0
+    np.testing.assert_array_equal(e.forward(L[7:8], ab[7:8], m[7:8], 0.0)[0], out[7])
+    np.testing.assert_array_equal(e.forward(L, ab, m, 0.0), out)
+    # one image of the batch against the oracle at the stated bf16 tolerance
+    ref = siggraph_torch.forward(make_sd(0, "he"), L[7:8], ab[7:8], m[7:8], 0.0)
+    d = np.abs(out[7:8] - ref)
+    assert d.max() <= BF16_MAX["he"] and d.mean() <= BF16_MEAN["he"], "bf16 N=32: max %.3f mean %.4f" % (d.max(), d.mean())
+
+
+def test_512_fp32(make_sd):
+    """512x512 input (BASELINE configs[4] geometry, local-hints net): trunk runs at 64x64."""
+    L, ab, m = workloads.random_batch(1, 512, seed=5)
+    e = get_engine(512, 512, 1, "fp32", 1, "torch", make_sd=make_sd)
+    out = e.forward(L, ab, m, 0.5)
+    ref = siggraph_torch.forward(make_sd(1, "torch"), L, ab, m, 0.5)
+    assert np.abs(out - ref).max() <= FP32_TOL["torch"]
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_dist_head(golden, make_sd, precision):
+    g = golden("dist64_he_s0")
+    e = get_engine(64, 64, 1, precision, 0, "he", dist=True, make_sd=make_sd)
+    out, dq = e.forward_dist(g["L_mc"], g["ab"], g["mask"], 0.0)
+    assert dq.shape == (1, 529, 16, 16)
+    np.testing.assert_allclose(dq.sum(axis=1), 1.0, atol=1e-4)
+    tol = 2e-4 if precision == "fp32" else 2e-2
+    assert np.abs(dq - g["class_probs_lowres"]).max() <= tol
+    assert np.abs(out - g["out_ab"]).max() <= (FP32_TOL["he"] if precision == "fp32" else BF16_MAX["he"])
+
+
+def test_errors_through_the_abi(make_sd):
+    from interactive_deep_colorization_amd import _native as N
+    e = engine.HipColorizer(64, 64, max_batch=2, precision="bf16")
+    z = np.zeros((1, 1, 64, 64), np.float32)
+    with pytest.raises(N.IdcError) as ei:                       # "I need to have a net!"
+        e.forward(z, np.zeros((1, 2, 64, 64)), z)
+    assert ei.value.status == -4
+    e.load_state_dict(make_sd(1, "torch"))
+    with pytest.raises(N.IdcError) as ei:
+        e.forward(np.zeros((3, 1, 64, 64)), np.zeros((3, 2, 64, 64)), np.zeros((3, 1, 64, 64)))
+    assert ei.value.status == -6                                # batch > max_batch
+    with pytest.raises(ValueError):
+        e.forward(np.zeros((1, 1, 32, 32)), np.zeros((1, 2, 32, 32)), np.zeros((1, 1, 32, 32)))
+    with pytest.raises(N.IdcError):
+        e.forward_dist(z, np.zeros((1, 2, 64, 64)), z)          # no dist head on this handle
+    e.close()
+
+
+def test_drop_in_api_end_to_end(golden, make_sd):
+    """The reference call sequence (ideepcolor.py:68-72, notebook cells) against the HIP backend."""
+    rgb = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "mortar_pestle_256_rgb.npy"))
+    g = golden("config2_mortar_5hints")
+    model = api.ColorizeImageTorch(Xd=256, maskcent=False, precision="fp32")
+    model.prep_net(path="", state_dict=make_sd(0, "he"))
+    model.set_image(rgb)
+    input_ab, mask = workloads.hints_config2(256, 5, 3, 0)
+    img = model.net_forward(input_ab, mask)
+    assert img.shape == (256, 256, 3) and img.dtype == np.uint8
+    assert np.abs(model.output_ab_raw[None] - g["out_ab"]).max() <= FP32_TOL["he"]
+    assert model.output_ab.shape == (2, 256, 256) and model.input_ab is input_ab
+    assert model.get_img_fullres().shape == (256, 256, 3)
+    assert model.get_result_PSNR() > 5
+    # Caffe i/o convention on the same kernels: raw inputs, x100 head
+    caffe = api.ColorizeImageCaffe(Xd=256, precision="fp32")
+    sd = dict(make_sd(0, "he"))
+    w0 = sd["model1.0.weight"].copy()           # fold the torch input normalisation into conv1_1
+    w0[:, 0] /= 100.0; w0[:, 1:3] /= 110.0; w0[:, 3] /= 110.0
+    sd["model1.0.weight"] = w0
+    caffe.prep_net(0, state_dict=sd)
+    caffe.set_image(rgb)
+    caffe.net_forward(input_ab, mask)
+    np.testing.assert_allclose(caffe.output_ab_raw * 1.1, model.output_ab_raw, atol=5e-3)
+    # distribution model + colour suggestions
+    dist = api.ColorizeImageTorchDist(Xd=256, precision="bf16")
+    dist.prep_net(path="", dist=True, state_dict=make_sd(0, "he"))
+    dist.set_image(rgb)
+    ret = dist.net_forward(input_ab, mask)
+    assert ret.shape == (2, 256, 256) and dist.dist_ab.shape == (529, 256, 256)
+    assert dist.dist_ab_grid.shape == (23, 23, 256, 256)
+    reccs, conf = dist.get_ab_reccs(135, 160, K=3, N=2000, return_conf=True)
+    assert reccs.shape == (3, 2) and abs(conf.sum() - 1) < 1e-6
