@@ -65,19 +65,26 @@ def cpu_baseline(sd, reps=3):
     import torch
     from interactive_deep_colorization_amd import workloads
     from oracle import siggraph_torch
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     L, ab, m = workloads.random_batch(1, H, seed=0)
-    siggraph_torch.forward(sd, L, ab, m, 0.0)                       # warm-up
-    ts = []
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        siggraph_torch.forward(sd, L, ab, m, 0.0)
-        ts.append(time.perf_counter() - t0)
-    p50 = statistics.median(ts)
+    best = None
+    # oneDNN thrashes when oversubscribed (256 threads on one 256x256 image: 22 s), so time a few
+    # thread counts and report the best one, with the thread count actually used
+    for cores in sorted(set(c for c in (8, 16, 32, 64) if c <= ncpu) or {ncpu}):
+        torch.set_num_threads(cores)
+        siggraph_torch.forward(sd, L, ab, m, 0.0)                   # warm-up
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            siggraph_torch.forward(sd, L, ab, m, 0.0)
+            ts.append(time.perf_counter() - t0)
+        p50 = statistics.median(ts)
+        if best is None or p50 < best[0]:
+            best = (p50, cores)
+    p50, cores = best
     return {"value": round(1.0 / p50, 3), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "%d x one 256x256 image (N=1, fp32, torch CPU oracle = the reference's ATen kernels), p50 %.3f s"
-                      % (reps, p50)}
+            "sample": "%d x one 256x256 image (N=1, fp32, torch CPU oracle = the reference's ATen kernels) at the "
+                      "best of 8/16/32/64 threads on a %d-cpu host, p50 %.3f s" % (reps, ncpu, p50)}
 
 
 def measure_latency(sd, device):

@@ -119,11 +119,18 @@ __global__ __launch_bounds__(WM* WP * 64) void conv_igemm(const ConvArgs a) {
     const int* const tap_tw = a.tw + phase * 9;
     const int ntaps = a.ntaps, nkc = a.nkc;
 
-    f32x4 acc[4][4];
+    // fp32 path: the MFMA is an exact sequential fmaf chain, so one accumulator over K = 9*Cin
+    // (up to 4608 terms) would carry ~4x the rounding noise of a blocked sum.  Accumulate each
+    // 128-byte channel chunk (<= 288 terms) separately and add it to the running total.
+    constexpr bool kBlockedAcc = sizeof(T) == 4;
+    f32x4 acc[4][4], tot[kBlockedAcc ? 4 : 1][kBlockedAcc ? 4 : 1];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) {
+            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kBlockedAcc) tot[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 
     u32x4 wreg[N_WITEMS];
     {
@@ -195,6 +202,21 @@ __global__ __launch_bounds__(WM* WP * 64) void conv_igemm(const ConvArgs a) {
             }
             cur ^= 1;
         }
+        if (kBlockedAcc) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    tot[i][j] += acc[i][j];
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+        }
+    }
+    if (kBlockedAcc) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = tot[i][j];
     }
 
     // ---- epilogue: lane owns couts co0..co0+15 of pixel px in each of its 4 rows ----------------
@@ -297,7 +319,8 @@ size_t conv_lds_bytes(ConvConfig cfg, int halo) { return conv_lds_bytes_c(cfg.wm
 
 #define IDC_FOR_EACH_CONV(X)                                                             \
     X(2, 2, 0) X(2, 2, 1) X(2, 2, 2) X(1, 4, 0) X(1, 4, 1) X(1, 4, 2) X(2, 4, 0) X(2, 4, 1) \
-    X(2, 4, 2) X(1, 2, 0) X(1, 2, 1) X(1, 2, 2) X(1, 1, 0) X(1, 1, 1) X(1, 1, 2)
+    X(2, 4, 2) X(1, 2, 0) X(1, 2, 1) X(1, 2, 2) X(1, 1, 0) X(1, 1, 1) X(1, 1, 2) X(2, 1, 0) X(2, 1, 1) \
+    X(2, 1, 2)
 
 hipError_t init_kernels() {
     hipError_t e;

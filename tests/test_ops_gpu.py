@@ -75,7 +75,7 @@ def test_conv_is_transpose_detecting(precision):
     x = np.zeros((1, cin, h, w), np.float32); x[0, 3, 2, 5] = 1.0
     wt = np.zeros((cout, cin, 3, 3), np.float32); wt[7, 3, 0, 2] = 2.0      # only tap (ky=0, kx=2)
     got = engine.op_conv2d(x, wt, np.zeros(cout, np.float32), precision=precision)
-    exp = np.zeros((1, cout, h, w), np.float32); exp[0, 7, 3, 3] = 2.0      # y = 2+1-0, x = 5+1-2
+    exp = np.zeros((1, cout, h, w), np.float32); exp[0, 7, 3, 4] = 2.0      # oy = 2-(0-1), ox = 5-(2-1)
     np.testing.assert_array_equal(got, exp)
 
 
