@@ -7,6 +7,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -277,6 +278,10 @@ static int find_tensor(idc_context* c, const char* name) {
 // launch would not fill the 256 CUs.
 static ConvConfig choose_config(int n, int Hs, int Ws, int coutpad, int nphase) {
     const int wm = coutpad >= 128 ? 2 : 1;
+    if (const char* f = getenv("IDC_FORCE_WP")) {        // tuning experiments only
+        const int wp = atoi(f);
+        if (wp == 1 || wp == 2 || wp == 4) return ConvConfig{wm, wp};
+    }
     const int cand_wp[3] = {wm == 1 ? 4 : 2, 2, 1};
     ConvConfig best{wm, cand_wp[0]};
     for (int i = 0; i < 3; ++i) {

@@ -37,6 +37,10 @@ struct ConvConfig { int wm, wp; };     // waves along cout (x64) and along pixel
 
 // precision: 0 fp32, 1 bf16.  halo: 0,1,2.  Returns hipSuccess or the launch error.
 hipError_t launch_conv(int precision, ConvConfig cfg, int halo, const ConvArgs& a, hipStream_t s);
+// Large-tile bf16 throughput kernel (32x32x16 MFMA, 8 waves, LDS-DMA weights).  cfg = {WCO, WPX}:
+// {4,2} = 256 couts x (32x8 sites), {2,4} = 128 couts x (32x16 sites).  a.wgt must point at the
+// layer's layout-2 weight image (idc_layout.h); tiles_x/tiles_y count 32 x 4*WPX tiles.
+hipError_t launch_conv_v2(ConvConfig cfg, int halo, const ConvArgs& a, hipStream_t s);
 // One-time: raise the dynamic-LDS limit of every conv instantiation.
 hipError_t init_kernels();
 size_t conv_lds_bytes(ConvConfig cfg, int halo);

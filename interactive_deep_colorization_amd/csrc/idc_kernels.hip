@@ -60,6 +60,57 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
     return base + (b >> 3);
 }
 
+
+// Fused epilogue for 16 consecutive output channels of one pixel:
+// y = act(acc + bias [+ resid]) [* bn_scale + bn_shift]  ->  32 B (bf16) or 64 B (fp32) store.
+template <bool OUT_BF16>
+__device__ __forceinline__ void epilogue16(const ConvArgs& a, float (&v)[16], size_t oidx, const float* bias,
+                                           const float* bsc, const float* bsh, bool has_bn) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] += bias[i];
+    if (a.resid != nullptr) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 rv = *(const float4*)(a.resid + oidx + q * 4);
+            v[q * 4 + 0] += rv.x; v[q * 4 + 1] += rv.y; v[q * 4 + 2] += rv.z; v[q * 4 + 3] += rv.w;
+        }
+    }
+    if (a.act == 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
+    } else if (a.act == 2) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = v[i] > 0.f ? v[i] : 0.2f * v[i];
+    }
+    if (has_bn) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = fmaf(v[i], bsc[i], bsh[i]);
+    }
+    if (!OUT_BF16 || a.out_f32) {
+        float* o = (float*)a.out + oidx;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *(float4*)(o + q * 4) = float4{v[q * 4 + 0], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]};
+    } else {
+        unsigned short* o = (unsigned short*)a.out + oidx;
+        uint4 p0, p1;
+        p0.x = pack_bf16x2(v[0], v[1]);   p0.y = pack_bf16x2(v[2], v[3]);
+        p0.z = pack_bf16x2(v[4], v[5]);   p0.w = pack_bf16x2(v[6], v[7]);
+        p1.x = pack_bf16x2(v[8], v[9]);   p1.y = pack_bf16x2(v[10], v[11]);
+        p1.z = pack_bf16x2(v[12], v[13]); p1.w = pack_bf16x2(v[14], v[15]);
+        *(uint4*)(o) = p0;
+        *(uint4*)(o + 8) = p1;
+    }
+}
+
+__device__ __forceinline__ void load16(float (&dst)[16], const float* src) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = *(const float4*)(src + q * 4);
+        dst[q * 4 + 0] = v.x; dst[q * 4 + 1] = v.y; dst[q * 4 + 2] = v.z; dst[q * 4 + 3] = v.w;
+    }
+}
+
 template <typename T, int WM, int WP, int HALO>
 __global__ __launch_bounds__(WM* WP * 64) void conv_igemm(const ConvArgs a) {
     constexpr int NT = WM * WP * 64;
@@ -162,19 +213,27 @@ __global__ __launch_bounds__(WM* WP * 64) void conv_igemm(const ConvArgs a) {
         for (int j = 0; j < N_HITEMS; ++j) *(u32x4*)(halo + (tid + j * NT) * kSlotBytes) = hreg[j];
         for (int t = 0; t < ntaps; ++t) {
             char* const wcur = wbuf + cur * W_BYTES;
+#ifndef IDC_ABL_NO_WWRITE
 #pragma unroll
             for (int j = 0; j < N_WITEMS; ++j)
                 *(u32x4*)(wcur + (tid + j * NT) * kSlotBytes) = wreg[j];
+#endif
+#ifndef IDC_ABL_NO_BARRIER
             __syncthreads();
+#endif
             // prefetch the next (tap, chunk) weight tile; it lands in registers under the MFMAs
             {
                 int t2 = t + 1, kc2 = kc;
                 if (t2 == ntaps) { t2 = 0; kc2 = kc + 1; }
                 if (kc2 == nkc) { t2 = t; kc2 = kc; }     // last step: harmless reload, keeps the loop branch-free
                 const char* src = wbase + (size_t)tap_tw[t2] * w_tap_stride + (size_t)kc2 * w_kc_stride;
+#ifndef IDC_ABL_NO_WLOAD
 #pragma unroll
                 for (int j = 0; j < N_WITEMS; ++j)
                     wreg[j] = *(const u32x4*)(src + (size_t)j * NT * kSlotBytes);
+#else
+                asm volatile("" :: "v"(src));
+#endif
             }
             if (t == ntaps - 1 && kc + 1 < nkc) load_halo(kc + 1);
             // keep the prefetch loads ABOVE the MFMA cluster (hipcc otherwise sinks them below it to
@@ -189,16 +248,30 @@ __global__ __launch_bounds__(WM* WP * 64) void conv_igemm(const ConvArgs a) {
             for (int ks = 0; ks < 2; ++ks) {
                 const int slot = ks * 4 + g;
                 u32x4 wf[4], xf[4];
+#ifndef IDC_ABL_NO_DSREAD
 #pragma unroll
                 for (int ci = 0; ci < 4; ++ci)
                     wf[ci] = *(const u32x4*)(wcur + wrow_byte + ci * 16 * kRowBytes + ((slot ^ wsw) * kSlotBytes));
 #pragma unroll
                 for (int pj = 0; pj < 4; ++pj)
                     xf[pj] = *(const u32x4*)(halo + xrow[pj] * kRowBytes + ((slot ^ swz(xrow[pj])) * kSlotBytes));
+#else
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci) {
+                    wf[ci] = u32x4{0x3c003c00u + (unsigned)slot, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+                    xf[ci] = u32x4{0x3c003c00u + (unsigned)xrow[ci], 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+                    asm volatile("" : "+v"(wf[ci]), "+v"(xf[ci]));
+                }
+#endif
+#ifndef IDC_ABL_NO_MFMA
 #pragma unroll
                 for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
                     for (int pj = 0; pj < 4; ++pj) Mma<T>::run(acc[ci][pj], wf[ci], xf[pj]);
+#else
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci) asm volatile("" :: "v"(wf[ci]), "v"(xf[ci]));
+#endif
             }
             cur ^= 1;
         }
@@ -223,68 +296,22 @@ __global__ __launch_bounds__(WM* WP * 64) void conv_igemm(const ConvArgs a) {
     const int CoutPad = a.ncg * kCoutGroup;
     const int co0 = (ct * WM + wm) * kCoutGroup + g * 16;
     float bias[16], bsc[16], bsh[16];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float4 v = *(const float4*)(a.bias + co0 + q * 4);
-        bias[q * 4 + 0] = v.x; bias[q * 4 + 1] = v.y; bias[q * 4 + 2] = v.z; bias[q * 4 + 3] = v.w;
-    }
+    load16(bias, a.bias + co0);
     const bool has_bn = a.bn_scale != nullptr;
-    if (has_bn) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 s4 = *(const float4*)(a.bn_scale + co0 + q * 4);
-            const float4 h4 = *(const float4*)(a.bn_shift + co0 + q * 4);
-            bsc[q * 4 + 0] = s4.x; bsc[q * 4 + 1] = s4.y; bsc[q * 4 + 2] = s4.z; bsc[q * 4 + 3] = s4.w;
-            bsh[q * 4 + 0] = h4.x; bsh[q * 4 + 1] = h4.y; bsh[q * 4 + 2] = h4.z; bsh[q * 4 + 3] = h4.w;
-        }
-    }
+    if (has_bn) { load16(bsc, a.bn_scale + co0); load16(bsh, a.bn_shift + co0); }
     const int so = a.so, Wout = Ws * so, Hout = Hs * so;
     const int ro = a.ro[phase], cof = a.co[phase];
-    const int act = a.act;
 #pragma unroll
     for (int pj = 0; pj < 4; ++pj) {
         const int sy = ty0 + wp * 4 + pj, sx = tx0 + px;
         if (sy < Hs && sx < Ws) {
             const size_t opix = ((size_t)n * Hout + (sy * so + ro)) * Wout + (sx * so + cof);
-            const size_t oidx = opix * CoutPad + co0;
             float v[16];
 #pragma unroll
             for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[ci * 4 + r] = acc[ci][pj][r] + bias[ci * 4 + r];
-            if (a.resid != nullptr) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 rv = *(const float4*)(a.resid + oidx + q * 4);
-                    v[q * 4 + 0] += rv.x; v[q * 4 + 1] += rv.y; v[q * 4 + 2] += rv.z; v[q * 4 + 3] += rv.w;
-                }
-            }
-            if (act == 1) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
-            } else if (act == 2) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = v[i] > 0.f ? v[i] : 0.2f * v[i];
-            }
-            if (has_bn) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = fmaf(v[i], bsc[i], bsh[i]);
-            }
-            if (a.out_f32 || sizeof(T) == 4) {
-                float* o = (float*)a.out + oidx;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *(float4*)(o + q * 4) = float4{v[q * 4 + 0], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]};
-            } else {
-                unsigned short* o = (unsigned short*)a.out + oidx;
-                uint4 p0, p1;
-                p0.x = pack_bf16x2(v[0], v[1]);   p0.y = pack_bf16x2(v[2], v[3]);
-                p0.z = pack_bf16x2(v[4], v[5]);   p0.w = pack_bf16x2(v[6], v[7]);
-                p1.x = pack_bf16x2(v[8], v[9]);   p1.y = pack_bf16x2(v[10], v[11]);
-                p1.z = pack_bf16x2(v[12], v[13]); p1.w = pack_bf16x2(v[14], v[15]);
-                *(uint4*)(o) = p0;
-                *(uint4*)(o + 8) = p1;
-            }
+                for (int r = 0; r < 4; ++r) v[ci * 4 + r] = acc[ci][pj][r];
+            epilogue16<sizeof(T) == 2>(a, v, opix * CoutPad + co0, bias, bsc, bsh, has_bn);
         }
     }
 }
@@ -315,6 +342,7 @@ static hipError_t set_lds_attr() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
+hipError_t init_kernels_v2();
 size_t conv_lds_bytes(ConvConfig cfg, int halo) { return conv_lds_bytes_c(cfg.wm, cfg.wp, halo); }
 
 #define IDC_FOR_EACH_CONV(X)                                                             \
@@ -329,7 +357,7 @@ hipError_t init_kernels() {
     e = set_lds_attr<__bf16, WM, WP, HL>(); if (e != hipSuccess) return e;
     IDC_FOR_EACH_CONV(X)
 #undef X
-    return hipSuccess;
+    return init_kernels_v2();
 }
 
 hipError_t launch_conv(int precision, ConvConfig cfg, int halo, const ConvArgs& a, hipStream_t s) {
@@ -337,6 +365,256 @@ hipError_t launch_conv(int precision, ConvConfig cfg, int halo, const ConvArgs& 
     if (cfg.wm == WM && cfg.wp == WP && halo == HL)                                     \
         return precision == 1 ? launch_conv_t<__bf16, WM, WP, HL>(a, s) : launch_conv_t<float, WM, WP, HL>(a, s);
     IDC_FOR_EACH_CONV(X)
+#undef X
+    return hipErrorInvalidConfiguration;
+}
+
+
+// ================================================================================================
+// conv_igemm_v2<WCO, WPX, HALO> -- the throughput kernel (bf16): 8 waves, 32x32x16 MFMA.
+//   * workgroup = (32 x 4*WPX) output sites of one image  x  64*WCO output channels;
+//     wave = 64 couts x 128 pixels (4 spatial rows of 32) = 2x4 accumulator tiles of 32x32
+//     (128 accumulator registers): 6 ds_read_b128 per 8 MFMA (v1: 8 per 16 half-size MFMA), i.e.
+//     the LDS array runs ~40 % busy at full MFMA rate instead of ~80 %;
+//   * weight tiles (pre-swizzled LDS images, layout 2 of idc_layout.h) go global -> LDS by
+//     LDS-DMA (global_load_lds_dwordx4, no VGPR round trip, no ds_write), 2-deep ring, issued one
+//     tap ahead right after the barrier; one vmcnt(0) + barrier per tap (= per 1024 MFMA cycles);
+//   * halo rows: register-prefetched under the last tap of the previous chunk (as v1);
+//   * swizzle (row>>1)&7: conflict-free for 32-row x 2-k-group fragments (tools/bank model).
+// ================================================================================================
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ int swz2(int row) { return (row >> 1) & 7; }
+
+template <int WCO, int WPX, int HALO>
+__global__ __launch_bounds__(WCO* WPX * 64) void conv_igemm_v2(const ConvArgs a) {
+    constexpr int NT = WCO * WPX * 64;
+    constexpr int TW = 32, TH = 4 * WPX;
+    constexpr int HWP = TW + 2 * HALO, HHP = TH + 2 * HALO, HROWS = HWP * HHP;
+    constexpr int BN = 64 * WCO;
+    constexpr int W_BYTES = BN * kRowBytes;
+    constexpr int N_HITEMS = (HROWS * kSlots + NT - 1) / NT;
+    constexpr int HALO_BYTES = N_HITEMS * NT * kSlotBytes;
+    constexpr int N_WITEMS = (W_BYTES / kSlotBytes) / NT;
+    static_assert((W_BYTES / kSlotBytes) % NT == 0, "weight tile must split evenly");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const halo = smem;
+    char* const wbuf = smem + HALO_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave % WCO, wpx = wave / WCO;
+    const int px = lane & 31, h = lane >> 5;
+
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int nct = a.ncg / WCO;
+    const int txi = b % a.tiles_x; b /= a.tiles_x;
+    const int tyi = b % a.tiles_y; b /= a.tiles_y;
+    const int n = b % a.N; b /= a.N;
+    const int ct = b % nct;
+    const int phase = b / nct;
+    const int ty0 = tyi * TH, tx0 = txi * TW;
+    const int Hs = a.Hs, Ws = a.Ws, si = a.si;
+    const int Win = Ws * si;
+    const int pix_bytes = a.nkc * kRowBytes;
+    const char* const in_img = (const char*)a.in + (size_t)n * (size_t)(Hs * si) * Win * pix_bytes;
+
+    int hoff[N_HITEMS];
+#pragma unroll
+    for (int j = 0; j < N_HITEMS; ++j) {
+        const int item = tid + j * NT;
+        const int hr = item >> 3, sig = item & 7;
+        const int hy = hr / HWP, hx = hr - hy * HWP;
+        const int sy = ty0 - HALO + hy, sx = tx0 - HALO + hx;
+        const bool inside = (unsigned)sy < (unsigned)Hs && (unsigned)sx < (unsigned)Ws;
+        const int s = sig ^ swz2(hr);
+        hoff[j] = (inside && item < HROWS * kSlots) ? ((sy * si) * Win + sx * si) * pix_bytes + s * kSlotBytes : -1;
+    }
+
+    const char* const wbase = (const char*)a.wgt + (size_t)(ct * WCO) * kWBlockBytes + (size_t)tid * kSlotBytes;
+    const size_t w_kc_stride = (size_t)a.ncg * kWBlockBytes;
+    const size_t w_tap_stride = w_kc_stride * a.nkc;
+    const int* const tap_dy = a.dy + phase * 9;
+    const int* const tap_dx = a.dx + phase * 9;
+    const int* const tap_tw = a.tw + phase * 9;
+    const int ntaps = a.ntaps, nkc = a.nkc;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // LDS-DMA of one weight tile: lane-linear destination (wave-uniform base + lane*16)
+    auto dma_w = [&](int t, int kc, int buf) {
+        const char* src = wbase + (size_t)tap_tw[t] * w_tap_stride + (size_t)kc * w_kc_stride;
+        char* dst = wbuf + buf * W_BYTES + wave * 64 * kSlotBytes;
+#pragma unroll
+        for (int j = 0; j < N_WITEMS; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)j * NT * kSlotBytes),
+                                             (__attribute__((address_space(3))) void*)(dst + j * NT * kSlotBytes), 16, 0, 0);
+    };
+    u32x4 hreg[N_HITEMS];
+    auto load_halo = [&](int kc) {
+#pragma unroll
+        for (int j = 0; j < N_HITEMS; ++j) {
+            const int off = hoff[j];
+            const u32x4 v = *(const u32x4*)(in_img + (off >= 0 ? off : 0) + kc * kRowBytes);
+            hreg[j] = off >= 0 ? v : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    load_halo(0);
+    dma_w(0, 0, 0);
+
+    const int wrow_byte = (wco * 64 + px) * kRowBytes;         // + mi*32 rows
+    // swz2(row) = (row>>1)&7 is the same for rows px and px+32 (and +64*wco): one slot term serves both
+    const int wslot0 = (h ^ swz2(px)) * kSlotBytes;
+    int cur = 0;
+    for (int kc = 0; kc < nkc; ++kc) {
+        __syncthreads();                       // previous chunk's halo reads are done
+#pragma unroll
+        for (int j = 0; j < N_HITEMS; ++j) *(u32x4*)(halo + (tid + j * NT) * kSlotBytes) = hreg[j];
+        for (int t = 0; t < ntaps; ++t) {
+            const char* const wcur = wbuf + cur * W_BYTES;
+#ifndef IDC_ABL_NO_BARRIER
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // my pieces of this tap's weight tile landed
+            __syncthreads();                   // everybody's landed; everybody left the other buffer
+#endif
+#ifndef IDC_ABL_NO_WLOAD
+            {
+                int t2 = t + 1, kc2 = kc;
+                if (t2 == ntaps) { t2 = 0; kc2 = kc + 1; }
+                if (kc2 < nkc) dma_w(t2, kc2, cur ^ 1);
+            }
+#endif
+            if (t == ntaps - 1 && kc + 1 < nkc) load_halo(kc + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const int dy = tap_dy[t], dx = tap_dx[t];
+            int xaddr[4];
+#pragma unroll
+            for (int pj = 0; pj < 4; ++pj) {
+                const int xr = (wpx * 4 + pj + HALO + dy) * HWP + (px + HALO + dx);
+                xaddr[pj] = xr * kRowBytes + ((h ^ swz2(xr)) * kSlotBytes);      // slot = kk*2 + h: kk*2 flips bits 1,2 only
+            }
+            // explicit 2-stage software pipeline over the four k16 steps of the chunk: fragments of
+            // step kk+1 are in flight while the 8 MFMAs of step kk issue
+            u32x4 wfA[2], xfA[4], wfB[2], xfB[4];
+            auto read_frags = [&](int kk, u32x4 (&wf)[2], u32x4 (&xf)[4]) {
+#ifndef IDC_ABL_NO_DSREAD
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    wf[mi] = *(const u32x4*)(wcur + ((wrow_byte + mi * 32 * kRowBytes + wslot0) ^ (kk * 2 * kSlotBytes)));
+#pragma unroll
+                for (int pj = 0; pj < 4; ++pj)
+                    xf[pj] = *(const u32x4*)(halo + (xaddr[pj] ^ (kk * 2 * kSlotBytes)));
+#else
+#pragma unroll
+                for (int pj = 0; pj < 4; ++pj) {
+                    xf[pj] = u32x4{0x3c003c00u + (unsigned)xaddr[pj], 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+                    wf[pj & 1] = u32x4{0x3c003c00u + (unsigned)kk, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+                    asm volatile("" : "+v"(xf[pj]), "+v"(wf[pj & 1]));
+                }
+#endif
+            };
+            auto mma8 = [&](const u32x4 (&wf)[2], const u32x4 (&xf)[4]) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int pj = 0; pj < 4; ++pj)
+                        acc[mi][pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[mi]),
+                                                                              __builtin_bit_cast(bf16x8, xf[pj]),
+                                                                              acc[mi][pj], 0, 0, 0);
+            };
+            // Pin the issue order (hipcc's scheduler otherwise collapses the pipeline to save
+            // registers): 6 reads up front, then per stage 1 MFMA : 1 ds_read interleaved.
+#define IDC_STAGE_INTERLEAVE()                                                        \
+    _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) {                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
+    }                                                                                 \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            read_frags(0, wfA, xfA);
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+            read_frags(1, wfB, xfB);
+            mma8(wfA, xfA);
+            IDC_STAGE_INTERLEAVE()
+            read_frags(2, wfA, xfA);
+            mma8(wfB, xfB);
+            IDC_STAGE_INTERLEAVE()
+            read_frags(3, wfB, xfB);
+            mma8(wfA, xfA);
+            IDC_STAGE_INTERLEAVE()
+            mma8(wfB, xfB);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+#undef IDC_STAGE_INTERLEAVE
+            cur ^= 1;
+        }
+    }
+
+    // ---- epilogue: lane (pixel px, half h) owns couts h*32 + mi*16 + reg of its wave's 64 ----------
+    const int CoutPad = a.ncg * kCoutGroup;
+    const bool has_bn = a.bn_scale != nullptr;
+    const int so = a.so, Wout = Ws * so, Hout = Hs * so;
+    const int ro = a.ro[phase], cof = a.co[phase];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int co0 = (ct * WCO + wco) * kCoutGroup + h * 32 + mi * 16;
+        float bias[16], bsc[16], bsh[16];
+        load16(bias, a.bias + co0);
+        if (has_bn) { load16(bsc, a.bn_scale + co0); load16(bsh, a.bn_shift + co0); }
+#pragma unroll
+        for (int pj = 0; pj < 4; ++pj) {
+            const int sy = ty0 + wpx * 4 + pj, sx = tx0 + px;
+            if (sy < Hs && sx < Ws) {
+                const size_t opix = ((size_t)n * Hout + (sy * so + ro)) * Wout + (sx * so + cof);
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = acc[mi][pj][r];
+                epilogue16<true>(a, v, opix * CoutPad + co0, bias, bsc, bsh, has_bn);
+            }
+        }
+    }
+}
+
+static constexpr size_t conv_v2_lds_bytes_c(int wco, int wpx, int halo) {
+    const int nt = wco * wpx * 64;
+    const int hrows = (32 + 2 * halo) * (4 * wpx + 2 * halo);
+    const int items = (hrows * kSlots + nt - 1) / nt;
+    return (size_t)items * nt * kSlotBytes + 2 * (size_t)(64 * wco) * kRowBytes;
+}
+
+template <int WCO, int WPX, int HALO>
+static hipError_t launch_conv_v2_t(const ConvArgs& a, hipStream_t s) {
+    constexpr size_t lds = conv_v2_lds_bytes_c(WCO, WPX, HALO);
+    const int nct = a.ncg / WCO;
+    const long long blocks = (long long)a.tiles_x * a.tiles_y * a.N * nct * a.nphase;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((conv_igemm_v2<WCO, WPX, HALO>), dim3((unsigned)blocks), dim3(WCO * WPX * 64), lds, s, a);
+    return hipGetLastError();
+}
+
+#define IDC_FOR_EACH_CONV_V2(X) X(4, 2, 0) X(4, 2, 1) X(4, 2, 2) X(2, 4, 0) X(2, 4, 1) X(2, 4, 2)
+
+hipError_t init_kernels_v2() {
+    hipError_t e;
+#define X(WCO, WPX, HL)                                                                                     \
+    e = hipFuncSetAttribute((const void*)conv_igemm_v2<WCO, WPX, HL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            (int)conv_v2_lds_bytes_c(WCO, WPX, HL));                                        \
+    if (e != hipSuccess) return e;
+    IDC_FOR_EACH_CONV_V2(X)
+#undef X
+    return hipSuccess;
+}
+
+// v2 tile = 32 sites wide, 4*wpx rows; cfg.wm = WCO (x64 couts), cfg.wp = WPX.
+hipError_t launch_conv_v2(ConvConfig cfg, int halo, const ConvArgs& a, hipStream_t s) {
+#define X(WCO, WPX, HL) \
+    if (cfg.wm == WCO && cfg.wp == WPX && halo == HL) return launch_conv_v2_t<WCO, WPX, HL>(a, s);
+    IDC_FOR_EACH_CONV_V2(X)
 #undef X
     return hipErrorInvalidConfiguration;
 }

@@ -1,0 +1,53 @@
+// Standalone timing harness for conv_igemm variants (tuning only; not part of the library).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DIDC_ABL_xxx] ablate.hip -o ablate_xxx
+// Usage: ablate [N=32] [HW=32] [C=512] [halo=1] [wm=2] [wp=2] [prec=1]
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../../interactive_deep_colorization_amd/csrc/idc_kernels.hip"
+
+__global__ void fill_bf16(unsigned short* p, size_t n, unsigned seed) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned x = (unsigned)i * 2654435761u + seed; x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+        float f = ((x & 0xffff) / 32768.0f - 1.0f) * 0.5f;
+        __bf16 h = (__bf16)f;
+        p[i] = __builtin_bit_cast(unsigned short, h);
+    }
+}
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+    int N = argc > 1 ? atoi(argv[1]) : 32, HW = argc > 2 ? atoi(argv[2]) : 32, C = argc > 3 ? atoi(argv[3]) : 512;
+    int halo = argc > 4 ? atoi(argv[4]) : 1, wm = argc > 5 ? atoi(argv[5]) : 2, wp = argc > 6 ? atoi(argv[6]) : 2;
+    int prec = argc > 7 ? atoi(argv[7]) : 1;
+    int v2 = argc > 8 ? atoi(argv[8]) : 0;
+    int ntaps = argc > 9 ? atoi(argv[9]) : 9;
+    const int eb = prec ? 2 : 4, kc = 128 / eb;
+    idc::ConvArgs a; memset(&a, 0, sizeof(a));
+    size_t act = (size_t)N * HW * HW * C * eb, wbytes = (size_t)9 * (C / kc) * (C / 64) * 8192;
+    void *in, *out, *w; float *bias;
+    CK(hipMalloc(&in, act)); CK(hipMalloc(&out, act)); CK(hipMalloc(&w, wbytes)); CK(hipMalloc(&bias, C * 4));
+    hipLaunchKernelGGL(fill_bf16, dim3(2048), dim3(256), 0, 0, (unsigned short*)in, act / 2, 1u);
+    hipLaunchKernelGGL(fill_bf16, dim3(2048), dim3(256), 0, 0, (unsigned short*)w, wbytes / 2, 7u);
+    CK(hipMemset(bias, 0, C * 4));
+    CK(idc::init_kernels());
+    a.in = in; a.out = out; a.wgt = w; a.bias = bias; a.N = N; a.Hs = HW; a.Ws = HW; a.si = 1; a.so = 1;
+    a.nkc = C / kc; a.ncg = C / 64; a.nphase = 1; a.ntaps = ntaps; a.tiles_x = v2 ? (HW + 31) / 32 : (HW + 15) / 16; a.tiles_y = (HW + 4 * wp - 1) / (4 * wp);
+    a.act = 1; a.out_f32 = 0;
+    for (int t = 0; t < 9; ++t) { a.dy[t] = (t / 3 - 1) * halo; a.dx[t] = (t % 3 - 1) * halo; a.tw[t] = t; }
+    idc::ConvConfig cfg{wm, wp};
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+#define LAUNCH() (v2 ? idc::launch_conv_v2(cfg, halo, a, 0) : idc::launch_conv(prec, cfg, halo, a, 0))
+    for (int i = 0; i < 5; ++i) CK(LAUNCH());
+    CK(hipDeviceSynchronize());
+    const int reps = 20;
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; ++i) CK(LAUNCH());
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+    double flops = 2.0 * N * HW * HW * (double)C * C * ntaps;
+    printf("%-28s N=%d HW=%d C=%d halo=%d cfg=<%d,%d> prec=%d v2=%d ntaps=%d : %.4f ms  %.1f TFLOP/s\n", ABL_NAME, N, HW, C, halo, wm, wp, prec, v2, ntaps, ms, flops / ms / 1e9);
+    return 0;
+}
