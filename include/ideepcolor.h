@@ -50,6 +50,11 @@ typedef enum idc_precision { IDC_FP32 = 0, IDC_BF16 = 1 } idc_precision;
 
 /* ---- library ------------------------------------------------------------------------------- */
 int idc_version(void);
+/* Process-wide tile-shape policy of the conv kernels (speed only -- every policy computes the same
+ * function): 0 automatic (default), 1 small tiles only (conv_igemm), 2 the large-tile bf16 kernel
+ * (conv_igemm_v2) wherever it applies.  Exists so that the parity tests can drive every kernel
+ * variant at small sizes.  No reference counterpart. */
+int idc_set_tile_policy(int policy);
 /* Number of visible HIP devices (0 when none; never fails). */
 int idc_device_count(void);
 /* Text of the last error on this handle (h may be NULL: last error of a failed idc_create or of a

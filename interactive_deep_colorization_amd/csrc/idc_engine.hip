@@ -41,6 +41,8 @@ BlobPlan make_blob_plan(int precision, unsigned flags) {
         lb.ncg = cout_pad(s.cout) / kCoutGroup;
         lb.w_bytes = (size_t)weight_taps(s.kind) * lb.nkc * lb.ncg * kWBlockBytes;
         off = align_up(off, 256); lb.w_off = off; off += lb.w_bytes;
+        lb.w2_off = (size_t)-1;
+        if (precision == IDC_BF16 && v2_eligible(s)) { off = align_up(off, 256); lb.w2_off = off; off += lb.w_bytes; }
         off = align_up(off, 256); lb.bias_off = off; off += (size_t)cout_pad(s.cout) * 4;
         if (s.bnkey) {
             off = align_up(off, 256); lb.bn_scale_off = off; off += (size_t)cout_pad(s.cout) * 4;
@@ -76,16 +78,22 @@ static bool dims_are(const TensorView& t, std::initializer_list<int64_t> d) {
     return true;
 }
 
-// Write one element of the packed weight image.
-static inline void put_w(uint8_t* wimg, int precision, int nkc, int ncg, int tw, int co, int k, float v) {
+// Write one element of the packed weight image (layout 1: small-tile kernels, layout 2: conv_igemm_v2).
+static inline void put_w(uint8_t* wimg, int precision, int layout, int nkc, int ncg, int tw, int co, int k, float v) {
     const int kc_e = kc_elems(precision), eb = elem_bytes(precision), eps = kSlotBytes / eb;
     const int kc = k / kc_e, kin = k % kc_e;
     const int s = kin / eps, e = kin % eps;
     const int cg = co / kCoutGroup, col = co % kCoutGroup;
-    // inverse of cg_row_to_cout: col = g*16 + ci*4 + reg  ->  lam = ci*16 + g*4 + reg
-    const int gq = col >> 4, ci = (col >> 2) & 3, reg = col & 3;
-    const int lam = ci * 16 + gq * 4 + reg;
-    const int sig = s ^ swz(lam);
+    int lam, sig;
+    if (layout == 2) {
+        lam = cg_cout_to_row2(col);
+        sig = s ^ swz2(lam);
+    } else {
+        // inverse of cg_row_to_cout: col = g*16 + ci*4 + reg  ->  lam = ci*16 + g*4 + reg
+        const int gq = col >> 4, ci = (col >> 2) & 3, reg = col & 3;
+        lam = ci * 16 + gq * 4 + reg;
+        sig = s ^ swz(lam);
+    }
     const size_t off = ((size_t)(tw * nkc + kc) * ncg + cg) * kWBlockBytes + (size_t)lam * kRowBytes +
                        (size_t)sig * kSlotBytes + (size_t)e * eb;
     if (precision == IDC_BF16) {
@@ -97,7 +105,7 @@ static inline void put_w(uint8_t* wimg, int precision, int nkc, int ncg, int tw,
 }
 
 // Pack one conv-like layer: weights in torch layout -> MFMA-tiled, swizzled image.
-static void pack_layer_weights(uint8_t* wimg, int precision, const LayerSpec& s, const LayerBlob& lb,
+static void pack_layer_weights(uint8_t* wimg, int precision, int layout, const LayerSpec& s, const LayerBlob& lb,
                                const float* w) {
     memset(wimg, 0, lb.w_bytes);
     const int cin = s.cin, cout = s.cout;
@@ -105,21 +113,21 @@ static void pack_layer_weights(uint8_t* wimg, int precision, const LayerSpec& s,
         for (int co = 0; co < cout; ++co)
             for (int ci = 0; ci < cin; ++ci)
                 for (int t = 0; t < 9; ++t)
-                    put_w(wimg, precision, lb.nkc, lb.ncg, t, co, ci, w[((size_t)co * cin + ci) * 9 + t]);
+                    put_w(wimg, precision, layout, lb.nkc, lb.ncg, t, co, ci, w[((size_t)co * cin + ci) * 9 + t]);
     } else if (s.kind == kConvIm2col) {          // K index = tap*4 + c  (pack_input_kernel order)
         for (int co = 0; co < cout; ++co)
             for (int ci = 0; ci < cin; ++ci)
                 for (int t = 0; t < 9; ++t)
-                    put_w(wimg, precision, lb.nkc, lb.ncg, 0, co, t * 4 + ci, w[((size_t)co * cin + ci) * 9 + t]);
+                    put_w(wimg, precision, layout, lb.nkc, lb.ncg, 0, co, t * 4 + ci, w[((size_t)co * cin + ci) * 9 + t]);
     } else if (s.kind == kConv1x1) {
         for (int co = 0; co < cout; ++co)
             for (int ci = 0; ci < cin; ++ci)
-                put_w(wimg, precision, lb.nkc, lb.ncg, 0, co, ci, w[(size_t)co * cin + ci]);
+                put_w(wimg, precision, layout, lb.nkc, lb.ncg, 0, co, ci, w[(size_t)co * cin + ci]);
     } else {                                      // ConvTranspose2d weight is (Cin, Cout, 4, 4)
         for (int ci = 0; ci < cin; ++ci)
             for (int co = 0; co < cout; ++co)
                 for (int t = 0; t < 16; ++t)
-                    put_w(wimg, precision, lb.nkc, lb.ncg, t, co, ci, w[((size_t)ci * cout + co) * 16 + t]);
+                    put_w(wimg, precision, layout, lb.nkc, lb.ncg, t, co, ci, w[((size_t)ci * cout + co) * 16 + t]);
     }
 }
 
@@ -172,7 +180,8 @@ static int pack_weights_impl(int precision, unsigned flags, const idc_tensor_des
         else ok = dims_are(*w, {s.cout, s.cin, 3, 3});
         if (!ok) return fail(err, IDC_ERR_MISSING_KEY, "key '%s' has the wrong shape", wk.c_str());
         if (!dims_are(*b, {s.cout})) return fail(err, IDC_ERR_MISSING_KEY, "key '%s' has the wrong shape", bk.c_str());
-        pack_layer_weights(base + lb.w_off, precision, s, lb, w->data);
+        pack_layer_weights(base + lb.w_off, precision, 1, s, lb, w->data);
+        if (lb.w2_off != (size_t)-1) pack_layer_weights(base + lb.w2_off, precision, 2, s, lb, w->data);
         float* bias = (float*)(base + lb.bias_off);
         for (int c = 0; c < s.cout; ++c) bias[c] = b->data[c];
         if (s.bnkey) {
@@ -226,6 +235,7 @@ struct Layer {
     int src = -1, dst = -1, resid = -1;
     int halo = 0;
     ConvConfig cfg{2, 2};
+    bool v2 = false;                     // bf16 large-tile kernel (layout-2 weights)
     ConvArgs args;                       // pointers patched per forward where they depend on weights
     double flops = 0, min_bytes = 0;
 };
@@ -273,15 +283,15 @@ static int find_tensor(idc_context* c, const char* name) {
     return -1;
 }
 
-// Tile-shape choice (speed only).  cout<=64 layers can only use one 64-wide cout group per wave
-// column; otherwise prefer 128 couts x 128 pixels and fall back to smaller pixel tiles when the
-// launch would not fill the 256 CUs.
+// Tile policy (speed only; every choice computes the same result): 0 = automatic, 1 = always the
+// small-tile kernels (conv_igemm), 2 = the large-tile bf16 kernel (conv_igemm_v2) wherever it applies.
+static int g_tile_policy = 0;
+
+// Small-tile kernel shape.  cout<=64 layers can only use one 64-wide cout group per wave column;
+// otherwise prefer 128 couts x 128 pixels and fall back to smaller pixel tiles when the launch would
+// not fill the 256 CUs.
 static ConvConfig choose_config(int n, int Hs, int Ws, int coutpad, int nphase) {
     const int wm = coutpad >= 128 ? 2 : 1;
-    if (const char* f = getenv("IDC_FORCE_WP")) {        // tuning experiments only
-        const int wp = atoi(f);
-        if (wp == 1 || wp == 2 || wp == 4) return ConvConfig{wm, wp};
-    }
     const int cand_wp[3] = {wm == 1 ? 4 : 2, 2, 1};
     ConvConfig best{wm, cand_wp[0]};
     for (int i = 0; i < 3; ++i) {
@@ -330,15 +340,29 @@ static void fill_taps(Layer& L) {
     }
 }
 
-static void set_geometry(Layer& L, int n, int Hs, int Ws) {
+// n_policy: the batch the kernel variant is chosen for (the handle's max_batch, so that a handle's
+// numerics do not depend on how many images a call carries); n: the batch actually launched.
+static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, int Ws) {
     ConvArgs& a = L.args;
     a.N = n; a.Hs = Hs; a.Ws = Ws;
     a.nkc = L.blob.nkc; a.ncg = L.blob.ncg;
-    L.cfg = choose_config(n, Hs, Ws, L.blob.ncg * kCoutGroup, a.nphase);
-    a.tiles_x = (Ws + 15) / 16;
-    a.tiles_y = (Hs + 4 * L.cfg.wp - 1) / (4 * L.cfg.wp);
     a.act = L.spec->act;
     a.out_f32 = L.spec->out_f32;
+    // large-tile bf16 kernel: 256 couts x (32x8 sites) when the cout groups divide by 4, else
+    // 128 couts x (32x16 sites); used when its grid covers at least half of the 256 CUs
+    L.v2 = false;
+    if (precision == IDC_BF16 && v2_eligible(*L.spec) && g_tile_policy != 1) {
+        const ConvConfig c2 = (a.ncg % 4 == 0) ? ConvConfig{4, 2} : ConvConfig{2, 4};
+        const int tx = (Ws + 31) / 32, ty = (Hs + 4 * c2.wp - 1) / (4 * c2.wp);
+        const long long blocks = (long long)tx * ty * n_policy * (a.ncg / c2.wm) * a.nphase;
+        if (g_tile_policy == 2 || blocks >= 128) {
+            L.v2 = true; L.cfg = c2; a.tiles_x = tx; a.tiles_y = ty;
+            return;
+        }
+    }
+    L.cfg = choose_config(n_policy, Hs, Ws, L.blob.ncg * kCoutGroup, a.nphase);
+    a.tiles_x = (Ws + 15) / 16;
+    a.tiles_y = (Hs + 4 * L.cfg.wp - 1) / (4 * L.cfg.wp);
 }
 
 static double layer_flops(const LayerSpec& s, int H, int W) {       // per image, SURVEY.md Appendix A
@@ -372,14 +396,17 @@ static int build_graph(idc_context* c) {
             L.resid = find_tensor(c, s.resid);
             if (L.resid < 0) return fail(&c->err, IDC_ERR_INVALID_ARG, "graph: unknown residual '%s'", s.resid);
         }
-        L.dst = add_tensor(s.name, s.cout, cout_pad(s.cout), s.level, s.out_f32 || c->precision == IDC_FP32);
+        // fp32 storage: everything on the fp32 path; on the bf16 path only the class logits (the
+        // shortcut-branch partial sums are kept in bf16 and widened again in the consumer's epilogue)
+        L.dst = add_tensor(s.name, s.cout, cout_pad(s.cout), s.level,
+                           c->precision == IDC_FP32 || (s.out_f32 && s.kind == kConv1x1));
         fill_taps(L);
         L.flops = layer_flops(s, c->H, c->W);
         const Tensor& ti = c->tensors[L.src];
         const Tensor& to = c->tensors[L.dst];
         const double in_px = (double)(ti.H / s.in_stride) * (ti.W / s.in_stride);
         L.min_bytes = in_px * ti.Cpad * (ti.is_f32 ? 4 : eb) + (double)to.H * to.W * to.Cpad * (to.is_f32 ? 4 : eb) +
-                      (L.resid >= 0 ? (double)to.H * to.W * to.Cpad * 4 : 0.0);
+                      (L.resid >= 0 ? (double)to.H * to.W * to.Cpad * (c->tensors[L.resid].is_f32 ? 4 : eb) : 0.0);
         c->layers.push_back(L);
     }
     c->t_conv10_2 = find_tensor(c, "conv10_2");
@@ -425,16 +452,18 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
         const Tensor& to = c->tensors[L.dst];
         const int Hs = L.spec->kind == kDeconv4x4 ? ti.H : to.H;
         const int Ws = L.spec->kind == kDeconv4x4 ? ti.W : to.W;
-        set_geometry(L, n, Hs, Ws);
+        set_geometry(L, c->precision, n, c->max_batch, Hs, Ws);
         ConvArgs& a = L.args;
         a.in = ti.ptr; a.out = to.ptr;
-        a.resid = L.resid >= 0 ? (const float*)c->tensors[L.resid].ptr : nullptr;
-        a.wgt = c->d_blob + L.blob.w_off;
+        a.out_f32 = to.is_f32;
+        a.resid = L.resid >= 0 ? c->tensors[L.resid].ptr : nullptr;
+        a.resid_bf16 = (L.resid >= 0 && !c->tensors[L.resid].is_f32) ? 1 : 0;
+        a.wgt = c->d_blob + (L.v2 ? L.blob.w2_off : L.blob.w_off);
         a.bias = (const float*)(c->d_blob + L.blob.bias_off);
         a.bn_scale = L.blob.bn_scale_off != (size_t)-1 ? (const float*)(c->d_blob + L.blob.bn_scale_off) : nullptr;
         a.bn_shift = L.blob.bn_shift_off != (size_t)-1 ? (const float*)(c->d_blob + L.blob.bn_shift_off) : nullptr;
         tic();
-        HIPCHK(c, launch_conv(c->precision, L.cfg, L.halo, a, s));
+        HIPCHK(c, L.v2 ? launch_conv_v2(L.cfg, L.halo, a, s) : launch_conv(c->precision, L.cfg, L.halo, a, s));
         toc();
     }
     tic();
@@ -517,6 +546,12 @@ static int check_device(int device_id, std::string* err) {
 extern "C" {
 
 int idc_version(void) { return IDC_VERSION; }
+
+int idc_set_tile_policy(int policy) {
+    if (policy < 0 || policy > 2) return fail(nullptr, IDC_ERR_INVALID_ARG, "tile policy %d not in 0..2", policy);
+    g_tile_policy = policy;
+    return IDC_OK;
+}
 
 int idc_device_count(void) {
     int count = 0;
@@ -688,7 +723,8 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
     } else if (layer <= nl) {
         const Layer& L = h->layers[layer - 1];
         snprintf(out->name, sizeof(out->name), "%s", L.spec->name);
-        snprintf(out->kernel, sizeof(out->kernel), "conv_igemm<%s>", h->precision == IDC_BF16 ? "bf16" : "f32");
+        snprintf(out->kernel, sizeof(out->kernel), L.v2 ? "conv_igemm_v2<%d,%d>" : (h->precision == IDC_BF16 ? "conv_igemm<bf16,%d,%d>" : "conv_igemm<f32,%d,%d>"),
+                 L.cfg.wm, L.cfg.wp);
         out->flops = L.flops; out->min_bytes = L.min_bytes; out->launches = 1;
     } else if (layer == nl + 1) {
         snprintf(out->name, sizeof(out->name), "head");
@@ -782,15 +818,17 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     L.blob.w_bytes = (size_t)weight_taps(spec.kind) * L.blob.nkc * L.blob.ncg * kWBlockBytes;
     const int cpad = cout_pad(spec.cout);
     std::vector<uint8_t> wimg(L.blob.w_bytes);
-    pack_layer_weights(wimg.data(), precision, spec, L.blob, weight);
+    const int Hs = h / spec.in_stride, Ws = w / spec.in_stride;
+    const int so = spec.kind == kDeconv4x4 ? 2 : 1;
+    const int Ho = Hs * so, Wo = Ws * so;
+    fill_taps(L);
+    set_geometry(L, precision, n, n, Hs, Ws);
+    pack_layer_weights(wimg.data(), precision, L.v2 ? 2 : 1, spec, L.blob, weight);
     std::vector<float> hb(cpad, 0.f), hs(cpad, 1.f), ht(cpad, 0.f);
     for (int c = 0; c < spec.cout; ++c) {
         hb[c] = bias[c];
         if (bn_scale) { hs[c] = bn_scale[c]; ht[c] = bn_shift ? bn_shift[c] : 0.f; }
     }
-    const int Hs = h / spec.in_stride, Ws = w / spec.in_stride;
-    const int so = spec.kind == kDeconv4x4 ? 2 : 1;
-    const int Ho = Hs * so, Wo = Ws * so;
     DevBuf d_x, d_xn, d_w, d_b, d_s, d_t, d_r, d_rn, d_yn, d_y;
     const size_t xin = (size_t)n * spec.cin * h * w, yout = (size_t)n * spec.cout * Ho * Wo;
     HIPCHK(nullctx, d_x.alloc(xin * 4));
@@ -805,22 +843,23 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     HIPCHK(nullctx, hipMemcpy(d_s.p, hs.data(), cpad * 4, hipMemcpyHostToDevice));
     HIPCHK(nullctx, hipMemcpy(d_t.p, ht.data(), cpad * 4, hipMemcpyHostToDevice));
     HIPCHK(nullctx, launch_nchw_to_nhwc(precision, (const float*)d_x.p, d_xn.p, n, spec.cin, h, w, spec.cin, nullptr));
+    // bf16 precision: the residual arrives and the output leaves in bf16, as inside the network
+    const int io_bf16 = precision == IDC_BF16 ? 1 : 0;
     if (resid) {
         HIPCHK(nullctx, d_r.alloc(yout * 4));
         HIPCHK(nullctx, d_rn.alloc((size_t)n * Ho * Wo * cpad * 4));
         HIPCHK(nullctx, hipMemcpy(d_r.p, resid, yout * 4, hipMemcpyHostToDevice));
-        HIPCHK(nullctx, launch_nchw_to_nhwc(0, (const float*)d_r.p, d_rn.p, n, spec.cout, Ho, Wo, cpad, nullptr));
+        HIPCHK(nullctx, launch_nchw_to_nhwc(io_bf16, (const float*)d_r.p, d_rn.p, n, spec.cout, Ho, Wo, cpad, nullptr));
     }
-    fill_taps(L);
-    set_geometry(L, n, Hs, Ws);
     ConvArgs& a = L.args;
     a.in = d_xn.p; a.out = d_yn.p; a.wgt = d_w.p; a.bias = (const float*)d_b.p;
     a.bn_scale = bn_scale ? (const float*)d_s.p : nullptr;
     a.bn_shift = bn_scale ? (const float*)d_t.p : nullptr;
-    a.resid = resid ? (const float*)d_rn.p : nullptr;
-    a.out_f32 = 1;
-    HIPCHK(nullctx, launch_conv(precision, L.cfg, L.halo, a, nullptr));
-    HIPCHK(nullctx, launch_nhwc_to_nchw(0, d_yn.p, (float*)d_y.p, n, spec.cout, Ho, Wo, cpad, nullptr));
+    a.resid = resid ? d_rn.p : nullptr;
+    a.resid_bf16 = io_bf16;
+    a.out_f32 = io_bf16 ? 0 : 1;
+    HIPCHK(nullctx, L.v2 ? launch_conv_v2(L.cfg, L.halo, a, nullptr) : launch_conv(precision, L.cfg, L.halo, a, nullptr));
+    HIPCHK(nullctx, launch_nhwc_to_nchw(io_bf16, d_yn.p, (float*)d_y.p, n, spec.cout, Ho, Wo, cpad, nullptr));
     HIPCHK(nullctx, hipMemcpy(y, d_y.p, yout * 4, hipMemcpyDeviceToHost));
     HIPCHK(nullctx, hipDeviceSynchronize());
     return IDC_OK;

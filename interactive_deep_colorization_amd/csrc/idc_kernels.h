@@ -17,7 +17,7 @@ struct ConvArgs {
     const void* in;         // NHWC [N][Hs*si][Ws*si][Cin]          (T)
     const void* wgt;        // packed [tap][kc][cout group][64][128B] (T), see idc_layout.h
     void* out;              // NHWC [N][Hs*so][Ws*so][CoutPad]       (T, or fp32 if out_f32)
-    const float* resid;     // optional NHWC fp32, geometry of `out`: added before the activation
+    const void* resid;      // optional NHWC (fp32, or bf16 if resid_bf16), geometry of `out`: added before the activation
     const float* bias;      // [CoutPad]
     const float* bn_scale;  // optional [CoutPad]: y = act(.)*scale + shift  (eval-BN after ReLU)
     const float* bn_shift;
@@ -29,6 +29,7 @@ struct ConvArgs {
     int tiles_x, tiles_y;   // tiles per image
     int act;                // 0 none, 1 ReLU, 2 LeakyReLU(0.2)
     int out_f32;
+    int resid_bf16;
     int dy[36], dx[36], tw[36];   // [phase*9 + t]: tap offset in sites, packed-weight tap index
     int ro[4], co[4];
 };

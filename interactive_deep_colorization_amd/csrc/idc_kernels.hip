@@ -61,18 +61,28 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
 }
 
 
-// Fused epilogue for 16 consecutive output channels of one pixel:
-// y = act(acc + bias [+ resid]) [* bn_scale + bn_shift]  ->  32 B (bf16) or 64 B (fp32) store.
-template <bool OUT_BF16>
-__device__ __forceinline__ void epilogue16(const ConvArgs& a, float (&v)[16], size_t oidx, const float* bias,
-                                           const float* bsc, const float* bsh, bool has_bn) {
+// Fused epilogue arithmetic for 16 consecutive output channels of one pixel (in place):
+// v = act(v + bias [+ resid]) [* bn_scale + bn_shift]
+__device__ __forceinline__ void epilogue_values16(const ConvArgs& a, float (&v)[16], size_t oidx, const float* bias,
+                                                  const float* bsc, const float* bsh, bool has_bn) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] += bias[i];
     if (a.resid != nullptr) {
+        if (a.resid_bf16) {
+            const uint4* rp = (const uint4*)((const unsigned short*)a.resid + oidx);
+            const uint4 r0 = rp[0], r1 = rp[1];
+            const unsigned rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 rv = *(const float4*)(a.resid + oidx + q * 4);
-            v[q * 4 + 0] += rv.x; v[q * 4 + 1] += rv.y; v[q * 4 + 2] += rv.z; v[q * 4 + 3] += rv.w;
+            for (int q = 0; q < 8; ++q) {
+                v[2 * q] += __uint_as_float(rr[q] << 16);
+                v[2 * q + 1] += __uint_as_float(rr[q] & 0xffff0000u);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 rv = *(const float4*)((const float*)a.resid + oidx + q * 4);
+                v[q * 4 + 0] += rv.x; v[q * 4 + 1] += rv.y; v[q * 4 + 2] += rv.z; v[q * 4 + 3] += rv.w;
+            }
         }
     }
     if (a.act == 1) {
@@ -86,6 +96,20 @@ __device__ __forceinline__ void epilogue16(const ConvArgs& a, float (&v)[16], si
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = fmaf(v[i], bsc[i], bsh[i]);
     }
+}
+
+__device__ __forceinline__ void pack16_bf16(const float (&v)[16], uint4& p0, uint4& p1) {
+    p0.x = pack_bf16x2(v[0], v[1]);   p0.y = pack_bf16x2(v[2], v[3]);
+    p0.z = pack_bf16x2(v[4], v[5]);   p0.w = pack_bf16x2(v[6], v[7]);
+    p1.x = pack_bf16x2(v[8], v[9]);   p1.y = pack_bf16x2(v[10], v[11]);
+    p1.z = pack_bf16x2(v[12], v[13]); p1.w = pack_bf16x2(v[14], v[15]);
+}
+
+// epilogue_values16 + a direct store from the MFMA layout: 32 B (bf16) or 64 B (fp32) per lane.
+template <bool OUT_BF16>
+__device__ __forceinline__ void epilogue16(const ConvArgs& a, float (&v)[16], size_t oidx, const float* bias,
+                                           const float* bsc, const float* bsh, bool has_bn) {
+    epilogue_values16(a, v, oidx, bias, bsc, bsh, has_bn);
     if (!OUT_BF16 || a.out_f32) {
         float* o = (float*)a.out + oidx;
 #pragma unroll
@@ -94,10 +118,7 @@ __device__ __forceinline__ void epilogue16(const ConvArgs& a, float (&v)[16], si
     } else {
         unsigned short* o = (unsigned short*)a.out + oidx;
         uint4 p0, p1;
-        p0.x = pack_bf16x2(v[0], v[1]);   p0.y = pack_bf16x2(v[2], v[3]);
-        p0.z = pack_bf16x2(v[4], v[5]);   p0.w = pack_bf16x2(v[6], v[7]);
-        p1.x = pack_bf16x2(v[8], v[9]);   p1.y = pack_bf16x2(v[10], v[11]);
-        p1.z = pack_bf16x2(v[12], v[13]); p1.w = pack_bf16x2(v[14], v[15]);
+        pack16_bf16(v, p0, p1);
         *(uint4*)(o) = p0;
         *(uint4*)(o + 8) = p1;
     }
@@ -383,8 +404,12 @@ hipError_t launch_conv(int precision, ConvConfig cfg, int halo, const ConvArgs& 
 //   * swizzle (row>>1)&7: conflict-free for 32-row x 2-k-group fragments (tools/bank model).
 // ================================================================================================
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-__device__ __forceinline__ int swz2(int row) { return (row >> 1) & 7; }
+#ifdef IDC_TIMING
+__device__ long long* g_idc_dbg;
+#define IDC_STAMP(i) do { if (tid == 0) g_idc_dbg[(size_t)blockIdx.x * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define IDC_STAMP(i) do {} while (0)
+#endif
 
 template <int WCO, int WPX, int HALO>
 __global__ __launch_bounds__(WCO* WPX * 64) void conv_igemm_v2(const ConvArgs a) {
@@ -407,6 +432,7 @@ __global__ __launch_bounds__(WCO* WPX * 64) void conv_igemm_v2(const ConvArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wco = wave % WCO, wpx = wave / WCO;
     const int px = lane & 31, h = lane >> 5;
+    IDC_STAMP(0);
 
     int b = xcd_remap(blockIdx.x, gridDim.x);
     const int nct = a.ncg / WCO;
@@ -484,6 +510,7 @@ __global__ __launch_bounds__(WCO* WPX * 64) void conv_igemm_v2(const ConvArgs a)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // my pieces of this tap's weight tile landed
             __syncthreads();                   // everybody's landed; everybody left the other buffer
 #endif
+            if (kc == 0 && t == 0) IDC_STAMP(1);
 #ifndef IDC_ABL_NO_WLOAD
             {
                 int t2 = t + 1, kc2 = kc;
@@ -555,29 +582,91 @@ __global__ __launch_bounds__(WCO* WPX * 64) void conv_igemm_v2(const ConvArgs a)
         }
     }
 
+    IDC_STAMP(2);
     // ---- epilogue: lane (pixel px, half h) owns couts h*32 + mi*16 + reg of its wave's 64 ----------
     const int CoutPad = a.ncg * kCoutGroup;
     const bool has_bn = a.bn_scale != nullptr;
     const int so = a.so, Wout = Ws * so, Hout = Hs * so;
     const int ro = a.ro[phase], cof = a.co[phase];
+    const int cow = (ct * WCO + wco) * kCoutGroup;             // first cout of this wave
+    if (a.out_f32) {
+        // fp32 outputs (class logits): straight from the MFMA layout, 64 B per lane
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const int co0 = (ct * WCO + wco) * kCoutGroup + h * 32 + mi * 16;
-        float bias[16], bsc[16], bsh[16];
-        load16(bias, a.bias + co0);
-        if (has_bn) { load16(bsc, a.bn_scale + co0); load16(bsh, a.bn_shift + co0); }
+        for (int mi = 0; mi < 2; ++mi) {
+            const int co0 = cow + h * 32 + mi * 16;
+            float bias[16], bsc[16], bsh[16];
+            load16(bias, a.bias + co0);
+            if (has_bn) { load16(bsc, a.bn_scale + co0); load16(bsh, a.bn_shift + co0); }
 #pragma unroll
-        for (int pj = 0; pj < 4; ++pj) {
-            const int sy = ty0 + wpx * 4 + pj, sx = tx0 + px;
-            if (sy < Hs && sx < Ws) {
-                const size_t opix = ((size_t)n * Hout + (sy * so + ro)) * Wout + (sx * so + cof);
-                float v[16];
+            for (int pj = 0; pj < 4; ++pj) {
+                const int sy = ty0 + wpx * 4 + pj, sx = tx0 + px;
+                if (sy < Hs && sx < Ws) {
+                    const size_t opix = ((size_t)n * Hout + (sy * so + ro)) * Wout + (sx * so + cof);
+                    float v[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = acc[mi][pj][r];
-                epilogue16<true>(a, v, opix * CoutPad + co0, bias, bsc, bsh, has_bn);
+                    for (int r = 0; r < 16; ++r) v[r] = acc[mi][pj][r];
+                    epilogue16<true>(a, v, opix * CoutPad + co0, bias, bsc, bsh, has_bn);
+                }
             }
         }
+    } else {
+        // bf16 outputs: the MFMA layout gives a lane 2 x 32 B of one pixel, i.e. a store instruction
+        // would touch 64 pieces of 32 different 128-B lines.  Transpose through a wave-private 8 KiB
+        // LDS tile ([64 pixels][128 B], slot ^ (row&7) swizzle, conflict-free both ways) so that every
+        // global_store_dwordx4 writes 8 whole lines (8 lanes x 16 B = the wave's 64 couts of a pixel).
+        __syncthreads();                                       // every wave left the halo / weight tiles
+        char* const tbuf = smem + wave * 8192;
+        float bias[2][16], bsc[2][16], bsh[2][16];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int co0 = cow + h * 32 + mi * 16;
+            load16(bias[mi], a.bias + co0);
+            if (has_bn) { load16(bsc[mi], a.bn_scale + co0); load16(bsh[mi], a.bn_shift + co0); }
+        }
+        const int rr = lane >> 3, cc = lane & 7;               // read side: row within 8, 16-B piece
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int pjj = 0; pjj < 2; ++pjj) {
+                const int pj = half * 2 + pjj;
+                const int sy = ty0 + wpx * 4 + pj, sx = tx0 + px;
+                const bool inside = sy < Hs && sx < Ws;
+                const size_t opix = ((size_t)n * Hout + (sy * so + ro)) * Wout + (sx * so + cof);
+                const int row = pjj * 32 + px;
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    float v[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = acc[mi][pj][r];
+                    if (inside || a.resid == nullptr)
+                        epilogue_values16(a, v, opix * CoutPad + cow + h * 32 + mi * 16, bias[mi], bsc[mi], bsh[mi], has_bn);
+                    uint4 p0, p1;
+                    pack16_bf16(v, p0, p1);
+                    const int slot = h * 4 + mi * 2;
+                    *(uint4*)(tbuf + row * kRowBytes + ((slot ^ (row & 7)) * kSlotBytes)) = p0;
+                    *(uint4*)(tbuf + row * kRowBytes + (((slot + 1) ^ (row & 7)) * kSlotBytes)) = p1;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's tile is complete (same-wave LDS ops are in order)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = i * 8 + rr;
+                const uint4 u = *(const uint4*)(tbuf + row * kRowBytes + ((cc ^ (row & 7)) * kSlotBytes));
+                const int pj = half * 2 + (i >> 2), pxx = (i & 3) * 8 + rr;
+                const int sy = ty0 + wpx * 4 + pj, sx = tx0 + pxx;
+                if (sy < Hs && sx < Ws) {
+                    const size_t opix = ((size_t)n * Hout + (sy * so + ro)) * Wout + (sx * so + cof);
+                    *(uint4*)((unsigned short*)a.out + opix * CoutPad + cow + cc * 8) = u;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads retired before the tile is rewritten
+        }
     }
+    IDC_STAMP(3);
+#ifdef IDC_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    IDC_STAMP(4);
+#endif
 }
 
 static constexpr size_t conv_v2_lds_bytes_c(int wco, int wpx, int halo) {
@@ -597,7 +686,9 @@ static hipError_t launch_conv_v2_t(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-#define IDC_FOR_EACH_CONV_V2(X) X(4, 2, 0) X(4, 2, 1) X(4, 2, 2) X(2, 4, 0) X(2, 4, 1) X(2, 4, 2)
+#define IDC_FOR_EACH_CONV_V2(X)                                                                 \
+    X(4, 2, 0) X(4, 2, 1) X(4, 2, 2) X(2, 4, 0) X(2, 4, 1) X(2, 4, 2) X(2, 2, 0) X(2, 2, 1) X(2, 2, 2) \
+    X(1, 4, 0) X(1, 4, 1) X(1, 4, 2)
 
 hipError_t init_kernels_v2() {
     hipError_t e;

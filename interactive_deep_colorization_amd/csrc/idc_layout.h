@@ -37,6 +37,18 @@ __host__ __device__ inline int cg_row_to_cout(int lam) {
     return (r >> 2) * 16 + ci * 4 + (r & 3);
 }
 
+// ---- layout 2 (bf16 large-tile kernel, 32x32x16 MFMA) -------------------------------------------
+// Same [tap][cin-chunk][cout group][64 rows][8 slots] blocks, but
+//   * swizzle swz2(row) = (row>>1)&7: an operand fragment is 32 rows x 2 k-groups per ds_read_b128;
+//   * row permutation for the 32x32 D layout (reg r of lane (col, hgrp) is row (r/4)*8 + hgrp*4 + r%4):
+//     row mi*32 + (r>>2)*8 + hh*4 + (r&3) holds cout hh*32 + mi*16 + r, so a lane ends up with 16
+//     consecutive couts per accumulator and 32 consecutive ones over its two accumulators.
+__host__ __device__ inline int swz2(int row) { return (row >> 1) & 7; }
+__host__ __device__ inline int cg_cout_to_row2(int col) {
+    const int hh = col >> 5, mi = (col >> 4) & 1, r = col & 15;
+    return mi * 32 + (r >> 2) * 8 + hh * 4 + (r & 3);
+}
+
 inline int elem_bytes(int precision) { return precision == 1 ? 2 : 4; }       // IDC_BF16 == 1
 inline int kc_elems(int precision) { return kRowBytes / elem_bytes(precision); }  // 64 or 32
 

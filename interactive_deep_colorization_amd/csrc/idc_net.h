@@ -70,10 +70,13 @@ inline int cout_pad(int cout) { return cout <= 64 ? 64 : ((cout + 127) / 128) * 
 inline int weight_taps(LayerKind k) { return k == kConv3x3 ? 9 : (k == kDeconv4x4 ? 16 : 1); }
 // channels of the GEMM K dimension per tap, before padding to the 128-byte chunk
 inline int k_channels(const LayerSpec& s) { return s.kind == kConvIm2col ? 36 : s.cin; }
+// layers the bf16 large-tile kernel (conv_igemm_v2, >= 128 couts per workgroup) can run
+inline bool v2_eligible(const LayerSpec& s) { return s.kind != kConvIm2col && cout_pad(s.cout) >= 128; }
 
 // Where one layer's parameters live inside the packed blob (byte offsets).
 struct LayerBlob {
     size_t w_off, w_bytes;        // [tap][kc][cg][64][128B]
+    size_t w2_off;                // same size, layout 2 (bf16 large-tile kernel) or (size_t)-1
     size_t bias_off;              // fp32 [cout_pad]
     size_t bn_scale_off, bn_shift_off;   // fp32 [cout_pad] or (size_t)-1
     int nkc, ncg;

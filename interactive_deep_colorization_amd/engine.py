@@ -59,6 +59,15 @@ def _tensor_descs(sd):
     return arr, len(names), keep
 
 
+TILE_POLICIES = {"auto": 0, "small": 1, "large": 2}
+
+
+def set_tile_policy(policy="auto"):
+    """Process-wide tile-shape policy of the conv kernels (speed only; same results): "auto",
+    "small" (conv_igemm only) or "large" (conv_igemm_v2 wherever it applies, bf16)."""
+    N.check(N.load().idc_set_tile_policy(TILE_POLICIES[policy] if isinstance(policy, str) else int(policy)))
+
+
 def pack_weights(sd, precision="bf16", dist=False):
     """Host-only: reference ``state_dict`` -> packed device-ready blob (uint8 ndarray).
     Needs no GPU (used by rank 0 before the RCCL broadcast)."""

@@ -93,6 +93,8 @@ def _plan(precision, dist):
         ntap = {"c3": 9, "dc": 16, "c1": 1, "im2col": 1}[kind]
         e = dict(wkey=wkey, bnkey=bnkey, kind=kind, cin=cin, cout=cout, cpad=cpad, nkc=nkc, ncg=cpad // 64, ntap=ntap)
         off = _al(off); e["w_off"] = off; off += ntap * nkc * e["ncg"] * 8192
+        if precision == "bf16" and kind != "im2col" and cpad >= 128:   # second image: layout 2 (conv_igemm_v2)
+            off = _al(off); e["w2_off"] = off; off += ntap * nkc * e["ncg"] * 8192
         off = _al(off); e["b_off"] = off; off += cpad * 4
         if bnkey:
             off = _al(off); e["s_off"] = off; off += cpad * 4
@@ -108,16 +110,23 @@ def _bf16_bits(x):
     return (((u + 0x7fff + ((u >> 16) & 1)) >> 16) & 0xffff).astype(np.uint16)
 
 
-def _read_w(blob, e, precision, tw, co, k):
+def _read_w(blob, e, precision, tw, co, k, layout=1):
     """Element (tap tw, cout co, K index k) of a layer's packed image, per idc_layout.h."""
     eb = 2 if precision == "bf16" else 4
     kc_e, eps = 128 // eb, 16 // eb
     kc, kin = divmod(k, kc_e)
     s, el = divmod(kin, eps)
     cg, col = divmod(co, 64)
-    g, ci, reg = col >> 4, (col >> 2) & 3, col & 3
-    lam = ci * 16 + g * 4 + reg
-    off = e["w_off"] + ((tw * e["nkc"] + kc) * e["ncg"] + cg) * 8192 + lam * 128 + ((s ^ (lam & 7)) * 16) + el * eb
+    if layout == 1:      # 16x16 MFMA D layout: row ci*16 + g*4 + reg holds cout g*16 + ci*4 + reg; swizzle row&7
+        g, ci, reg = col >> 4, (col >> 2) & 3, col & 3
+        lam = ci * 16 + g * 4 + reg
+        sw = lam & 7
+    else:                # 32x32 MFMA D layout: row mi*32 + (r>>2)*8 + hh*4 + (r&3) holds cout hh*32 + mi*16 + r
+        hh, mi, r = col >> 5, (col >> 4) & 1, col & 15
+        lam = mi * 32 + (r >> 2) * 8 + hh * 4 + (r & 3)
+        sw = (lam >> 1) & 7
+    base = e["w_off"] if layout == 1 else e["w2_off"]
+    off = base + ((tw * e["nkc"] + kc) * e["ncg"] + cg) * 8192 + lam * 128 + ((s ^ sw) * 16) + el * eb
     if precision == "bf16":
         return int(blob[off:off + 2].view(np.uint16)[0])
     return float(blob[off:off + 4].view(np.float32)[0])
@@ -148,6 +157,8 @@ def test_pack_weights_layout(make_sd, precision, dist):
             got = _read_w(blob, e, precision, tw, co, k)
             if precision == "bf16":
                 assert got == int(_bf16_bits(np.float32(val)).ravel()[0]), (e["wkey"], co, ci)
+                if "w2_off" in e:
+                    assert _read_w(blob, e, precision, tw, co, k, layout=2) == got, (e["wkey"], co, ci, "layout 2")
             else:
                 assert got == float(val), (e["wkey"], co, ci)
         np.testing.assert_array_equal(blob[e["b_off"]:e["b_off"] + e["cout"] * 4].view(np.float32), sd[e["wkey"] + ".bias"])

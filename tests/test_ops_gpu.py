@@ -15,6 +15,24 @@ from interactive_deep_colorization_amd import engine
 
 pytestmark = pytest.mark.gpu
 TOL = {"fp32": 2e-5, "bf16": 2.5e-2}
+# every kernel variant is driven at the small test sizes: fp32 = conv_igemm<f32>, bf16 = conv_igemm<bf16>
+# (small tiles), bf16-large = conv_igemm_v2 (32x32x16 MFMA, LDS-transposed stores) forced by the tile policy
+PRECISIONS = ["fp32", "bf16", "bf16-large"]
+
+
+@pytest.fixture(autouse=True)
+def _reset_tile_policy():
+    yield
+    engine.set_tile_policy("auto")
+
+
+def _prec(precision):
+    """'bf16-large' -> ('bf16', tile policy 'large'); sets the policy for the coming op call."""
+    if precision == "bf16-large":
+        engine.set_tile_policy("large")
+        return "bf16"
+    engine.set_tile_policy("small")
+    return precision
 
 
 def _ref_conv(x, w, b, dilation, in_stride, act, bn_s, bn_t, resid):
@@ -51,9 +69,10 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv3x3(case, precision):
+    precision = _prec(precision)
     n, cin, cout, h, w, dil, stride, act, bn, use_res = case
     rs = np.random.RandomState(hash(case) % (2 ** 31))
     x = rs.standard_normal((n, cin, h, w)).astype(np.float32)
@@ -68,9 +87,10 @@ def test_conv3x3(case, precision):
     _check(got, ref, precision, "conv3x3 %s" % (case,))
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", PRECISIONS)
 def test_conv_is_transpose_detecting(precision):
     """Asymmetric single-tap weights: an (ky,kx) or (cin,cout) transpose cannot pass."""
+    precision = _prec(precision)
     cin, cout, h, w = 64, 128, 8, 16
     x = np.zeros((1, cin, h, w), np.float32); x[0, 3, 2, 5] = 1.0
     wt = np.zeros((cout, cin, 3, 3), np.float32); wt[7, 3, 0, 2] = 2.0      # only tap (ky=0, kx=2)
@@ -79,9 +99,10 @@ def test_conv_is_transpose_detecting(precision):
     np.testing.assert_array_equal(got, exp)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("shape", [(1, 128, 128, 8, 8), (2, 256, 128, 6, 20), (1, 512, 256, 4, 4)])
 def test_deconv4x4s2(shape, precision):
+    precision = _prec(precision)
     n, cin, cout, h, w = shape
     rs = np.random.RandomState(cin + cout + h)
     x = rs.standard_normal((n, cin, h, w)).astype(np.float32)
@@ -99,9 +120,10 @@ def test_deconv4x4s2(shape, precision):
     _check(got0, ref0, precision, "deconv (no act) %s" % (shape,))
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", PRECISIONS)
 def test_conv1x1_padded_cout(precision):
     """model_class shape class: Cout = 529 is padded to 640 inside; only 529 come back."""
+    precision = _prec(precision)
     rs = np.random.RandomState(5)
     x = rs.standard_normal((1, 256, 8, 16)).astype(np.float32)
     wt = (rs.standard_normal((529, 256, 1, 1)) / 16).astype(np.float32)

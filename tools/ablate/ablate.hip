@@ -40,6 +40,11 @@ int main(int argc, char** argv) {
     idc::ConvConfig cfg{wm, wp};
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 #define LAUNCH() (v2 ? idc::launch_conv_v2(cfg, halo, a, 0) : idc::launch_conv(prec, cfg, halo, a, 0))
+#ifdef IDC_TIMING
+    int nb = a.tiles_x * a.tiles_y * N * (a.ncg / wm);
+    long long* dbg; CK(hipMalloc(&dbg, (size_t)nb * 64)); CK(hipMemset(dbg, 0, (size_t)nb * 64));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(idc::g_idc_dbg), &dbg, sizeof(dbg)));
+#endif
     for (int i = 0; i < 5; ++i) CK(LAUNCH());
     CK(hipDeviceSynchronize());
     const int reps = 20;
@@ -48,6 +53,18 @@ int main(int argc, char** argv) {
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
     double flops = 2.0 * N * HW * HW * (double)C * C * ntaps;
+#ifdef IDC_TIMING
+    {
+        CK(LAUNCH()); CK(hipDeviceSynchronize());
+        std::vector<long long> h((size_t)nb * 8); CK(hipMemcpy(h.data(), dbg, (size_t)nb * 64, hipMemcpyDeviceToHost));
+        long long t0 = h[0]; for (int b = 0; b < nb; ++b) if (h[b * 8] < t0) t0 = h[b * 8];
+        double s[5] = {0, 0, 0, 0, 0}; long long tend = 0;
+        for (int b = 0; b < nb; ++b) { for (int i = 0; i < 5; ++i) s[i] += (double)(h[b * 8 + i] - (i ? h[b * 8 + i - 1] : t0)); if (h[b * 8 + 4] > tend) tend = h[b * 8 + 4]; }
+        printf("  timing (ticks, mean over %d blocks): start-offset %.0f | prologue %.0f | mainloop %.0f | epilogue-issue %.0f | store-drain %.0f | kernel span %lld\n",
+               nb, s[0] / nb, s[1] / nb, s[2] / nb, s[3] / nb, s[4] / nb, tend - t0);
+        for (int b : {0, 1, 8, nb / 2, nb - 1}) printf("   block %5d: start %lld pro %lld main %lld epi %lld drain %lld\n", b, h[b * 8] - t0, h[b * 8 + 1] - h[b * 8], h[b * 8 + 2] - h[b * 8 + 1], h[b * 8 + 3] - h[b * 8 + 2], h[b * 8 + 4] - h[b * 8 + 3]);
+    }
+#endif
     printf("%-28s N=%d HW=%d C=%d halo=%d cfg=<%d,%d> prec=%d v2=%d ntaps=%d : %.4f ms  %.1f TFLOP/s\n", ABL_NAME, N, HW, C, halo, wm, wp, prec, v2, ntaps, ms, flops / ms / 1e9);
     return 0;
 }
