@@ -50,6 +50,8 @@ BlobPlan make_blob_plan(int precision, unsigned flags) {
         } else {
             lb.bn_scale_off = lb.bn_shift_off = (size_t)-1;
         }
+        lb.fbias_off = (size_t)-1;
+        if (s.resid) { off = align_up(off, 256); lb.fbias_off = off; off += (size_t)cout_pad(s.cout) * 4; }
         p.layers.push_back(lb);
         p.active.push_back(i);
     }
@@ -202,6 +204,19 @@ static int pack_weights_impl(int precision, unsigned flags, const idc_tensor_des
             }
         }
     }
+    // layers that sum a shortcut branch: bias of the fused launch = own bias + the shortcut conv's bias
+    for (size_t li = 0; li < plan.active.size(); ++li) {
+        const LayerSpec& s = specs[plan.active[li]];
+        if (plan.layers[li].fbias_off == (size_t)-1) continue;
+        float* fb = (float*)(base + plan.layers[li].fbias_off);
+        const float* own = (const float*)(base + plan.layers[li].bias_off);
+        for (int ch = 0; ch < cout_pad(s.cout); ++ch) fb[ch] = own[ch];
+        for (size_t lj = 0; lj < plan.active.size(); ++lj)
+            if (strcmp(specs[plan.active[lj]].name, s.resid) == 0) {
+                const float* sb = (const float*)(base + plan.layers[lj].bias_off);
+                for (int ch = 0; ch < cout_pad(s.cout); ++ch) fb[ch] += sb[ch];
+            }
+    }
     {
         const TensorView *w = nullptr, *b = nullptr;
         if (!need("model_out.0.weight", &w) || !dims_are(*w, {2, 128, 1, 1}))
@@ -236,6 +251,9 @@ struct Layer {
     int halo = 0;
     ConvConfig cfg{2, 2};
     bool v2 = false;                     // bf16 large-tile kernel (layout-2 weights)
+    bool fused_head = false;             // conv10_2 only: model_out + tanh run in this layer's epilogue
+    int fused_short = -1;                // deconv layers: index of the shortcut conv layer riding in this launch's K loop
+    bool skip = false;                   // shortcut conv layer fused into its consumer: not launched
     ConvArgs args;                       // pointers patched per forward where they depend on weights
     double flops = 0, min_bytes = 0;
 };
@@ -286,6 +304,10 @@ static int find_tensor(idc_context* c, const char* name) {
 // Tile policy (speed only; every choice computes the same result): 0 = automatic, 1 = always the
 // small-tile kernels (conv_igemm), 2 = the large-tile bf16 kernel (conv_igemm_v2) wherever it applies.
 static int g_tile_policy = 0;
+// Shortcut fusion (conv_igemm_v2<.,.,1,true>) is correct (parity-tested under tile policy 2) but measured slower
+// than two launches on MI355X (4x re-reads of the skip tensor by the four phase workgroups, VGPR spills around
+// the staged K loop): 0.87 ms -> 1.25 ms at level 1.  Off unless the tile policy forces every variant on.
+static bool fuse_shortcut_enabled() { return g_tile_policy == 2 || getenv("IDC_FUSE_SHORTCUT") != nullptr; }          // large-tile deconv launches also run the shortcut conv they are summed with
 
 // Small-tile kernel shape.  cout<=64 layers can only use one 64-wide cout group per wave column;
 // otherwise prefer 128 couts x 128 pixels and fall back to smaller pixel tiles when the launch would
@@ -447,28 +469,65 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
     HIPCHK(c, launch_pack_input(c->precision, dL, dab, dmask, c->tensors[c->t_input].ptr, n, c->H, c->W, c->l_div,
                                 c->ab_div, c->mask_mul, maskcent, s));
     toc();
+    // pass 1: kernel variant per layer, then which shortcut convs ride in their consumer's launch
     for (auto& L : c->layers) {
         const Tensor& ti = c->tensors[L.src];
         const Tensor& to = c->tensors[L.dst];
         const int Hs = L.spec->kind == kDeconv4x4 ? ti.H : to.H;
         const int Ws = L.spec->kind == kDeconv4x4 ? ti.W : to.W;
         set_geometry(L, c->precision, n, c->max_batch, Hs, Ws);
+        L.fused_short = -1; L.skip = false;
+    }
+    for (auto& L : c->layers) {
+        if (L.spec->kind != kDeconv4x4 || L.resid < 0 || !L.v2 || !fuse_shortcut_enabled()) continue;
+        for (size_t j = 0; j < c->layers.size(); ++j) {
+            Layer& P = c->layers[j];
+            const LayerSpec& ps = *P.spec;
+            if (P.dst != L.resid) continue;
+            const Tensor& pin = c->tensors[P.src];
+            const Tensor& to = c->tensors[L.dst];
+            if (ps.kind == kConv3x3 && ps.dilation == 1 && ps.in_stride == 1 && ps.act == 0 && !ps.bnkey && !ps.resid &&
+                ps.cout == L.spec->cout && pin.H == to.H && pin.W == to.W && !pin.is_f32 && P.blob.w2_off != (size_t)-1) {
+                L.fused_short = (int)j; P.skip = true;
+            }
+        }
+    }
+    bool head_done = false;
+    for (auto& L : c->layers) {
+        const Tensor& ti = c->tensors[L.src];
+        const Tensor& to = c->tensors[L.dst];
+        if (L.skip) { tic(); toc(); continue; }
         ConvArgs& a = L.args;
         a.in = ti.ptr; a.out = to.ptr;
         a.out_f32 = to.is_f32;
-        a.resid = L.resid >= 0 ? c->tensors[L.resid].ptr : nullptr;
-        a.resid_bf16 = (L.resid >= 0 && !c->tensors[L.resid].is_f32) ? 1 : 0;
         a.wgt = c->d_blob + (L.v2 ? L.blob.w2_off : L.blob.w_off);
         a.bias = (const float*)(c->d_blob + L.blob.bias_off);
         a.bn_scale = L.blob.bn_scale_off != (size_t)-1 ? (const float*)(c->d_blob + L.blob.bn_scale_off) : nullptr;
         a.bn_shift = L.blob.bn_shift_off != (size_t)-1 ? (const float*)(c->d_blob + L.blob.bn_shift_off) : nullptr;
+        if (L.fused_short >= 0) {            // model8up(.) + model3short8(.) in one K loop (model.py:156,170,172)
+            const Layer& P = c->layers[L.fused_short];
+            a.resid = nullptr; a.resid_bf16 = 0;
+            a.in2 = c->tensors[P.src].ptr; a.wgt2 = c->d_blob + P.blob.w2_off; a.nkc2 = P.blob.nkc;
+            a.bias = (const float*)(c->d_blob + L.blob.fbias_off);
+        } else {
+            a.resid = L.resid >= 0 ? c->tensors[L.resid].ptr : nullptr;
+            a.resid_bf16 = (L.resid >= 0 && !c->tensors[L.resid].is_f32) ? 1 : 0;
+            a.in2 = nullptr; a.wgt2 = nullptr; a.nkc2 = 0;
+        }
+        // the regression head rides in conv10_2's epilogue when one workgroup owns all 128 channels
+        L.fused_head = L.dst == c->t_conv10_2 && L.v2 && L.cfg.wm == 2 && a.ncg == 2 && L.spec->bnkey == nullptr;
+        a.head_w = L.fused_head ? (const float*)(c->d_blob + c->plan.head_w_off) : nullptr;
+        a.head_b = (const float*)(c->d_blob + c->plan.head_b_off);
+        a.head_out = dout; a.head_mul = c->out_mul;
+        head_done = head_done || L.fused_head;
         tic();
         HIPCHK(c, L.v2 ? launch_conv_v2(L.cfg, L.halo, a, s) : launch_conv(c->precision, L.cfg, L.halo, a, s));
         toc();
     }
     tic();
-    HIPCHK(c, launch_head(c->precision, c->tensors[c->t_conv10_2].ptr, (const float*)(c->d_blob + c->plan.head_w_off),
-                          (const float*)(c->d_blob + c->plan.head_b_off), dout, n, c->H, c->W, c->out_mul, s));
+    if (!head_done)
+        HIPCHK(c, launch_head(c->precision, c->tensors[c->t_conv10_2].ptr, (const float*)(c->d_blob + c->plan.head_w_off),
+                              (const float*)(c->d_blob + c->plan.head_b_off), dout, n, c->H, c->W, c->out_mul, s));
     toc();
     tic();
     if (ddist) {
@@ -723,9 +782,22 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
     } else if (layer <= nl) {
         const Layer& L = h->layers[layer - 1];
         snprintf(out->name, sizeof(out->name), "%s", L.spec->name);
-        snprintf(out->kernel, sizeof(out->kernel), L.v2 ? "conv_igemm_v2<%d,%d>" : (h->precision == IDC_BF16 ? "conv_igemm<bf16,%d,%d>" : "conv_igemm<f32,%d,%d>"),
-                 L.cfg.wm, L.cfg.wp);
-        out->flops = L.flops; out->min_bytes = L.min_bytes; out->launches = 1;
+        if (L.skip) {                        // its MACs and bytes are accounted to the launch that runs them
+            for (const Layer& C : h->layers)
+                if (C.fused_short == layer - 1) snprintf(out->kernel, sizeof(out->kernel), "fused into %s", C.spec->name);
+            out->flops = 0; out->min_bytes = 0; out->launches = 0;
+        } else {
+            snprintf(out->kernel, sizeof(out->kernel), L.v2 ? "conv_igemm_v2<%d,%d>" : (h->precision == IDC_BF16 ? "conv_igemm<bf16,%d,%d>" : "conv_igemm<f32,%d,%d>"),
+                     L.cfg.wm, L.cfg.wp);
+            if (L.fused_head) strncat(out->kernel, "+head", sizeof(out->kernel) - strlen(out->kernel) - 1);
+            out->flops = L.flops; out->min_bytes = L.min_bytes; out->launches = 1;
+            if (L.fused_short >= 0) {
+                const Layer& P = h->layers[L.fused_short];
+                strncat(out->kernel, "+shortcut", sizeof(out->kernel) - strlen(out->kernel) - 1);
+                out->flops += P.flops;
+                out->min_bytes += P.min_bytes - 2.0 * (double)h->tensors[P.dst].H * h->tensors[P.dst].W * h->tensors[P.dst].Cpad * eb;
+            }
+        }
     } else if (layer == nl + 1) {
         snprintf(out->name, sizeof(out->name), "head");
         snprintf(out->kernel, sizeof(out->kernel), "head_kernel");
@@ -857,6 +929,8 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     a.bn_shift = bn_scale ? (const float*)d_t.p : nullptr;
     a.resid = resid ? d_rn.p : nullptr;
     a.resid_bf16 = io_bf16;
+    a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_mul = 0.f;
+    a.in2 = nullptr; a.wgt2 = nullptr; a.nkc2 = 0;
     a.out_f32 = io_bf16 ? 0 : 1;
     HIPCHK(nullctx, L.v2 ? launch_conv_v2(L.cfg, L.halo, a, nullptr) : launch_conv(precision, L.cfg, L.halo, a, nullptr));
     HIPCHK(nullctx, launch_nhwc_to_nchw(io_bf16, d_yn.p, (float*)d_y.p, n, spec.cout, Ho, Wo, cpad, nullptr));

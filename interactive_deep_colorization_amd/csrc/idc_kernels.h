@@ -30,6 +30,19 @@ struct ConvArgs {
     int act;                // 0 none, 1 ReLU, 2 LeakyReLU(0.2)
     int out_f32;
     int resid_bf16;
+    // fused shortcut conv (conv_igemm_v2, deconv launches only): a 3x3 conv (pad 1, bias folded into
+    // `bias`) of in2 = NHWC [N][2*Hs][2*Ws][nkc2 * 64] bf16 accumulated into the same output pixels;
+    // wgt2 = its layout-2 weight image (same couts).  model.py:156,170,172.
+    const void* in2;
+    const void* wgt2;
+    int nkc2;
+    // fused regression head (conv_igemm_v2<2,*> only, when one workgroup owns all 128 couts):
+    // head_out[n][c][y][x] = head_mul * tanh(head_b[c] + sum_k head_w[c][k] * y[k]), y = this layer's
+    // fp32 result (not stored at all).  model_out + tanh + *110, model.py:108-109,174-175.
+    const float* head_w;    // [2][128] or nullptr
+    const float* head_b;    // [2]
+    float* head_out;        // NCHW fp32 [N][2][Hs][Ws]
+    float head_mul;
     int dy[36], dx[36], tw[36];   // [phase*9 + t]: tap offset in sites, packed-weight tap index
     int ro[4], co[4];
 };

@@ -406,13 +406,13 @@ hipError_t launch_conv(int precision, ConvConfig cfg, int halo, const ConvArgs& 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 #ifdef IDC_TIMING
 __device__ long long* g_idc_dbg;
-#define IDC_STAMP(i) do { if (tid == 0) g_idc_dbg[(size_t)blockIdx.x * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define IDC_STAMP(i) do { if (tid == 0) g_idc_dbg[(size_t)blockIdx.x * 16 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define IDC_STAMP(i) do {} while (0)
 #endif
 
-template <int WCO, int WPX, int HALO>
-__global__ __launch_bounds__(WCO* WPX * 64) void conv_igemm_v2(const ConvArgs a) {
+template <int WCO, int WPX, int HALO, bool FUSED>
+__global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs a) {
     constexpr int NT = WCO * WPX * 64;
     constexpr int TW = 32, TH = 4 * WPX;
     constexpr int HWP = TW + 2 * HALO, HHP = TH + 2 * HALO, HROWS = HWP * HHP;
@@ -434,38 +434,59 @@ __global__ __launch_bounds__(WCO* WPX * 64) void conv_igemm_v2(const ConvArgs a)
     const int px = lane & 31, h = lane >> 5;
     IDC_STAMP(0);
 
+    // tile order: (deconv phase, cout tile) vary fastest, so the workgroups that share an input halo run
+    // back to back on one XCD (xcd_remap) and read it from that XCD's L2
     int b = xcd_remap(blockIdx.x, gridDim.x);
     const int nct = a.ncg / WCO;
+    const int phase = b % a.nphase; b /= a.nphase;
+    const int ct = b % nct; b /= nct;
     const int txi = b % a.tiles_x; b /= a.tiles_x;
-    const int tyi = b % a.tiles_y; b /= a.tiles_y;
-    const int n = b % a.N; b /= a.N;
-    const int ct = b % nct;
-    const int phase = b / nct;
+    const int tyi = b % a.tiles_y;
+    const int n = b / a.tiles_y;
     const int ty0 = tyi * TH, tx0 = txi * TW;
-    const int Hs = a.Hs, Ws = a.Ws, si = a.si;
-    const int Win = Ws * si;
-    const int pix_bytes = a.nkc * kRowBytes;
-    const char* const in_img = (const char*)a.in + (size_t)n * (size_t)(Hs * si) * Win * pix_bytes;
-
-    int hoff[N_HITEMS];
-#pragma unroll
-    for (int j = 0; j < N_HITEMS; ++j) {
-        const int item = tid + j * NT;
-        const int hr = item >> 3, sig = item & 7;
-        const int hy = hr / HWP, hx = hr - hy * HWP;
-        const int sy = ty0 - HALO + hy, sx = tx0 - HALO + hx;
-        const bool inside = (unsigned)sy < (unsigned)Hs && (unsigned)sx < (unsigned)Ws;
-        const int s = sig ^ swz2(hr);
-        hoff[j] = (inside && item < HROWS * kSlots) ? ((sy * si) * Win + sx * si) * pix_bytes + s * kSlotBytes : -1;
-    }
-
-    const char* const wbase = (const char*)a.wgt + (size_t)(ct * WCO) * kWBlockBytes + (size_t)tid * kSlotBytes;
-    const size_t w_kc_stride = (size_t)a.ncg * kWBlockBytes;
-    const size_t w_tap_stride = w_kc_stride * a.nkc;
+    const int Hs = a.Hs, Ws = a.Ws;
+    const int ro = a.ro[phase], cof = a.co[phase];
     const int* const tap_dy = a.dy + phase * 9;
     const int* const tap_dx = a.dx + phase * 9;
     const int* const tap_tw = a.tw + phase * 9;
-    const int ntaps = a.ntaps, nkc = a.nkc;
+    const size_t w_kc_stride = (size_t)a.ncg * kWBlockBytes;   // next cin chunk (both sources: same couts)
+    const size_t w_lane = (size_t)(ct * WCO) * kWBlockBytes + (size_t)tid * kSlotBytes;
+
+    // ---- K loop = a list of stages, all accumulating into the same output sites -------------------
+    // stage 0: the layer itself (a.in / a.wgt / tap tables: 3x3 conv, 1x1 conv or one deconv phase);
+    // stages 1..4 (only with a.in2, deconv launches): the fused shortcut 3x3 conv of in2 at the output
+    // resolution (model.py:156,170,172: model8up(.) + model3short8(.)).  Output pixel (2m+r, 2n+s)
+    // reads in2 at (2m+r+ky, 2n+s+kx): taps whose row/col parity is (pa,pb) form a stride-2 gather of
+    // in2 with offset (pa,pb) and site shifts in {-1,0,+1} -- same halo machinery, four more stages.
+    struct Stage { const char* img; const char* wb; int nkc, ntaps, si, oy, ox; };
+    auto make_stage = [&](int q) -> Stage {
+        Stage st;
+        if (!FUSED || q == 0) {
+            const size_t pix = (size_t)a.nkc * kRowBytes;
+            st.img = (const char*)a.in + (size_t)n * (size_t)(Hs * a.si) * (Ws * a.si) * pix;
+            st.wb = (const char*)a.wgt + w_lane;
+            st.nkc = a.nkc; st.ntaps = a.ntaps; st.si = a.si; st.oy = 0; st.ox = 0;
+        } else {
+            const int pa = (q - 1) >> 1, pb = (q - 1) & 1;
+            const size_t pix = (size_t)a.nkc2 * kRowBytes;
+            st.img = (const char*)a.in2 + (size_t)n * (size_t)(Hs * 2) * (Ws * 2) * pix;
+            st.wb = (const char*)a.wgt2 + w_lane;
+            st.nkc = a.nkc2; st.ntaps = (pa == ro ? 1 : 2) * (pb == cof ? 1 : 2); st.si = 2; st.oy = pa; st.ox = pb;
+        }
+        return st;
+    };
+    // tap t of stage q: site shift (dy, dx) and index of its packed weight tile
+    auto tap_of = [&](int q, int t, int& dy, int& dx, int& tw) {
+        if (!FUSED || q == 0) { dy = tap_dy[t]; dx = tap_dx[t]; tw = tap_tw[t]; return; }
+        const int pa = (q - 1) >> 1, pb = (q - 1) & 1;
+        const int nx = pb == cof ? 1 : 2;
+        const int iy = nx == 2 ? (t >> 1) : t, ix = nx == 2 ? (t & 1) : 0;
+        const int ky = pa == ro ? 0 : (iy ? 1 : -1), kx = pb == cof ? 0 : (ix ? 1 : -1);
+        dy = pa == ro ? 0 : (iy ? ro : ro - 1);                 // (r + ky - pa) / 2
+        dx = pb == cof ? 0 : (ix ? cof : cof - 1);
+        tw = (ky + 1) * 3 + (kx + 1);
+    };
+    constexpr int nstage = FUSED ? 5 : 1;
 
     f32x16 acc[2][4];
 #pragma unroll
@@ -476,110 +497,131 @@ __global__ __launch_bounds__(WCO* WPX * 64) void conv_igemm_v2(const ConvArgs a)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // LDS-DMA of one weight tile: lane-linear destination (wave-uniform base + lane*16)
-    auto dma_w = [&](int t, int kc, int buf) {
-        const char* src = wbase + (size_t)tap_tw[t] * w_tap_stride + (size_t)kc * w_kc_stride;
+    auto dma_w = [&](const Stage& st, int tw, int kc, int buf) {
+        const char* src = st.wb + ((size_t)tw * st.nkc + kc) * w_kc_stride;
         char* dst = wbuf + buf * W_BYTES + wave * 64 * kSlotBytes;
 #pragma unroll
         for (int j = 0; j < N_WITEMS; ++j)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)j * NT * kSlotBytes),
                                              (__attribute__((address_space(3))) void*)(dst + j * NT * kSlotBytes), 16, 0, 0);
     };
+    // halo staging of one 128-byte channel chunk: item = (halo row, physical slot), zero outside the image;
+    // the rows go to registers now and to LDS after the chunk-end barrier (issue early / write late)
     u32x4 hreg[N_HITEMS];
-    auto load_halo = [&](int kc) {
+    auto load_halo = [&](const Stage& st, int kc) {
+        const int Win = Ws * st.si, pix_bytes = st.nkc * kRowBytes;
 #pragma unroll
         for (int j = 0; j < N_HITEMS; ++j) {
-            const int off = hoff[j];
-            const u32x4 v = *(const u32x4*)(in_img + (off >= 0 ? off : 0) + kc * kRowBytes);
-            hreg[j] = off >= 0 ? v : u32x4{0u, 0u, 0u, 0u};
+            const int item = tid + j * NT;
+            const int hr = item >> 3, sig = item & 7;
+            const int hy = hr / HWP, hx = hr - hy * HWP;
+            const int sy = ty0 - HALO + hy, sx = tx0 - HALO + hx;
+            const bool inside = (unsigned)sy < (unsigned)Hs && (unsigned)sx < (unsigned)Ws && item < HROWS * kSlots;
+            const int off = ((sy * st.si + st.oy) * Win + sx * st.si + st.ox) * pix_bytes + ((sig ^ swz2(hr)) + kc * kSlots) * kSlotBytes;
+            const u32x4 v = *(const u32x4*)(st.img + (inside ? off : 0));
+            hreg[j] = inside ? v : u32x4{0u, 0u, 0u, 0u};
         }
     };
-    load_halo(0);
-    dma_w(0, 0, 0);
+
+    Stage cur = make_stage(0);
+    load_halo(cur, 0);
+    {
+        int dy0, dx0, tw0;
+        tap_of(0, 0, dy0, dx0, tw0);
+        dma_w(cur, tw0, 0, 0);
+    }
 
     const int wrow_byte = (wco * 64 + px) * kRowBytes;         // + mi*32 rows
     // swz2(row) = (row>>1)&7 is the same for rows px and px+32 (and +64*wco): one slot term serves both
     const int wslot0 = (h ^ swz2(px)) * kSlotBytes;
-    int cur = 0;
-    for (int kc = 0; kc < nkc; ++kc) {
-        __syncthreads();                       // previous chunk's halo reads are done
+    int buf = 0;
+    bool first = true;
+    for (int q = 0; q < nstage; ++q) {
+        for (int kc = 0; kc < cur.nkc; ++kc) {
+            __syncthreads();                   // previous chunk's halo reads are done
 #pragma unroll
-        for (int j = 0; j < N_HITEMS; ++j) *(u32x4*)(halo + (tid + j * NT) * kSlotBytes) = hreg[j];
-        for (int t = 0; t < ntaps; ++t) {
-            const char* const wcur = wbuf + cur * W_BYTES;
-#ifndef IDC_ABL_NO_BARRIER
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // my pieces of this tap's weight tile landed
-            __syncthreads();                   // everybody's landed; everybody left the other buffer
-#endif
-            if (kc == 0 && t == 0) IDC_STAMP(1);
-#ifndef IDC_ABL_NO_WLOAD
-            {
-                int t2 = t + 1, kc2 = kc;
-                if (t2 == ntaps) { t2 = 0; kc2 = kc + 1; }
-                if (kc2 < nkc) dma_w(t2, kc2, cur ^ 1);
-            }
-#endif
-            if (t == ntaps - 1 && kc + 1 < nkc) load_halo(kc + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            const int dy = tap_dy[t], dx = tap_dx[t];
-            int xaddr[4];
-#pragma unroll
-            for (int pj = 0; pj < 4; ++pj) {
-                const int xr = (wpx * 4 + pj + HALO + dy) * HWP + (px + HALO + dx);
-                xaddr[pj] = xr * kRowBytes + ((h ^ swz2(xr)) * kSlotBytes);      // slot = kk*2 + h: kk*2 flips bits 1,2 only
-            }
-            // explicit 2-stage software pipeline over the four k16 steps of the chunk: fragments of
-            // step kk+1 are in flight while the 8 MFMAs of step kk issue
-            u32x4 wfA[2], xfA[4], wfB[2], xfB[4];
-            auto read_frags = [&](int kk, u32x4 (&wf)[2], u32x4 (&xf)[4]) {
-#ifndef IDC_ABL_NO_DSREAD
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-                    wf[mi] = *(const u32x4*)(wcur + ((wrow_byte + mi * 32 * kRowBytes + wslot0) ^ (kk * 2 * kSlotBytes)));
-#pragma unroll
-                for (int pj = 0; pj < 4; ++pj)
-                    xf[pj] = *(const u32x4*)(halo + (xaddr[pj] ^ (kk * 2 * kSlotBytes)));
-#else
+            for (int j = 0; j < N_HITEMS; ++j) *(u32x4*)(halo + (tid + j * NT) * kSlotBytes) = hreg[j];
+            const bool last_kc = kc + 1 == cur.nkc;
+            for (int t = 0; t < cur.ntaps; ++t) {
+                const char* const wcur = wbuf + buf * W_BYTES;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // my pieces of this tap's weight tile landed
+                __syncthreads();               // everybody's landed; everybody left the other buffer
+                if (first) { IDC_STAMP(1); first = false; }
+                int dy, dx, tw;
+                tap_of(q, t, dy, dx, tw);
+                // issue the NEXT step's loads: its weight tile (LDS-DMA into the other buffer) and, when
+                // it opens a new chunk / stage, that chunk's halo rows (to registers, written after the
+                // chunk-end barrier) -- they land under this tap's 32 MFMAs per wave
+                if (t + 1 < cur.ntaps) {
+                    int dy2, dx2, tw2;
+                    tap_of(q, t + 1, dy2, dx2, tw2);
+                    dma_w(cur, tw2, kc, buf ^ 1);
+                } else if (!last_kc) {
+                    int dy2, dx2, tw2;
+                    tap_of(q, 0, dy2, dx2, tw2);
+                    dma_w(cur, tw2, kc + 1, buf ^ 1);
+                    load_halo(cur, kc + 1);
+                } else if (q + 1 < nstage) {
+                    const Stage nxt = make_stage(q + 1);
+                    int dy2, dx2, tw2;
+                    tap_of(q + 1, 0, dy2, dx2, tw2);
+                    dma_w(nxt, tw2, 0, buf ^ 1);
+                    load_halo(nxt, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                int xaddr[4];
 #pragma unroll
                 for (int pj = 0; pj < 4; ++pj) {
-                    xf[pj] = u32x4{0x3c003c00u + (unsigned)xaddr[pj], 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
-                    wf[pj & 1] = u32x4{0x3c003c00u + (unsigned)kk, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
-                    asm volatile("" : "+v"(xf[pj]), "+v"(wf[pj & 1]));
+                    const int xr = (wpx * 4 + pj + HALO + dy) * HWP + (px + HALO + dx);
+                    xaddr[pj] = xr * kRowBytes + ((h ^ swz2(xr)) * kSlotBytes);      // slot = kk*2 + h: kk*2 flips bits 1,2 only
                 }
-#endif
-            };
-            auto mma8 = [&](const u32x4 (&wf)[2], const u32x4 (&xf)[4]) {
+                // explicit 2-stage software pipeline over the four k16 steps of the chunk: fragments of
+                // step kk+1 are in flight while the 8 MFMAs of step kk issue
+                u32x4 wfA[2], xfA[4], wfB[2], xfB[4];
+                auto read_frags = [&](int kk, u32x4 (&wf)[2], u32x4 (&xf)[4]) {
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                    for (int mi = 0; mi < 2; ++mi)
+                        wf[mi] = *(const u32x4*)(wcur + ((wrow_byte + mi * 32 * kRowBytes + wslot0) ^ (kk * 2 * kSlotBytes)));
 #pragma unroll
                     for (int pj = 0; pj < 4; ++pj)
-                        acc[mi][pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[mi]),
-                                                                              __builtin_bit_cast(bf16x8, xf[pj]),
-                                                                              acc[mi][pj], 0, 0, 0);
-            };
-            // Pin the issue order (hipcc's scheduler otherwise collapses the pipeline to save
-            // registers): 6 reads up front, then per stage 1 MFMA : 1 ds_read interleaved.
+                        xf[pj] = *(const u32x4*)(halo + (xaddr[pj] ^ (kk * 2 * kSlotBytes)));
+                };
+                auto mma8 = [&](const u32x4 (&wf)[2], const u32x4 (&xf)[4]) {
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int pj = 0; pj < 4; ++pj)
+                            acc[mi][pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[mi]),
+                                                                                  __builtin_bit_cast(bf16x8, xf[pj]),
+                                                                                  acc[mi][pj], 0, 0, 0);
+                };
+                // Pin the issue order (hipcc's scheduler otherwise collapses the pipeline to save
+                // registers): 6 reads up front, then per stage 1 MFMA : 1 ds_read interleaved.
 #define IDC_STAGE_INTERLEAVE()                                                        \
     _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) {                               \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
     }                                                                                 \
     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            read_frags(0, wfA, xfA);
-            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-            read_frags(1, wfB, xfB);
-            mma8(wfA, xfA);
-            IDC_STAGE_INTERLEAVE()
-            read_frags(2, wfA, xfA);
-            mma8(wfB, xfB);
-            IDC_STAGE_INTERLEAVE()
-            read_frags(3, wfB, xfB);
-            mma8(wfA, xfA);
-            IDC_STAGE_INTERLEAVE()
-            mma8(wfB, xfB);
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                read_frags(0, wfA, xfA);
+                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                read_frags(1, wfB, xfB);
+                mma8(wfA, xfA);
+                IDC_STAGE_INTERLEAVE()
+                read_frags(2, wfA, xfA);
+                mma8(wfB, xfB);
+                IDC_STAGE_INTERLEAVE()
+                read_frags(3, wfB, xfB);
+                mma8(wfA, xfA);
+                IDC_STAGE_INTERLEAVE()
+                mma8(wfB, xfB);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
 #undef IDC_STAGE_INTERLEAVE
-            cur ^= 1;
+                buf ^= 1;
+            }
         }
+        IDC_STAMP(8 + q);
+        if (q + 1 < nstage) cur = make_stage(q + 1);
     }
 
     IDC_STAMP(2);
@@ -587,7 +629,6 @@ __global__ __launch_bounds__(WCO* WPX * 64) void conv_igemm_v2(const ConvArgs a)
     const int CoutPad = a.ncg * kCoutGroup;
     const bool has_bn = a.bn_scale != nullptr;
     const int so = a.so, Wout = Ws * so, Hout = Hs * so;
-    const int ro = a.ro[phase], cof = a.co[phase];
     const int cow = (ct * WCO + wco) * kCoutGroup;             // first cout of this wave
     if (a.out_f32) {
         // fp32 outputs (class logits): straight from the MFMA layout, 64 B per lane
@@ -610,56 +651,116 @@ __global__ __launch_bounds__(WCO* WPX * 64) void conv_igemm_v2(const ConvArgs a)
             }
         }
     } else {
-        // bf16 outputs: the MFMA layout gives a lane 2 x 32 B of one pixel, i.e. a store instruction
-        // would touch 64 pieces of 32 different 128-B lines.  Transpose through a wave-private 8 KiB
-        // LDS tile ([64 pixels][128 B], slot ^ (row&7) swizzle, conflict-free both ways) so that every
-        // global_store_dwordx4 writes 8 whole lines (8 lanes x 16 B = the wave's 64 couts of a pixel).
+        // bf16 outputs.  The MFMA layout gives a lane 2 x 16 couts of one pixel, so a direct store
+        // instruction would touch 64 pieces of 32 different 128-B lines (measured: +13..20 % kernel
+        // time).  Instead the raw fp32 accumulators of one pixel row (32 pixels x the wave's 64 couts)
+        // go through a wave-private 8 KiB LDS tile ([32][64] fp32, 16-B slot ^ (row&7): conflict-free
+        // both ways) and come back with lane = (pixel l>>3, 8 consecutive couts l&7): bias, shortcut
+        // sum, activation and eval-BN run on that layout with 8-wide per-lane constants, and every
+        // global load/store instruction covers 8 whole 128-B lines.
+        const bool fuse_head = WCO == 2 && a.head_w != nullptr;
         __syncthreads();                                       // every wave left the halo / weight tiles
-        char* const tbuf = smem + wave * 8192;
-        float bias[2][16], bsc[2][16], bsh[2][16];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int co0 = cow + h * 32 + mi * 16;
-            load16(bias[mi], a.bias + co0);
-            if (has_bn) { load16(bsc[mi], a.bn_scale + co0); load16(bsh[mi], a.bn_shift + co0); }
+        float* const tb = (float*)(smem + wave * 8192);
+        float* const part = (float*)(smem + (NT / 64) * 8192);  // fused head: [wave][pj][32 px][2]
+        const int rr = lane >> 3, cc = lane & 7;
+        const int co8 = cow + cc * 8;
+        float cb[8], cs[8], ct[8], hw0[8], hw1[8];
+        {
+            const float4 b0 = *(const float4*)(a.bias + co8), b1 = *(const float4*)(a.bias + co8 + 4);
+            cb[0] = b0.x; cb[1] = b0.y; cb[2] = b0.z; cb[3] = b0.w; cb[4] = b1.x; cb[5] = b1.y; cb[6] = b1.z; cb[7] = b1.w;
         }
-        const int rr = lane >> 3, cc = lane & 7;               // read side: row within 8, 16-B piece
+        if (has_bn) {
+            const float4 s0 = *(const float4*)(a.bn_scale + co8), s1 = *(const float4*)(a.bn_scale + co8 + 4);
+            const float4 t0 = *(const float4*)(a.bn_shift + co8), t1 = *(const float4*)(a.bn_shift + co8 + 4);
+            cs[0] = s0.x; cs[1] = s0.y; cs[2] = s0.z; cs[3] = s0.w; cs[4] = s1.x; cs[5] = s1.y; cs[6] = s1.z; cs[7] = s1.w;
+            ct[0] = t0.x; ct[1] = t0.y; ct[2] = t0.z; ct[3] = t0.w; ct[4] = t1.x; ct[5] = t1.y; ct[6] = t1.z; ct[7] = t1.w;
+        }
+        if (fuse_head) {
+            const float4 u0 = *(const float4*)(a.head_w + co8), u1 = *(const float4*)(a.head_w + co8 + 4);
+            const float4 q0 = *(const float4*)(a.head_w + 128 + co8), q1 = *(const float4*)(a.head_w + 128 + co8 + 4);
+            hw0[0] = u0.x; hw0[1] = u0.y; hw0[2] = u0.z; hw0[3] = u0.w; hw0[4] = u1.x; hw0[5] = u1.y; hw0[6] = u1.z; hw0[7] = u1.w;
+            hw1[0] = q0.x; hw1[1] = q0.y; hw1[2] = q0.z; hw1[3] = q0.w; hw1[4] = q1.x; hw1[5] = q1.y; hw1[6] = q1.z; hw1[7] = q1.w;
+        }
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int pj = 0; pj < 4; ++pj) {
 #pragma unroll
-            for (int pjj = 0; pjj < 2; ++pjj) {
-                const int pj = half * 2 + pjj;
-                const int sy = ty0 + wpx * 4 + pj, sx = tx0 + px;
-                const bool inside = sy < Hs && sx < Ws;
-                const size_t opix = ((size_t)n * Hout + (sy * so + ro)) * Wout + (sx * so + cof);
-                const int row = pjj * 32 + px;
+            for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    float v[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = acc[mi][pj][r];
-                    if (inside || a.resid == nullptr)
-                        epilogue_values16(a, v, opix * CoutPad + cow + h * 32 + mi * 16, bias[mi], bsc[mi], bsh[mi], has_bn);
-                    uint4 p0, p1;
-                    pack16_bf16(v, p0, p1);
-                    const int slot = h * 4 + mi * 2;
-                    *(uint4*)(tbuf + row * kRowBytes + ((slot ^ (row & 7)) * kSlotBytes)) = p0;
-                    *(uint4*)(tbuf + row * kRowBytes + (((slot + 1) ^ (row & 7)) * kSlotBytes)) = p1;
+                for (int q = 0; q < 4; ++q) {
+                    const int slot = h * 8 + mi * 4 + q;
+                    *(f32x4*)(tb + px * 64 + ((slot ^ (px & 7)) * 4)) =
+                        f32x4{acc[mi][pj][q * 4 + 0], acc[mi][pj][q * 4 + 1], acc[mi][pj][q * 4 + 2], acc[mi][pj][q * 4 + 3]};
                 }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's tile is complete (same-wave LDS ops are in order)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS ops are in order: the row tile is complete
+            const int sy = ty0 + wpx * 4 + pj;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < 4; ++i) {
                 const int row = i * 8 + rr;
-                const uint4 u = *(const uint4*)(tbuf + row * kRowBytes + ((cc ^ (row & 7)) * kSlotBytes));
-                const int pj = half * 2 + (i >> 2), pxx = (i & 3) * 8 + rr;
-                const int sy = ty0 + wpx * 4 + pj, sx = tx0 + pxx;
-                if (sy < Hs && sx < Ws) {
-                    const size_t opix = ((size_t)n * Hout + (sy * so + ro)) * Wout + (sx * so + cof);
-                    *(uint4*)((unsigned short*)a.out + opix * CoutPad + cow + cc * 8) = u;
+                const f32x4 x0 = *(const f32x4*)(tb + row * 64 + (((2 * cc) ^ (row & 7)) * 4));
+                const f32x4 x1 = *(const f32x4*)(tb + row * 64 + (((2 * cc + 1) ^ (row & 7)) * 4));
+                float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+                const int sx = tx0 + row;
+                const bool inside = sy < Hs && sx < Ws;
+                const size_t oidx = (((size_t)n * Hout + (sy * so + ro)) * Wout + (sx * so + cof)) * CoutPad + co8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += cb[e];
+                if (a.resid != nullptr && inside) {
+                    if (a.resid_bf16) {
+                        const uint4 r4 = *(const uint4*)((const unsigned short*)a.resid + oidx);
+                        const unsigned rw[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[2 * e] += __uint_as_float(rw[e] << 16);
+                            v[2 * e + 1] += __uint_as_float(rw[e] & 0xffff0000u);
+                        }
+                    } else {
+                        const float4 r0 = *(const float4*)((const float*)a.resid + oidx);
+                        const float4 r1 = *(const float4*)((const float*)a.resid + oidx + 4);
+                        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+                        v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+                    }
+                }
+                if (a.act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                } else if (a.act == 2) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+                }
+                if (has_bn) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], cs[e], ct[e]);
+                }
+                if (fuse_head) {
+                    // model_out (1x1, 128 -> 2): 8 couts per lane, the pixel's other 56 in the 7 neighbour lanes
+                    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { s0 = fmaf(v[e], hw0[e], s0); s1 = fmaf(v[e], hw1[e], s1); }
+#pragma unroll
+                    for (int m = 1; m <= 4; m <<= 1) { s0 += __shfl_xor(s0, m, 64); s1 += __shfl_xor(s1, m, 64); }
+                    if (cc == 0) *(float2*)(part + ((wave * 4 + pj) * 32 + row) * 2) = float2{s0, s1};
+                } else if (inside) {
+                    uint4 o;
+                    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+                    o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+                    *(uint4*)((unsigned short*)a.out + oidx) = o;
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads retired before the tile is rewritten
+        }
+        if (fuse_head) {
+            // the two cout waves of a pixel row meet in LDS; wave wco == 0 finishes: lane (px, h) = channel h
+            __syncthreads();
+            if (wco == 0) {
+                const float hb = a.head_b[h];
+#pragma unroll
+                for (int pj = 0; pj < 4; ++pj) {
+                    const float p = part[((wave * 4 + pj) * 32 + px) * 2 + h] + part[(((wave + 1) * 4 + pj) * 32 + px) * 2 + h];
+                    const int sy = ty0 + wpx * 4 + pj, sx = tx0 + px;
+                    if (sy < Hs && sx < Ws)
+                        a.head_out[(((size_t)n * 2 + h) * Hs + sy) * Ws + sx] = tanhf(p + hb) * a.head_mul;
+                }
+            }
         }
     }
     IDC_STAMP(3);
@@ -682,19 +783,29 @@ static hipError_t launch_conv_v2_t(const ConvArgs& a, hipStream_t s) {
     const int nct = a.ncg / WCO;
     const long long blocks = (long long)a.tiles_x * a.tiles_y * a.N * nct * a.nphase;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((conv_igemm_v2<WCO, WPX, HALO>), dim3((unsigned)blocks), dim3(WCO * WPX * 64), lds, s, a);
+    if (a.in2 != nullptr) {
+        if constexpr (HALO == 1) {           // fused shortcut: 4-phase deconv launches only
+            if (a.nphase != 4 || a.so != 2 || a.si != 1 || a.wgt2 == nullptr) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((conv_igemm_v2<WCO, WPX, 1, true>), dim3((unsigned)blocks), dim3(WCO * WPX * 64), lds, s, a);
+        } else {
+            return hipErrorInvalidValue;
+        }
+    } else {
+        hipLaunchKernelGGL((conv_igemm_v2<WCO, WPX, HALO, false>), dim3((unsigned)blocks), dim3(WCO * WPX * 64), lds, s, a);
+    }
     return hipGetLastError();
 }
 
-#define IDC_FOR_EACH_CONV_V2(X)                                                                 \
-    X(4, 2, 0) X(4, 2, 1) X(4, 2, 2) X(2, 4, 0) X(2, 4, 1) X(2, 4, 2) X(2, 2, 0) X(2, 2, 1) X(2, 2, 2) \
-    X(1, 4, 0) X(1, 4, 1) X(1, 4, 2)
+#define IDC_FOR_EACH_CONV_V2(X) X(4, 2, 0) X(4, 2, 1) X(4, 2, 2) X(2, 4, 0) X(2, 4, 1) X(2, 4, 2)
 
 hipError_t init_kernels_v2() {
     hipError_t e;
 #define X(WCO, WPX, HL)                                                                                     \
-    e = hipFuncSetAttribute((const void*)conv_igemm_v2<WCO, WPX, HL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+    e = hipFuncSetAttribute((const void*)conv_igemm_v2<WCO, WPX, HL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                             (int)conv_v2_lds_bytes_c(WCO, WPX, HL));                                        \
+    if (e != hipSuccess) return e;                                                                          \
+    if (HL == 1) e = hipFuncSetAttribute((const void*)conv_igemm_v2<WCO, WPX, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         (int)conv_v2_lds_bytes_c(WCO, WPX, 1));                            \
     if (e != hipSuccess) return e;
     IDC_FOR_EACH_CONV_V2(X)
 #undef X

@@ -79,6 +79,7 @@ struct LayerBlob {
     size_t w2_off;                // same size, layout 2 (bf16 large-tile kernel) or (size_t)-1
     size_t bias_off;              // fp32 [cout_pad]
     size_t bn_scale_off, bn_shift_off;   // fp32 [cout_pad] or (size_t)-1
+    size_t fbias_off;             // layers with a shortcut sum: fp32 [cout_pad] = bias + the shortcut conv's bias, or (size_t)-1
     int nkc, ncg;
 };
 

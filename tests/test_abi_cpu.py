@@ -99,6 +99,8 @@ def _plan(precision, dist):
         if bnkey:
             off = _al(off); e["s_off"] = off; off += cpad * 4
             off = _al(off); e["t_off"] = off; off += cpad * 4
+        if kind == "dc":           # deconv layers sum a shortcut conv: bias of the fused launch = own + shortcut bias
+            off = _al(off); e["fb_off"] = off; off += cpad * 4
         plan.append(e)
     off = _al(off); head_w = off; off += 1024
     off = _al(off); head_b = off; off += 8
@@ -168,6 +170,10 @@ def test_pack_weights_layout(make_sd, precision, dist):
             s = g_ / np.sqrt(var + 1e-5)
             np.testing.assert_allclose(blob[e["s_off"]:e["s_off"] + e["cout"] * 4].view(np.float32), s, rtol=1e-6)
             np.testing.assert_allclose(blob[e["t_off"]:e["t_off"] + e["cout"] * 4].view(np.float32), b_ - mu * s, rtol=1e-5, atol=1e-6)
+    for dc, short in (("model8up.0", "model3short8.0"), ("model9up.0", "model2short9.0"), ("model10up.0", "model1short10.0")):
+        e = [x for x in plan if x["wkey"] == dc][0]
+        np.testing.assert_array_equal(blob[e["fb_off"]:e["fb_off"] + e["cout"] * 4].view(np.float32),
+                                      sd[dc + ".bias"] + sd[short + ".bias"])
     np.testing.assert_array_equal(blob[head_w:head_w + 1024].view(np.float32), sd["model_out.0.weight"].ravel())
     np.testing.assert_array_equal(blob[head_b:head_b + 8].view(np.float32), sd["model_out.0.bias"])
     # the im2col operand of conv1_1 is 64 wide: K slots 36..63 are zero padding

@@ -85,7 +85,14 @@ def test_bf16_within_stated_tolerance(golden, make_sd, name, tiles):
     assert ("conv_igemm_v2" in kernels) == (tiles == "large"), kernels
     _, _, acts = siggraph_torch.forward(make_sd(seed, style), g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]),
                                         return_acts=True, dtype=torch.float64)
+    # large tiles: the tanh head rides in conv10_2's epilogue and each shortcut conv in its deconv's K loop;
+    # those tensors are never materialised (their consumers are checked instead)
+    table = e.layer_table()
+    fused = set(r["name"] for r in table if r["kernel"].endswith("+head") or r["kernel"].startswith("fused into"))
+    assert (fused == {"conv10_2", "conv3_3_short", "conv2_2_short", "conv1_2_short"}) == (tiles == "large"), fused
     for k in ACT_NAMES:
+        if k in fused:                                         # never materialised: only the head output leaves the kernel
+            continue
         got = e.activation(k, n)
         err = np.abs(got - acts[k]).max()
         assert err <= 0.04 * (1 + np.abs(acts[k]).max()), "layer %s (%s tiles): max-abs err %.3e" % (k, tiles, err)

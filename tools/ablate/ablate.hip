@@ -37,12 +37,27 @@ int main(int argc, char** argv) {
     a.nkc = C / kc; a.ncg = C / 64; a.nphase = 1; a.ntaps = ntaps; a.tiles_x = v2 ? (HW + 31) / 32 : (HW + 15) / 16; a.tiles_y = (HW + 4 * wp - 1) / (4 * wp);
     a.act = 1; a.out_f32 = 0;
     for (int t = 0; t < 9; ++t) { a.dy[t] = (t / 3 - 1) * halo; a.dx[t] = (t % 3 - 1) * halo; a.tw[t] = t; }
+    if (v2 == 2) {      // fused shortcut: 4-phase deconv of `in` (C ch @ HW) + 3x3 conv of in2 (C2 ch @ 2HW)
+        int C2 = argc > 10 ? atoi(argv[10]) : C;
+        void *in2, *w2;
+        size_t act2 = (size_t)N * 4 * HW * HW * C2 * 2, wb2 = (size_t)9 * (C2 / 64) * (C / 64) * 8192;
+        CK(hipMalloc(&in2, act2)); CK(hipMalloc(&w2, wb2));
+        hipLaunchKernelGGL(fill_bf16, dim3(2048), dim3(256), 0, 0, (unsigned short*)in2, act2 / 2, 3u);
+        hipLaunchKernelGGL(fill_bf16, dim3(2048), dim3(256), 0, 0, (unsigned short*)w2, wb2 / 2, 9u);
+        CK(hipFree(out)); CK(hipMalloc(&out, act * 4));
+        CK(hipFree(w)); CK(hipMalloc(&w, (size_t)16 * (C / 64) * (C / 64) * 8192));
+        hipLaunchKernelGGL(fill_bf16, dim3(2048), dim3(256), 0, 0, (unsigned short*)w, (size_t)16 * (C / 64) * (C / 64) * 8192 / 2, 7u);
+        a.out = out; a.wgt = w; a.in2 = in2; a.wgt2 = w2; a.nkc2 = C2 / 64; a.nphase = 4; a.ntaps = 4; a.so = 2;
+        static const int T_k[2][2] = {{1, 3}, {0, 2}}, T_d[2][2] = {{0, -1}, {1, 0}};
+        for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) { int ph = r * 2 + c; a.ro[ph] = r; a.co[ph] = c;
+            for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) { int t = ph * 9 + i * 2 + j; a.dy[t] = T_d[r][i]; a.dx[t] = T_d[c][j]; a.tw[t] = T_k[r][i] * 4 + T_k[c][j]; } }
+    }
     idc::ConvConfig cfg{wm, wp};
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 #define LAUNCH() (v2 ? idc::launch_conv_v2(cfg, halo, a, 0) : idc::launch_conv(prec, cfg, halo, a, 0))
 #ifdef IDC_TIMING
-    int nb = a.tiles_x * a.tiles_y * N * (a.ncg / wm);
-    long long* dbg; CK(hipMalloc(&dbg, (size_t)nb * 64)); CK(hipMemset(dbg, 0, (size_t)nb * 64));
+    int nb = a.tiles_x * a.tiles_y * N * (a.ncg / wm) * a.nphase;
+    long long* dbg; CK(hipMalloc(&dbg, (size_t)nb * 128)); CK(hipMemset(dbg, 0, (size_t)nb * 128));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(idc::g_idc_dbg), &dbg, sizeof(dbg)));
 #endif
     for (int i = 0; i < 5; ++i) CK(LAUNCH());
@@ -52,17 +67,19 @@ int main(int argc, char** argv) {
     for (int i = 0; i < reps; ++i) CK(LAUNCH());
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
-    double flops = 2.0 * N * HW * HW * (double)C * C * ntaps;
+    double flops = v2 == 2 ? 2.0 * N * 4 * HW * HW * (double)C * (4.0 * C + 9.0 * (argc > 10 ? atoi(argv[10]) : C)) : 2.0 * N * HW * HW * (double)C * C * ntaps;
 #ifdef IDC_TIMING
     {
         CK(LAUNCH()); CK(hipDeviceSynchronize());
-        std::vector<long long> h((size_t)nb * 8); CK(hipMemcpy(h.data(), dbg, (size_t)nb * 64, hipMemcpyDeviceToHost));
-        long long t0 = h[0]; for (int b = 0; b < nb; ++b) if (h[b * 8] < t0) t0 = h[b * 8];
+        std::vector<long long> h((size_t)nb * 16); CK(hipMemcpy(h.data(), dbg, (size_t)nb * 128, hipMemcpyDeviceToHost));
+        long long t0 = h[0]; for (int b = 0; b < nb; ++b) if (h[b * 16] < t0) t0 = h[b * 16];
         double s[5] = {0, 0, 0, 0, 0}; long long tend = 0;
-        for (int b = 0; b < nb; ++b) { for (int i = 0; i < 5; ++i) s[i] += (double)(h[b * 8 + i] - (i ? h[b * 8 + i - 1] : t0)); if (h[b * 8 + 4] > tend) tend = h[b * 8 + 4]; }
+        for (int b = 0; b < nb; ++b) { for (int i = 0; i < 5; ++i) s[i] += (double)(h[b * 16 + i] - (i ? h[b * 16 + i - 1] : t0)); if (h[b * 16 + 4] > tend) tend = h[b * 16 + 4]; }
+        if (v2 == 2) { double st[5] = {0,0,0,0,0}; for (int b = 0; b < nb; ++b) for (int q = 0; q < 5; ++q) st[q] += (double)(h[b * 16 + 8 + q] - (q ? h[b * 16 + 8 + q - 1] : h[b * 16 + 1]));
+            printf("  stage spans (mean ticks): deconv %.0f | p00 %.0f | p01 %.0f | p10 %.0f | p11 %.0f\n", st[0] / nb, st[1] / nb, st[2] / nb, st[3] / nb, st[4] / nb); }
         printf("  timing (ticks, mean over %d blocks): start-offset %.0f | prologue %.0f | mainloop %.0f | epilogue-issue %.0f | store-drain %.0f | kernel span %lld\n",
                nb, s[0] / nb, s[1] / nb, s[2] / nb, s[3] / nb, s[4] / nb, tend - t0);
-        for (int b : {0, 1, 8, nb / 2, nb - 1}) printf("   block %5d: start %lld pro %lld main %lld epi %lld drain %lld\n", b, h[b * 8] - t0, h[b * 8 + 1] - h[b * 8], h[b * 8 + 2] - h[b * 8 + 1], h[b * 8 + 3] - h[b * 8 + 2], h[b * 8 + 4] - h[b * 8 + 3]);
+        for (int b : {0, 1, 8, nb / 2, nb - 1}) printf("   block %5d: start %lld pro %lld main %lld epi %lld drain %lld\n", b, h[b * 16] - t0, h[b * 16 + 1] - h[b * 16], h[b * 16 + 2] - h[b * 16 + 1], h[b * 16 + 3] - h[b * 16 + 2], h[b * 16 + 4] - h[b * 16 + 3]);
     }
 #endif
     printf("%-28s N=%d HW=%d C=%d halo=%d cfg=<%d,%d> prec=%d v2=%d ntaps=%d : %.4f ms  %.1f TFLOP/s\n", ABL_NAME, N, HW, C, halo, wm, wp, prec, v2, ntaps, ms, flops / ms / 1e9);

@@ -1,0 +1,7 @@
+#!/bin/bash
+# Register / scratch usage of every kernel in idc_kernels.hip (hipcc remarks), one line each.
+cd "$(dirname "$0")/../interactive_deep_colorization_amd/csrc"
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -I../../include "$@" -c idc_kernels.hip -o /tmp/idc_k.o \
+    -Rpass-analysis=kernel-resource-usage 2>&1 | grep "remark:" | sed 's/ \[-Rpass.*//' |
+  awk '/Function Name:/ {name=$NF} / VGPRs:/ {v=$NF} /AGPRs:/ {a=$NF} /ScratchSize/ {s=$NF} /VGPRs Spill/ {sp=$NF} /TotalSGPRs:/ {sg=$NF}
+       /LDS Size/ {printf "%-62s vgpr %3s agpr %3s sgpr %3s scratch %4s spill %3s\n", name, v, a, sg, s, sp}'
