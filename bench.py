@@ -60,31 +60,37 @@ def seeded_weights():
     return weights.make_state_dict(0, "he")
 
 
-def cpu_baseline(sd, reps=3):
-    """The reference path on the host cores: torch-CPU oracle, N=1, fp32, all cores."""
+def cpu_baseline(sd, budget_s=12.0):
+    """The reference path on the host cores: the torch-CPU oracle (the reference's own ATen/oneDNN kernels,
+    models/pytorch/model.py:148-175 restated batched), N=1 per call as the reference runs it, fp32.
+    A short probe picks the thread count (oneDNN thrashes when oversubscribed: 256 threads on one 256x256
+    image take 22 s), then a bounded sample of about `budget_s` seconds of forwards is timed at that count."""
     import torch
     from interactive_deep_colorization_amd import workloads
     from oracle import siggraph_torch
     ncpu = os.cpu_count() or 1
     L, ab, m = workloads.random_batch(1, H, seed=0)
-    best = None
-    # oneDNN thrashes when oversubscribed (256 threads on one 256x256 image: 22 s), so time a few
-    # thread counts and report the best one, with the thread count actually used
+    probe = {}
     for cores in sorted(set(c for c in (8, 16, 32, 64) if c <= ncpu) or {ncpu}):
         torch.set_num_threads(cores)
         siggraph_torch.forward(sd, L, ab, m, 0.0)                   # warm-up
-        ts = []
-        for _ in range(reps):
-            t0 = time.perf_counter()
-            siggraph_torch.forward(sd, L, ab, m, 0.0)
-            ts.append(time.perf_counter() - t0)
-        p50 = statistics.median(ts)
-        if best is None or p50 < best[0]:
-            best = (p50, cores)
-    p50, cores = best
-    return {"value": round(1.0 / p50, 3), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "%d x one 256x256 image (N=1, fp32, torch CPU oracle = the reference's ATen kernels) at the "
-                      "best of 8/16/32/64 threads on a %d-cpu host, p50 %.3f s" % (reps, ncpu, p50)}
+        t0 = time.perf_counter()
+        siggraph_torch.forward(sd, L, ab, m, 0.0)
+        probe[cores] = time.perf_counter() - t0
+    cores = min(probe, key=probe.get)
+    torch.set_num_threads(cores)
+    n_img = max(5, min(200, int(budget_s / probe[cores])))
+    ts = []
+    for i in range(n_img):
+        Li, abi, mi = workloads.random_batch(1, H, seed=0, start=i)
+        t0 = time.perf_counter()
+        siggraph_torch.forward(sd, Li, abi, mi, 0.0)
+        ts.append(time.perf_counter() - t0)
+    total = sum(ts)
+    return {"value": round(n_img / total, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "%d distinct 256x256 images of the bench workload, one per call (N=1, fp32, torch CPU oracle = the "
+                      "reference's ATen kernels), %d threads (best of 8/16/32/64 probed) on a %d-cpu host: %.1f s, "
+                      "p50 %.3f s per image" % (n_img, cores, ncpu, total, statistics.median(ts))}
 
 
 def measure_latency(sd, device):
@@ -182,6 +188,7 @@ def main():
     # ---- accounting -------------------------------------------------------------------------------------
     table = e.layer_table()
     conv_rows = [(r, float(layer_ms[r["index"]])) for r in table if r["kernel"].startswith("conv_igemm")]
+    traffic = _pmc_traffic()
     conv_ms = sum(ms for _, ms in conv_rows)
     conv_flops = sum(r["flops"] for r, _ in conv_rows) * nb                 # algorithmic, per launch-set
     other_ms = float(sum(layer_ms)) - conv_ms
@@ -210,9 +217,14 @@ def main():
                    "parallelism": "independent images sharded over %d GPU(s); one RCCL weight broadcast" % world,
                    "weights_broadcast_ms": sc.weights_broadcast_ms},
         "roofline": {"bound": "mfma", "achieved": round(achieved_tflops, 2), "peak": peak, "unit": "TFLOP/s",
-                     "frac": round(achieved_tflops / peak, 4), "traffic": _pmc_traffic(),
-                     "kernel": "conv_igemm<%s> (29 launches per forward)" % args.precision,
+                     "frac": round(achieved_tflops / peak, 4), "traffic": traffic.get("conv_family_bytes_per_forward"),
+                     "kernel": "conv_igemm family (conv_igemm_v2 / conv_igemm, %s): the %d conv/deconv launches of one "
+                               "forward taken together" % (args.precision, len(conv_rows)),
+                     "launches_per_forward": len(conv_rows),
                      "algorithmic_flop_per_forward": conv_flops,
+                     "avg_launch_us": round(conv_ms / max(len(conv_rows), 1) * 1e3, 2),
+                     "traffic_per_launch": traffic.get("conv_family_bytes_per_launch"),
+                     "traffic_all_kernels_per_forward": traffic.get("hbm_bytes_per_forward"),
                      "conv_ms_per_forward": round(conv_ms, 4), "other_kernels_ms_per_forward": round(other_ms, 4),
                      "slowest_layers_ms": {r["name"]: round(ms, 4) for r, ms in worst},
                      "whole_forward_frac": round(FLOP_PER_IMAGE_256 * nb / (ms_per_step * 1e-3) / 1e12 / peak, 4)},
@@ -232,14 +244,17 @@ def main():
 
 
 def _pmc_traffic():
-    """HBM bytes per forward from the rocprofv3 PMC passes, if a summary was committed
-    (profiles/pmc_traffic.json, produced by tools/pmc_traffic.py); else null."""
+    """HBM bytes from the rocprofv3 PMC passes of this same command (profiles/pmc_traffic.json, written by
+    tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE passes with the gfx950 corrections of
+    MI355X_MICROARCH.md); empty when no summary is committed."""
     p = os.path.join(REPO, "profiles", "pmc_traffic.json")
     try:
         with open(p) as f:
-            return json.load(f).get("hbm_bytes_per_forward")
+            d = json.load(f)
+        d["conv_family_bytes_per_forward"] = d["conv_family_bytes_per_launch"] * d["conv_family_launches_per_forward"]
+        return d
     except Exception:
-        return None
+        return {}
 
 
 if __name__ == "__main__":
