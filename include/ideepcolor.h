@@ -47,6 +47,8 @@ typedef enum idc_precision { IDC_FP32 = 0, IDC_BF16 = 1 } idc_precision;
 /* idc_create flags */
 #define IDC_FLAG_DIST_HEAD   0x1u  /* also build model_class (529-bin) head: SIGGRAPHGenerator(dist=True), model.py:105,159-160 */
 #define IDC_FLAG_HIP_GRAPH   0x2u  /* replay the forward as one hipGraph (batch-1 click latency path) */
+#define IDC_FLAG_GLOBAL_HINTS 0x4u /* also build the Global-Hints branch of models/global_model/deploy_nodist.prototxt:37-172,
+                                      501-518 (needs the glob.* tensors, see idc_set_global_hints) */
 
 /* ---- library ------------------------------------------------------------------------------- */
 int idc_version(void);
@@ -117,6 +119,18 @@ int idc_forward_device(idc_handle h, int n, const float* d_L_mc, const float* d_
  * its nearest x4 upsample, model.py:160: out_cl[:, :, y, x] == dist_q[:, :, y/4, x/4]).         */
 int idc_forward_dist(idc_handle h, int n, const float* L_mc, const float* ab, const float* mask,
                      float maskcent, float* out_ab, float* dist_q);
+/* ---- Global Hints: replaces the glob_ab_313_mask / s_avg_mask inputs of the Caffe global net
+ *      (models/global_model/deploy_nodist.prototxt:7-18) as filled by ColorizeImageCaffeGlobDist.net_forward
+ *      (colorize_image.py:451-459).  Needs IDC_FLAG_GLOBAL_HINTS.  glob_ab_313_mask [n,314] = 313-bin ab
+ *      histogram + 0/1 flag; s_avg_mask [n,2] = mean saturation + flag, or NULL for zeros (the reference
+ *      wrapper never fills it).  The values stay in effect for every later forward (images beyond n and a
+ *      handle that was never given hints see all-zero inputs -- which is what the reference feeds for
+ *      glob_dist == -1: the branch still runs and adds BN(relu(bias)) chains to conv4_3norm).
+ *      Weights: 1x1 convs "glob.s_conv1", "glob.glob_conv1" .. "glob.glob_conv4" (.weight (512,Cin,1,1), .bias)
+ *      and BatchNorms "glob.bn1" .. "glob.bn4" (weight, bias, running_mean, running_var) -- the Caffe layer
+ *      names of the prototxt, in the key style of the converted caffemodel.pth. ----------------------- */
+int idc_set_global_hints(idc_handle h, int n, const float* glob_ab_313_mask, const float* s_avg_mask);
+int idc_clear_global_hints(idc_handle h);
 int idc_sync(idc_handle h);
 /* The hipStream_t all work of this handle is enqueued on (as void*). */
 void* idc_stream(idc_handle h);

@@ -313,13 +313,16 @@ class ColorizeImageCaffe(ColorizeImageBase):
         self.pts_in_hull_path = os.path.join(_PKG_DIR, 'color_bins', 'pts_in_hull.npy')
         self.pts_in_hull = np.load(self.pts_in_hull_path) if os.path.exists(self.pts_in_hull_path) else None
 
+    _global_hints = False
+
     def prep_net(self, gpu_id, prototxt_path='', caffemodel_path='', state_dict=None):
         print('gpu_id = %d, net_path = %s, model_path = %s' % (gpu_id, prototxt_path, caffemodel_path))
         if gpu_id == -1:
             raise RuntimeError('cpu mode is not available: this backend runs on gfx950 only')
         sd = read_state_dict(caffemodel_path) if state_dict is None else state_dict
         self.gpu_id = gpu_id
-        self.net = HipColorizer(H=self.Xd, W=self.Xd, max_batch=1, precision=self.precision, device=int(gpu_id))
+        self.net = HipColorizer(H=self.Xd, W=self.Xd, max_batch=1, precision=self.precision, device=int(gpu_id),
+                                global_hints=self._global_hints)
         self.net.set_io_scales(l_div=1., ab_div=1., mask_mul=1., out_mul=100.)
         self.net.load_state_dict(sd)
         self.net_set = True
@@ -329,3 +332,44 @@ class ColorizeImageCaffe(ColorizeImageBase):
             return -1
         raw = self.net.forward(self.img_l_mc, self.input_ab_mc, self.input_mask_mult, 0.0)[0]
         return self._finish_forward(raw)
+
+
+class ColorizeImageCaffeGlobDist(ColorizeImageCaffe):
+    """Caffe colorization with an additional global ab histogram as input (``:445-463``): the Global-Hints
+    net ``models/global_model/deploy_nodist.prototxt``.  Its ``conv1_1`` sees only L (``bw_conv1_1``,
+    prototxt ``:189-202``; the ab/mask planes are silenced ``:28-32``), and a 314-d histogram+flag vector
+    (plus a 2-d saturation vector the wrapper leaves at zero) runs through four 1x1 conv/ReLU/BN stages and
+    is added to ``conv4_3norm`` at every position (``:37-172,501-518``).  The state_dict uses the torch key
+    names for the trunk plus ``glob.*`` for the branch (see ``include/ideepcolor.h``); a ``model1.0.weight``
+    with one input channel (L only) is widened to four with zero ab/mask columns."""
+    _global_hints = True
+
+    def __init__(self, Xd=256, precision='fp32'):
+        ColorizeImageCaffe.__init__(self, Xd, precision=precision)
+        self.glob_mask_mult = 1.
+        self.glob_layer = 'glob_ab_313_mask'
+
+    def prep_net(self, gpu_id, prototxt_path='', caffemodel_path='', state_dict=None):
+        sd = dict(read_state_dict(caffemodel_path) if state_dict is None else state_dict)
+        w = np.asarray(sd['model1.0.weight'])
+        if w.shape[1] == 1:                                   # bw_conv1_1 only: ab / mask never reach the net
+            w4 = np.zeros((w.shape[0], 4) + tuple(w.shape[2:]), np.float32)
+            w4[:, :1] = w
+            sd['model1.0.weight'] = w4
+        ColorizeImageCaffe.prep_net(self, gpu_id, prototxt_path, caffemodel_path, state_dict=sd)
+
+    def net_forward(self, input_ab, input_mask, glob_dist=-1):
+        # glob_dist is a 313 array, or -1 (reference :451-459)
+        if not self.net_set:
+            print('I need to have a net!')
+            return -1
+        g = np.zeros((1, 314), np.float32)
+        if np.array(glob_dist).flatten()[0] != -1:
+            g[0, :313] = np.asarray(glob_dist, np.float32).ravel()
+            g[0, 313] = self.glob_mask_mult
+        self.net.set_global_hints(g)
+        self.output_rgb = ColorizeImageCaffe.net_forward(self, input_ab, input_mask)
+        if isinstance(self.output_rgb, int):
+            return self.output_rgb
+        self._set_out_ab_()
+        return self.output_rgb

@@ -28,7 +28,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 BlobPlan make_blob_plan(int precision, unsigned flags) {
     BlobPlan p;
     p.precision = precision;
-    p.flags = flags & IDC_FLAG_DIST_HEAD;
+    p.flags = flags & (IDC_FLAG_DIST_HEAD | IDC_FLAG_GLOBAL_HINTS);
     const auto& specs = layer_specs();
     size_t off = sizeof(BlobHeader);
     const int kc = kc_elems(precision);
@@ -57,6 +57,8 @@ BlobPlan make_blob_plan(int precision, unsigned flags) {
     }
     off = align_up(off, 256); p.head_w_off = off; off += 2 * 128 * 4;
     off = align_up(off, 256); p.head_b_off = off; off += 2 * 4;
+    p.glob_off = (size_t)-1;
+    if (flags & IDC_FLAG_GLOBAL_HINTS) { off = align_up(off, 256); p.glob_off = off; off += glob_param_floats() * 4; }
     p.total_bytes = align_up(off, 256);
     return p;
 }
@@ -226,6 +228,49 @@ static int pack_weights_impl(int precision, unsigned flags, const idc_tensor_des
         memcpy(base + plan.head_w_off, w->data, 2 * 128 * 4);
         memcpy(base + plan.head_b_off, b->data, 2 * 4);
     }
+    if (plan.glob_off != (size_t)-1) {
+        // Global-hints branch (deploy_nodist.prototxt:37-172): stage 1 = glob_conv1 (314 in) + s_conv1 (2 in) summed
+        // before the ReLU (Eltwise :66-72), stages 2..4 = glob_conv2..4; each followed by ReLU then BatchNorm.
+        // Stored transposed [k][512] + (bias, bn scale, bn shift) per stage, all fp32.
+        float* gp = (float*)(base + plan.glob_off);
+        auto conv1x1 = [&](const char* key, int cin, const TensorView** w, const TensorView** b) -> bool {
+            const std::string wk = std::string(key) + ".weight", bk = std::string(key) + ".bias";
+            return need(wk, w) && need(bk, b) && dims_are(**w, {kGlobC, cin, 1, 1}) && dims_are(**b, {kGlobC});
+        };
+        auto bn_fold = [&](const char* key, float* sc, float* sh) -> bool {
+            const TensorView *g = nullptr, *be = nullptr, *mu = nullptr, *var = nullptr;
+            const std::string p = key;
+            if (!need(p + ".weight", &g) || !need(p + ".bias", &be) || !need(p + ".running_mean", &mu) ||
+                !need(p + ".running_var", &var)) return false;
+            if (!dims_are(*g, {kGlobC}) || !dims_are(*be, {kGlobC}) || !dims_are(*mu, {kGlobC}) || !dims_are(*var, {kGlobC})) return false;
+            for (int c = 0; c < kGlobC; ++c) {
+                const double sd_ = (double)g->data[c] / sqrt((double)var->data[c] + 1e-5);
+                sc[c] = (float)sd_; sh[c] = (float)((double)be->data[c] - (double)mu->data[c] * sd_);
+            }
+            return true;
+        };
+        const TensorView *wg = nullptr, *bg = nullptr, *ws = nullptr, *bs = nullptr;
+        if (!conv1x1("glob.glob_conv1", 314, &wg, &bg) || !conv1x1("glob.s_conv1", 2, &ws, &bs))
+            return fail(err, IDC_ERR_MISSING_KEY, "missing or mis-shaped global-hints keys 'glob.glob_conv1' / 'glob.s_conv1'");
+        for (int k = 0; k < 314; ++k) for (int c = 0; c < kGlobC; ++c) gp[(size_t)k * kGlobC + c] = wg->data[(size_t)c * 314 + k];
+        for (int k = 0; k < 2; ++k) for (int c = 0; c < kGlobC; ++c) gp[(size_t)(314 + k) * kGlobC + c] = ws->data[(size_t)c * 2 + k];
+        float* q = gp + (size_t)kGlobIn * kGlobC;
+        for (int c = 0; c < kGlobC; ++c) q[c] = bg->data[c] + bs->data[c];
+        if (!bn_fold("glob.bn1", q + kGlobC, q + 2 * kGlobC))
+            return fail(err, IDC_ERR_MISSING_KEY, "missing or mis-shaped BatchNorm keys under 'glob.bn1'");
+        q += 3 * kGlobC;
+        for (int st = 2; st <= 4; ++st) {
+            char ck[32], bk[32];
+            snprintf(ck, sizeof(ck), "glob.glob_conv%d", st); snprintf(bk, sizeof(bk), "glob.bn%d", st);
+            const TensorView *w = nullptr, *b = nullptr;
+            if (!conv1x1(ck, kGlobC, &w, &b)) return fail(err, IDC_ERR_MISSING_KEY, "missing or mis-shaped key '%s'", ck);
+            for (int k = 0; k < kGlobC; ++k) for (int c = 0; c < kGlobC; ++c) q[(size_t)k * kGlobC + c] = w->data[(size_t)c * kGlobC + k];
+            float* r = q + (size_t)kGlobC * kGlobC;
+            for (int c = 0; c < kGlobC; ++c) r[c] = b->data[c];
+            if (!bn_fold(bk, r + kGlobC, r + 2 * kGlobC)) return fail(err, IDC_ERR_MISSING_KEY, "missing or mis-shaped BatchNorm keys under '%s'", bk);
+            q = r + 3 * kGlobC;
+        }
+    }
     BlobHeader h;
     memset(&h, 0, sizeof(h));
     h.magic = kBlobMagic; h.version = IDC_VERSION; h.precision = (uint32_t)precision; h.flags = plan.flags;
@@ -278,6 +323,8 @@ struct idc_context {
     float *h_in = nullptr, *h_out = nullptr, *h_dist = nullptr;
     float *d_L = nullptr, *d_ab = nullptr, *d_mask = nullptr, *d_out = nullptr, *d_dist = nullptr;
     float* d_scratch = nullptr; size_t scratch_bytes = 0;
+    float *d_glob_in = nullptr, *d_glob_vec = nullptr;   // global hints: [max_batch][316] inputs, [max_batch][512] branch output
+    int t_conv4_3 = -1;
     bool profiling = false;
     std::vector<hipEvent_t> ev;          // kProfRing slots x 2 per timed step: [pack, layers..., head, softmax]
     int n_timed = 0;
@@ -433,6 +480,7 @@ static int build_graph(idc_context* c) {
     }
     c->t_conv10_2 = find_tensor(c, "conv10_2");
     c->t_logits = find_tensor(c, "class_logits");
+    c->t_conv4_3 = find_tensor(c, "conv4_3");
     return IDC_OK;
 }
 
@@ -452,6 +500,11 @@ static int alloc_graph(idc_context* c) {
         HIPCHK(c, hipMalloc((void**)&c->d_dist, dq));
         HIPCHK(c, hipHostMalloc((void**)&c->h_dist, dq, hipHostMallocDefault));
     }
+    if (c->flags & IDC_FLAG_GLOBAL_HINTS) {
+        HIPCHK(c, hipMalloc((void**)&c->d_glob_in, nb * kGlobIn * 4));
+        HIPCHK(c, hipMalloc((void**)&c->d_glob_vec, nb * kGlobC * 4));
+        HIPCHK(c, hipMemset(c->d_glob_in, 0, nb * kGlobIn * 4));
+    }
     c->n_timed = (int)c->layers.size() + 3;
     c->ev.resize((size_t)c->n_timed * 2 * kProfRing);
     for (auto& e : c->ev) HIPCHK(c, hipEventCreate(&e));
@@ -468,6 +521,8 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
     tic();
     HIPCHK(c, launch_pack_input(c->precision, dL, dab, dmask, c->tensors[c->t_input].ptr, n, c->H, c->W, c->l_div,
                                 c->ab_div, c->mask_mul, maskcent, s));
+    if (c->flags & IDC_FLAG_GLOBAL_HINTS)      // four GEMVs per image; its output is consumed by conv4_3's epilogue
+        HIPCHK(c, launch_glob_branch(c->d_glob_in, (const float*)(c->d_blob + c->plan.glob_off), c->d_glob_vec, n, s));
     toc();
     // pass 1: kernel variant per layer, then which shortcut convs ride in their consumer's launch
     for (auto& L : c->layers) {
@@ -500,6 +555,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
         ConvArgs& a = L.args;
         a.in = ti.ptr; a.out = to.ptr;
         a.out_f32 = to.is_f32;
+        a.img_shift = ((c->flags & IDC_FLAG_GLOBAL_HINTS) && L.dst == c->t_conv4_3) ? c->d_glob_vec : nullptr;
         a.wgt = c->d_blob + (L.v2 ? L.blob.w2_off : L.blob.w_off);
         a.bias = (const float*)(c->d_blob + L.blob.bias_off);
         a.bn_scale = L.blob.bn_scale_off != (size_t)-1 ? (const float*)(c->d_blob + L.blob.bn_scale_off) : nullptr;
@@ -581,7 +637,7 @@ static void destroy_ctx(idc_context* c) {
     for (auto& t : c->tensors) if (t.ptr) (void)hipFree(t.ptr);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->own_blob && c->d_blob) (void)hipFree(c->d_blob);
-    void* dev[] = {c->d_L, c->d_ab, c->d_mask, c->d_out, c->d_dist, c->d_scratch};
+    void* dev[] = {c->d_L, c->d_ab, c->d_mask, c->d_out, c->d_dist, c->d_scratch, c->d_glob_in, c->d_glob_vec};
     for (void* p : dev) if (p) (void)hipFree(p);
     void* host[] = {c->h_in, c->h_out, c->h_dist};
     for (void* p : host) if (p) (void)hipHostFree(p);
@@ -755,6 +811,31 @@ int idc_forward_device(idc_handle h, int n, const float* d_L_mc, const float* d_
     rc = run_graph(h, n, d_L_mc, d_ab, d_mask, maskcent, d_out_ab, (h->flags & IDC_FLAG_DIST_HEAD) ? h->d_dist : nullptr);
     if (rc) return rc;
     if (sync) HIPCHK(h, hipStreamSynchronize(h->stream));
+    return IDC_OK;
+}
+
+int idc_set_global_hints(idc_handle h, int n, const float* glob_ab_313_mask, const float* s_avg_mask) {
+    if (!h) return fail(nullptr, IDC_ERR_INVALID_ARG, "null handle");
+    if (!(h->flags & IDC_FLAG_GLOBAL_HINTS)) return fail(&h->err, IDC_ERR_UNSUPPORTED, "handle was created without IDC_FLAG_GLOBAL_HINTS");
+    if (n <= 0 || n > h->max_batch) return fail(&h->err, IDC_ERR_BATCH, "batch %d outside 1..%d", n, h->max_batch);
+    if (!glob_ab_313_mask) return fail(&h->err, IDC_ERR_INVALID_ARG, "null glob_ab_313_mask");
+    HIPCHK(h, hipSetDevice(h->device));
+    std::vector<float> host((size_t)h->max_batch * kGlobIn, 0.f);
+    for (int i = 0; i < n; ++i) {
+        memcpy(&host[(size_t)i * kGlobIn], glob_ab_313_mask + (size_t)i * 314, 314 * 4);
+        if (s_avg_mask) memcpy(&host[(size_t)i * kGlobIn + 314], s_avg_mask + (size_t)i * 2, 2 * 4);
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(h->d_glob_in, host.data(), host.size() * 4, hipMemcpyHostToDevice));
+    return IDC_OK;
+}
+
+int idc_clear_global_hints(idc_handle h) {
+    if (!h) return fail(nullptr, IDC_ERR_INVALID_ARG, "null handle");
+    if (!(h->flags & IDC_FLAG_GLOBAL_HINTS)) return fail(&h->err, IDC_ERR_UNSUPPORTED, "handle was created without IDC_FLAG_GLOBAL_HINTS");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemset(h->d_glob_in, 0, (size_t)h->max_batch * kGlobIn * 4));
     return IDC_OK;
 }
 

@@ -21,6 +21,8 @@ struct ConvArgs {
     const float* bias;      // [CoutPad]
     const float* bn_scale;  // optional [CoutPad]: y = act(.)*scale + shift  (eval-BN after ReLU)
     const float* bn_shift;
+    const float* img_shift; // optional fp32 [N][CoutPad]: per-image vector added after the BN affine (global hints:
+                            // glob_conv4norm_rep + conv4_3norm, models/global_model/deploy_nodist.prototxt:501-518)
     int N, Hs, Ws;
     int si, so;
     int nkc;                // Cin / KC   (KC = 128 B of channels)
@@ -71,6 +73,14 @@ hipError_t launch_head(int precision, const void* x, const float* w, const float
 // NHWC fp32 logits [npix][cstride] -> NCHW fp32 probabilities [N][nclass][H][W]
 hipError_t launch_softmax_nchw(const float* logits, float* out, int N, int H, int W, int nclass,
                                int cstride, float temperature, hipStream_t s);
+// Global-hints branch (models/global_model/deploy_nodist.prototxt:37-172): per image
+//   y1 = BN1(relu(Wg g + bg + Ws s + bs)),  y_{i+1} = BN_{i+1}(relu(W_{i+1} y_i + b_{i+1})), i = 1..3  ->  out [N][512]
+// in [N][316] = 314 histogram+flag values then the 2 saturation values; params = the packed fp32 section
+// described at glob_param_floats() (transposed weights [k][512], then bias / BN scale / BN shift).
+hipError_t launch_glob_branch(const float* in, const float* params, float* out, int N, hipStream_t s);
+constexpr int kGlobIn = 316, kGlobC = 512;
+constexpr size_t glob_param_floats() { return (size_t)kGlobIn * kGlobC + 3 * kGlobC + 3 * ((size_t)kGlobC * kGlobC + 3 * kGlobC); }
+
 // layout converters for the single-operator test entry points and idc_get_activation
 hipError_t launch_nchw_to_nhwc(int precision, const float* src, void* dst, int N, int C, int H, int W,
                                int Cpad, hipStream_t s);

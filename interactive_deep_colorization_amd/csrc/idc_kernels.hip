@@ -64,7 +64,8 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
 // Fused epilogue arithmetic for 16 consecutive output channels of one pixel (in place):
 // v = act(v + bias [+ resid]) [* bn_scale + bn_shift]
 __device__ __forceinline__ void epilogue_values16(const ConvArgs& a, float (&v)[16], size_t oidx, const float* bias,
-                                                  const float* bsc, const float* bsh, bool has_bn) {
+                                                  const float* bsc, const float* bsh, bool has_bn,
+                                                  const float* ishift = nullptr) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] += bias[i];
     if (a.resid != nullptr) {
@@ -96,6 +97,13 @@ __device__ __forceinline__ void epilogue_values16(const ConvArgs& a, float (&v)[
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = fmaf(v[i], bsc[i], bsh[i]);
     }
+    if (ishift != nullptr) {                     // per-image vector (16 consecutive channels) after the BN affine
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 g = *(const float4*)(ishift + q * 4);
+            v[q * 4 + 0] += g.x; v[q * 4 + 1] += g.y; v[q * 4 + 2] += g.z; v[q * 4 + 3] += g.w;
+        }
+    }
 }
 
 __device__ __forceinline__ void pack16_bf16(const float (&v)[16], uint4& p0, uint4& p1) {
@@ -108,8 +116,9 @@ __device__ __forceinline__ void pack16_bf16(const float (&v)[16], uint4& p0, uin
 // epilogue_values16 + a direct store from the MFMA layout: 32 B (bf16) or 64 B (fp32) per lane.
 template <bool OUT_BF16>
 __device__ __forceinline__ void epilogue16(const ConvArgs& a, float (&v)[16], size_t oidx, const float* bias,
-                                           const float* bsc, const float* bsh, bool has_bn) {
-    epilogue_values16(a, v, oidx, bias, bsc, bsh, has_bn);
+                                           const float* bsc, const float* bsh, bool has_bn,
+                                           const float* ishift = nullptr) {
+    epilogue_values16(a, v, oidx, bias, bsc, bsh, has_bn, ishift);
     if (!OUT_BF16 || a.out_f32) {
         float* o = (float*)a.out + oidx;
 #pragma unroll
@@ -332,7 +341,8 @@ __global__ __launch_bounds__(WM* WP * 64) void conv_igemm(const ConvArgs a) {
             for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[ci * 4 + r] = acc[ci][pj][r];
-            epilogue16<sizeof(T) == 2>(a, v, opix * CoutPad + co0, bias, bsc, bsh, has_bn);
+            epilogue16<sizeof(T) == 2>(a, v, opix * CoutPad + co0, bias, bsc, bsh, has_bn,
+                                       a.img_shift ? a.img_shift + (size_t)n * CoutPad + co0 : nullptr);
         }
     }
 }
@@ -646,7 +656,8 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
                     float v[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) v[r] = acc[mi][pj][r];
-                    epilogue16<true>(a, v, opix * CoutPad + co0, bias, bsc, bsh, has_bn);
+                    epilogue16<true>(a, v, opix * CoutPad + co0, bias, bsc, bsh, has_bn,
+                                     a.img_shift ? a.img_shift + (size_t)n * CoutPad + co0 : nullptr);
                 }
             }
         }
@@ -730,6 +741,12 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
                 if (has_bn) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], cs[e], ct[e]);
+                }
+                if (a.img_shift != nullptr) {            // global hints: per-image vector after the BN affine
+                    const float4 g0 = *(const float4*)(a.img_shift + (size_t)n * CoutPad + co8);
+                    const float4 g1 = *(const float4*)(a.img_shift + (size_t)n * CoutPad + co8 + 4);
+                    v[0] += g0.x; v[1] += g0.y; v[2] += g0.z; v[3] += g0.w;
+                    v[4] += g1.x; v[5] += g1.y; v[6] += g1.z; v[7] += g1.w;
                 }
                 if (fuse_head) {
                     // model_out (1x1, 128 -> 2): 8 couts per lane, the pixel's other 56 in the 7 neighbour lanes
@@ -990,6 +1007,43 @@ hipError_t launch_softmax_nchw(const float* logits, float* out, int N, int H, in
     const int blocks = (int)(want < 8192 ? want : 8192);
     hipLaunchKernelGGL(softmax_nchw_kernel, dim3(blocks), dim3(256), 0, s, logits, out, npix, H * W, nclass, cstride,
                        temperature);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Global-hints branch: four 1x1 conv + ReLU + BN stages on a 1x1 "image" = four GEMVs per image
+// (models/global_model/deploy_nodist.prototxt:37-172).  One workgroup per image, thread c owns output
+// channel c; weights are stored transposed [k][512] so that a wave reads 256 contiguous bytes per k.
+// ~1 MMAC per image: latency-bound, runs once per forward ahead of the conv stack.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void glob_branch_kernel(const float* __restrict__ in, const float* __restrict__ p,
+                                                          float* __restrict__ out) {
+    __shared__ float x[kGlobC];
+    const int c = threadIdx.x, n = blockIdx.x;
+    const float* g = in + (size_t)n * kGlobIn;
+    if (c < kGlobIn) x[c] = g[c];
+    __syncthreads();
+    const float* w = p;                                   // stage 1: [316][512], rows 0..313 glob_conv1, 314..315 s_conv1
+    float acc = 0.f;
+    for (int k = 0; k < kGlobIn; ++k) acc = fmaf(w[(size_t)k * kGlobC + c], x[k], acc);
+    const float* q = p + (size_t)kGlobIn * kGlobC;        // bias (bg + bs), bn scale, bn shift
+    float y = fmaf(fmaxf(acc + q[c], 0.f), q[kGlobC + c], q[2 * kGlobC + c]);
+    q += 3 * kGlobC;
+    for (int stage = 0; stage < 3; ++stage) {
+        __syncthreads();
+        x[c] = y;
+        __syncthreads();
+        acc = 0.f;
+        for (int k = 0; k < kGlobC; ++k) acc = fmaf(q[(size_t)k * kGlobC + c], x[k], acc);
+        const float* r = q + (size_t)kGlobC * kGlobC;
+        y = fmaf(fmaxf(acc + r[c], 0.f), r[kGlobC + c], r[2 * kGlobC + c]);
+        q = r + 3 * kGlobC;
+    }
+    out[(size_t)n * kGlobC + c] = y;
+}
+
+hipError_t launch_glob_branch(const float* in, const float* params, float* out, int N, hipStream_t s) {
+    hipLaunchKernelGGL(glob_branch_kernel, dim3(N), dim3(512), 0, s, in, params, out);
     return hipGetLastError();
 }
 

@@ -89,6 +89,7 @@ struct BlobPlan {
     std::vector<LayerBlob> layers;       // parallel to the ACTIVE layer list
     std::vector<int> active;             // indices into layer_specs()
     size_t head_w_off, head_b_off;       // model_out.0: fp32 [2][128], [2]
+    size_t glob_off;                     // global-hints branch parameters (fp32, glob_param_floats()) or (size_t)-1
     size_t total_bytes;
 };
 

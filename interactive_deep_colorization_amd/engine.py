@@ -68,12 +68,16 @@ def set_tile_policy(policy="auto"):
     N.check(N.load().idc_set_tile_policy(TILE_POLICIES[policy] if isinstance(policy, str) else int(policy)))
 
 
-def pack_weights(sd, precision="bf16", dist=False):
+def _flags(dist=False, global_hints=False):
+    return (N.IDC_FLAG_DIST_HEAD if dist else 0) | (N.IDC_FLAG_GLOBAL_HINTS if global_hints else 0)
+
+
+def pack_weights(sd, precision="bf16", dist=False, global_hints=False):
     """Host-only: reference ``state_dict`` -> packed device-ready blob (uint8 ndarray).
     Needs no GPU (used by rank 0 before the RCCL broadcast)."""
     lib = N.load()
     prec = _PREC[precision]
-    flags = N.IDC_FLAG_DIST_HEAD if dist else 0
+    flags = _flags(dist, global_hints)
     nbytes = lib.idc_weights_blob_bytes(prec, flags)
     blob = np.zeros(nbytes, dtype=np.uint8)
     arr, n, keep = _tensor_descs(sd)
@@ -83,7 +87,7 @@ def pack_weights(sd, precision="bf16", dist=False):
 
 
 class HipColorizer(object):
-    def __init__(self, H=256, W=None, max_batch=1, precision="bf16", device=0, dist=False):
+    def __init__(self, H=256, W=None, max_batch=1, precision="bf16", device=0, dist=False, global_hints=False):
         self.lib = N.load()
         self.H, self.W = int(H), int(H if W is None else W)
         self.max_batch = int(max_batch)
@@ -91,7 +95,8 @@ class HipColorizer(object):
         self._prec = _PREC[precision]
         self.dist = bool(dist)
         self.device = int(device)
-        self._flags = N.IDC_FLAG_DIST_HEAD if dist else 0
+        self.global_hints = bool(global_hints)
+        self._flags = _flags(dist, global_hints)
         self._h = ctypes.c_void_p()
         N.check(self.lib.idc_create(self.device, self.H, self.W, self.max_batch, self._prec, self._flags,
                                     ctypes.byref(self._h)))
@@ -133,6 +138,18 @@ class HipColorizer(object):
 
     def set_io_scales(self, l_div=100., ab_div=110., mask_mul=1., out_mul=110.):
         self._chk(self.lib.idc_set_io_scales(self._h, l_div, ab_div, mask_mul, out_mul))
+
+    # ---- global hints (models/global_model/deploy_nodist.prototxt inputs) ------------------
+    def set_global_hints(self, glob_ab_313_mask, s_avg_mask=None):
+        """(n,314) histogram+flag rows and optional (n,2) saturation+flag rows; in effect until cleared."""
+        g = _f32c(np.atleast_2d(glob_ab_313_mask))
+        if g.shape[1] != 314:
+            raise ValueError("glob_ab_313_mask must be (n, 314), got %s" % (g.shape,))
+        sat = None if s_avg_mask is None else _f32c(np.atleast_2d(s_avg_mask), (g.shape[0], 2))
+        self._chk(self.lib.idc_set_global_hints(self._h, g.shape[0], _fptr(g), _fptr(sat) if sat is not None else None))
+
+    def clear_global_hints(self):
+        self._chk(self.lib.idc_clear_global_hints(self._h))
 
     # ---- forward --------------------------------------------------------------------------
     def _prep(self, L_mc, ab, mask):

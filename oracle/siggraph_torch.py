@@ -49,8 +49,22 @@ def _bn(x, sd, key, dtype):
                         training=False, eps=BN_EPS)
 
 
+def global_branch(sd, glob, sat, dtype=torch.float32):
+    """Global-Hints branch, restated from ``models/global_model/deploy_nodist.prototxt:37-172`` (Caffe only in the
+    reference; PARITY UNPINNED: no Caffe here to run it against).  ``glob`` (N,314), ``sat`` (N,2) ->
+    (N,512): ``relu(glob_conv1(g) + s_conv1(s))`` -> BN, then three ``1x1 conv -> ReLU -> BN`` stages
+    (conv, ReLU, BatchNorm order of the prototxt; Eltwise default op = SUM ``:66-72``)."""
+    g = torch.from_numpy(np.ascontiguousarray(np.asarray(glob, np.float32))).to(dtype)[:, :, None, None]
+    s = torch.from_numpy(np.ascontiguousarray(np.asarray(sat, np.float32))).to(dtype)[:, :, None, None]
+    y = F.relu(_conv(g, sd, "glob.glob_conv1", dtype) + _conv(s, sd, "glob.s_conv1", dtype))
+    y = _bn(y, sd, "glob.bn1", dtype)
+    for i in (2, 3, 4):
+        y = _bn(F.relu(_conv(y, sd, "glob.glob_conv%d" % i, dtype)), sd, "glob.bn%d" % i, dtype)
+    return y                                                   # (N,512,1,1)
+
+
 def forward(sd, L_mc, ab, mask, maskcent=0.0, dist=False, dtype=torch.float32,
-            return_acts=False, num_threads=None):
+            return_acts=False, num_threads=None, glob=None, sat=None, l_div=100., ab_div=110., out_mul=110.):
     """Batched restatement.
 
     L_mc (N,1,H,W) in [-50,50]; ab (N,2,H,W) raw Lab ab; mask (N,1,H,W) in {0,1}
@@ -68,7 +82,7 @@ def forward(sd, L_mc, ab, mask, maskcent=0.0, dist=False, dtype=torch.float32,
         B = torch.from_numpy(np.ascontiguousarray(np.asarray(ab, dtype=np.float64))).to(f32)
         M = torch.from_numpy(np.ascontiguousarray(np.asarray(mask, dtype=np.float64))).to(f32)
         M = M - maskcent
-        x = torch.cat((A / 100., B / 110., M), dim=1).to(dtype)          # :148
+        x = torch.cat((A / l_div, B / ab_div, M), dim=1).to(dtype)         # :148 (Caffe twin: l_div = ab_div = 1)
         acts = {}
         relu = F.relu
 
@@ -88,7 +102,14 @@ def forward(sd, L_mc, ab, mask, maskcent=0.0, dist=False, dtype=torch.float32,
         x = relu(_conv(x, sd, "model4.0", dtype)); acts["conv4_1"] = x
         x = relu(_conv(x, sd, "model4.2", dtype)); acts["conv4_2"] = x
         x = relu(_conv(x, sd, "model4.4", dtype))
-        x = _bn(x, sd, "model4.6", dtype); acts["conv4_3"] = x
+        x = _bn(x, sd, "model4.6", dtype)
+        if glob is not None:       # Global Hints: SpatialRepLayer broadcast + Eltwise SUM onto conv4_3norm
+            if sat is None:        # (deploy_nodist.prototxt:501-518; caffe_traininglayers.py:45-46)
+                sat = np.zeros((np.asarray(glob).shape[0], 2), np.float32)
+            gvec = global_branch(sd, glob, sat, dtype)
+            acts["glob_conv4norm"] = gvec
+            x = x + gvec
+        acts["conv4_3"] = x
         for blk, d in (("5", 2), ("6", 2), ("7", 1)):                   # :152-154
             for j, idx in enumerate(("0", "2", "4")):
                 x = relu(_conv(x, sd, "model%s.%s" % (blk, idx), dtype, dilation=d))
@@ -116,7 +137,7 @@ def forward(sd, L_mc, ab, mask, maskcent=0.0, dist=False, dtype=torch.float32,
         up10 = _deconv(conv9_3, sd, "model10up.0", dtype) + short10      # :172
         x = relu(up10); acts["conv10_1"] = x
         x = F.leaky_relu(_conv(x, sd, "model10.1", dtype), 0.2); acts["conv10_2"] = x   # :101-102
-        out = torch.tanh(_conv(x, sd, "model_out.0", dtype)) * 110      # :108-109,174-175
+        out = torch.tanh(_conv(x, sd, "model_out.0", dtype)) * out_mul  # :108-109,174-175 (Caffe twin: x100)
         acts["out_ab"] = out
     res = out.numpy()
     if return_acts:

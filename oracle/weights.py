@@ -41,6 +41,29 @@ LAYER_SPECS = [
 ]
 
 
+GLOB_SPECS = [  # Global-Hints branch (models/global_model/deploy_nodist.prototxt:37-172); our key names
+    ("glob.s_conv1", 2), ("glob.glob_conv1", 314), ("glob.glob_conv2", 512), ("glob.glob_conv3", 512),
+    ("glob.glob_conv4", 512),
+]
+
+
+def add_global_branch(sd, seed=0):
+    """Add seeded ``glob.*`` tensors (1x1 convs + BatchNorms of the Global-Hints branch) to ``sd`` in place.
+    Gains are chosen so that the 512-vector added to conv4_3norm is O(1), i.e. it visibly changes the output."""
+    rs = np.random.RandomState(seed + 4242)
+    for key, cin in GLOB_SPECS:
+        gain = 8.0 if cin == 314 else (1.0 if cin == 2 else np.sqrt(2.0))   # histogram entries are ~1/313
+        sd[key + ".weight"] = (rs.standard_normal((512, cin, 1, 1)) * gain / np.sqrt(cin)).astype(np.float32)
+        sd[key + ".bias"] = rs.uniform(-0.1, 0.3, 512).astype(np.float32)
+    for i in range(1, 5):
+        key = "glob.bn%d" % i
+        sd[key + ".weight"] = rs.uniform(0.8, 1.2, 512).astype(np.float32)
+        sd[key + ".bias"] = rs.uniform(-0.2, 0.2, 512).astype(np.float32)
+        sd[key + ".running_mean"] = rs.uniform(0.0, 0.4, 512).astype(np.float32)
+        sd[key + ".running_var"] = rs.uniform(0.25, 0.6, 512).astype(np.float32)
+    return sd
+
+
 def make_state_dict(seed=0, style="he", include_class=True):
     """Return ``{key: np.ndarray}`` with the reference key set.
 

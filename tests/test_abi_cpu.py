@@ -196,3 +196,28 @@ def test_pack_weights_errors(make_sd):
         engine.pack_weights(no_class, "bf16", dist=True)
     a = engine.pack_weights(sd, "bf16"); b = engine.pack_weights(sd, "bf16")
     assert np.array_equal(a, b)                                        # deterministic bytes (checksummed header)
+
+
+def test_pack_global_hints_section(make_sd):
+    """IDC_FLAG_GLOBAL_HINTS appends the branch parameters (fp32, transposed [k][512] + bias / BN scale / shift
+    per stage); missing glob.* keys are IDC_ERR_MISSING_KEY."""
+    from oracle import weights
+    sd = weights.add_global_branch(dict(make_sd(0, "he")), 0)
+    plain = engine.pack_weights(sd, "fp32")
+    blob = engine.pack_weights(sd, "fp32", global_hints=True)
+    n_f = 316 * 512 + 3 * 512 + 3 * (512 * 512 + 3 * 512)
+    off = (plain.size + 255) // 256 * 256
+    assert blob.size == (off + n_f * 4 + 255) // 256 * 256
+    sec = blob[off:off + n_f * 4].view(np.float32)
+    wg, ws = sd["glob.glob_conv1.weight"][:, :, 0, 0], sd["glob.s_conv1.weight"][:, :, 0, 0]
+    np.testing.assert_array_equal(sec[:314 * 512].reshape(314, 512), wg.T)
+    np.testing.assert_array_equal(sec[314 * 512:316 * 512].reshape(2, 512), ws.T)
+    q = sec[316 * 512:]
+    np.testing.assert_array_equal(q[:512], sd["glob.glob_conv1.bias"] + sd["glob.s_conv1.bias"])
+    s1 = sd["glob.bn1.weight"].astype(np.float64) / np.sqrt(sd["glob.bn1.running_var"].astype(np.float64) + 1e-5)
+    np.testing.assert_allclose(q[512:1024], s1, rtol=1e-6)
+    w2 = q[1536:1536 + 512 * 512].reshape(512, 512)
+    np.testing.assert_array_equal(w2, sd["glob.glob_conv2.weight"][:, :, 0, 0].T)
+    with pytest.raises(N.IdcError) as ei:
+        engine.pack_weights(make_sd(0, "he"), "fp32", global_hints=True)
+    assert ei.value.status == -5
