@@ -47,6 +47,8 @@ typedef enum idc_precision { IDC_FP32 = 0, IDC_BF16 = 1 } idc_precision;
 /* idc_create flags */
 #define IDC_FLAG_DIST_HEAD   0x1u  /* also build model_class (529-bin) head: SIGGRAPHGenerator(dist=True), model.py:105,159-160 */
 #define IDC_FLAG_HIP_GRAPH   0x2u  /* replay the forward as one hipGraph (batch-1 click latency path) */
+#define IDC_FLAG_DIST313     0x8u  /* also build the 313-bin distribution / soft-decode head of
+                                      models/reference_model/deploy_nopred.prototxt:650-850 (needs the pred.* tensors, see idc_forward_dist313) */
 #define IDC_FLAG_GLOBAL_HINTS 0x4u /* also build the Global-Hints branch of models/global_model/deploy_nodist.prototxt:37-172,
                                       501-518 (needs the glob.* tensors, see idc_set_global_hints) */
 
@@ -131,6 +133,20 @@ int idc_forward_dist(idc_handle h, int n, const float* L_mc, const float* ab, co
  *      names of the prototxt, in the key style of the converted caffemodel.pth. ----------------------- */
 int idc_set_global_hints(idc_handle h, int n, const float* glob_ab_313_mask, const float* s_avg_mask);
 int idc_clear_global_hints(idc_handle h);
+/* ---- 313-bin distribution head + annealed-mean soft-decode: the Caffe distribution net
+ *      models/reference_model/deploy_nopred.prototxt:650-850 as driven by ColorizeImageCaffeDist
+ *      (colorize_image.py:466-507).  Needs IDC_FLAG_DIST313.  Hyper-column sum conv3_pred + conv4..7_pred
+ *      (ConvTranspose 4x4 s2) + conv8_pred -> ReLU -> pred_313 (1x1, 313 logits at H/4) -> the two grouped
+ *      bilinear x2 deconvs (kernel set at colorize_image.py:410-413) -> per full-resolution pixel
+ *          dist_S  = softmax(S * logits)                 [n,313,H,W]  (S = 0.2, colorize_image.py:482-485), may be NULL
+ *          pred_ab = W_ab . softmax(2.6 * logits) + b_ab [n,2,H,W]    (W_ab = pts_in_hull.T, colorize_image.py:405-407)
+ *      out_ab (may be NULL) receives the regression head as in idc_forward.
+ *      Weights: "pred.conv3_pred", "pred.conv8_pred" (384,256,3,3); "pred.conv4_pred" .. "pred.conv7_pred"
+ *      ConvTranspose (512,384,4,4); "pred.pred_313" (313,384,1,1); "pred.pred_ab" (2,313,1,1) -- .weight/.bias. */
+int idc_forward_dist313(idc_handle h, int n, const float* L_mc, const float* ab, const float* mask,
+                        float maskcent, float* out_ab, float* pred_ab, float* dist_S);
+/* Temperature of dist_S (the reference's scale_S parameter, colorize_image.py:482-485).  Default 0.2. */
+int idc_set_dist_temperature(idc_handle h, float S);
 int idc_sync(idc_handle h);
 /* The hipStream_t all work of this handle is enqueued on (as void*). */
 void* idc_stream(idc_handle h);

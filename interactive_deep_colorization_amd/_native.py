@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libideepcolor_hip.so")
 
 IDC_FP32, IDC_BF16 = 0, 1
-IDC_FLAG_DIST_HEAD, IDC_FLAG_HIP_GRAPH, IDC_FLAG_GLOBAL_HINTS = 0x1, 0x2, 0x4
+IDC_FLAG_DIST_HEAD, IDC_FLAG_HIP_GRAPH, IDC_FLAG_GLOBAL_HINTS, IDC_FLAG_DIST313 = 0x1, 0x2, 0x4, 0x8
 IDC_OK = 0
 STATUS_NAMES = {0: "IDC_OK", -1: "IDC_ERR_INVALID_ARG", -2: "IDC_ERR_NO_DEVICE", -3: "IDC_ERR_HIP",
                 -4: "IDC_ERR_NO_WEIGHTS", -5: "IDC_ERR_MISSING_KEY", -6: "IDC_ERR_BATCH",
@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = [
     "idc_version", "idc_set_tile_policy", "idc_device_count", "idc_last_error", "idc_create", "idc_destroy", "idc_set_io_scales",
     "idc_weights_blob_bytes", "idc_pack_weights", "idc_set_weights_host", "idc_set_weights_device",
     "idc_load_weights", "idc_weights_device_ptr", "idc_forward", "idc_forward_device", "idc_forward_dist",
-    "idc_set_global_hints", "idc_clear_global_hints", "idc_sync", "idc_stream", "idc_num_layers", "idc_layer_info_get", "idc_set_profiling",
+    "idc_forward_dist313", "idc_set_dist_temperature", "idc_set_global_hints", "idc_clear_global_hints", "idc_sync", "idc_stream", "idc_num_layers", "idc_layer_info_get", "idc_set_profiling",
     "idc_layer_times_ms", "idc_get_activation", "idc_op_conv2d", "idc_op_deconv4x4s2",
 ]
 
@@ -82,6 +82,8 @@ def load():
     proto("idc_forward", ci, [vp, ci, c_float_p, c_float_p, c_float_p, cf, c_float_p])
     proto("idc_forward_device", ci, [vp, ci, vp, vp, vp, cf, vp, ci])
     proto("idc_forward_dist", ci, [vp, ci, c_float_p, c_float_p, c_float_p, cf, c_float_p, c_float_p])
+    proto("idc_forward_dist313", ci, [vp, ci, c_float_p, c_float_p, c_float_p, cf, c_float_p, c_float_p, c_float_p])
+    proto("idc_set_dist_temperature", ci, [vp, cf])
     proto("idc_set_global_hints", ci, [vp, ci, c_float_p, c_float_p])
     proto("idc_clear_global_hints", ci, [vp])
     proto("idc_sync", ci, [vp])

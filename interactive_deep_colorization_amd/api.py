@@ -314,6 +314,7 @@ class ColorizeImageCaffe(ColorizeImageBase):
         self.pts_in_hull = np.load(self.pts_in_hull_path) if os.path.exists(self.pts_in_hull_path) else None
 
     _global_hints = False
+    _dist313 = False
 
     def prep_net(self, gpu_id, prototxt_path='', caffemodel_path='', state_dict=None):
         print('gpu_id = %d, net_path = %s, model_path = %s' % (gpu_id, prototxt_path, caffemodel_path))
@@ -322,7 +323,7 @@ class ColorizeImageCaffe(ColorizeImageBase):
         sd = read_state_dict(caffemodel_path) if state_dict is None else state_dict
         self.gpu_id = gpu_id
         self.net = HipColorizer(H=self.Xd, W=self.Xd, max_batch=1, precision=self.precision, device=int(gpu_id),
-                                global_hints=self._global_hints)
+                                global_hints=self._global_hints, dist313=self._dist313)
         self.net.set_io_scales(l_div=1., ab_div=1., mask_mul=1., out_mul=100.)
         self.net.load_state_dict(sd)
         self.net_set = True
@@ -373,3 +374,74 @@ class ColorizeImageCaffeGlobDist(ColorizeImageCaffe):
             return self.output_rgb
         self._set_out_ab_()
         return self.output_rgb
+
+
+class ColorizeImageCaffeDist(ColorizeImageCaffe):
+    """Caffe model which includes distribution prediction (``:466-561``): the 313-bin net
+    ``models/reference_model/deploy_nopred.prototxt``.  ``net_forward`` returns the colourised image built from
+    ``pred_ab`` (the annealed-mean decode ``sum_q softmax(2.6 l)_q * pts_in_hull[q]``, prototxt ``:826-850``) and
+    keeps ``dist_ab`` = ``dist_ab_S`` (313, X, X) = ``softmax(S * l)`` for ``get_ab_reccs``.  The state_dict carries
+    the trunk under the torch key names plus ``pred.*`` (see ``include/ideepcolor.h``); when ``pred.pred_ab.weight``
+    is absent it is set from ``pts_in_hull`` exactly as the reference does at load time (``:405-407``)."""
+    _dist313 = True
+
+    def __init__(self, Xd=256, precision='fp32'):
+        ColorizeImageCaffe.__init__(self, Xd, precision=precision)
+        self.dist_ab_set = False
+        self.scale_S_layer = 'scale_S'
+        self.dist_ab_S_layer = 'dist_ab_S'
+        grid_path = os.path.join(os.path.dirname(self.pts_in_hull_path), 'pts_grid.npy')
+        hull_path = os.path.join(os.path.dirname(self.pts_in_hull_path), 'in_hull.npy')
+        self.pts_grid = np.load(grid_path) if os.path.exists(grid_path) else None      # 529x2, all points
+        self.in_hull = np.load(hull_path) if os.path.exists(hull_path) else None       # 529 bool
+        self.AB, self.A, self.B = 529, 23, 23
+        self.dist_ab_full = np.zeros((self.AB, self.Xd, self.Xd))
+        self.dist_ab_grid = np.zeros((self.A, self.B, self.Xd, self.Xd))
+        self.dist_entropy = np.zeros((self.Xd, self.Xd))
+
+    def prep_net(self, gpu_id, prototxt_path='', caffemodel_path='', S=.2, state_dict=None):
+        sd = dict(read_state_dict(caffemodel_path) if state_dict is None else state_dict)
+        if 'pred.pred_ab.weight' not in sd:
+            if self.pts_in_hull is None:
+                raise RuntimeError('pred.pred_ab.weight is absent and pts_in_hull.npy was not found at %s'
+                                   % self.pts_in_hull_path)
+            print('Setting ab cluster centers in layer: %s' % self.pred_ab_layer)
+            sd['pred.pred_ab.weight'] = np.ascontiguousarray(np.asarray(self.pts_in_hull, np.float32).T)[:, :, None, None]
+        sd.setdefault('pred.pred_ab.bias', np.zeros(2, np.float32))
+        self._centres = np.asarray(sd['pred.pred_ab.weight'], np.float32)[:, :, 0, 0].T          # 313x2
+        ColorizeImageCaffe.prep_net(self, gpu_id, prototxt_path, caffemodel_path, state_dict=sd)
+        self.S = S
+        self.net.set_dist_temperature(S)
+
+    def net_forward(self, input_ab, input_mask):
+        if ColorizeImageBase.net_forward(self, input_ab, input_mask) == -1:
+            return -1
+        _, pred, dist = self.net.forward_dist313(self.img_l_mc, self.input_ab_mc, self.input_mask_mult, 0.0)
+        ret = self._finish_forward(pred[0])
+        self.dist_ab = dist[0]                                   # in-gamut, 313 x X x X
+        self.dist_ab_set = True
+        if self.in_hull is not None:                             # full 529 grid, as the reference keeps it
+            self.dist_ab_full[self.in_hull, :, :] = self.dist_ab
+            self.dist_ab_grid = self.dist_ab_full.reshape((self.A, self.B, self.Xd, self.Xd))
+        return ret
+
+    def get_ab_reccs(self, h, w, K=5, N=25000, return_conf=False):
+        """Recommended colours at (h, w): N samples of the 313-bin pdf, k-means, sorted by occupancy (``:509-543``)."""
+        if not self.dist_ab_set:
+            print('Need to set prediction first')
+            return 0
+        from sklearn.cluster import KMeans
+        cmf = np.cumsum(self.dist_ab[:, h, w])
+        cmf = cmf / cmf[-1]
+        rnd_pts = np.random.uniform(low=0, high=1.0, size=N)
+        inds = np.minimum(np.digitize(rnd_pts, bins=cmf), 312)
+        rnd_pts_ab = self._centres[inds, :]
+        kmeans = KMeans(n_clusters=K, n_init=10).fit(rnd_pts_ab)
+        k_label_cnt = np.histogram(kmeans.labels_, np.arange(0, K + 1))[0]
+        k_inds = np.argsort(k_label_cnt, axis=0)[::-1]
+        cluster_per = 1. * k_label_cnt[k_inds] / N
+        cluster_centers = kmeans.cluster_centers_[k_inds, :]
+        return (cluster_centers, cluster_per) if return_conf else cluster_centers
+
+    def compute_entropy(self):
+        self.dist_entropy = np.sum(self.dist_ab * np.log(self.dist_ab), axis=0)

@@ -28,13 +28,14 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 BlobPlan make_blob_plan(int precision, unsigned flags) {
     BlobPlan p;
     p.precision = precision;
-    p.flags = flags & (IDC_FLAG_DIST_HEAD | IDC_FLAG_GLOBAL_HINTS);
+    p.flags = flags & (IDC_FLAG_DIST_HEAD | IDC_FLAG_GLOBAL_HINTS | IDC_FLAG_DIST313);
     const auto& specs = layer_specs();
     size_t off = sizeof(BlobHeader);
     const int kc = kc_elems(precision);
     for (int i = 0; i < (int)specs.size(); ++i) {
         const LayerSpec& s = specs[i];
-        if (s.dist_only && !(flags & IDC_FLAG_DIST_HEAD)) continue;
+        if (s.dist_only == 1 && !(flags & IDC_FLAG_DIST_HEAD)) continue;
+        if (s.dist_only == 2 && !(flags & IDC_FLAG_DIST313)) continue;
         LayerBlob lb;
         const int kch = k_channels(s);
         lb.nkc = (s.kind == kConvIm2col) ? (64 / kc) : (kch + kc - 1) / kc;   // conv1_1 operand is 64 wide
@@ -57,6 +58,8 @@ BlobPlan make_blob_plan(int precision, unsigned flags) {
     }
     off = align_up(off, 256); p.head_w_off = off; off += 2 * 128 * 4;
     off = align_up(off, 256); p.head_b_off = off; off += 2 * 4;
+    p.pred_ab_off = (size_t)-1;
+    if (flags & IDC_FLAG_DIST313) { off = align_up(off, 256); p.pred_ab_off = off; off += (2 * 313 + 2) * 4; }
     p.glob_off = (size_t)-1;
     if (flags & IDC_FLAG_GLOBAL_HINTS) { off = align_up(off, 256); p.glob_off = off; off += glob_param_floats() * 4; }
     p.total_bytes = align_up(off, 256);
@@ -228,6 +231,15 @@ static int pack_weights_impl(int precision, unsigned flags, const idc_tensor_des
         memcpy(base + plan.head_w_off, w->data, 2 * 128 * 4);
         memcpy(base + plan.head_b_off, b->data, 2 * 4);
     }
+    if (plan.pred_ab_off != (size_t)-1) {      // pred_ab: 1x1 conv 313 -> 2 (deploy_nopred.prototxt:842-850; weight = pts_in_hull.T)
+        const TensorView *w = nullptr, *b = nullptr;
+        if (!need("pred.pred_ab.weight", &w) || !dims_are(*w, {2, 313, 1, 1}))
+            return fail(err, IDC_ERR_MISSING_KEY, "missing or mis-shaped key 'pred.pred_ab.weight' (2,313,1,1: the ab bin centres)");
+        if (!need("pred.pred_ab.bias", &b) || !dims_are(*b, {2}))
+            return fail(err, IDC_ERR_MISSING_KEY, "missing or mis-shaped key 'pred.pred_ab.bias'");
+        memcpy(base + plan.pred_ab_off, w->data, 2 * 313 * 4);
+        memcpy(base + plan.pred_ab_off + 2 * 313 * 4, b->data, 2 * 4);
+    }
     if (plan.glob_off != (size_t)-1) {
         // Global-hints branch (deploy_nodist.prototxt:37-172): stage 1 = glob_conv1 (314 in) + s_conv1 (2 in) summed
         // before the ReLU (Eltwise :66-72), stages 2..4 = glob_conv2..4; each followed by ReLU then BatchNorm.
@@ -299,7 +311,7 @@ struct Layer {
     bool fused_head = false;             // conv10_2 only: model_out + tanh run in this layer's epilogue
     int fused_short = -1;                // deconv layers: index of the shortcut conv layer riding in this launch's K loop
     bool skip = false;                   // shortcut conv layer fused into its consumer: not launched
-    ConvArgs args;                       // pointers patched per forward where they depend on weights
+    ConvArgs args{};                     // zero-initialised; pointers patched per forward where they depend on weights
     double flops = 0, min_bytes = 0;
 };
 
@@ -324,7 +336,10 @@ struct idc_context {
     float *d_L = nullptr, *d_ab = nullptr, *d_mask = nullptr, *d_out = nullptr, *d_dist = nullptr;
     float* d_scratch = nullptr; size_t scratch_bytes = 0;
     float *d_glob_in = nullptr, *d_glob_vec = nullptr;   // global hints: [max_batch][316] inputs, [max_batch][512] branch output
-    int t_conv4_3 = -1;
+    int t_conv4_3 = -1, t_pred313 = -1;
+    float *d_pred_ab = nullptr, *d_dist313 = nullptr, *h_pred_ab = nullptr, *h_dist313 = nullptr;   // 313 head outputs
+    float dist_S = 0.2f;
+    bool want_dist313 = false;           // the next forward also writes the full-resolution dist_S
     bool profiling = false;
     std::vector<hipEvent_t> ev;          // kProfRing slots x 2 per timed step: [pack, layers..., head, softmax]
     int n_timed = 0;
@@ -465,10 +480,9 @@ static int build_graph(idc_context* c) {
             L.resid = find_tensor(c, s.resid);
             if (L.resid < 0) return fail(&c->err, IDC_ERR_INVALID_ARG, "graph: unknown residual '%s'", s.resid);
         }
-        // fp32 storage: everything on the fp32 path; on the bf16 path only the class logits (the
-        // shortcut-branch partial sums are kept in bf16 and widened again in the consumer's epilogue)
-        L.dst = add_tensor(s.name, s.cout, cout_pad(s.cout), s.level,
-                           c->precision == IDC_FP32 || (s.out_f32 && s.kind == kConv1x1));
+        // fp32 storage: everything on the fp32 path; on the bf16 path the class / 313 logits and the hyper-column
+        // partial sums of the 313 head (LayerSpec.out_f32)
+        L.dst = add_tensor(s.name, s.cout, cout_pad(s.cout), s.level, c->precision == IDC_FP32 || s.out_f32);
         fill_taps(L);
         L.flops = layer_flops(s, c->H, c->W);
         const Tensor& ti = c->tensors[L.src];
@@ -481,6 +495,7 @@ static int build_graph(idc_context* c) {
     c->t_conv10_2 = find_tensor(c, "conv10_2");
     c->t_logits = find_tensor(c, "class_logits");
     c->t_conv4_3 = find_tensor(c, "conv4_3");
+    c->t_pred313 = find_tensor(c, "pred_313");
     return IDC_OK;
 }
 
@@ -499,6 +514,11 @@ static int alloc_graph(idc_context* c) {
         const size_t dq = nb * 529 * (hw / 16) * 4;
         HIPCHK(c, hipMalloc((void**)&c->d_dist, dq));
         HIPCHK(c, hipHostMalloc((void**)&c->h_dist, dq, hipHostMallocDefault));
+    }
+    if (c->flags & IDC_FLAG_DIST313) {
+        HIPCHK(c, hipMalloc((void**)&c->d_pred_ab, nb * hw * 2 * 4));
+        HIPCHK(c, hipHostMalloc((void**)&c->h_pred_ab, nb * hw * 2 * 4, hipHostMallocDefault));
+        HIPCHK(c, hipMalloc((void**)&c->d_dist313, nb * hw * 313 * 4));      // 82 MB per 256x256 image: sized for 288 GB parts
     }
     if (c->flags & IDC_FLAG_GLOBAL_HINTS) {
         HIPCHK(c, hipMalloc((void**)&c->d_glob_in, nb * kGlobIn * 4));
@@ -590,6 +610,11 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
         const Tensor& tl = c->tensors[c->t_logits];
         HIPCHK(c, launch_softmax_nchw((const float*)tl.ptr, ddist, n, tl.H, tl.W, 529, tl.Cpad, 0.2f, s));
     }
+    if (c->flags & IDC_FLAG_DIST313) {         // bilinear x4 + softmax(S.) + softmax(2.6 .) -> pred_ab decode
+        const Tensor& tp = c->tensors[c->t_pred313];
+        HIPCHK(c, launch_dist313((const float*)tp.ptr, (const float*)(c->d_blob + c->plan.pred_ab_off), c->d_pred_ab,
+                                 c->want_dist313 ? c->d_dist313 : nullptr, n, c->H, c->W, tp.Cpad, c->dist_S, 2.6f, s));
+    }
     toc();
     c->last_n = n;
     if (c->profiling) ++c->prof_count;
@@ -625,7 +650,7 @@ static int forward_host(idc_context* c, int n, const float* L_mc, const float* a
     const size_t dq = (size_t)n * 529 * (hw / 16) * 4;
     if (dist_q) HIPCHK(c, hipMemcpyAsync(c->h_dist, c->d_dist, dq, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    memcpy(out_ab, c->h_out, (size_t)n * hw * 2 * 4);
+    if (out_ab != c->h_out) memcpy(out_ab, c->h_out, (size_t)n * hw * 2 * 4);
     if (dist_q) memcpy(dist_q, c->h_dist, dq);
     return IDC_OK;
 }
@@ -637,9 +662,9 @@ static void destroy_ctx(idc_context* c) {
     for (auto& t : c->tensors) if (t.ptr) (void)hipFree(t.ptr);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->own_blob && c->d_blob) (void)hipFree(c->d_blob);
-    void* dev[] = {c->d_L, c->d_ab, c->d_mask, c->d_out, c->d_dist, c->d_scratch, c->d_glob_in, c->d_glob_vec};
+    void* dev[] = {c->d_L, c->d_ab, c->d_mask, c->d_out, c->d_dist, c->d_scratch, c->d_glob_in, c->d_glob_vec, c->d_pred_ab, c->d_dist313};
     for (void* p : dev) if (p) (void)hipFree(p);
-    void* host[] = {c->h_in, c->h_out, c->h_dist};
+    void* host[] = {c->h_in, c->h_out, c->h_dist, c->h_pred_ab};
     for (void* p : host) if (p) (void)hipHostFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -836,6 +861,29 @@ int idc_clear_global_hints(idc_handle h) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemset(h->d_glob_in, 0, (size_t)h->max_batch * kGlobIn * 4));
+    return IDC_OK;
+}
+
+int idc_forward_dist313(idc_handle h, int n, const float* L_mc, const float* ab, const float* mask, float maskcent,
+                        float* out_ab, float* pred_ab, float* dist_S) {
+    int rc = check_forward_args(h, n);
+    if (rc) return rc;
+    if (!(h->flags & IDC_FLAG_DIST313)) return fail(&h->err, IDC_ERR_UNSUPPORTED, "handle was created without IDC_FLAG_DIST313");
+    if (!pred_ab) return fail(&h->err, IDC_ERR_INVALID_ARG, "null pred_ab");
+    const size_t hw = (size_t)h->H * h->W;
+    h->want_dist313 = dist_S != nullptr;
+    rc = forward_host(h, n, L_mc, ab, mask, maskcent, out_ab ? out_ab : h->h_out, nullptr);
+    h->want_dist313 = false;
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpy(pred_ab, h->d_pred_ab, (size_t)n * hw * 2 * 4, hipMemcpyDeviceToHost));
+    if (dist_S) HIPCHK(h, hipMemcpy(dist_S, h->d_dist313, (size_t)n * hw * 313 * 4, hipMemcpyDeviceToHost));
+    return IDC_OK;
+}
+
+int idc_set_dist_temperature(idc_handle h, float S) {
+    if (!h) return fail(nullptr, IDC_ERR_INVALID_ARG, "null handle");
+    if (!(S > 0.f)) return fail(&h->err, IDC_ERR_INVALID_ARG, "temperature must be positive");
+    h->dist_S = S;
     return IDC_OK;
 }
 

@@ -73,6 +73,15 @@ hipError_t launch_head(int precision, const void* x, const float* w, const float
 // NHWC fp32 logits [npix][cstride] -> NCHW fp32 probabilities [N][nclass][H][W]
 hipError_t launch_softmax_nchw(const float* logits, float* out, int N, int H, int W, int nclass,
                                int cstride, float temperature, hipStream_t s);
+// 313-bin head tail (models/reference_model/deploy_nopred.prototxt:776-850): logits fp32 NHWC [N][H/4][W/4][cstride]
+// (313 valid) -> the two grouped bilinear x2 deconvs (fixed kernel, colorize_image.py:410-413; per axis
+// out[4m+j] = ((4-j) in[m] + j in[m+1]) / 4 with in[M] = 0) -> per full-resolution pixel
+//   dist_S [N][313][H][W] = softmax(S * l)  (optional, may be nullptr)
+//   pred_ab [N][2][H][W]  = sum_q softmax(2.6 * l)_q * w_ab[c][q] + b_ab[c]
+// w_ab: fp32 [2][313] then [2] bias.
+hipError_t launch_dist313(const float* logits, const float* w_ab, float* pred_ab, float* dist_S, int N, int H, int W,
+                          int cstride, float S, float T, hipStream_t s);
+
 // Global-hints branch (models/global_model/deploy_nodist.prototxt:37-172): per image
 //   y1 = BN1(relu(Wg g + bg + Ws s + bs)),  y_{i+1} = BN_{i+1}(relu(W_{i+1} y_i + b_{i+1})), i = 1..3  ->  out [N][512]
 // in [N][316] = 314 histogram+flag values then the 2 saturation values; params = the packed fp32 section

@@ -1011,6 +1011,99 @@ hipError_t launch_softmax_nchw(const float* logits, float* out, int N, int H, in
 }
 
 // ------------------------------------------------------------------------------------------------
+// dist313: bilinear x4 upsample of the 313 logits + two channel softmaxes + annealed-mean decode.
+// One wave per 4x4 block of output pixels (they share the same four quarter-resolution neighbours, read once:
+// 4 x 1252 B coalesced); lane l owns bins l, l+64, ... (5 per lane); 64-lane xor-shuffle reductions.
+// HBM-bound only when dist_S is requested (313 floats per output pixel); otherwise L2-resident.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dist313_kernel(const float* __restrict__ logits, const float* __restrict__ w_ab,
+                                                      float* __restrict__ pred_ab, float* __restrict__ dist_S, int N,
+                                                      int H, int W, int cstride, float S, float T) {
+    constexpr int NB = 313, PER = 5;
+    const int lane = threadIdx.x & 63;
+    const int h4 = H >> 2, w4 = W >> 2;
+    const long long nblk = (long long)N * h4 * w4;
+    float wa[PER], wb[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int q = lane + i * 64;
+        wa[i] = q < NB ? w_ab[q] : 0.f;
+        wb[i] = q < NB ? w_ab[NB + q] : 0.f;
+    }
+    const float ba = w_ab[2 * NB], bb = w_ab[2 * NB + 1];
+    const long long stride = (long long)gridDim.x * (blockDim.x >> 6);
+    for (long long blk = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); blk < nblk; blk += stride) {
+        const int n0 = (int)(blk % w4), m0 = (int)((blk / w4) % h4), n = (int)(blk / ((long long)w4 * h4));
+        float l00[PER], l01[PER], l10[PER], l11[PER];
+        const float* base = logits + ((size_t)n * h4 * w4) * cstride;
+        const bool has_r = n0 + 1 < w4, has_d = m0 + 1 < h4;          // beyond the far border the deconv sees zeros
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int q = lane + i * 64;
+            const bool ok = q < NB;
+            l00[i] = ok ? base[((size_t)m0 * w4 + n0) * cstride + q] : 0.f;
+            l01[i] = (ok && has_r) ? base[((size_t)m0 * w4 + n0 + 1) * cstride + q] : 0.f;
+            l10[i] = (ok && has_d) ? base[((size_t)(m0 + 1) * w4 + n0) * cstride + q] : 0.f;
+            l11[i] = (ok && has_r && has_d) ? base[((size_t)(m0 + 1) * w4 + n0 + 1) * cstride + q] : 0.f;
+        }
+        for (int jy = 0; jy < 4; ++jy) {
+            const float wy1 = 0.25f * jy, wy0 = 1.f - wy1;
+            for (int jx = 0; jx < 4; ++jx) {
+                const float wx1 = 0.25f * jx, wx0 = 1.f - wx1;
+                float v[PER];
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    // second x2 stage applied to the first (exactly the composition of the two Caffe layers)
+                    v[i] = wy0 * (wx0 * l00[i] + wx1 * l01[i]) + wy1 * (wx0 * l10[i] + wx1 * l11[i]);
+                    mx = fmaxf(mx, (lane + i * 64) < NB ? v[i] : -3.0e38f);
+                }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+                // softmax is shift-invariant; S, T > 0 so the same max serves both temperatures
+                float es[PER], sumS = 0.f, sumT = 0.f, accA = 0.f, accB = 0.f;
+#pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    const bool ok = (lane + i * 64) < NB;
+                    es[i] = ok ? expf(S * (v[i] - mx)) : 0.f;
+                    const float et = ok ? expf(T * (v[i] - mx)) : 0.f;
+                    sumS += es[i]; sumT += et;
+                    accA = fmaf(et, wa[i], accA); accB = fmaf(et, wb[i], accB);
+                }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) {
+                    sumS += __shfl_xor(sumS, o, 64); sumT += __shfl_xor(sumT, o, 64);
+                    accA += __shfl_xor(accA, o, 64); accB += __shfl_xor(accB, o, 64);
+                }
+                const int y = m0 * 4 + jy, x = n0 * 4 + jx;
+                const size_t hw = (size_t)H * W, pix = (size_t)y * W + x;
+                if (lane == 0) {
+                    pred_ab[((size_t)n * 2 + 0) * hw + pix] = accA / sumT + ba;
+                    pred_ab[((size_t)n * 2 + 1) * hw + pix] = accB / sumT + bb;
+                }
+                if (dist_S != nullptr) {
+                    const float inv = 1.0f / sumS;
+#pragma unroll
+                    for (int i = 0; i < PER; ++i) {
+                        const int q = lane + i * 64;
+                        if (q < NB) dist_S[((size_t)n * NB + q) * hw + pix] = es[i] * inv;
+                    }
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_dist313(const float* logits, const float* w_ab, float* pred_ab, float* dist_S, int N, int H, int W,
+                          int cstride, float S, float T, hipStream_t s) {
+    const long long nblk = (long long)N * (H / 4) * (W / 4);
+    const long long want = (nblk + 3) / 4;
+    const int blocks = (int)(want < 16384 ? want : 16384);
+    hipLaunchKernelGGL(dist313_kernel, dim3(blocks), dim3(256), 0, s, logits, w_ab, pred_ab, dist_S, N, H, W, cstride, S, T);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Global-hints branch: four 1x1 conv + ReLU + BN stages on a 1x1 "image" = four GEMVs per image
 // (models/global_model/deploy_nodist.prototxt:37-172).  One workgroup per image, thread c owns output
 // channel c; weights are stored transposed [k][512] so that a wave reads 256 contiguous bytes per k.

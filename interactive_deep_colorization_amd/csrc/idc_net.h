@@ -26,7 +26,7 @@ struct LayerSpec {
     const char* resid;      // fp32 tensor summed before the activation (model.py:156,170,172) or nullptr
     int out_f32;            // keep the output in fp32 (shortcut branches, class logits)
     int level;              // output resolution = H / level
-    int dist_only;          // only built with IDC_FLAG_DIST_HEAD
+    int dist_only;          // 1: only built with IDC_FLAG_DIST_HEAD; 2: only with IDC_FLAG_DIST313
 };
 
 inline const std::vector<LayerSpec>& layer_specs() {
@@ -51,17 +51,27 @@ inline const std::vector<LayerSpec>& layer_specs() {
         {"conv7_1",       "model7.0",        nullptr,     kConv3x3,    512, 512, 1, 1, 1, "conv6_3",        nullptr,         0, 8, 0},
         {"conv7_2",       "model7.2",        nullptr,     kConv3x3,    512, 512, 1, 1, 1, "conv7_1",        nullptr,         0, 8, 0},
         {"conv7_3",       "model7.4",        "model7.6",  kConv3x3,    512, 512, 1, 1, 1, "conv7_2",        nullptr,         0, 8, 0},
-        {"conv3_3_short", "model3short8.0",  nullptr,     kConv3x3,    256, 256, 1, 1, 0, "conv3_3",        nullptr,         1, 4, 0},
+        {"conv3_3_short", "model3short8.0",  nullptr,     kConv3x3,    256, 256, 1, 1, 0, "conv3_3",        nullptr,         0, 4, 0},
         {"conv8_1",       "model8up.0",      nullptr,     kDeconv4x4,  512, 256, 1, 1, 1, "conv7_3",        "conv3_3_short", 0, 4, 0},
         {"conv8_2",       "model8.1",        nullptr,     kConv3x3,    256, 256, 1, 1, 1, "conv8_1",        nullptr,         0, 4, 0},
         {"conv8_3",       "model8.3",        "model8.5",  kConv3x3,    256, 256, 1, 1, 1, "conv8_2",        nullptr,         0, 4, 0},
         {"class_logits",  "model_class.0",   nullptr,     kConv1x1,    256, 529, 1, 1, 0, "conv8_3",        nullptr,         1, 4, 1},
-        {"conv2_2_short", "model2short9.0",  nullptr,     kConv3x3,    128, 128, 1, 1, 0, "conv2_2",        nullptr,         1, 2, 0},
+        {"conv2_2_short", "model2short9.0",  nullptr,     kConv3x3,    128, 128, 1, 1, 0, "conv2_2",        nullptr,         0, 2, 0},
         {"conv9_1",       "model9up.0",      nullptr,     kDeconv4x4,  256, 128, 1, 1, 1, "conv8_3",        "conv2_2_short", 0, 2, 0},
         {"conv9_2",       "model9.1",        "model9.3",  kConv3x3,    128, 128, 1, 1, 1, "conv9_1",        nullptr,         0, 2, 0},
-        {"conv1_2_short", "model1short10.0", nullptr,     kConv3x3,     64, 128, 1, 1, 0, "conv1_2",        nullptr,         1, 1, 0},
+        {"conv1_2_short", "model1short10.0", nullptr,     kConv3x3,     64, 128, 1, 1, 0, "conv1_2",        nullptr,         0, 1, 0},
         {"conv10_1",      "model10up.0",     nullptr,     kDeconv4x4,  128, 128, 1, 1, 1, "conv9_2",        "conv1_2_short", 0, 1, 0},
         {"conv10_2",      "model10.1",       nullptr,     kConv3x3,    128, 128, 1, 1, 2, "conv10_1",       nullptr,         0, 1, 0},
+        // ---- 313-bin distribution head (models/reference_model/deploy_nopred.prototxt:650-775; IDC_FLAG_DIST313) ----
+        // hyper-column sum conv3_pred + conv4..7_pred + conv8_pred (Eltwise SUM :747-757) kept in fp32 and chained
+        // through the shortcut-sum input of each launch; the ReLU (:758-763) rides on the last one
+        {"conv3_pred",    "pred.conv3_pred", nullptr,     kConv3x3,    256, 384, 1, 1, 0, "conv3_3",        nullptr,         1, 4, 2},
+        {"conv34_pred",   "pred.conv4_pred", nullptr,     kDeconv4x4,  512, 384, 1, 1, 0, "conv4_3",        "conv3_pred",    1, 4, 2},
+        {"conv345_pred",  "pred.conv5_pred", nullptr,     kDeconv4x4,  512, 384, 1, 1, 0, "conv5_3",        "conv34_pred",   1, 4, 2},
+        {"conv3456_pred", "pred.conv6_pred", nullptr,     kDeconv4x4,  512, 384, 1, 1, 0, "conv6_3",        "conv345_pred",  1, 4, 2},
+        {"conv34567_pred","pred.conv7_pred", nullptr,     kDeconv4x4,  512, 384, 1, 1, 0, "conv7_3",        "conv3456_pred", 1, 4, 2},
+        {"conv345678_pred","pred.conv8_pred",nullptr,     kConv3x3,    256, 384, 1, 1, 1, "conv8_3",        "conv34567_pred",0, 4, 2},
+        {"pred_313",      "pred.pred_313",   nullptr,     kConv1x1,    384, 313, 1, 1, 0, "conv345678_pred", nullptr,        1, 4, 2},
     };
     return specs;
 }
@@ -89,6 +99,7 @@ struct BlobPlan {
     std::vector<LayerBlob> layers;       // parallel to the ACTIVE layer list
     std::vector<int> active;             // indices into layer_specs()
     size_t head_w_off, head_b_off;       // model_out.0: fp32 [2][128], [2]
+    size_t pred_ab_off;                  // pred_ab 1x1 decode: fp32 [2][313] weights then [2] bias, or (size_t)-1
     size_t glob_off;                     // global-hints branch parameters (fp32, glob_param_floats()) or (size_t)-1
     size_t total_bytes;
 };

@@ -68,16 +68,17 @@ def set_tile_policy(policy="auto"):
     N.check(N.load().idc_set_tile_policy(TILE_POLICIES[policy] if isinstance(policy, str) else int(policy)))
 
 
-def _flags(dist=False, global_hints=False):
-    return (N.IDC_FLAG_DIST_HEAD if dist else 0) | (N.IDC_FLAG_GLOBAL_HINTS if global_hints else 0)
+def _flags(dist=False, global_hints=False, dist313=False):
+    return ((N.IDC_FLAG_DIST_HEAD if dist else 0) | (N.IDC_FLAG_GLOBAL_HINTS if global_hints else 0) |
+            (N.IDC_FLAG_DIST313 if dist313 else 0))
 
 
-def pack_weights(sd, precision="bf16", dist=False, global_hints=False):
+def pack_weights(sd, precision="bf16", dist=False, global_hints=False, dist313=False):
     """Host-only: reference ``state_dict`` -> packed device-ready blob (uint8 ndarray).
     Needs no GPU (used by rank 0 before the RCCL broadcast)."""
     lib = N.load()
     prec = _PREC[precision]
-    flags = _flags(dist, global_hints)
+    flags = _flags(dist, global_hints, dist313)
     nbytes = lib.idc_weights_blob_bytes(prec, flags)
     blob = np.zeros(nbytes, dtype=np.uint8)
     arr, n, keep = _tensor_descs(sd)
@@ -87,7 +88,7 @@ def pack_weights(sd, precision="bf16", dist=False, global_hints=False):
 
 
 class HipColorizer(object):
-    def __init__(self, H=256, W=None, max_batch=1, precision="bf16", device=0, dist=False, global_hints=False):
+    def __init__(self, H=256, W=None, max_batch=1, precision="bf16", device=0, dist=False, global_hints=False, dist313=False):
         self.lib = N.load()
         self.H, self.W = int(H), int(H if W is None else W)
         self.max_batch = int(max_batch)
@@ -96,7 +97,8 @@ class HipColorizer(object):
         self.dist = bool(dist)
         self.device = int(device)
         self.global_hints = bool(global_hints)
-        self._flags = _flags(dist, global_hints)
+        self.dist313 = bool(dist313)
+        self._flags = _flags(dist, global_hints, dist313)
         self._h = ctypes.c_void_p()
         N.check(self.lib.idc_create(self.device, self.H, self.W, self.max_batch, self._prec, self._flags,
                                     ctypes.byref(self._h)))
@@ -177,6 +179,20 @@ class HipColorizer(object):
         self._chk(self.lib.idc_forward_dist(self._h, n, _fptr(L), _fptr(A), _fptr(M), float(maskcent),
                                             _fptr(out), _fptr(dq)))
         return out, dq
+
+    def forward_dist313(self, L_mc, ab, mask, maskcent=0.0, want_dist=True):
+        """313-bin head of the Caffe distribution net: returns (out_ab regression, pred_ab soft-decode (N,2,H,W),
+        dist_S (N,313,H,W) full-resolution softmax(S*logits) or None)."""
+        n, L, A, M = self._prep(L_mc, ab, mask)
+        out = np.empty((n, 2, self.H, self.W), np.float32)
+        pred = np.empty((n, 2, self.H, self.W), np.float32)
+        dist = np.empty((n, 313, self.H, self.W), np.float32) if want_dist else None
+        self._chk(self.lib.idc_forward_dist313(self._h, n, _fptr(L), _fptr(A), _fptr(M), float(maskcent), _fptr(out),
+                                               _fptr(pred), _fptr(dist) if want_dist else None))
+        return out, pred, dist
+
+    def set_dist_temperature(self, S):
+        self._chk(self.lib.idc_set_dist_temperature(self._h, float(S)))
 
     def forward_device(self, n, d_L, d_ab, d_mask, d_out, maskcent=0.0, sync=False):
         """Device-pointer form (ints / objects with ``data_ptr()``); enqueued on the handle stream."""

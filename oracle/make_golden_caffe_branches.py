@@ -40,6 +40,25 @@ def global_hints_case(name="glob64_he_s3", seed=3, n=2, X=64):
     print("%s: out [%.1f, %.1f], f32 vs f64 %.2e" % (name, out.min(), out.max(), np.abs(out - out64).max()))
 
 
+def dist313_case(name="dist313_64_he_s2", seed=2, X=64):
+    sd = weights.add_pred313_head(weights.make_state_dict(seed, "he", include_class=False), seed)
+    L, ab, mask = workloads.random_batch(1, X, seed=12, max_points=5, max_p=2)
+    out, _, acts = siggraph_torch.forward(sd, L, ab, mask, 0.0, dist313=True, return_acts=True)
+    o64, _, a64 = siggraph_torch.forward(sd, L, ab, mask, 0.0, dist313=True, return_acts=True, dtype=torch.float64)
+    rs = np.random.RandomState(0)
+    pos = rs.randint(0, X * X, 48)                                # sampled pixels of the 313 x X x X distribution
+    dS = acts["dist_ab_S"][0].reshape(313, -1)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), L_mc=L.astype(np.float32), ab=ab.astype(np.float32),
+                        mask=mask.astype(np.float32), out_ab=out.astype(np.float32),
+                        pred_313=acts["pred_313"].astype(np.float32), pred_ab=acts["pred_ab"].astype(np.float32),
+                        pred_ab_f64=a64["pred_ab"], dist_pos=pos, dist_samples=dS[:, pos].astype(np.float32),
+                        dist_entropy=-(dS * np.log(dS)).sum(0).astype(np.float32), weight_seed=np.int64(seed))
+    print("%s: pred_ab [%.1f, %.1f], f32 vs f64 %.2e, logits std %.2f" % (
+        name, acts["pred_ab"].min(), acts["pred_ab"].max(), np.abs(acts["pred_ab"] - a64["pred_ab"]).max(),
+        acts["pred_313"].std()))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     global_hints_case()
+    dist313_case()

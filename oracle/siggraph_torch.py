@@ -49,6 +49,27 @@ def _bn(x, sd, key, dtype):
                         training=False, eps=BN_EPS)
 
 
+BILINEAR_US = ((.25, .5, .25, 0.), (.5, 1., .5, 0.), (.25, .5, .25, 0.), (0., 0., 0., 0.))   # colorize_image.py:410-413
+
+
+def pred313_head(sd, feats, dtype=torch.float32, S=0.2, T=2.6):
+    """313-bin head, restated from ``models/reference_model/deploy_nopred.prototxt:650-850`` (Caffe only in the
+    reference; PARITY UNPINNED).  ``feats`` = dict of the post-BN block outputs conv3_3 .. conv8_3.
+    Returns (pred_313 logits at H/4, dist_ab_S (N,313,H,W), pred_ab (N,2,H,W))."""
+    hyper = _conv(feats["conv3_3"], sd, "pred.conv3_pred", dtype)                       # :650-665
+    for i in (4, 5, 6, 7):                                                             # :666-729 Deconvolution 4x4 s2 p1
+        hyper = hyper + _deconv(feats["conv%d_3" % i], sd, "pred.conv%d_pred" % i, dtype)
+    hyper = F.relu(hyper + _conv(feats["conv8_3"], sd, "pred.conv8_pred", dtype))      # :730-763 Eltwise SUM, ReLU
+    logits = _conv(hyper, sd, "pred.pred_313", dtype)                                  # :764-775
+    k = torch.tensor(BILINEAR_US, dtype=dtype)[None, None].repeat(313, 1, 1, 1)        # grouped, shared kernel, no bias
+    up = F.conv_transpose2d(logits, k, None, stride=2, padding=1, groups=313)          # pred_313_us :776-790
+    up = F.conv_transpose2d(up, k, None, stride=2, padding=1, groups=313)              # pred_313_rs :791-805
+    dist_S = F.softmax(up * S, dim=1)                                                  # scale_S + Softmax :807-821
+    dist_T = F.softmax(up * T, dim=1)                                                  # scale_T + Softmax :826-840
+    pred_ab = _conv(dist_T, sd, "pred.pred_ab", dtype)                                 # :842-850, weight = pts_in_hull.T
+    return logits, dist_S, pred_ab
+
+
 def global_branch(sd, glob, sat, dtype=torch.float32):
     """Global-Hints branch, restated from ``models/global_model/deploy_nodist.prototxt:37-172`` (Caffe only in the
     reference; PARITY UNPINNED: no Caffe here to run it against).  ``glob`` (N,314), ``sat`` (N,2) ->
@@ -64,7 +85,8 @@ def global_branch(sd, glob, sat, dtype=torch.float32):
 
 
 def forward(sd, L_mc, ab, mask, maskcent=0.0, dist=False, dtype=torch.float32,
-            return_acts=False, num_threads=None, glob=None, sat=None, l_div=100., ab_div=110., out_mul=110.):
+            return_acts=False, num_threads=None, glob=None, sat=None, l_div=100., ab_div=110., out_mul=110.,
+            dist313=False, S=0.2):
     """Batched restatement.
 
     L_mc (N,1,H,W) in [-50,50]; ab (N,2,H,W) raw Lab ab; mask (N,1,H,W) in {0,1}
@@ -123,6 +145,11 @@ def forward(sd, L_mc, ab, mask, maskcent=0.0, dist=False, dtype=torch.float32,
         x = relu(_conv(x, sd, "model8.1", dtype)); acts["conv8_2"] = x
         x = relu(_conv(x, sd, "model8.3", dtype))
         conv8_3 = _bn(x, sd, "model8.5", dtype); acts["conv8_3"] = conv8_3
+        if dist313:
+            feats = {"conv3_3": conv3_3, "conv4_3": acts["conv4_3"], "conv5_3": acts["conv5_3"],
+                     "conv6_3": acts["conv6_3"], "conv7_3": conv7_3, "conv8_3": conv8_3}
+            lg, dS, pab = pred313_head(sd, feats, dtype, S=S)
+            acts["pred_313"] = lg; acts["dist_ab_S"] = dS; acts["pred_ab"] = pab
         out_cl = None
         if dist:                                                         # :160
             logits = _conv(conv8_3, sd, "model_class.0", dtype)

@@ -64,6 +64,36 @@ def add_global_branch(sd, seed=0):
     return sd
 
 
+def synthetic_ab_centres(seed=0):
+    """A stand-in for data/color_bins/pts_in_hull.npy (313x2, the in-gamut ab bin centres on a 10-unit grid):
+    313 distinct points of the 23x23 grid -110..110, seeded.  (The real table is reference DATA, loaded by the
+    wrapper from the reference checkout exactly where the reference loads it, colorize_image.py:388-389.)"""
+    rs = np.random.RandomState(seed + 313)
+    grid = np.stack(np.meshgrid(np.arange(-110, 120, 10), np.arange(-110, 120, 10), indexing="ij"), -1).reshape(-1, 2)
+    r2 = (grid ** 2).sum(1) + rs.uniform(0, 1, grid.shape[0])          # the 313 grid points closest to grey
+    return grid[np.sort(np.argsort(r2)[:313])].astype(np.float32)
+
+
+def add_pred313_head(sd, seed=0, centres=None):
+    """Seeded ``pred.*`` tensors of the 313-bin head (models/reference_model/deploy_nopred.prototxt:650-850)."""
+    rs = np.random.RandomState(seed + 31337)
+    def conv(key, cin, k, deconv=False, gain=1.0):
+        fan = cin * (4 if deconv else k * k)
+        shape = (cin, 384, k, k) if deconv else (384, cin, k, k)
+        sd[key + ".weight"] = (rs.standard_normal(shape) * gain / np.sqrt(fan)).astype(np.float32)
+        sd[key + ".bias"] = rs.uniform(-0.1, 0.1, 384).astype(np.float32)
+    g = 1.0 / np.sqrt(6.0) * np.sqrt(2.0)                               # six summed branches share the variance
+    conv("pred.conv3_pred", 256, 3, gain=g); conv("pred.conv8_pred", 256, 3, gain=g)
+    for i in (4, 5, 6, 7):
+        conv("pred.conv%d_pred" % i, 512, 4, deconv=True, gain=g)
+    sd["pred.pred_313.weight"] = (rs.standard_normal((313, 384, 1, 1)) * 6.0 / np.sqrt(384)).astype(np.float32)
+    sd["pred.pred_313.bias"] = rs.uniform(-0.5, 0.5, 313).astype(np.float32)
+    c = synthetic_ab_centres(seed) if centres is None else np.asarray(centres, np.float32)
+    sd["pred.pred_ab.weight"] = np.ascontiguousarray(c.T)[:, :, None, None].astype(np.float32)   # (2,313,1,1)
+    sd["pred.pred_ab.bias"] = rs.uniform(-1, 1, 2).astype(np.float32)
+    return sd
+
+
 def make_state_dict(seed=0, style="he", include_class=True):
     """Return ``{key: np.ndarray}`` with the reference key set.
 
