@@ -59,6 +59,10 @@ int idc_version(void);
  * (conv_igemm_v2) wherever it applies.  Exists so that the parity tests can drive every kernel
  * variant at small sizes.  No reference counterpart. */
 int idc_set_tile_policy(int policy);
+/* Split-K policy of the small-tile kernels (speed only): 0 automatic (launches too small to fill the chip: the
+ * batch-1 click path), 1 never, 2 always (tests).  The slice sums are added in a fixed order: results stay
+ * deterministic and independent of how many images a call carries. */
+int idc_set_splitk_policy(int policy);
 /* Number of visible HIP devices (0 when none; never fails). */
 int idc_device_count(void);
 /* Text of the last error on this handle (h may be NULL: last error of a failed idc_create or of a

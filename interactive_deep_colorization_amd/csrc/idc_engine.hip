@@ -335,6 +335,7 @@ struct idc_context {
     float *h_in = nullptr, *h_out = nullptr, *h_dist = nullptr;
     float *d_L = nullptr, *d_ab = nullptr, *d_mask = nullptr, *d_out = nullptr, *d_dist = nullptr;
     float* d_scratch = nullptr; size_t scratch_bytes = 0;
+    float* d_partial = nullptr; size_t partial_bytes = 0;    // split-K slice sums (grown on demand)
     float *d_glob_in = nullptr, *d_glob_vec = nullptr;   // global hints: [max_batch][316] inputs, [max_batch][512] branch output
     int t_conv4_3 = -1, t_pred313 = -1;
     float *d_pred_ab = nullptr, *d_dist313 = nullptr, *h_pred_ab = nullptr, *h_dist313 = nullptr;   // 313 head outputs
@@ -366,6 +367,9 @@ static int find_tensor(idc_context* c, const char* name) {
 // Tile policy (speed only; every choice computes the same result): 0 = automatic, 1 = always the
 // small-tile kernels (conv_igemm), 2 = the large-tile bf16 kernel (conv_igemm_v2) wherever it applies.
 static int g_tile_policy = 0;
+// Split-K policy of the small-tile kernels (speed only): 0 = automatic (launches that would leave most CUs idle,
+// i.e. the batch-1 click path), 1 = never, 2 = always split as far as the cin chunks allow (tests).
+static int g_splitk_policy = 0;
 // Shortcut fusion (conv_igemm_v2<.,.,1,true>) is correct (parity-tested under tile policy 2) but measured slower
 // than two launches on MI355X (4x re-reads of the skip tensor by the four phase workgroups, VGPR spills around
 // the staged K loop): 0.87 ms -> 1.25 ms at level 1.  Off unless the tile policy forces every variant on.
@@ -441,12 +445,26 @@ static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, i
         const long long blocks = (long long)tx * ty * n_policy * (a.ncg / c2.wm) * a.nphase;
         if (g_tile_policy == 2 || blocks >= 128) {
             L.v2 = true; L.cfg = c2; a.tiles_x = tx; a.tiles_y = ty;
+            a.ksplit = 1; a.kc_per = a.nkc;
             return;
         }
     }
     L.cfg = choose_config(n_policy, Hs, Ws, L.blob.ncg * kCoutGroup, a.nphase);
     a.tiles_x = (Ws + 15) / 16;
     a.tiles_y = (Hs + 4 * L.cfg.wp - 1) / (4 * L.cfg.wp);
+    // split-K: a launch of < 128 workgroups (batch-1 trunk layers: 32..64) cannot fill 256 CUs and each workgroup
+    // walks all 9*Cin/64 tap-steps alone; cut the cin chunks into slices until ~256 workgroups exist
+    a.ksplit = 1; a.kc_per = a.nkc;
+    const long long tiles = (long long)a.tiles_x * a.tiles_y * n_policy * (a.ncg / L.cfg.wm) * a.nphase;
+    if (g_splitk_policy != 1 && a.nkc >= 2 && (g_splitk_policy == 2 || tiles < 128)) {
+        long long want = g_splitk_policy == 2 ? a.nkc : (256 + tiles - 1) / tiles;
+        if (want > a.nkc) want = a.nkc;
+        if (want >= 2) {
+            a.kc_per = (int)((a.nkc + want - 1) / want);
+            a.ksplit = (a.nkc + a.kc_per - 1) / a.kc_per;          // every slice is non-empty
+            if (a.ksplit < 2) { a.ksplit = 1; a.kc_per = a.nkc; }
+        }
+    }
 }
 
 static double layer_flops(const LayerSpec& s, int H, int W) {       // per image, SURVEY.md Appendix A
@@ -596,8 +614,20 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
         a.head_b = (const float*)(c->d_blob + c->plan.head_b_off);
         a.head_out = dout; a.head_mul = c->out_mul;
         head_done = head_done || L.fused_head;
+        if (a.ksplit > 1) {
+            const size_t need = (size_t)a.ksplit * n * to.H * to.W * to.Cpad * 4;
+            if (c->partial_bytes < need) {
+                HIPCHK(c, hipStreamSynchronize(s));
+                if (c->d_partial) (void)hipFree(c->d_partial);
+                c->d_partial = nullptr; c->partial_bytes = 0;
+                HIPCHK(c, hipMalloc((void**)&c->d_partial, need));
+                c->partial_bytes = need;
+            }
+            a.partial = c->d_partial;
+        }
         tic();
         HIPCHK(c, L.v2 ? launch_conv_v2(L.cfg, L.halo, a, s) : launch_conv(c->precision, L.cfg, L.halo, a, s));
+        if (a.ksplit > 1) HIPCHK(c, launch_splitk_epilogue(c->precision, a, s));
         toc();
     }
     tic();
@@ -662,7 +692,7 @@ static void destroy_ctx(idc_context* c) {
     for (auto& t : c->tensors) if (t.ptr) (void)hipFree(t.ptr);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->own_blob && c->d_blob) (void)hipFree(c->d_blob);
-    void* dev[] = {c->d_L, c->d_ab, c->d_mask, c->d_out, c->d_dist, c->d_scratch, c->d_glob_in, c->d_glob_vec, c->d_pred_ab, c->d_dist313};
+    void* dev[] = {c->d_L, c->d_ab, c->d_mask, c->d_out, c->d_dist, c->d_scratch, c->d_glob_in, c->d_glob_vec, c->d_pred_ab, c->d_dist313, c->d_partial};
     for (void* p : dev) if (p) (void)hipFree(p);
     void* host[] = {c->h_in, c->h_out, c->h_dist, c->h_pred_ab};
     for (void* p : host) if (p) (void)hipHostFree(p);
@@ -686,6 +716,12 @@ static int check_device(int device_id, std::string* err) {
 extern "C" {
 
 int idc_version(void) { return IDC_VERSION; }
+
+int idc_set_splitk_policy(int policy) {
+    if (policy < 0 || policy > 2) return fail(nullptr, IDC_ERR_INVALID_ARG, "split-K policy %d not in 0..2", policy);
+    g_splitk_policy = policy;
+    return IDC_OK;
+}
 
 int idc_set_tile_policy(int policy) {
     if (policy < 0 || policy > 2) return fail(nullptr, IDC_ERR_INVALID_ARG, "tile policy %d not in 0..2", policy);
@@ -919,6 +955,10 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
             snprintf(out->kernel, sizeof(out->kernel), L.v2 ? "conv_igemm_v2<%d,%d>" : (h->precision == IDC_BF16 ? "conv_igemm<bf16,%d,%d>" : "conv_igemm<f32,%d,%d>"),
                      L.cfg.wm, L.cfg.wp);
             if (L.fused_head) strncat(out->kernel, "+head", sizeof(out->kernel) - strlen(out->kernel) - 1);
+            if (L.args.ksplit > 1) {
+                char sk[16]; snprintf(sk, sizeof(sk), " splitK%d", L.args.ksplit);
+                strncat(out->kernel, sk, sizeof(out->kernel) - strlen(out->kernel) - 1);
+            }
             out->flops = L.flops; out->min_bytes = L.min_bytes; out->launches = 1;
             if (L.fused_short >= 0) {
                 const Layer& P = h->layers[L.fused_short];
@@ -1061,7 +1101,13 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_mul = 0.f;
     a.in2 = nullptr; a.wgt2 = nullptr; a.nkc2 = 0;
     a.out_f32 = io_bf16 ? 0 : 1;
+    DevBuf d_part;
+    if (a.ksplit > 1) {
+        HIPCHK(nullctx, d_part.alloc((size_t)a.ksplit * n * Ho * Wo * cpad * 4));
+        a.partial = (float*)d_part.p;
+    }
     HIPCHK(nullctx, L.v2 ? launch_conv_v2(L.cfg, L.halo, a, nullptr) : launch_conv(precision, L.cfg, L.halo, a, nullptr));
+    if (a.ksplit > 1) HIPCHK(nullctx, launch_splitk_epilogue(precision, a, nullptr));
     HIPCHK(nullctx, launch_nhwc_to_nchw(io_bf16, d_yn.p, (float*)d_y.p, n, spec.cout, Ho, Wo, cpad, nullptr));
     HIPCHK(nullctx, hipMemcpy(y, d_y.p, yout * 4, hipMemcpyDeviceToHost));
     HIPCHK(nullctx, hipDeviceSynchronize());

@@ -32,6 +32,12 @@ struct ConvArgs {
     int act;                // 0 none, 1 ReLU, 2 LeakyReLU(0.2)
     int out_f32;
     int resid_bf16;
+    // split-K (conv_igemm only; small launches = the batch-1 click path): workgroup slice `sid` of ksplit
+    // runs cin chunks [sid*kc_per, min(nkc, (sid+1)*kc_per)) and stores its raw fp32 accumulators to
+    // partial[sid][output pixel][CoutPad]; splitk_epilogue then sums the slices in fixed order and applies
+    // bias / shortcut / activation / BN.  ksplit <= 1: off.
+    int ksplit, kc_per;
+    float* partial;
     // fused shortcut conv (conv_igemm_v2, deconv launches only): a 3x3 conv (pad 1, bias folded into
     // `bias`) of in2 = NHWC [N][2*Hs][2*Ws][nkc2 * 64] bf16 accumulated into the same output pixels;
     // wgt2 = its layout-2 weight image (same couts).  model.py:156,170,172.
@@ -57,6 +63,9 @@ hipError_t launch_conv(int precision, ConvConfig cfg, int halo, const ConvArgs& 
 // {4,2} = 256 couts x (32x8 sites), {2,4} = 128 couts x (32x16 sites).  a.wgt must point at the
 // layer's layout-2 weight image (idc_layout.h); tiles_x/tiles_y count 32 x 4*WPX tiles.
 hipError_t launch_conv_v2(ConvConfig cfg, int halo, const ConvArgs& a, hipStream_t s);
+// Second half of a split-K launch: out = act(sum_s partial[s] + bias [+ resid]) [* bn_scale + bn_shift] [+ img_shift]
+// over all N*Hout*Wout*CoutPad outputs (geometry and epilogue fields taken from the same ConvArgs).
+hipError_t launch_splitk_epilogue(int precision, const ConvArgs& a, hipStream_t s);
 // One-time: raise the dynamic-LDS limit of every conv instantiation.
 hipError_t init_kernels();
 size_t conv_lds_bytes(ConvConfig cfg, int halo);

@@ -166,6 +166,8 @@ __global__ __launch_bounds__(WM* WP * 64) void conv_igemm(const ConvArgs a) {
     // ---- which tile -------------------------------------------------------------------------
     int b = xcd_remap(blockIdx.x, gridDim.x);
     const int nct = a.ncg / WM;
+    const int ksplit = a.ksplit > 1 ? a.ksplit : 1;
+    const int sid = b % ksplit; b /= ksplit;                      // split-K slice (fastest: slices of a tile share its halo pixels)
     const int txi = b % a.tiles_x; b /= a.tiles_x;
     const int tyi = b % a.tiles_y; b /= a.tiles_y;
     const int n = b % a.N; b /= a.N;
@@ -198,7 +200,9 @@ __global__ __launch_bounds__(WM* WP * 64) void conv_igemm(const ConvArgs a) {
     const int* const tap_dy = a.dy + phase * 9;
     const int* const tap_dx = a.dx + phase * 9;
     const int* const tap_tw = a.tw + phase * 9;
-    const int ntaps = a.ntaps, nkc = a.nkc;
+    const int ntaps = a.ntaps;
+    const int kc0 = ksplit > 1 ? sid * a.kc_per : 0;
+    const int nkc = ksplit > 1 ? (kc0 + a.kc_per < a.nkc ? kc0 + a.kc_per : a.nkc) : a.nkc;   // this slice: chunks [kc0, nkc)
 
     // fp32 path: the MFMA is an exact sequential fmaf chain, so one accumulator over K = 9*Cin
     // (up to 4608 terms) would carry ~4x the rounding noise of a blocked sum.  Accumulate each
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(WM* WP * 64) void conv_igemm(const ConvArgs a) {
 
     u32x4 wreg[N_WITEMS];
     {
-        const char* src = wbase + (size_t)tap_tw[0] * w_tap_stride;
+        const char* src = wbase + (size_t)tap_tw[0] * w_tap_stride + (size_t)kc0 * w_kc_stride;
 #pragma unroll
         for (int j = 0; j < N_WITEMS; ++j) wreg[j] = *(const u32x4*)(src + (size_t)j * NT * kSlotBytes);
     }
@@ -235,9 +239,9 @@ __global__ __launch_bounds__(WM* WP * 64) void conv_igemm(const ConvArgs a) {
             hreg[j] = off >= 0 ? v : u32x4{0u, 0u, 0u, 0u};      // zero padding / rows past the tile
         }
     };
-    load_halo(0);
+    load_halo(kc0);
 
-    for (int kc = 0; kc < nkc; ++kc) {
+    for (int kc = kc0; kc < nkc; ++kc) {
         __syncthreads();                       // every wave is done reading the previous halo
 #pragma unroll
         for (int j = 0; j < N_HITEMS; ++j) *(u32x4*)(halo + (tid + j * NT) * kSlotBytes) = hreg[j];
@@ -325,6 +329,22 @@ __global__ __launch_bounds__(WM* WP * 64) void conv_igemm(const ConvArgs a) {
     // ---- epilogue: lane owns couts co0..co0+15 of pixel px in each of its 4 rows ----------------
     const int CoutPad = a.ncg * kCoutGroup;
     const int co0 = (ct * WM + wm) * kCoutGroup + g * 16;
+    if (ksplit > 1) {                          // raw fp32 slice sums; splitk_epilogue finishes the layer
+        const int so = a.so, Wout = Ws * so, Hout = Hs * so;
+        const int ro = a.ro[phase], cof = a.co[phase];
+        float* const slab = a.partial + (size_t)sid * a.N * Hout * Wout * CoutPad;
+#pragma unroll
+        for (int pj = 0; pj < 4; ++pj) {
+            const int sy = ty0 + wp * 4 + pj, sx = tx0 + px;
+            if (sy < Hs && sx < Ws) {
+                float* o = slab + (((size_t)n * Hout + (sy * so + ro)) * Wout + (sx * so + cof)) * CoutPad + co0;
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci)
+                    *(float4*)(o + ci * 4) = float4{acc[ci][pj][0], acc[ci][pj][1], acc[ci][pj][2], acc[ci][pj][3]};
+            }
+        }
+        return;
+    }
     float bias[16], bsc[16], bsh[16];
     load16(bias, a.bias + co0);
     const bool has_bn = a.bn_scale != nullptr;
@@ -360,8 +380,9 @@ static hipError_t launch_conv_t(const ConvArgs& a, hipStream_t s) {
     constexpr int NT = WM * WP * 64;
     constexpr size_t lds = conv_lds_bytes_c(WM, WP, HALO);
     const int nct = a.ncg / WM;
-    const long long blocks = (long long)a.tiles_x * a.tiles_y * a.N * nct * a.nphase;
+    const long long blocks = (long long)a.tiles_x * a.tiles_y * a.N * nct * a.nphase * (a.ksplit > 1 ? a.ksplit : 1);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (a.ksplit > 1 && (a.partial == nullptr || a.kc_per <= 0)) return hipErrorInvalidValue;
     hipLaunchKernelGGL((conv_igemm<T, WM, WP, HALO>), dim3((unsigned)blocks), dim3(NT), lds, s, a);
     return hipGetLastError();
 }
@@ -400,6 +421,80 @@ hipError_t launch_conv(int precision, ConvConfig cfg, int halo, const ConvArgs& 
     return hipErrorInvalidConfiguration;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// splitk_epilogue: sum the split-K slices in fixed order (deterministic) and finish the layer.
+// One thread = 8 consecutive channels of one output pixel (32-byte slab reads, 16/32-byte stores).
+// ------------------------------------------------------------------------------------------------
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvArgs a) {
+    const int CoutPad = a.ncg * kCoutGroup;
+    const int c8 = CoutPad >> 3;
+    const int Hout = a.Hs * a.so, Wout = a.Ws * a.so;
+    const long long npix = (long long)a.N * Hout * Wout;
+    const long long total = npix * c8;
+    const size_t slab = (size_t)npix * CoutPad;
+    const bool has_bn = a.bn_scale != nullptr;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int cq = (int)(i % c8);
+        const long long pix = i / c8;
+        const int co = cq * 8;
+        const size_t oidx = (size_t)pix * CoutPad + co;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < a.ksplit; ++s) {
+            const float4 p0 = *(const float4*)(a.partial + (size_t)s * slab + oidx);
+            const float4 p1 = *(const float4*)(a.partial + (size_t)s * slab + oidx + 4);
+            v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w; v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += a.bias[co + e];
+        if (a.resid != nullptr) {
+            if (a.resid_bf16) {
+                const uint4 r4 = *(const uint4*)((const unsigned short*)a.resid + oidx);
+                const unsigned rw[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(rw[e] << 16); v[2 * e + 1] += __uint_as_float(rw[e] & 0xffff0000u); }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += ((const float*)a.resid)[oidx + e];
+            }
+        }
+        if (a.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (a.act == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+        }
+        if (has_bn) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], a.bn_scale[co + e], a.bn_shift[co + e]);
+        }
+        if (a.img_shift != nullptr) {
+            const long long n = pix / ((long long)Hout * Wout);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += a.img_shift[(size_t)n * CoutPad + co + e];
+        }
+        if (!OUT_BF16 || a.out_f32) {
+            float* o = (float*)a.out + oidx;
+            *(float4*)o = float4{v[0], v[1], v[2], v[3]};
+            *(float4*)(o + 4) = float4{v[4], v[5], v[6], v[7]};
+        } else {
+            uint4 o;
+            o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+            o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+            *(uint4*)((unsigned short*)a.out + oidx) = o;
+        }
+    }
+}
+
+hipError_t launch_splitk_epilogue(int precision, const ConvArgs& a, hipStream_t s) {
+    const long long total = (long long)a.N * a.Hs * a.so * a.Ws * a.so * (a.ncg * kCoutGroup / 8);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (precision == 1) hipLaunchKernelGGL(splitk_epilogue_kernel<true>, dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(splitk_epilogue_kernel<false>, dim3(blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
 
 // ================================================================================================
 // conv_igemm_v2<WCO, WPX, HALO> -- the throughput kernel (bf16): 8 waves, 32x32x16 MFMA.

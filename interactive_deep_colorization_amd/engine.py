@@ -73,6 +73,14 @@ def _flags(dist=False, global_hints=False, dist313=False):
             (N.IDC_FLAG_DIST313 if dist313 else 0))
 
 
+SPLITK_POLICIES = {"auto": 0, "never": 1, "always": 2}
+
+
+def set_splitk_policy(policy="auto"):
+    """Process-wide split-K policy of the small-tile kernels (speed only): "auto", "never" or "always"."""
+    N.check(N.load().idc_set_splitk_policy(SPLITK_POLICIES[policy] if isinstance(policy, str) else int(policy)))
+
+
 def pack_weights(sd, precision="bf16", dist=False, global_hints=False, dist313=False):
     """Host-only: reference ``state_dict`` -> packed device-ready blob (uint8 ndarray).
     Needs no GPU (used by rank 0 before the RCCL broadcast)."""

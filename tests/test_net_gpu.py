@@ -67,6 +67,7 @@ def test_fp32_matches_reference_golden_layer_by_layer(golden, make_sd, name):
 def _reset_tile_policy():
     yield
     engine.set_tile_policy("auto")
+    engine.set_splitk_policy("auto")
 
 
 @pytest.mark.parametrize("tiles", ["small", "large"])
@@ -159,6 +160,29 @@ def test_512_fp32(make_sd):
     out = e.forward(L, ab, m, 0.5)
     ref = siggraph_torch.forward(make_sd(1, "torch"), L, ab, m, 0.5)
     assert np.abs(out - ref).max() <= FP32_TOL["torch"]
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_splitk_matches_unsplit(golden, make_sd, precision):
+    """Split-K (the batch-1 click path: slices of the cin chunks + a fixed-order reduction) computes the same
+    network: against the golden output at the usual tolerance, and within summation-order noise of the unsplit run."""
+    g = golden("net64_he_s0_mc05")
+    n, _, H, W = g["L_mc"].shape
+    engine.set_tile_policy("small")
+    e = get_engine(H, W, n, precision, 0, "he", make_sd=make_sd)
+    engine.set_splitk_policy("never")
+    base = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
+    assert not any("splitK" in r["kernel"] for r in e.layer_table())
+    engine.set_splitk_policy("always")
+    out = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
+    assert sum("splitK" in r["kernel"] for r in e.layer_table()) >= 20
+    np.testing.assert_array_equal(e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"])), out)   # deterministic
+    np.testing.assert_array_equal(e.forward(g["L_mc"][:1], g["ab"][:1], g["mask"][:1], float(g["maskcent"]))[0], out[0])
+    d = np.abs(out - g["out_ab"])
+    if precision == "fp32":
+        assert d.max() <= FP32_TOL["he"] and np.abs(out - base).max() <= 2e-3
+    else:
+        assert d.max() <= BF16_MAX["he"] and d.mean() <= BF16_MEAN["he"]
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])

@@ -17,21 +17,27 @@ pytestmark = pytest.mark.gpu
 TOL = {"fp32": 2e-5, "bf16": 2.5e-2}
 # every kernel variant is driven at the small test sizes: fp32 = conv_igemm<f32>, bf16 = conv_igemm<bf16>
 # (small tiles), bf16-large = conv_igemm_v2 (32x32x16 MFMA, LDS-transposed stores) forced by the tile policy
-PRECISIONS = ["fp32", "bf16", "bf16-large"]
+PRECISIONS = ["fp32", "bf16", "bf16-large", "fp32-splitk", "bf16-splitk"]
 
 
 @pytest.fixture(autouse=True)
 def _reset_tile_policy():
     yield
     engine.set_tile_policy("auto")
+    engine.set_splitk_policy("auto")
 
 
 def _prec(precision):
-    """'bf16-large' -> ('bf16', tile policy 'large'); sets the policy for the coming op call."""
+    """'bf16-large' -> ('bf16', tile policy 'large'); 'x-splitk' -> small tiles with split-K forced (every cin
+    chunk its own slice + splitk_epilogue); sets the policies for the coming op call."""
+    engine.set_splitk_policy("never")
     if precision == "bf16-large":
         engine.set_tile_policy("large")
         return "bf16"
     engine.set_tile_policy("small")
+    if precision.endswith("-splitk"):
+        engine.set_splitk_policy("always")
+        return precision.split("-")[0]
     return precision
 
 
