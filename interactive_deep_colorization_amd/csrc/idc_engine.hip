@@ -452,12 +452,13 @@ static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, i
     L.cfg = choose_config(n_policy, Hs, Ws, L.blob.ncg * kCoutGroup, a.nphase);
     a.tiles_x = (Ws + 15) / 16;
     a.tiles_y = (Hs + 4 * L.cfg.wp - 1) / (4 * L.cfg.wp);
-    // split-K: a launch of < 128 workgroups (batch-1 trunk layers: 32..64) cannot fill 256 CUs and each workgroup
-    // walks all 9*Cin/64 tap-steps alone; cut the cin chunks into slices until ~256 workgroups exist
+    // split-K: a launch of < 256 workgroups (batch-1: 32..128) cannot fill 256 CUs and each workgroup walks all
+    // 9*Cin/64 tap-steps alone; cut the cin chunks into slices until ~512 workgroups exist
     a.ksplit = 1; a.kc_per = a.nkc;
     const long long tiles = (long long)a.tiles_x * a.tiles_y * n_policy * (a.ncg / L.cfg.wm) * a.nphase;
-    if (g_splitk_policy != 1 && a.nkc >= 2 && (g_splitk_policy == 2 || tiles < 128)) {
-        long long want = g_splitk_policy == 2 ? a.nkc : (256 + tiles - 1) / tiles;
+    if (g_splitk_policy != 1 && a.nkc >= 2 && (g_splitk_policy == 2 || tiles < (precision == IDC_FP32 ? 256 : 128))) {
+        // fp32 tap-steps are 16x longer than bf16 ones: worth twice as many slices (measured: 3.0 -> 2.0 ms at N=1)
+        long long want = g_splitk_policy == 2 ? a.nkc : ((precision == IDC_FP32 ? 512 : 256) + tiles - 1) / tiles;
         if (want > a.nkc) want = a.nkc;
         if (want >= 2) {
             a.kc_per = (int)((a.nkc + want - 1) / want);
