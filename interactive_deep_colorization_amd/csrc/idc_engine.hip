@@ -488,7 +488,8 @@ static int build_graph(idc_context* c) {
         c->tensors.push_back(t);
         return (int)c->tensors.size() - 1;
     };
-    c->t_input = add_tensor("data_l_ab_mask", 36, 64, 1, 0);
+    c->t_input = add_tensor("data_l_ab_mask", 36, 64, 1, 0);      // never materialised: built inside conv1_1's operand staging
+    c->tensors[c->t_input].bytes = 256;
     for (size_t li = 0; li < c->plan.active.size(); ++li) {
         const LayerSpec& s = specs[c->plan.active[li]];
         Layer L;
@@ -557,9 +558,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
     const size_t ring = (size_t)(c->prof_count % kProfRing) * c->n_timed * 2;
     auto tic = [&]() { if (c->profiling) (void)hipEventRecord(c->ev[ring + step * 2], s); };
     auto toc = [&]() { if (c->profiling) (void)hipEventRecord(c->ev[ring + step * 2 + 1], s); ++step; };
-    tic();
-    HIPCHK(c, launch_pack_input(c->precision, dL, dab, dmask, c->tensors[c->t_input].ptr, n, c->H, c->W, c->l_div,
-                                c->ab_div, c->mask_mul, maskcent, s));
+    tic();   // (slot 0: the input pack is fused into conv1_1's operand staging; only the global-hints branch runs here)
     if (c->flags & IDC_FLAG_GLOBAL_HINTS)      // four GEMVs per image; its output is consumed by conv4_3's epilogue
         HIPCHK(c, launch_glob_branch(c->d_glob_in, (const float*)(c->d_blob + c->plan.glob_off), c->d_glob_vec, n, s));
     toc();
@@ -595,6 +594,12 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
         a.in = ti.ptr; a.out = to.ptr;
         a.out_f32 = to.is_f32;
         a.img_shift = ((c->flags & IDC_FLAG_GLOBAL_HINTS) && L.dst == c->t_conv4_3) ? c->d_glob_vec : nullptr;
+        if (L.spec->kind == kConvIm2col) {          // model.py:139-148 input pack, fused into the operand staging
+            a.pk_L = dL; a.pk_ab = dab; a.pk_mask = dmask;
+            a.pk_ldiv = c->l_div; a.pk_abdiv = c->ab_div; a.pk_mmul = c->mask_mul; a.pk_mcent = maskcent;
+        } else {
+            a.pk_L = nullptr;
+        }
         a.wgt = c->d_blob + (L.v2 ? L.blob.w2_off : L.blob.w_off);
         a.bias = (const float*)(c->d_blob + L.blob.bias_off);
         a.bn_scale = L.blob.bn_scale_off != (size_t)-1 ? (const float*)(c->d_blob + L.blob.bn_scale_off) : nullptr;
@@ -942,9 +947,9 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
     const double hw = (double)h->H * h->W;
     const int eb = elem_bytes(h->precision);
     if (layer == 0) {
-        snprintf(out->name, sizeof(out->name), "pack_input");
-        snprintf(out->kernel, sizeof(out->kernel), "pack_input_kernel");
-        out->min_bytes = hw * 4 * 4 + hw * 64 * eb; out->launches = 1;
+        snprintf(out->name, sizeof(out->name), "glob_branch");
+        snprintf(out->kernel, sizeof(out->kernel), (h->flags & IDC_FLAG_GLOBAL_HINTS) ? "glob_branch_kernel" : "(input pack fused into conv1_1)");
+        out->min_bytes = 0; out->launches = (h->flags & IDC_FLAG_GLOBAL_HINTS) ? 1 : 0;
     } else if (layer <= nl) {
         const Layer& L = h->layers[layer - 1];
         snprintf(out->name, sizeof(out->name), "%s", L.spec->name);

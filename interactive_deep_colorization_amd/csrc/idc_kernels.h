@@ -38,6 +38,15 @@ struct ConvArgs {
     // bias / shortcut / activation / BN.  ksplit <= 1: off.
     int ksplit, kc_per;
     float* partial;
+    // fused input pack (conv_igemm, HALO = 0, the conv1_1 launch): when pk_L != nullptr the "halo" rows are not
+    // loaded from `in` but built from the reference's input planes (NCHW fp32: L [N,1,H,W], ab [N,2,H,W],
+    // mask [N,1,H,W]) -- model.py:139-148 (cast, mask - maskcent, cat(L/100, ab/110, mask)) fused with the im2col
+    // of conv1_1: channel tap*4 + c of a site = normalised input c at 3x3 neighbour `tap`, zero outside the image
+    // and for K >= 36.
+    const float* pk_L;
+    const float* pk_ab;
+    const float* pk_mask;
+    float pk_ldiv, pk_abdiv, pk_mmul, pk_mcent;
     // fused shortcut conv (conv_igemm_v2, deconv launches only): a 3x3 conv (pad 1, bias folded into
     // `bias`) of in2 = NHWC [N][2*Hs][2*Ws][nkc2 * 64] bf16 accumulated into the same output pixels;
     // wgt2 = its layout-2 weight image (same couts).  model.py:156,170,172.

@@ -232,6 +232,50 @@ __global__ __launch_bounds__(WM* WP * 64) void conv_igemm(const ConvArgs a) {
     // (issue-early / write-late), so HBM/L2 latency hides behind 32 MFMAs per wave.
     u32x4 hreg[N_HITEMS];
     auto load_halo = [&](int kc) {
+        if constexpr (HALO == 0) {
+            if (a.pk_L != nullptr) {               // conv1_1: build the im2col rows from the L / ab / mask planes
+                // step 1 (first call only): the tile's (TH+2)x(TW+2) input patch, normalised once per pixel, goes to
+                // LDS with coalesced plane reads (zero outside the image = conv1_1's own zero padding)
+                constexpr int PW = TW + 2, PH = TH + 2;
+                float4* const patch = (float4*)(wbuf + 2 * W_BYTES);
+                if (kc == kc0) {
+                    const size_t hw = (size_t)Hs * Ws;
+                    const float* const pL = a.pk_L + (size_t)n * hw;
+                    const float* const pA = a.pk_ab + (size_t)n * 2 * hw;
+                    const float* const pM = a.pk_mask + (size_t)n * hw;
+                    for (int idx = tid; idx < PW * PH; idx += NT) {
+                        const int py = idx / PW, pxx = idx - py * PW;
+                        const int yy = ty0 - 1 + py, xx = tx0 - 1 + pxx;
+                        float4 c = float4{0.f, 0.f, 0.f, 0.f};
+                        if ((unsigned)yy < (unsigned)Hs && (unsigned)xx < (unsigned)Ws) {
+                            const size_t p = (size_t)yy * Ws + xx;
+                            c = float4{pL[p] / a.pk_ldiv, pA[p] / a.pk_abdiv, pA[hw + p] / a.pk_abdiv, pM[p] * a.pk_mmul - a.pk_mcent};
+                        }
+                        patch[idx] = c;
+                    }
+                    __syncthreads();
+                }
+                // step 2: this thread's 16-byte pieces of the im2col rows (K index = tap*4 + channel)
+#pragma unroll
+                for (int j = 0; j < N_HITEMS; ++j) {
+                    const int item = tid + j * NT;
+                    const int hr = item >> 3, sl = (item & 7) ^ swz(hr);          // logical slot of this piece
+                    const int hy = hr / HWP, hx = hr - hy * HWP;
+                    const bool live = ty0 + hy < Hs && tx0 + hx < Ws && item < HROWS * kSlots;
+                    if constexpr (sizeof(T) == 2) {                               // 8 bf16 = taps 2*sl, 2*sl+1
+                        const int t0 = sl * 2, t1 = sl * 2 + 1;
+                        const float4 c0 = (live && t0 < 9) ? patch[(hy + t0 / 3) * PW + hx + t0 % 3] : float4{0.f, 0.f, 0.f, 0.f};
+                        const float4 c1 = (live && t1 < 9) ? patch[(hy + t1 / 3) * PW + hx + t1 % 3] : float4{0.f, 0.f, 0.f, 0.f};
+                        hreg[j] = u32x4{pack_bf16x2(c0.x, c0.y), pack_bf16x2(c0.z, c0.w), pack_bf16x2(c1.x, c1.y), pack_bf16x2(c1.z, c1.w)};
+                    } else {                                                      // 4 fp32 = tap kc*8 + sl
+                        const int t0 = kc * 8 + sl;
+                        const float4 c0 = (live && t0 < 9) ? patch[(hy + t0 / 3) * PW + hx + t0 % 3] : float4{0.f, 0.f, 0.f, 0.f};
+                        hreg[j] = u32x4{__float_as_uint(c0.x), __float_as_uint(c0.y), __float_as_uint(c0.z), __float_as_uint(c0.w)};
+                    }
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < N_HITEMS; ++j) {
             const int off = hoff[j];
@@ -345,12 +389,12 @@ __global__ __launch_bounds__(WM* WP * 64) void conv_igemm(const ConvArgs a) {
         }
         return;
     }
-    float bias[16], bsc[16], bsh[16];
-    load16(bias, a.bias + co0);
     const bool has_bn = a.bn_scale != nullptr;
-    if (has_bn) { load16(bsc, a.bn_scale + co0); load16(bsh, a.bn_shift + co0); }
     const int so = a.so, Wout = Ws * so, Hout = Hs * so;
     const int ro = a.ro[phase], cof = a.co[phase];
+    float bias[16], bsc[16], bsh[16];
+    load16(bias, a.bias + co0);
+    if (has_bn) { load16(bsc, a.bn_scale + co0); load16(bsh, a.bn_shift + co0); }
 #pragma unroll
     for (int pj = 0; pj < 4; ++pj) {
         const int sy = ty0 + wp * 4 + pj, sx = tx0 + px;
@@ -372,7 +416,8 @@ static constexpr size_t conv_lds_bytes_c(int wm, int wp, int halo) {
     const int nt = wm * wp * 64;
     const int hrows = (16 + 2 * halo) * (4 * wp + 2 * halo);
     const int items = (hrows * kSlots + nt - 1) / nt;
-    return (size_t)items * nt * kSlotBytes + 2 * (size_t)(64 * wm) * kRowBytes;
+    // HALO == 0 instantiations also serve conv1_1's fused input pack: + the (TH+2)x(TW+2) float4 input patch
+    return (size_t)items * nt * kSlotBytes + 2 * (size_t)(64 * wm) * kRowBytes + (halo == 0 ? (size_t)18 * (4 * wp + 2) * 16 : 0);
 }
 
 template <typename T, int WM, int WP, int HALO>
