@@ -5,8 +5,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" = one pass of the hot path (pack_input -> 29 implicit-GEMM conv/deconv launches -> tanh
-head, i.e. SIGGRAPHGenerator.forward, models/pytorch/model.py:134-175) over one batch of 32
+A "step" = one pass of the hot path (input pack fused into conv1_1 -> 29 implicit-GEMM conv/deconv launches,
+the tanh head riding in the last one, i.e. SIGGRAPHGenerator.forward, models/pytorch/model.py:134-175) over one batch of 32
 synthetic 256x256 inputs per GPU, bf16 MFMA path -- BASELINE.json configs[2] ("Batch 32 random
 256x256 L-channels with random sparse hint masks, 1x MI355X bf16"), the configuration the
 images/sec target is quoted on.  Inputs and outputs are resident in HBM during the timed region.
@@ -19,7 +19,8 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   cpu_baseline  : the torch-CPU oracle (same ATen kernels as the reference's PyTorch backend)
                   timed on this box's host cores on a bounded sample (rank 0, N=1 only);
   latency       : p50 per-click recolor latency, BASELINE.json configs[1] (one 256x256 image,
-                  5 hint points), fp32 and bf16, kernel-only and through the blocking C-ABI call.
+                  5 hint points), fp32 and bf16: kernels only (device-resident), the blocking C-ABI call with
+                  host buffers, and the whole reference-API net_forward (forward + Lab->RGB + refresh).
 """
 import argparse
 import json
@@ -123,6 +124,29 @@ def measure_latency(sd, device):
         out[prec] = {"device_resident_p50_ms": round(statistics.median(tk) * 1e3, 4),
                      "c_abi_host_call_p50_ms": round(statistics.median(th) * 1e3, 4)}
         e.close()
+        # (iii) the whole reference-API call: ColorizeImageTorch.net_forward = guards + forward + Lab->RGB +
+        # the rgb->Lab refresh of output_ab (colorize_image.py:249-268), colour steps on the device
+        try:
+            import contextlib
+            import io
+            from interactive_deep_colorization_amd import api
+            rgb = np.load(os.path.join(REPO, "tests", "golden", "mortar_pestle_256_rgb.npy"))
+            with contextlib.redirect_stdout(io.StringIO()):
+                model = api.ColorizeImageTorch(Xd=256, precision=prec)
+                model.prep_net(gpu_id=device, state_dict=sd)
+                model.set_image(rgb)
+            for _ in range(10):
+                model.net_forward(hab, hm)
+            ta = []
+            for _ in range(100):
+                t0 = time.perf_counter()
+                model.net_forward(hab, hm)
+                ta.append(time.perf_counter() - t0)
+            out[prec]["api_net_forward_p50_ms"] = round(statistics.median(ta) * 1e3, 4)
+            model.net.close()
+        except Exception as ex:                      # the latency leg must never sink the bench line
+            out[prec]["api_net_forward_p50_ms"] = None
+            out[prec]["api_error"] = repr(ex)[:200]
     return out
 
 

@@ -151,6 +151,17 @@ int idc_forward_dist313(idc_handle h, int n, const float* L_mc, const float* ab,
                         float maskcent, float* out_ab, float* pred_ab, float* dist_S);
 /* Temperature of dist_S (the reference's scale_S parameter, colorize_image.py:482-485).  Default 0.2. */
 int idc_set_dist_temperature(idc_handle h, float S);
+/* ---- colour post-processing on the device: replaces lab2rgb_transpose + _set_out_ab_
+ *      (colorize_image.py:20-28,196-198,264-267), i.e. skimage.color.lab2rgb / rgb2lab (sRGB, D65, 2 degree
+ *      observer), which the reference runs on the host inside every net_forward.
+ *      rgb [n,H,W,3] uint8 = (clip(lab2rgb(L, ab), 0, 1) * 255) truncated, exactly the reference expression;
+ *      lab_q [n,3,H,W] float64 (may be NULL) = rgb2lab(rgb / 255): the "refreshed" output_lab / output_ab the
+ *      reference keeps.  Arithmetic in float64 like skimage.
+ *      idc_forward_rgb = idc_forward followed by the post step on the device-resident result, with
+ *      L = L_mc + l_cent (l_cent = 50, colorize_image.py:205); out_ab may be NULL. ------------------------- */
+int idc_lab2rgb(idc_handle h, int n, const float* L, const float* ab, uint8_t* rgb, double* lab_q);
+int idc_forward_rgb(idc_handle h, int n, const float* L_mc, const float* ab, const float* mask, float maskcent,
+                    float l_cent, float* out_ab, uint8_t* rgb, double* lab_q);
 int idc_sync(idc_handle h);
 /* The hipStream_t all work of this handle is enqueued on (as void*). */
 void* idc_stream(idc_handle h);

@@ -123,13 +123,18 @@ class ColorizeImageBase(object):
         self.input_mask_mult = input_mask * self.mask_mult
         return 0
 
-    def _finish_forward(self, raw_ab):
+    def _finish_forward(self, raw_ab, rgb=None, lab_q=None):
         """Lab->RGB of the prediction, then refresh ``output_ab`` from the uint8 result -- the
         reference does this round trip too (``:264-267,196-198``), so ``output_ab`` is the
-        quantised map while ``output_ab_raw`` (extra) is the net's own output."""
+        quantised map while ``output_ab_raw`` (extra) is the net's own output.  Both colour steps run on
+        the device (``idc_lab2rgb`` / fused in ``idc_forward_rgb``: float64, skimage's formulas)."""
         self.output_ab_raw = raw_ab
-        self.output_rgb = lab2rgb_transpose(self.img_l, raw_ab)
-        self._set_out_ab_()
+        if rgb is None:
+            rgb, lab_q = self.net.lab2rgb(self.img_l[None], raw_ab[None])
+            rgb, lab_q = rgb[0], lab_q[0]
+        self.output_rgb = rgb
+        self.output_lab = lab_q
+        self.output_ab = lab_q[1:]
         return self.output_rgb
 
     def _set_out_ab_(self):
@@ -221,8 +226,9 @@ class ColorizeImageTorch(ColorizeImageBase):
         if ColorizeImageBase.net_forward(self, input_ab, input_mask) == -1:
             return -1
         # the device boundary -- stands for self.net.forward(...)[0].cpu().data.numpy() at :263
-        raw = self.net.forward(self.img_l_mc, self.input_ab_mc, self.input_mask_mult, self.mask_cent)[0]
-        return self._finish_forward(raw)
+        raw, rgb, lab_q = self.net.forward_rgb(self.img_l_mc, self.input_ab_mc, self.input_mask_mult, self.mask_cent,
+                                               l_cent=self.l_mean)
+        return self._finish_forward(raw[0], rgb[0], lab_q[0])
 
 
 class ColorizeImageTorchDist(ColorizeImageTorch):
@@ -331,8 +337,8 @@ class ColorizeImageCaffe(ColorizeImageBase):
     def net_forward(self, input_ab, input_mask):
         if ColorizeImageBase.net_forward(self, input_ab, input_mask) == -1:
             return -1
-        raw = self.net.forward(self.img_l_mc, self.input_ab_mc, self.input_mask_mult, 0.0)[0]
-        return self._finish_forward(raw)
+        raw, rgb, lab_q = self.net.forward_rgb(self.img_l_mc, self.input_ab_mc, self.input_mask_mult, 0.0, l_cent=self.l_mean)
+        return self._finish_forward(raw[0], rgb[0], lab_q[0])
 
 
 class ColorizeImageCaffeGlobDist(ColorizeImageCaffe):

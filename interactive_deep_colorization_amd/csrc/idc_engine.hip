@@ -340,6 +340,8 @@ struct idc_context {
     int t_conv4_3 = -1, t_pred313 = -1;
     float *d_pred_ab = nullptr, *d_dist313 = nullptr, *h_pred_ab = nullptr, *h_dist313 = nullptr;   // 313 head outputs
     float dist_S = 0.2f;
+    unsigned char *d_rgb = nullptr, *h_rgb = nullptr;   // colour post-processing (allocated on first use)
+    double *d_labq = nullptr, *h_labq = nullptr;
     bool want_dist313 = false;           // the next forward also writes the full-resolution dist_S
     bool profiling = false;
     std::vector<hipEvent_t> ev;          // kProfRing slots x 2 per timed step: [pack, layers..., head, softmax]
@@ -698,9 +700,9 @@ static void destroy_ctx(idc_context* c) {
     for (auto& t : c->tensors) if (t.ptr) (void)hipFree(t.ptr);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->own_blob && c->d_blob) (void)hipFree(c->d_blob);
-    void* dev[] = {c->d_L, c->d_ab, c->d_mask, c->d_out, c->d_dist, c->d_scratch, c->d_glob_in, c->d_glob_vec, c->d_pred_ab, c->d_dist313, c->d_partial};
+    void* dev[] = {c->d_L, c->d_ab, c->d_mask, c->d_out, c->d_dist, c->d_scratch, c->d_glob_in, c->d_glob_vec, c->d_pred_ab, c->d_dist313, c->d_partial, c->d_rgb, c->d_labq};
     for (void* p : dev) if (p) (void)hipFree(p);
-    void* host[] = {c->h_in, c->h_out, c->h_dist, c->h_pred_ab};
+    void* host[] = {c->h_in, c->h_out, c->h_dist, c->h_pred_ab, c->h_rgb, c->h_labq};
     for (void* p : host) if (p) (void)hipHostFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -927,6 +929,56 @@ int idc_set_dist_temperature(idc_handle h, float S) {
     if (!(S > 0.f)) return fail(&h->err, IDC_ERR_INVALID_ARG, "temperature must be positive");
     h->dist_S = S;
     return IDC_OK;
+}
+
+static int ensure_post_buffers(idc_context* h) {
+    if (h->d_rgb) return IDC_OK;
+    const size_t hw = (size_t)h->H * h->W, nb = (size_t)h->max_batch;
+    HIPCHK(h, hipMalloc((void**)&h->d_rgb, nb * hw * 3));
+    HIPCHK(h, hipMalloc((void**)&h->d_labq, nb * hw * 3 * 8));
+    HIPCHK(h, hipHostMalloc((void**)&h->h_rgb, nb * hw * 3, hipHostMallocDefault));
+    HIPCHK(h, hipHostMalloc((void**)&h->h_labq, nb * hw * 3 * 8, hipHostMallocDefault));
+    return IDC_OK;
+}
+
+// post step on device-resident planes: d_Lp [n,1,H,W] (+ l_add), d_abp [n,2,H,W] -> host rgb / lab_q
+static int run_lab_post(idc_context* h, int n, const float* d_Lp, float l_add, const float* d_abp, uint8_t* rgb, double* lab_q) {
+    const size_t hw = (size_t)h->H * h->W;
+    int rc = ensure_post_buffers(h);
+    if (rc) return rc;
+    HIPCHK(h, launch_lab_post(d_Lp, l_add, d_abp, h->d_rgb, lab_q ? h->d_labq : nullptr, n, h->H, h->W, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_rgb, h->d_rgb, (size_t)n * hw * 3, hipMemcpyDeviceToHost, h->stream));
+    if (lab_q) HIPCHK(h, hipMemcpyAsync(h->h_labq, h->d_labq, (size_t)n * hw * 3 * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    memcpy(rgb, h->h_rgb, (size_t)n * hw * 3);
+    if (lab_q) memcpy(lab_q, h->h_labq, (size_t)n * hw * 3 * 8);
+    return IDC_OK;
+}
+
+int idc_lab2rgb(idc_handle h, int n, const float* L, const float* ab, uint8_t* rgb, double* lab_q) {
+    if (!h) return fail(nullptr, IDC_ERR_INVALID_ARG, "null handle");
+    if (n <= 0 || n > h->max_batch) return fail(&h->err, IDC_ERR_BATCH, "batch %d outside 1..%d", n, h->max_batch);
+    if (!L || !ab || !rgb) return fail(&h->err, IDC_ERR_INVALID_ARG, "null tensor pointer");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t hw = (size_t)h->H * h->W;
+    memcpy(h->h_in, L, (size_t)n * hw * 4);
+    memcpy(h->h_in + (size_t)n * hw, ab, (size_t)n * hw * 2 * 4);
+    HIPCHK(h, hipMemcpyAsync(h->d_L, h->h_in, (size_t)n * hw * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_out, h->h_in + (size_t)n * hw, (size_t)n * hw * 2 * 4, hipMemcpyHostToDevice, h->stream));
+    return run_lab_post(h, n, h->d_L, 0.f, h->d_out, rgb, lab_q);
+}
+
+int idc_forward_rgb(idc_handle h, int n, const float* L_mc, const float* ab, const float* mask, float maskcent,
+                    float l_cent, float* out_ab, uint8_t* rgb, double* lab_q) {
+    int rc = check_forward_args(h, n);
+    if (rc) return rc;
+    if (!rgb) return fail(&h->err, IDC_ERR_INVALID_ARG, "null rgb");
+    rc = ensure_post_buffers(h);
+    if (rc) return rc;
+    // forward (leaves L_mc in d_L and the ab map in d_out), then the colour step on the same stream
+    rc = forward_host(h, n, L_mc, ab, mask, maskcent, out_ab ? out_ab : h->h_out, nullptr);
+    if (rc) return rc;
+    return run_lab_post(h, n, h->d_L, l_cent, h->d_out, rgb, lab_q);
 }
 
 int idc_sync(idc_handle h) {

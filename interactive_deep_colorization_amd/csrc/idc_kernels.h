@@ -108,6 +108,11 @@ hipError_t launch_glob_branch(const float* in, const float* params, float* out, 
 constexpr int kGlobIn = 316, kGlobC = 512;
 constexpr size_t glob_param_floats() { return (size_t)kGlobIn * kGlobC + 3 * kGlobC + 3 * ((size_t)kGlobC * kGlobC + 3 * kGlobC); }
 
+// Lab -> sRGB uint8 (+ optional rgb -> Lab refresh), float64 like skimage (colorize_image.py:20-28,31-36):
+// L [N,1,H,W] fp32 (+ l_add), ab [N,2,H,W] fp32 -> rgb [N,H,W,3] u8, lab_q [N,3,H,W] f64 (or nullptr)
+hipError_t launch_lab_post(const float* L, float l_add, const float* ab, unsigned char* rgb, double* lab_q, int N,
+                           int H, int W, hipStream_t s);
+
 // layout converters for the single-operator test entry points and idc_get_activation
 hipError_t launch_nchw_to_nhwc(int precision, const float* src, void* dst, int N, int C, int H, int W,
                                int Cpad, hipStream_t s);

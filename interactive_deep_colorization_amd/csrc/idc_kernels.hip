@@ -1281,6 +1281,70 @@ hipError_t launch_glob_branch(const float* in, const float* params, float* out, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// lab_post: skimage.color.lab2rgb -> uint8 -> skimage.color.rgb2lab, per pixel, in float64 (the reference
+// computes this on the host in float64 inside every net_forward: colorize_image.py:20-36,196-198,264-267).
+// Same constants and operation order as oracle/colorspace.py.  Elementwise, one thread
+// per pixel; 65536 pixels per 256x256 image -- latency-, not bandwidth-relevant (it removes ~10 ms of host
+// numpy from the per-click path).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lab_post_kernel(const float* __restrict__ Lp, float l_add, const float* __restrict__ ab,
+                                                       unsigned char* __restrict__ rgb, double* __restrict__ lab_q,
+                                                       long long npix, int HW) {
+    const double M[3][3] = {{0.412453, 0.357580, 0.180423}, {0.212671, 0.715160, 0.072169}, {0.019334, 0.119193, 0.950227}};
+    // inverse of M (numpy.linalg.inv of the matrix above, float64)
+    const double Mi[3][3] = {{3.240481343200526, -1.5371515162713185, -0.4985363261688878},
+                             {-0.9692549499965682, 1.8759900014898907, 0.04155592655829284},
+                             {0.05564663913517716, -0.20404133836651123, 1.0573110696453443}};
+    const double white[3] = {0.95047, 1.0, 1.08883};
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
+        const long long n = p / HW, r = p - n * HW;
+        const double L = (double)Lp[p] + (double)l_add;
+        const double a = (double)ab[(n * 2 + 0) * HW + r], b = (double)ab[(n * 2 + 1) * HW + r];
+        double f[3];
+        f[1] = (L + 16.0) / 116.0;
+        f[0] = a / 500.0 + f[1];
+        f[2] = fmax(f[1] - b / 200.0, 0.0);                                  // skimage zeroes negative z
+        double xyz[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) xyz[i] = (f[i] > 0.2068966 ? f[i] * f[i] * f[i] : (f[i] - 16.0 / 116.0) / 7.787) * white[i];
+        unsigned char q[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double lin = xyz[0] * Mi[c][0] + xyz[1] * Mi[c][1] + xyz[2] * Mi[c][2];
+            double s = lin > 0.0031308 ? 1.055 * pow(fmax(lin, 0.0), 1.0 / 2.4) - 0.055 : 12.92 * lin;
+            s = fmin(fmax(s, 0.0), 1.0);
+            q[c] = (unsigned char)(s * 255.0);                               // astype('uint8'): truncation
+            rgb[p * 3 + c] = q[c];
+        }
+        if (lab_q != nullptr) {
+            double lin[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double v = (double)q[c] / 255.0;
+                lin[c] = v > 0.04045 ? pow((v + 0.055) / 1.055, 2.4) : v / 12.92;
+            }
+            double g[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double t = (lin[0] * M[i][0] + lin[1] * M[i][1] + lin[2] * M[i][2]) / white[i];
+                g[i] = t > 0.008856 ? cbrt(t) : 7.787 * t + 16.0 / 116.0;
+            }
+            lab_q[(n * 3 + 0) * HW + r] = 116.0 * g[1] - 16.0;
+            lab_q[(n * 3 + 1) * HW + r] = 500.0 * (g[0] - g[1]);
+            lab_q[(n * 3 + 2) * HW + r] = 200.0 * (g[1] - g[2]);
+        }
+    }
+}
+
+hipError_t launch_lab_post(const float* L, float l_add, const float* ab, unsigned char* rgb, double* lab_q, int N,
+                           int H, int W, hipStream_t s) {
+    const long long npix = (long long)N * H * W;
+    const int blocks = (int)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096);
+    hipLaunchKernelGGL(lab_post_kernel, dim3(blocks), dim3(256), 0, s, L, l_add, ab, rgb, lab_q, npix, H * W);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // layout converters (test entry points / activation dumps only -- not on the hot path)
 // ------------------------------------------------------------------------------------------------
 template <typename T>

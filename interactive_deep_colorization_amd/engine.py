@@ -188,6 +188,31 @@ class HipColorizer(object):
                                             _fptr(out), _fptr(dq)))
         return out, dq
 
+    def lab2rgb(self, L, ab, want_lab=True):
+        """Device colour step: L (n,1,H,W) in [0,100], ab (n,2,H,W) -> (rgb (n,H,W,3) uint8, lab_q (n,3,H,W) f64 or None)
+        = ``lab2rgb_transpose`` + the rgb->Lab refresh of the reference (colorize_image.py:20-36,196-198)."""
+        L = np.asarray(L)
+        if L.ndim == 3:
+            L, ab = L[None], np.asarray(ab)[None]
+        n = L.shape[0]
+        Lc, Ac = _f32c(L, (n, 1, self.H, self.W)), _f32c(ab, (n, 2, self.H, self.W))
+        rgb = np.empty((n, self.H, self.W, 3), np.uint8)
+        labq = np.empty((n, 3, self.H, self.W), np.float64) if want_lab else None
+        self._chk(self.lib.idc_lab2rgb(self._h, n, _fptr(Lc), _fptr(Ac), rgb.ctypes.data_as(ctypes.c_void_p),
+                                       labq.ctypes.data_as(ctypes.c_void_p) if want_lab else None))
+        return rgb, labq
+
+    def forward_rgb(self, L_mc, ab, mask, maskcent=0.0, l_cent=50.0, want_lab=True):
+        """forward + the colour step on the device: (out_ab (n,2,H,W) f32, rgb (n,H,W,3) u8, lab_q (n,3,H,W) f64 | None)."""
+        n, L, A, M = self._prep(L_mc, ab, mask)
+        out = np.empty((n, 2, self.H, self.W), np.float32)
+        rgb = np.empty((n, self.H, self.W, 3), np.uint8)
+        labq = np.empty((n, 3, self.H, self.W), np.float64) if want_lab else None
+        self._chk(self.lib.idc_forward_rgb(self._h, n, _fptr(L), _fptr(A), _fptr(M), float(maskcent), float(l_cent), _fptr(out),
+                                           rgb.ctypes.data_as(ctypes.c_void_p),
+                                           labq.ctypes.data_as(ctypes.c_void_p) if want_lab else None))
+        return out, rgb, labq
+
     def forward_dist313(self, L_mc, ab, mask, maskcent=0.0, want_dist=True):
         """313-bin head of the Caffe distribution net: returns (out_ab regression, pred_ab soft-decode (N,2,H,W),
         dist_S (N,313,H,W) full-resolution softmax(S*logits) or None)."""

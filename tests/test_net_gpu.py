@@ -248,3 +248,25 @@ def test_drop_in_api_end_to_end(golden, make_sd):
     assert dist.dist_ab_grid.shape == (23, 23, 256, 256)
     reccs, conf = dist.get_ab_reccs(135, 160, K=3, N=2000, return_conf=True)
     assert reccs.shape == (3, 2) and abs(conf.sum() - 1) < 1e-6
+
+
+def test_device_colour_post_matches_host_formulas(golden, make_sd):
+    """idc_lab2rgb / idc_forward_rgb against the numpy restatement of skimage's lab2rgb /
+    rgb2lab (oracle/colorspace.py): uint8 RGB equal up to the truncation knife edge (<= 1 LSB on <= 0.01 % of the
+    values), refreshed Lab = rgb2lab of the device's own uint8 image to 1e-9."""
+    from oracle import colorspace as ocs
+    g = golden("config2_mortar_5hints")
+    e = get_engine(256, 256, 1, "fp32", 0, "he", make_sd=make_sd)
+    L = g["L_mc"] + 50.0
+    rs = np.random.RandomState(3)
+    ab = rs.uniform(-100, 100, (1, 2, 256, 256)).astype(np.float32)         # includes far out-of-gamut colours
+    rgb, labq = e.lab2rgb(L, ab)
+    ref = (np.clip(ocs.lab2rgb(np.concatenate((L[0], ab[0]), 0).transpose(1, 2, 0).astype(np.float64)), 0, 1) * 255).astype("uint8")
+    diff = np.abs(rgb[0].astype(int) - ref.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() <= 1e-4, (diff.max(), (diff > 0).mean())
+    np.testing.assert_allclose(labq[0], ocs.rgb2lab(rgb[0]).transpose(2, 0, 1), atol=1e-9)
+    out, rgb2, labq2 = e.forward_rgb(g["L_mc"], g["ab"], g["mask"], 0.0, l_cent=50.0)
+    assert np.abs(out - g["out_ab"]).max() <= FP32_TOL["he"]
+    rgb3, labq3 = e.lab2rgb(L, out)
+    np.testing.assert_array_equal(rgb2, rgb3)
+    np.testing.assert_array_equal(labq2, labq3)
