@@ -121,7 +121,7 @@ static void pack_layer_weights(uint8_t* wimg, int precision, int layout, const L
             for (int ci = 0; ci < cin; ++ci)
                 for (int t = 0; t < 9; ++t)
                     put_w(wimg, precision, layout, lb.nkc, lb.ncg, t, co, ci, w[((size_t)co * cin + ci) * 9 + t]);
-    } else if (s.kind == kConvIm2col) {          // K index = tap*4 + c  (pack_input_kernel order)
+    } else if (s.kind == kConvIm2col) {          // K index = tap*4 + c  (the order conv1_1's fused input pack builds)
         for (int co = 0; co < cout; ++co)
             for (int ci = 0; ci < cin; ++ci)
                 for (int t = 0; t < 9; ++t)

@@ -79,11 +79,6 @@ hipError_t launch_splitk_epilogue(int precision, const ConvArgs& a, hipStream_t 
 hipError_t init_kernels();
 size_t conv_lds_bytes(ConvConfig cfg, int halo);
 
-// L/ab/mask planes (NCHW fp32) -> im2col'd conv1_1 operand [N][H][W][64]: channel tap*4+c holds
-// normalised input c of the 3x3 neighbour `tap` (zero outside the image, zero for k >= 36).
-hipError_t launch_pack_input(int precision, const float* L, const float* ab, const float* mask,
-                             void* out, int N, int H, int W, float l_div, float ab_div,
-                             float mask_mul, float maskcent, hipStream_t s);
 // conv1x1(128->2) + tanh + *out_mul, NHWC (T) -> NCHW fp32
 hipError_t launch_head(int precision, const void* x, const float* w, const float* b, float* out,
                        int N, int H, int W, float out_mul, hipStream_t s);

@@ -291,27 +291,19 @@ __global__ __launch_bounds__(WM* WP * 64) void conv_igemm(const ConvArgs a) {
         for (int j = 0; j < N_HITEMS; ++j) *(u32x4*)(halo + (tid + j * NT) * kSlotBytes) = hreg[j];
         for (int t = 0; t < ntaps; ++t) {
             char* const wcur = wbuf + cur * W_BYTES;
-#ifndef IDC_ABL_NO_WWRITE
 #pragma unroll
             for (int j = 0; j < N_WITEMS; ++j)
                 *(u32x4*)(wcur + (tid + j * NT) * kSlotBytes) = wreg[j];
-#endif
-#ifndef IDC_ABL_NO_BARRIER
             __syncthreads();
-#endif
             // prefetch the next (tap, chunk) weight tile; it lands in registers under the MFMAs
             {
                 int t2 = t + 1, kc2 = kc;
                 if (t2 == ntaps) { t2 = 0; kc2 = kc + 1; }
                 if (kc2 == nkc) { t2 = t; kc2 = kc; }     // last step: harmless reload, keeps the loop branch-free
                 const char* src = wbase + (size_t)tap_tw[t2] * w_tap_stride + (size_t)kc2 * w_kc_stride;
-#ifndef IDC_ABL_NO_WLOAD
 #pragma unroll
                 for (int j = 0; j < N_WITEMS; ++j)
                     wreg[j] = *(const u32x4*)(src + (size_t)j * NT * kSlotBytes);
-#else
-                asm volatile("" :: "v"(src));
-#endif
             }
             if (t == ntaps - 1 && kc + 1 < nkc) load_halo(kc + 1);
             // keep the prefetch loads ABOVE the MFMA cluster (hipcc otherwise sinks them below it to
@@ -326,30 +318,16 @@ __global__ __launch_bounds__(WM* WP * 64) void conv_igemm(const ConvArgs a) {
             for (int ks = 0; ks < 2; ++ks) {
                 const int slot = ks * 4 + g;
                 u32x4 wf[4], xf[4];
-#ifndef IDC_ABL_NO_DSREAD
 #pragma unroll
                 for (int ci = 0; ci < 4; ++ci)
                     wf[ci] = *(const u32x4*)(wcur + wrow_byte + ci * 16 * kRowBytes + ((slot ^ wsw) * kSlotBytes));
 #pragma unroll
                 for (int pj = 0; pj < 4; ++pj)
                     xf[pj] = *(const u32x4*)(halo + xrow[pj] * kRowBytes + ((slot ^ swz(xrow[pj])) * kSlotBytes));
-#else
-#pragma unroll
-                for (int ci = 0; ci < 4; ++ci) {
-                    wf[ci] = u32x4{0x3c003c00u + (unsigned)slot, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
-                    xf[ci] = u32x4{0x3c003c00u + (unsigned)xrow[ci], 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
-                    asm volatile("" : "+v"(wf[ci]), "+v"(xf[ci]));
-                }
-#endif
-#ifndef IDC_ABL_NO_MFMA
 #pragma unroll
                 for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
                     for (int pj = 0; pj < 4; ++pj) Mma<T>::run(acc[ci][pj], wf[ci], xf[pj]);
-#else
-#pragma unroll
-                for (int ci = 0; ci < 4; ++ci) asm volatile("" :: "v"(wf[ci]), "v"(xf[ci]));
-#endif
             }
             cur ^= 1;
         }
@@ -976,69 +954,6 @@ hipError_t launch_conv_v2(ConvConfig cfg, int halo, const ConvArgs& a, hipStream
     IDC_FOR_EACH_CONV_V2(X)
 #undef X
     return hipErrorInvalidConfiguration;
-}
-
-// ------------------------------------------------------------------------------------------------
-// pack_input: models/pytorch/model.py:139-148 (cast, mask - maskcent, cat(L/100, ab/110, mask))
-// fused with the im2col of conv1_1 so that the 4->64 conv is a K=64 GEMM on the MFMA.
-// One thread = one (pixel, 16-byte/32-byte slot of 8 channels = taps 2q, 2q+1).
-// ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ L, const float* __restrict__ ab,
-                                                         const float* __restrict__ mask, T* __restrict__ out,
-                                                         int N, int H, int W, float l_div, float ab_div,
-                                                         float mask_mul, float maskcent) {
-    const long long total = (long long)N * H * W * 8;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int q = (int)(i & 7);
-        const long long pix = i >> 3;
-        const int x = (int)(pix % W);
-        const int y = (int)((pix / W) % H);
-        const int n = (int)(pix / ((long long)W * H));
-        float v[8];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int tap = q * 2 + h;
-            float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-            if (tap < 9) {
-                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
-                    const size_t p = (size_t)yy * W + xx;
-                    const size_t hw = (size_t)H * W;
-                    c0 = L[(size_t)n * hw + p] / l_div;
-                    c1 = ab[((size_t)n * 2 + 0) * hw + p] / ab_div;
-                    c2 = ab[((size_t)n * 2 + 1) * hw + p] / ab_div;
-                    c3 = mask[(size_t)n * hw + p] * mask_mul - maskcent;
-                }
-            }
-            v[h * 4 + 0] = c0; v[h * 4 + 1] = c1; v[h * 4 + 2] = c2; v[h * 4 + 3] = c3;
-        }
-        if (sizeof(T) == 4) {
-            float4* o = (float4*)((float*)out + pix * 64 + q * 8);
-            o[0] = float4{v[0], v[1], v[2], v[3]};
-            o[1] = float4{v[4], v[5], v[6], v[7]};
-        } else {
-            uint4 p;
-            p.x = pack_bf16x2(v[0], v[1]); p.y = pack_bf16x2(v[2], v[3]);
-            p.z = pack_bf16x2(v[4], v[5]); p.w = pack_bf16x2(v[6], v[7]);
-            *(uint4*)((unsigned short*)out + pix * 64 + q * 8) = p;
-        }
-    }
-}
-
-hipError_t launch_pack_input(int precision, const float* L, const float* ab, const float* mask, void* out,
-                             int N, int H, int W, float l_div, float ab_div, float mask_mul, float maskcent,
-                             hipStream_t s) {
-    const long long total = (long long)N * H * W * 8;
-    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    if (precision == 1)
-        hipLaunchKernelGGL(pack_input_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, L, ab, mask, (__bf16*)out, N, H, W,
-                           l_div, ab_div, mask_mul, maskcent);
-    else
-        hipLaunchKernelGGL(pack_input_kernel<float>, dim3(blocks), dim3(256), 0, s, L, ab, mask, (float*)out, N, H, W,
-                           l_div, ab_div, mask_mul, maskcent);
-    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------

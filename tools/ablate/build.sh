@@ -1,14 +1,9 @@
 #!/bin/bash
-# builds every ablation variant of the conv kernel (tuning harness)
+# Builds the standalone timing harness of the conv kernels (tuning tool, not part of the library):
+#   ablate_BASE    plain timing          ablate_TIMING  + in-kernel cycle stamps (IDC_TIMING)
+# usage of the binaries: see ablate.hip (N HW C halo wm wp prec v2 ntaps [C2]); run1..6.sh / run_pmc*.sh are the
+# gpurun scripts used during round 1.
 cd "$(dirname "$0")"
-build() { name=$1; shift; hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -DABL_NAME=\"$name\" "$@" ablate.hip -o ablate_$name 2>&1 | grep -E "error|Error"; }
-build BASE &
-build NO_WLOAD -DIDC_ABL_NO_WLOAD &
-build NO_WWRITE -DIDC_ABL_NO_WWRITE &
-build NO_BARRIER -DIDC_ABL_NO_BARRIER &
-build NO_MFMA -DIDC_ABL_NO_MFMA &
-build MFMA_DSREAD_ONLY -DIDC_ABL_NO_WLOAD -DIDC_ABL_NO_WWRITE -DIDC_ABL_NO_BARRIER &
-build MFMA_ONLY -DIDC_ABL_NO_WLOAD -DIDC_ABL_NO_WWRITE -DIDC_ABL_NO_BARRIER -DIDC_ABL_NO_DSREAD &
-build NO_DSREAD -DIDC_ABL_NO_DSREAD &
-wait
-ls -la ablate_* 
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -DABL_NAME=\"BASE\" ablate.hip -o ablate_BASE
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -DABL_NAME=\"TIMING\" -DIDC_TIMING ablate.hip -o ablate_TIMING
+ls -la ablate_BASE ablate_TIMING

@@ -7,8 +7,8 @@ WRITE_SIZE cannot share a pass: MI355X_MICROARCH.md, rocprofv3 PMC slots) -> pro
 Units and the gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in
 KiB; on this rocprofv3 FETCH_SIZE reports exactly half of the bytes of a wide coalesced (16 B/lane)
 read stream, which is what every load of these kernels is, so read bytes = 2 * FETCH_SIZE * 1024.
-WRITE_SIZE is calibrated here on pack_input (it writes N*H*W*64 bf16 = 268,435,456 B at N=32 and
-the counter reads 262,144 KiB): write bytes = WRITE_SIZE * 1024.
+WRITE_SIZE was calibrated on a kernel with a known write volume (the round-1 input-pack kernel, and now
+conv1_1: N*H*W*64 bf16 = 268,435,456 B at N=32, counter 262,144 KiB): write bytes = WRITE_SIZE * 1024.
 """
 import collections
 import json
