@@ -162,6 +162,14 @@ int idc_set_dist_temperature(idc_handle h, float S);
 int idc_lab2rgb(idc_handle h, int n, const float* L, const float* ab, uint8_t* rgb, double* lab_q);
 int idc_forward_rgb(idc_handle h, int n, const float* L_mc, const float* ab, const float* mask, float maskcent,
                     float l_cent, float* out_ab, uint8_t* rgb, double* lab_q);
+/* ---- Global statistics of a reference image: replaces the global_stats.prototxt net the
+ *      notebook runs to obtain glob_dist (DemoGlobalHistogramTransfer.ipynb:176-186; models/global_model/
+ *      global_stats.prototxt:10-31,101-111,214-244; caffe_traininglayers.py:53-119,161-196; color_quantization.py:7-33):
+ *      RGB uint8 -> Lab (skimage rgb2lab) -> 4x4 average pool of ab -> hard 1-nearest-neighbour assignment to the
+ *      313 bin centres (NN = 1: weight 1) -> global average = histogram [n,313] (rows sum to 1); s_avg [n] (may be
+ *      NULL) = global mean of the HSV saturation (skimage rgb2hsv), the value s_avg_mask would carry.
+ *      rgb [n,H,W,3] with the handle's H, W; centres [313,2] = pts_in_hull (a, b). ------------------------------ */
+int idc_global_histogram(idc_handle h, int n, const uint8_t* rgb, const float* centres, float* hist, float* s_avg);
 int idc_sync(idc_handle h);
 /* The hipStream_t all work of this handle is enqueued on (as void*). */
 void* idc_stream(idc_handle h);

@@ -365,6 +365,16 @@ class ColorizeImageCaffeGlobDist(ColorizeImageCaffe):
             sd['model1.0.weight'] = w4
         ColorizeImageCaffe.prep_net(self, gpu_id, prototxt_path, caffemodel_path, state_dict=sd)
 
+    def get_global_histogram(self, ref_rgb, pts_in_hull=None):
+        """The notebook's ``get_global_histogram`` (``DemoGlobalHistogramTransfer.ipynb:176-186``), i.e. the
+        ``global_stats.prototxt`` net, on the device: an Xd x Xd RGB uint8 reference image -> the 313-bin global ab
+        histogram to pass as ``glob_dist``.  ``pts_in_hull`` defaults to the table loaded like the reference does."""
+        centres = self.pts_in_hull if pts_in_hull is None else pts_in_hull
+        if centres is None:
+            raise RuntimeError('pts_in_hull.npy was not found at %s; pass pts_in_hull' % self.pts_in_hull_path)
+        hist, _ = self.net.global_histogram(ref_rgb, np.asarray(centres, np.float32))
+        return hist[0]
+
     def net_forward(self, input_ab, input_mask, glob_dist=-1):
         # glob_dist is a 313 array, or -1 (reference :451-459)
         if not self.net_set:

@@ -931,6 +931,12 @@ int idc_set_dist_temperature(idc_handle h, float S) {
     return IDC_OK;
 }
 
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
+};
+
 static int ensure_post_buffers(idc_context* h) {
     if (h->d_rgb) return IDC_OK;
     const size_t hw = (size_t)h->H * h->W, nb = (size_t)h->max_batch;
@@ -979,6 +985,35 @@ int idc_forward_rgb(idc_handle h, int n, const float* L_mc, const float* ab, con
     rc = forward_host(h, n, L_mc, ab, mask, maskcent, out_ab ? out_ab : h->h_out, nullptr);
     if (rc) return rc;
     return run_lab_post(h, n, h->d_L, l_cent, h->d_out, rgb, lab_q);
+}
+
+int idc_global_histogram(idc_handle h, int n, const uint8_t* rgb, const float* centres, float* hist, float* s_avg) {
+    if (!h) return fail(nullptr, IDC_ERR_INVALID_ARG, "null handle");
+    if (n <= 0 || n > h->max_batch) return fail(&h->err, IDC_ERR_BATCH, "batch %d outside 1..%d", n, h->max_batch);
+    if (!rgb || !centres || !hist) return fail(&h->err, IDC_ERR_INVALID_ARG, "null pointer");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = ensure_post_buffers(h);                      // d_rgb doubles as the upload buffer of the reference image
+    if (rc) return rc;
+    const size_t hw = (size_t)h->H * h->W;
+    DevBuf d_c, d_counts, d_sat;
+    HIPCHK(h, d_c.alloc(626 * 4)); HIPCHK(h, d_counts.alloc((size_t)n * 313 * 4)); HIPCHK(h, d_sat.alloc((size_t)n * 8));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(h->d_rgb, rgb, (size_t)n * hw * 3, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(d_c.p, centres, 626 * 4, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemset(d_counts.p, 0, (size_t)n * 313 * 4));
+    HIPCHK(h, hipMemset(d_sat.p, 0, (size_t)n * 8));
+    HIPCHK(h, launch_global_stats(h->d_rgb, (const float*)d_c.p, (unsigned*)d_counts.p, (double*)d_sat.p, n, h->H, h->W, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::vector<unsigned> cnt((size_t)n * 313);
+    std::vector<double> sat(n);
+    HIPCHK(h, hipMemcpy(cnt.data(), d_counts.p, cnt.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(sat.data(), d_sat.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    const double nblk = (double)(h->H / 4) * (h->W / 4);
+    for (int i = 0; i < n; ++i) {
+        for (int k = 0; k < 313; ++k) hist[(size_t)i * 313 + k] = (float)(cnt[(size_t)i * 313 + k] / nblk);
+        if (s_avg) s_avg[i] = (float)(sat[i] / (double)hw);
+    }
+    return IDC_OK;
 }
 
 int idc_sync(idc_handle h) {
@@ -1091,11 +1126,6 @@ int idc_get_activation(idc_handle h, const char* name, int n, float* out, size_t
 }
 
 // ---- single operators -----------------------------------------------------------------------------
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
-};
 
 static int run_single_op(int device_id, int precision, LayerSpec spec, int n, int h, int w, const float* x,
                          const float* weight, const float* bias, const float* bn_scale, const float* bn_shift,

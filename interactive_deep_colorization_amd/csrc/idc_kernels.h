@@ -108,6 +108,11 @@ constexpr size_t glob_param_floats() { return (size_t)kGlobIn * kGlobC + 3 * kGl
 hipError_t launch_lab_post(const float* L, float l_add, const float* ab, unsigned char* rgb, double* lab_q, int N,
                            int H, int W, hipStream_t s);
 
+// Global statistics (global_stats.prototxt): rgb u8 [N,H,W,3] -> counts [N][313] (uint32, zeroed by the caller) of
+// the 4x4-pooled ab values' nearest centre, and sat_sum [N] (float64, zeroed) = sum of HSV saturation over pixels.
+hipError_t launch_global_stats(const unsigned char* rgb, const float* centres, unsigned* counts, double* sat_sum, int N,
+                               int H, int W, hipStream_t s);
+
 // layout converters for the single-operator test entry points and idc_get_activation
 hipError_t launch_nchw_to_nhwc(int precision, const float* src, void* dst, int N, int C, int H, int W,
                                int Cpad, hipStream_t s);

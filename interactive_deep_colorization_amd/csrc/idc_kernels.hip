@@ -1260,6 +1260,73 @@ hipError_t launch_lab_post(const float* L, float l_add, const float* ab, unsigne
 }
 
 // ------------------------------------------------------------------------------------------------
+// global_stats: the reference's global_stats.prototxt on one reference image -- rgb2lab per pixel (float64, the
+// skimage formulas of lab_post_kernel), 4x4 average pool of ab (Pooling AVE k4 s4, :101-111), hard assignment of
+// each pooled value to its nearest of the 313 centres (NNEncLayer with NN = 1, caffe_traininglayers.py:161-196),
+// counted with integer atomics (deterministic); plus the sum of the HSV saturation (BGR2HSVLayer :53-85).
+// One thread per 4x4 block.  A 256x256 image is 4096 blocks: latency-, not bandwidth-relevant.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rgb8_to_lab(const unsigned char* q, double& L, double& a, double& b) {
+    const double M[3][3] = {{0.412453, 0.357580, 0.180423}, {0.212671, 0.715160, 0.072169}, {0.019334, 0.119193, 0.950227}};
+    const double white[3] = {0.95047, 1.0, 1.08883};
+    double lin[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double v = (double)q[c] / 255.0;
+        lin[c] = v > 0.04045 ? pow((v + 0.055) / 1.055, 2.4) : v / 12.92;
+    }
+    double g[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double t = (lin[0] * M[i][0] + lin[1] * M[i][1] + lin[2] * M[i][2]) / white[i];
+        g[i] = t > 0.008856 ? cbrt(t) : 7.787 * t + 16.0 / 116.0;
+    }
+    L = 116.0 * g[1] - 16.0; a = 500.0 * (g[0] - g[1]); b = 200.0 * (g[1] - g[2]);
+}
+
+__global__ __launch_bounds__(256) void global_stats_kernel(const unsigned char* __restrict__ rgb, const float* __restrict__ centres,
+                                                           unsigned* __restrict__ counts, double* __restrict__ sat_sum,
+                                                           int N, int H, int W) {
+    __shared__ float cc[313 * 2];
+    for (int i = threadIdx.x; i < 626; i += blockDim.x) cc[i] = centres[i];
+    __syncthreads();
+    const int h4 = H >> 2, w4 = W >> 2;
+    const long long nblk = (long long)N * h4 * w4;
+    for (long long blk = (long long)blockIdx.x * blockDim.x + threadIdx.x; blk < nblk; blk += (long long)gridDim.x * blockDim.x) {
+        const int bx = (int)(blk % w4), by = (int)((blk / w4) % h4), n = (int)(blk / ((long long)w4 * h4));
+        double sa = 0.0, sb = 0.0, ssat = 0.0;
+        for (int dy = 0; dy < 4; ++dy)
+            for (int dx = 0; dx < 4; ++dx) {
+                const unsigned char* q = rgb + (((size_t)n * H + by * 4 + dy) * W + bx * 4 + dx) * 3;
+                double L, a, b;
+                rgb8_to_lab(q, L, a, b);
+                sa += a; sb += b;
+                const double r = q[0] / 255.0, g = q[1] / 255.0, bl = q[2] / 255.0;
+                const double mx = fmax(r, fmax(g, bl)), mn = fmin(r, fmin(g, bl));
+                ssat += mx > 0.0 ? (mx - mn) / mx : 0.0;                     // skimage rgb2hsv saturation
+            }
+        const float pa = (float)(sa / 16.0), pb = (float)(sb / 16.0);      // Caffe blobs are fp32
+        int best = 0;
+        float bd = 3.0e38f;
+        for (int k = 0; k < 313; ++k) {
+            const float da = pa - cc[2 * k], db = pb - cc[2 * k + 1];
+            const float d = da * da + db * db;
+            if (d < bd) { bd = d; best = k; }
+        }
+        atomicAdd(&counts[(size_t)n * 313 + best], 1u);
+        atomicAdd(&sat_sum[n], ssat);
+    }
+}
+
+hipError_t launch_global_stats(const unsigned char* rgb, const float* centres, unsigned* counts, double* sat_sum, int N,
+                               int H, int W, hipStream_t s) {
+    const long long nblk = (long long)N * (H / 4) * (W / 4);
+    const int blocks = (int)((nblk + 255) / 256 < 1024 ? (nblk + 255) / 256 : 1024);
+    hipLaunchKernelGGL(global_stats_kernel, dim3(blocks), dim3(256), 0, s, rgb, centres, counts, sat_sum, N, H, W);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // layout converters (test entry points / activation dumps only -- not on the hot path)
 // ------------------------------------------------------------------------------------------------
 template <typename T>

@@ -188,6 +188,22 @@ class HipColorizer(object):
                                             _fptr(out), _fptr(dq)))
         return out, dq
 
+    def global_histogram(self, rgb, centres, want_sat=True):
+        """Global statistics of reference image(s) (the reference's global_stats.prototxt): rgb (n,H,W,3) or (H,W,3)
+        uint8, centres (313,2) -> (hist (n,313) float32 summing to 1, s_avg (n,) mean HSV saturation or None)."""
+        rgb = np.ascontiguousarray(np.asarray(rgb), dtype=np.uint8)
+        if rgb.ndim == 3:
+            rgb = rgb[None]
+        n = rgb.shape[0]
+        if rgb.shape != (n, self.H, self.W, 3):
+            raise ValueError("rgb must be (n,%d,%d,3), got %s" % (self.H, self.W, rgb.shape))
+        c = _f32c(centres, (313, 2))
+        hist = np.empty((n, 313), np.float32)
+        sat = np.empty(n, np.float32) if want_sat else None
+        self._chk(self.lib.idc_global_histogram(self._h, n, rgb.ctypes.data_as(ctypes.c_void_p), _fptr(c), _fptr(hist),
+                                                _fptr(sat) if want_sat else None))
+        return hist, sat
+
     def lab2rgb(self, L, ab, want_lab=True):
         """Device colour step: L (n,1,H,W) in [0,100], ab (n,2,H,W) -> (rgb (n,H,W,3) uint8, lab_q (n,3,H,W) f64 or None)
         = ``lab2rgb_transpose`` + the rgb->Lab refresh of the reference (colorize_image.py:20-36,196-198)."""

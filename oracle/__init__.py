@@ -23,9 +23,11 @@ Pinning status
   reference-generated fixtures are the only pins that exist.
 * ``siggraph_numpy``: independent float64 restatement (im2col + matmul) used to
   cross-check the torch restatement and to measure the fp32 noise floor.
-* ``colorspace`` (skimage restatement) and ``caffe_heads`` (313-bin decode and
-  global-hints branch, Caffe prototxt restatements): PARITY UNPINNED -- neither
-  skimage nor Caffe can be installed here; they follow the published formulas
-  and the prototxt line by line and are checked against textbook known answers
-  only.
+* ``colorspace`` (skimage restatement) and the Caffe-only branches inside
+  ``siggraph_torch`` (``pred313_head``: 313-bin distribution + soft-decode,
+  ``global_branch``: Global-Hints fusion; restatements of the prototxt):
+  PARITY UNPINNED -- neither skimage nor Caffe can be installed here and the
+  reference ships no weights or outputs for them; they follow the published
+  formulas / the prototxt line by line (fixtures:
+  ``oracle/make_golden_caffe_branches.py``).
 """

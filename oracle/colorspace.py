@@ -72,3 +72,22 @@ def lab2rgb_transpose(img_l, img_ab):
 def rgb2lab_transpose(img_rgb):
     """``data/colorize_image.py:31-36``: XxXx3 -> 3xXxX."""
     return rgb2lab(img_rgb).transpose((2, 0, 1))
+
+
+def global_stats(rgb_u8, centres):
+    """``models/global_model/global_stats.prototxt`` restated (PARITY UNPINNED: Caffe Python layers, not runnable
+    here): rgb2lab -> 4x4 average pool of ab (``:101-111``) -> 1-nearest-neighbour hard assignment to the 313
+    centres (``NNEncLayer`` with NN = 1, ``caffe_traininglayers.py:161-196`` / ``color_quantization.py:7-33``)
+    -> global mean (``:224-233``); and the global mean of the HSV saturation (``:10-21,123-141``).
+    (X, Y, 3) uint8 -> (hist (313,), s_avg)."""
+    lab = rgb2lab(rgb_u8)
+    X, Y = lab.shape[:2]
+    ab = lab[..., 1:].astype(np.float32).reshape(X // 4, 4, Y // 4, 4, 2).astype(np.float64).mean(axis=(1, 3)).astype(np.float32)
+    c = np.asarray(centres, np.float32)
+    d = ((ab[:, :, None, :] - c[None, None]) ** 2).sum(-1)
+    idx = d.argmin(-1)
+    hist = np.bincount(idx.ravel(), minlength=313).astype(np.float64) / idx.size
+    v = np.asarray(rgb_u8, np.float64) / 255.0
+    mx, mn = v.max(-1), v.min(-1)
+    sat = np.where(mx > 0, (mx - mn) / np.where(mx > 0, mx, 1), 0.0)
+    return hist.astype(np.float32), float(sat.mean())

@@ -159,3 +159,24 @@ def test_caffe_dist_api_class(golden):
     assert model.dist_ab.shape == (313, 256, 256) and abs(model.dist_ab[:, 100, 100].sum() - 1) < 1e-3
     reccs, conf = model.get_ab_reccs(135, 160, K=3, N=2000, return_conf=True)
     assert reccs.shape == (3, 2) and abs(conf.sum() - 1) < 1e-6
+
+
+def test_global_statistics_extractor():
+    """idc_global_histogram = models/global_model/global_stats.prototxt (the notebook's get_global_histogram) against
+    the numpy restatement: the histogram is a count of 4096 hard assignments, so it matches exactly except where a
+    pooled ab value is equidistant from two centres to the last bit (allowed: <= 2 of 4096 blocks move)."""
+    import os
+    from oracle import colorspace as ocs
+    rgb = np.load(os.path.join(os.path.dirname(__file__), "golden", "mortar_pestle_256_rgb.npy"))
+    rs = np.random.RandomState(1)
+    noise = rs.randint(0, 256, (256, 256, 3)).astype(np.uint8)
+    centres = weights.synthetic_ab_centres(0)
+    e = engine.HipColorizer(256, 256, max_batch=2, precision="bf16")
+    hist, sat = e.global_histogram(np.stack([rgb, noise]), centres)
+    for i, img in enumerate((rgb, noise)):
+        rh, rsat = ocs.global_stats(img, centres)
+        assert abs(hist[i].sum() - 1.0) < 1e-6
+        assert np.abs(hist[i] - rh).sum() <= 4.0 / 4096 + 1e-7, np.abs(hist[i] - rh).sum()
+        assert abs(sat[i] - rsat) < 1e-5
+    assert hist[0].max() > 0.05                                     # a real photo concentrates on few bins
+    e.close()
