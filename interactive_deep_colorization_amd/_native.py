@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libideepcolor_hip.so")
 
 IDC_FP32, IDC_BF16 = 0, 1
-IDC_FLAG_DIST_HEAD, IDC_FLAG_HIP_GRAPH, IDC_FLAG_GLOBAL_HINTS, IDC_FLAG_DIST313 = 0x1, 0x2, 0x4, 0x8
+IDC_FLAG_DIST_HEAD, IDC_FLAG_GLOBAL_HINTS, IDC_FLAG_DIST313 = 0x1, 0x4, 0x8
 IDC_OK = 0
 STATUS_NAMES = {0: "IDC_OK", -1: "IDC_ERR_INVALID_ARG", -2: "IDC_ERR_NO_DEVICE", -3: "IDC_ERR_HIP",
                 -4: "IDC_ERR_NO_WEIGHTS", -5: "IDC_ERR_MISSING_KEY", -6: "IDC_ERR_BATCH",
