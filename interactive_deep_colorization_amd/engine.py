@@ -268,7 +268,7 @@ class HipColorizer(object):
         return rows
 
     def set_profiling(self, on):
-        self._chk(self.lib.idc_set_profiling(self._h, 1 if on else 0))
+        self._chk(self.lib.idc_set_profiling(self._h, 2 if on == "forward" else (1 if on else 0)))
 
     def layer_times_ms(self):
         n = self.lib.idc_num_layers(self._h)

@@ -21,6 +21,6 @@ for p in stats pmc_fetch pmc_write pmc_sq; do
   [ -n "$f" ] && python tools/rocpd_summary.py $f > $OUT/${p}_summary.txt
   grep -h '"metric"' $OUT/$p.log | tail -1 > $OUT/${p}_benchline.json
 done
-python tools/pmc_traffic.py $(find $OUT/pmc_fetch -name "*.db" | head -1) $(find $OUT/pmc_write -name "*.db" | head -1) 7 $OUT/pmc_traffic.json
+python tools/pmc_traffic.py $(find $OUT/pmc_fetch -name "*.db" | head -1) $(find $OUT/pmc_write -name "*.db" | head -1) 12 $OUT/pmc_traffic.json
 find $OUT -name "*.db" -delete        # keep the summaries, drop the raw databases (size)
 ls -la $OUT
