@@ -270,3 +270,23 @@ def test_device_colour_post_matches_host_formulas(golden, make_sd):
     rgb3, labq3 = e.lab2rgb(L, out)
     np.testing.assert_array_equal(rgb2, rgb3)
     np.testing.assert_array_equal(labq2, labq3)
+
+
+@pytest.mark.parametrize("precision,tiles", [("fp32", "auto"), ("bf16", "small"), ("bf16", "large")])
+def test_ragged_geometry_40x72_batch3(make_sd, precision, tiles):
+    """H, W multiples of 8 only (40 x 72: every level has partial tiles, the 5x9 trunk is smaller than one tile and
+    than the dilation-2 halo), odd batch; against the oracle run here."""
+    L, ab, m = workloads.random_batch(3, 40, 72, seed=31, max_points=4, max_p=2)
+    sd = make_sd(2, "he")
+    engine.set_tile_policy(tiles)
+    e = engine.HipColorizer(40, 72, max_batch=3, precision=precision)
+    e.load_state_dict(sd)
+    out = e.forward(L, ab, m, 0.5)
+    ref = siggraph_torch.forward(sd, L, ab, m, 0.5)
+    d = np.abs(out - ref)
+    if precision == "fp32":
+        assert d.max() <= FP32_TOL["he"], d.max()
+    else:
+        assert d.max() <= BF16_MAX["he"] and d.mean() <= BF16_MEAN["he"], (d.max(), d.mean())
+    np.testing.assert_array_equal(e.forward(L[2:3], ab[2:3], m[2:3], 0.5)[0], out[2])
+    e.close()
