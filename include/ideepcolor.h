@@ -123,7 +123,9 @@ int idc_forward_device(idc_handle h, int n, const float* d_L_mc, const float* d_
                        const float* d_mask, float maskcent, float* d_out_ab, int sync);
 /* dist=True variant (needs IDC_FLAG_DIST_HEAD): additionally writes the 529-bin distribution
  * softmax(0.2*logits) at quarter resolution, dist_q [n,529,H/4,W/4] (the reference's out_cl is
- * its nearest x4 upsample, model.py:160: out_cl[:, :, y, x] == dist_q[:, :, y/4, x/4]).         */
+ * its nearest x4 upsample, model.py:160: out_cl[:, :, y, x] == dist_q[:, :, y/4, x/4]).
+ * dist_q may be NULL: the distribution then stays resident on the device for idc_dist_at /
+ * idc_suggest_colors / idc_get_dist (no 8.7 MB-per-image copy-out on the click path).           */
 int idc_forward_dist(idc_handle h, int n, const float* L_mc, const float* ab, const float* mask,
                      float maskcent, float* out_ab, float* dist_q);
 /* ---- Global Hints: replaces the glob_ab_313_mask / s_avg_mask inputs of the Caffe global net
@@ -171,6 +173,46 @@ int idc_forward_rgb(idc_handle h, int n, const float* L_mc, const float* ab, con
  *      NULL) = global mean of the HSV saturation (skimage rgb2hsv), the value s_avg_mask would carry.
  *      rgb [n,H,W,3] with the handle's H, W; centres [313,2] = pts_in_hull (a, b). ------------------------------ */
 int idc_global_histogram(idc_handle h, int n, const uint8_t* rgb, const float* centres, float* hist, float* s_avg);
+
+/* ---- Click session: the image's L plane and the hint planes stay on the device, a click
+ *      sends its rectangle list only.  Replaces the host work in front of every net_forward of the GUI:
+ *      UIControl.get_input (ui/ui_control.py:177-187, PointEdit.updateInput :52-63: cv2.rectangle, filled, corners
+ *      inclusive, later edits paint over earlier ones, canvas starts black / mask 0) followed by rgb2lab of the
+ *      canvas and mask > 0 in gui_draw.compute_result (ui/gui_draw.py:273-277) -- mode IDC_HINT_RGB, c0..c2 = the
+ *      uint8 RGB of the edit; or the notebook's put_point (DemoInteractiveColorization.ipynb:131-139) -- mode
+ *      IDC_HINT_AB, (c0, c1) = the (a, b) value.  Rectangles are clipped to the image; uncovered pixels get
+ *      ab = 0, mask = 0.  mask_value = what a covered mask pixel holds (1; 110 for the Caffe nets' mask_mult).
+ *      idc_set_image_l: L_mc [H,W] = L - 50 of image slot img (colorize_image.py:68-77 img_l_mc), uploaded once.
+ *      idc_forward_resident: forward of slots 0..n-1 from the resident planes; out_ab [n,2,H,W], rgb [n,H,W,3] u8,
+ *      lab_q [n,3,H,W] f64 as in idc_forward_rgb -- each may be NULL.  Handles with a distribution head leave the
+ *      distribution resident (idc_keep_dist for the 313 head).  idc_get_hint_planes reads the planes back
+ *      (tests; the wrapper's input_ab / input_mask attributes). -------------------------------------------- */
+enum { IDC_HINT_AB = 0, IDC_HINT_RGB = 1 };
+typedef struct idc_hint { int32_t y0, x0, y1, x1; float c0, c1, c2; } idc_hint;
+int idc_set_image_l(idc_handle h, int img, const float* L_mc);
+int idc_set_hints(idc_handle h, int img, int n_hints, const idc_hint* hints, int mode, float mask_value);
+int idc_get_hint_planes(idc_handle h, int img, float* ab, float* mask);
+int idc_forward_resident(idc_handle h, int n, float maskcent, float l_cent, float* out_ab, uint8_t* rgb, double* lab_q);
+
+/* ---- Colour suggestions: ColorizeImageTorchDist.get_ab_reccs (colorize_image.py:322-354)
+ *      on the device-resident distribution of the last forward, instead of copying 529 x H x W probabilities to
+ *      the host per click.  idc_dist_bins: 529 / 313 / 0.  idc_dist_at: the B probabilities of pixel (y, x) of
+ *      image img (the 529 head is stored at H/4: pixel (y/4, x/4), model.py:131,160).  idc_get_dist: the whole
+ *      resident tensor ([n,529,H/4,W/4] or [n,313,H,W]).  idc_keep_dist: 313 handles write dist_S on every
+ *      forward (82 MB per 256x256 image of device traffic) so that suggestions can follow.
+ *      idc_suggest_colors: cmf = cumsum(pdf)/sum (fp32, sequential); N inverse-CDF draws (np.digitize) from the
+ *      counter-based generator u_i = lowbias32(i*0x9E3779B9 + seed*0x85EBCA6B + 0x165667B1) >> 8 / 2^24; k-means
+ *      with K clusters over the drawn colours centres[bin] ([B,2] = pts_grid / pts_in_hull) -- greedy k-means++
+ *      seeding (most-drawn bin, then argmax count x D^2), Lloyd to a fixed point, float64; out_centres [K,2] and
+ *      out_conf [K] (= cluster share of the N draws) ordered by occupancy, descending; out_counts [B] (may be
+ *      NULL) = draws per bin.  The reference draws from numpy's global RNG and uses sklearn's randomly seeded
+ *      KMeans, so its output is not reproducible run to run; this one is a deterministic function of seed. --- */
+int idc_dist_bins(idc_handle h);
+int idc_keep_dist(idc_handle h, int on);
+int idc_dist_at(idc_handle h, int img, int y, int x, float* pdf);
+int idc_get_dist(idc_handle h, int n, float* dist);
+int idc_suggest_colors(idc_handle h, int img, int y, int x, int K, int N, unsigned seed, const float* centres,
+                       double* out_centres, double* out_conf, unsigned* out_counts);
 int idc_sync(idc_handle h);
 /* The hipStream_t all work of this handle is enqueued on (as void*). */
 void* idc_stream(idc_handle h);

@@ -25,7 +25,10 @@ EXPORTED_SYMBOLS = [
     "idc_load_weights", "idc_weights_device_ptr", "idc_forward", "idc_forward_device", "idc_forward_dist",
     "idc_lab2rgb", "idc_forward_rgb", "idc_global_histogram", "idc_forward_dist313", "idc_set_dist_temperature", "idc_set_global_hints", "idc_clear_global_hints", "idc_sync", "idc_stream", "idc_num_layers", "idc_layer_info_get", "idc_set_profiling",
     "idc_layer_times_ms", "idc_get_activation", "idc_op_conv2d", "idc_op_deconv4x4s2",
+    "idc_set_image_l", "idc_set_hints", "idc_get_hint_planes", "idc_forward_resident",
+    "idc_dist_bins", "idc_keep_dist", "idc_dist_at", "idc_get_dist", "idc_suggest_colors",
 ]
+IDC_HINT_AB, IDC_HINT_RGB = 0, 1
 
 
 class IdcError(RuntimeError):
@@ -37,6 +40,12 @@ class IdcError(RuntimeError):
 class TensorDesc(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char_p), ("data", ctypes.POINTER(ctypes.c_float)),
                 ("ndim", ctypes.c_int), ("dims", ctypes.c_int64 * 4)]
+
+
+class Hint(ctypes.Structure):
+    """idc_hint: inclusive rectangle + (a, b) or (r, g, b)."""
+    _fields_ = [("y0", ctypes.c_int32), ("x0", ctypes.c_int32), ("y1", ctypes.c_int32), ("x1", ctypes.c_int32),
+                ("c0", ctypes.c_float), ("c1", ctypes.c_float), ("c2", ctypes.c_float)]
 
 
 class LayerInfo(ctypes.Structure):
@@ -102,6 +111,15 @@ def load():
                                 c_float_p, c_float_p, c_float_p, c_float_p])
     proto("idc_op_deconv4x4s2", ci, [ci, ci, ci, ci, ci, ci, c_float_p, ci, c_float_p, c_float_p, ci,
                                      c_float_p, c_float_p])
+    proto("idc_set_image_l", ci, [vp, ci, c_float_p])
+    proto("idc_set_hints", ci, [vp, ci, ci, ctypes.POINTER(Hint), ci, cf])
+    proto("idc_get_hint_planes", ci, [vp, ci, c_float_p, c_float_p])
+    proto("idc_forward_resident", ci, [vp, ci, cf, cf, c_float_p, vp, vp])
+    proto("idc_dist_bins", ci, [vp])
+    proto("idc_keep_dist", ci, [vp, ci])
+    proto("idc_dist_at", ci, [vp, ci, ci, ci, c_float_p])
+    proto("idc_get_dist", ci, [vp, ci, c_float_p])
+    proto("idc_suggest_colors", ci, [vp, ci, ci, ci, ci, ci, ctypes.c_uint, c_float_p, vp, vp, vp])
     _lib = lib
     return lib
 

@@ -59,6 +59,21 @@ def read_state_dict(path):
     return sd
 
 
+def _lazy(name, refresh):
+    """Attribute that is materialised from device memory on first read after a forward (the reference fills these
+    eagerly on the host in every ``net_forward``; here a click does not pay for copies nobody reads)."""
+    slot = '_lazy_' + name
+
+    def fget(self):
+        getattr(self, refresh)()
+        return self.__dict__.get(slot)
+
+    def fset(self, value):
+        self.__dict__[slot] = value
+
+    return property(fget, fset)
+
+
 class ColorizeImageBase(object):
     """Image state + getters shared by every backend (reference ``:39-198``).
 
@@ -71,9 +86,22 @@ class ColorizeImageBase(object):
         self.img_l_set = False
         self.net_set = False
         self.img_just_set = False
+        self._l_resident = False              # the image's L plane is in the engine's slot 0
+        self._hints_on_device = False         # input_ab / input_mask live on the device (net_forward_hints)
 
     def prep_net(self):
         raise Exception("Should be implemented by base class")
+
+    # input_ab / input_mask: plain attributes after net_forward; after net_forward_hints they are read back from the
+    # device planes only when something (get_input_img, get_sup_img, ...) asks for them
+    def _refresh_hint_planes(self):
+        if self._hints_on_device:
+            self._hints_on_device = False
+            ab, mask = self.net.hint_planes(0)
+            self.input_ab, self.input_mask = ab, mask / self.mask_mult
+
+    input_ab = _lazy('input_ab', '_refresh_hint_planes')
+    input_mask = _lazy('input_mask', '_refresh_hint_planes')
 
     # ------------------------------------------------------------------ image ingestion
     def _ingest(self, rgb_fullres, rgb_net):
@@ -98,6 +126,7 @@ class ColorizeImageBase(object):
         self.img_lab_mc = self.img_lab / scale - shift
         self.img_l_mc = self.img_lab_mc[[0]]          # = L - 50 for every shipped backend
         self.img_l_set = True
+        self._l_resident = False
 
     def load_image(self, input_path):
         """Read a file, keep the full-res copy, bilinear-resize to Xd x Xd (``:52-66``)."""
@@ -117,11 +146,40 @@ class ColorizeImageBase(object):
             if not ready:
                 print(complaint)
                 return -1
+        self._hints_on_device = False
         self.input_ab = input_ab
         self.input_mask = input_mask
         self.input_ab_mc = (input_ab - self.ab_mean) / self.ab_norm
         self.input_mask_mult = input_mask * self.mask_mult
         return 0
+
+    def _stage_hints(self, hints, mode):
+        """Guards of net_forward, then: L plane resident (uploaded once per image), hint list rasterised on the
+        device -- what ``UIControl.get_input`` + ``rgb2lab`` (``ui/ui_control.py:177-187``, ``ui/gui_draw.py:273-277``)
+        or the notebook's ``put_point`` do on the host before every forward."""
+        for ready, complaint in ((self.img_l_set, 'I need to have an image!'),
+                                 (self.net_set, 'I need to have a net!')):
+            if not ready:
+                print(complaint)
+                return -1
+        if self.ab_mean != 0 or self.ab_norm != 1:
+            raise ValueError('device-side hints assume raw ab inputs (ab_mean 0, ab_norm 1)')
+        if not self._l_resident:
+            self.net.set_image_l(self.img_l_mc, 0)
+            self._l_resident = True
+        self.net.set_hints(hints, mode=mode, img=0, mask_value=self.mask_mult)
+        self._hints_on_device = True
+        return 0
+
+    def net_forward_hints(self, hints, mode='rgb'):
+        """``net_forward`` for a list of edits instead of rasterised planes (not in the reference: it removes the last
+        per-click host work).  hints: rows ``(y0, x0, y1, x1, r, g, b)`` (mode 'rgb': uint8
+        colours, rectangle corners inclusive as ``cv2.rectangle``) or ``(y0, x0, y1, x1, a, b)`` (mode 'ab').
+        Returns what ``net_forward`` returns."""
+        if self._stage_hints(hints, mode) == -1:
+            return -1
+        raw, rgb, lab_q = self.net.forward_resident(1, getattr(self, 'mask_cent', 0), l_cent=self.l_mean)
+        return self._finish_forward(raw[0], rgb[0], lab_q[0])
 
     def _finish_forward(self, raw_ab, rgb=None, lab_q=None):
         """Lab->RGB of the prediction, then refresh ``output_ab`` from the uint8 result -- the
@@ -232,19 +290,40 @@ class ColorizeImageTorch(ColorizeImageBase):
 
 
 class ColorizeImageTorchDist(ColorizeImageTorch):
-    """Regression + 529-bin colour distribution and colour suggestions (``:279-372``)."""
+    """Regression + 529-bin colour distribution and colour suggestions (``:279-372``).
+
+    The distribution stays on the device after ``net_forward``: ``get_ab_reccs`` runs there
+    (``idc_suggest_colors``) and ``dist_ab`` / ``dist_ab_full`` / ``dist_ab_grid`` are copied out (and x4
+    nearest-upsampled, ``model.py:131,160``) only when read -- the reference moves 529 x X x X floats to the host
+    on every call."""
 
     def __init__(self, Xd=256, maskcent=False, precision='fp32'):
         ColorizeImageTorch.__init__(self, Xd, precision=precision)
         self.dist_ab_set = False
+        self._dist_on_device = False
         self.pts_grid = _grid_529()
         self.in_hull = np.ones(529, dtype=bool)
         self.AB = 529
         self.A = self.B = 23
+        self.dist_ab = None
         self.dist_ab_full = np.zeros((self.AB, Xd, Xd))
         self.dist_ab_grid = np.zeros((self.A, self.B, Xd, Xd))
         self.dist_entropy = np.zeros((Xd, Xd))
         self.mask_cent = .5 if maskcent else 0
+
+    def _refresh_dist(self):
+        if self._dist_on_device:
+            self._dist_on_device = False
+            dist_q = self.net.get_dist(1)[0]
+            # device holds softmax(0.2*logits) at X/4; the reference's out_cl is its nearest x4 upsample
+            self.dist_ab = np.repeat(np.repeat(dist_q, 4, axis=1), 4, axis=2)
+            full = self.__dict__['_lazy_dist_ab_full']
+            full[self.in_hull] = self.dist_ab
+            self.dist_ab_grid = full.reshape((self.A, self.B, self.Xd, self.Xd))
+
+    dist_ab = _lazy('dist_ab', '_refresh_dist')
+    dist_ab_full = _lazy('dist_ab_full', '_refresh_dist')
+    dist_ab_grid = _lazy('dist_ab_grid', '_refresh_dist')
 
     def prep_net(self, gpu_id=None, path='', dist=True, S=.2, state_dict=None):
         ColorizeImageTorch.prep_net(self, gpu_id=gpu_id, path=path, dist=dist, state_dict=state_dict)
@@ -252,34 +331,34 @@ class ColorizeImageTorchDist(ColorizeImageTorch):
     def net_forward(self, input_ab, input_mask):
         if ColorizeImageBase.net_forward(self, input_ab, input_mask) == -1:
             return -1
-        out_ab, dist_q = self.net.forward_dist(self.img_l_mc, self.input_ab_mc, self.input_mask_mult, self.mask_cent)
-        # device returns softmax(0.2*logits) at X/4; the reference's out_cl is its nearest x4
-        # upsample (models/pytorch/model.py:131,160)
-        self.dist_ab = np.repeat(np.repeat(dist_q[0], 4, axis=1), 4, axis=2)
+        out_ab, _ = self.net.forward_dist(self.img_l_mc, self.input_ab_mc, self.input_mask_mult, self.mask_cent,
+                                          want_dist=False)
+        self._dist_on_device = True
         self.dist_ab_set = True
-        self.dist_ab_full[self.in_hull] = self.dist_ab
-        self.dist_ab_grid = self.dist_ab_full.reshape((self.A, self.B, self.Xd, self.Xd))
         # the reference returns out_reg*110*110 here (model.py:166-168), a value nothing reads;
         # this returns the ab map itself
         return out_ab[0]
 
+    def net_forward_hints(self, hints, mode='rgb'):
+        if self._stage_hints(hints, mode) == -1:
+            return -1
+        out_ab, _, _ = self.net.forward_resident(1, self.mask_cent, want_rgb=False)
+        self._dist_on_device = True
+        self.dist_ab_set = True
+        return out_ab[0]
+
     def get_ab_reccs(self, h, w, K=5, N=25000, return_conf=False):
-        """K suggested colours at pixel (h,w): sample N points from the predicted pdf, k-means them,
-        order by cluster occupancy (``:322-354``)."""
+        """K suggested colours at pixel (h,w): N inverse-CDF draws from the predicted pdf, k-means, ordered by
+        cluster occupancy (``:322-354``) -- on the device.  Like the reference the draw depends on numpy's global
+        RNG state (one ``np.random.randint`` seeds the device generator); unlike sklearn's KMeans the clustering
+        itself is deterministic."""
         if not self.dist_ab_set:
             print('Need to set prediction first')
             return 0
-        from sklearn.cluster import KMeans
-        cmf = np.cumsum(self.dist_ab[:, h, w])
-        cmf = cmf / cmf[-1]
-        draws = np.random.uniform(low=0, high=1.0, size=N)
-        samples = self.pts_in_hull[np.digitize(draws, bins=cmf), :]
-        km = KMeans(n_clusters=K).fit(samples)
-        counts = np.histogram(km.labels_, np.arange(0, K + 1))[0]
-        order = np.argsort(counts, axis=0)[::-1]
-        centers = km.cluster_centers_[order, :]
+        seed = int(np.random.randint(0, 2 ** 31 - 1))
+        centers, conf = self.net.suggest_colors(h, w, self.pts_in_hull, K=K, N_draws=N, seed=seed)
         if return_conf:
-            return centers, 1. * counts[order] / N
+            return centers, conf
         return centers
 
     def compute_entropy(self):
@@ -404,6 +483,8 @@ class ColorizeImageCaffeDist(ColorizeImageCaffe):
     def __init__(self, Xd=256, precision='fp32'):
         ColorizeImageCaffe.__init__(self, Xd, precision=precision)
         self.dist_ab_set = False
+        self._dist_on_device = False
+        self.dist_ab = None
         self.scale_S_layer = 'scale_S'
         self.dist_ab_S_layer = 'dist_ab_S'
         grid_path = os.path.join(os.path.dirname(self.pts_in_hull_path), 'pts_grid.npy')
@@ -428,36 +509,45 @@ class ColorizeImageCaffeDist(ColorizeImageCaffe):
         ColorizeImageCaffe.prep_net(self, gpu_id, prototxt_path, caffemodel_path, state_dict=sd)
         self.S = S
         self.net.set_dist_temperature(S)
+        self.net.keep_dist(True)          # dist_ab_S stays on the device after every forward
+
+    def _refresh_dist(self):
+        if self._dist_on_device:
+            self._dist_on_device = False
+            self.dist_ab = self.net.get_dist(1)[0]               # in-gamut, 313 x X x X
+            if self.in_hull is not None:                         # full 529 grid, as the reference keeps it
+                full = self.__dict__['_lazy_dist_ab_full']
+                full[self.in_hull, :, :] = self.dist_ab
+                self.dist_ab_grid = full.reshape((self.A, self.B, self.Xd, self.Xd))
+
+    dist_ab = _lazy('dist_ab', '_refresh_dist')
+    dist_ab_full = _lazy('dist_ab_full', '_refresh_dist')
+    dist_ab_grid = _lazy('dist_ab_grid', '_refresh_dist')
 
     def net_forward(self, input_ab, input_mask):
         if ColorizeImageBase.net_forward(self, input_ab, input_mask) == -1:
             return -1
-        _, pred, dist = self.net.forward_dist313(self.img_l_mc, self.input_ab_mc, self.input_mask_mult, 0.0)
+        _, pred, _ = self.net.forward_dist313(self.img_l_mc, self.input_ab_mc, self.input_mask_mult, 0.0, want_dist=False)
         ret = self._finish_forward(pred[0])
-        self.dist_ab = dist[0]                                   # in-gamut, 313 x X x X
+        self._dist_on_device = True
         self.dist_ab_set = True
-        if self.in_hull is not None:                             # full 529 grid, as the reference keeps it
-            self.dist_ab_full[self.in_hull, :, :] = self.dist_ab
-            self.dist_ab_grid = self.dist_ab_full.reshape((self.A, self.B, self.Xd, self.Xd))
         return ret
 
+    def net_forward_hints(self, hints, mode='rgb'):
+        """Edits rasterised on the device, then the regular 313-head forward on the read-back planes."""
+        if self._stage_hints(hints, mode) == -1:
+            return -1
+        return self.net_forward(self.input_ab, self.input_mask)
+
     def get_ab_reccs(self, h, w, K=5, N=25000, return_conf=False):
-        """Recommended colours at (h, w): N samples of the 313-bin pdf, k-means, sorted by occupancy (``:509-543``)."""
+        """Recommended colours at (h, w): N draws of the 313-bin pdf, k-means, sorted by occupancy (``:509-543``) -- on
+        the device-resident ``dist_ab_S`` (see ``ColorizeImageTorchDist.get_ab_reccs``)."""
         if not self.dist_ab_set:
             print('Need to set prediction first')
             return 0
-        from sklearn.cluster import KMeans
-        cmf = np.cumsum(self.dist_ab[:, h, w])
-        cmf = cmf / cmf[-1]
-        rnd_pts = np.random.uniform(low=0, high=1.0, size=N)
-        inds = np.minimum(np.digitize(rnd_pts, bins=cmf), 312)
-        rnd_pts_ab = self._centres[inds, :]
-        kmeans = KMeans(n_clusters=K, n_init=10).fit(rnd_pts_ab)
-        k_label_cnt = np.histogram(kmeans.labels_, np.arange(0, K + 1))[0]
-        k_inds = np.argsort(k_label_cnt, axis=0)[::-1]
-        cluster_per = 1. * k_label_cnt[k_inds] / N
-        cluster_centers = kmeans.cluster_centers_[k_inds, :]
-        return (cluster_centers, cluster_per) if return_conf else cluster_centers
+        seed = int(np.random.randint(0, 2 ** 31 - 1))
+        centers, conf = self.net.suggest_colors(h, w, self._centres, K=K, N_draws=N, seed=seed)
+        return (centers, conf) if return_conf else centers
 
     def compute_entropy(self):
         self.dist_entropy = np.sum(self.dist_ab * np.log(self.dist_ab), axis=0)

@@ -342,7 +342,12 @@ struct idc_context {
     float dist_S = 0.2f;
     unsigned char *d_rgb = nullptr, *h_rgb = nullptr;   // colour post-processing (allocated on first use)
     double *d_labq = nullptr, *h_labq = nullptr;
+    float* d_post_in = nullptr;          // idc_lab2rgb staging (L + ab planes): the resident L / hint planes are left alone
     bool want_dist313 = false;           // the next forward also writes the full-resolution dist_S
+    bool keep_dist313 = false;           // idc_keep_dist: every forward leaves dist_S resident (colour suggestions)
+    int dist_n = 0;                      // images whose distribution is resident from the last forward (0 = none)
+    HintRect *d_hints = nullptr, *h_hints = nullptr; int hints_cap = 0;   // click session: hint list staging
+    float* d_centres = nullptr; double* d_sugg = nullptr; unsigned* d_sugg_counts = nullptr;   // colour suggestions
     int profiling = 0;                   // 0 off, 1 = an event pair around every launch, 2 = one pair around the whole forward
     std::vector<hipEvent_t> ev;          // kProfRing slots x 2 per timed step: [pack, layers..., head, softmax]
     int n_timed = 0;
@@ -652,9 +657,11 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
     if (c->flags & IDC_FLAG_DIST313) {         // bilinear x4 + softmax(S.) + softmax(2.6 .) -> pred_ab decode
         const Tensor& tp = c->tensors[c->t_pred313];
         HIPCHK(c, launch_dist313((const float*)tp.ptr, (const float*)(c->d_blob + c->plan.pred_ab_off), c->d_pred_ab,
-                                 c->want_dist313 ? c->d_dist313 : nullptr, n, c->H, c->W, tp.Cpad, c->dist_S, 2.6f, s));
+                                 (c->want_dist313 || c->keep_dist313) ? c->d_dist313 : nullptr, n, c->H, c->W, tp.Cpad,
+                                 c->dist_S, 2.6f, s));
     }
     toc();
+    c->dist_n = (ddist || ((c->flags & IDC_FLAG_DIST313) && (c->want_dist313 || c->keep_dist313))) ? n : 0;
     c->last_n = n;
     if (c->profiling == 2) (void)hipEventRecord(c->ev[ring + 1], s);
     if (c->profiling) ++c->prof_count;
@@ -669,11 +676,11 @@ static int check_forward_args(idc_context* c, int n) {
 }
 
 static int forward_host(idc_context* c, int n, const float* L_mc, const float* ab, const float* mask, float maskcent,
-                        float* out_ab, float* dist_q) {
+                        float* out_ab, float* dist_q, bool keep_dist = false) {
     int rc = check_forward_args(c, n);
     if (rc) return rc;
     if (!L_mc || !ab || !mask || !out_ab) return fail(&c->err, IDC_ERR_INVALID_ARG, "null tensor pointer");
-    if (dist_q && !(c->flags & IDC_FLAG_DIST_HEAD))
+    if ((dist_q || keep_dist) && !(c->flags & IDC_FLAG_DIST_HEAD))
         return fail(&c->err, IDC_ERR_UNSUPPORTED, "handle was created without IDC_FLAG_DIST_HEAD");
     HIPCHK(c, hipSetDevice(c->device));
     const size_t hw = (size_t)c->H * c->W;
@@ -684,7 +691,7 @@ static int forward_host(idc_context* c, int n, const float* L_mc, const float* a
     HIPCHK(c, hipMemcpyAsync(c->d_L, hL, (size_t)n * hw * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_ab, hab, (size_t)n * hw * 2 * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_mask, hm, (size_t)n * hw * 4, hipMemcpyHostToDevice, c->stream));
-    rc = run_graph(c, n, c->d_L, c->d_ab, c->d_mask, maskcent, c->d_out, dist_q ? c->d_dist : nullptr);
+    rc = run_graph(c, n, c->d_L, c->d_ab, c->d_mask, maskcent, c->d_out, (dist_q || keep_dist) ? c->d_dist : nullptr);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, (size_t)n * hw * 2 * 4, hipMemcpyDeviceToHost, c->stream));
     const size_t dq = (size_t)n * 529 * (hw / 16) * 4;
@@ -702,9 +709,9 @@ static void destroy_ctx(idc_context* c) {
     for (auto& t : c->tensors) if (t.ptr) (void)hipFree(t.ptr);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->own_blob && c->d_blob) (void)hipFree(c->d_blob);
-    void* dev[] = {c->d_L, c->d_ab, c->d_mask, c->d_out, c->d_dist, c->d_scratch, c->d_glob_in, c->d_glob_vec, c->d_pred_ab, c->d_dist313, c->d_partial, c->d_rgb, c->d_labq};
+    void* dev[] = {c->d_L, c->d_ab, c->d_mask, c->d_out, c->d_dist, c->d_scratch, c->d_glob_in, c->d_glob_vec, c->d_pred_ab, c->d_dist313, c->d_partial, c->d_rgb, c->d_labq, c->d_hints, c->d_centres, c->d_sugg, c->d_sugg_counts, c->d_post_in};
     for (void* p : dev) if (p) (void)hipFree(p);
-    void* host[] = {c->h_in, c->h_out, c->h_dist, c->h_pred_ab, c->h_rgb, c->h_labq};
+    void* host[] = {c->h_in, c->h_out, c->h_dist, c->h_pred_ab, c->h_rgb, c->h_labq, c->h_hints};
     for (void* p : host) if (p) (void)hipHostFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -869,8 +876,7 @@ int idc_forward(idc_handle h, int n, const float* L_mc, const float* ab, const f
 
 int idc_forward_dist(idc_handle h, int n, const float* L_mc, const float* ab, const float* mask, float maskcent,
                      float* out_ab, float* dist_q) {
-    if (!dist_q) return fail(h ? &h->err : nullptr, IDC_ERR_INVALID_ARG, "null dist_q");
-    return forward_host(h, n, L_mc, ab, mask, maskcent, out_ab, dist_q);
+    return forward_host(h, n, L_mc, ab, mask, maskcent, out_ab, dist_q, /*keep_dist=*/true);   // NULL dist_q: resident only
 }
 
 int idc_forward_device(idc_handle h, int n, const float* d_L_mc, const float* d_ab, const float* d_mask, float maskcent,
@@ -944,6 +950,7 @@ static int ensure_post_buffers(idc_context* h) {
     const size_t hw = (size_t)h->H * h->W, nb = (size_t)h->max_batch;
     HIPCHK(h, hipMalloc((void**)&h->d_rgb, nb * hw * 3));
     HIPCHK(h, hipMalloc((void**)&h->d_labq, nb * hw * 3 * 8));
+    HIPCHK(h, hipMalloc((void**)&h->d_post_in, nb * hw * 3 * 4));
     HIPCHK(h, hipHostMalloc((void**)&h->h_rgb, nb * hw * 3, hipHostMallocDefault));
     HIPCHK(h, hipHostMalloc((void**)&h->h_labq, nb * hw * 3 * 8, hipHostMallocDefault));
     return IDC_OK;
@@ -968,12 +975,13 @@ int idc_lab2rgb(idc_handle h, int n, const float* L, const float* ab, uint8_t* r
     if (n <= 0 || n > h->max_batch) return fail(&h->err, IDC_ERR_BATCH, "batch %d outside 1..%d", n, h->max_batch);
     if (!L || !ab || !rgb) return fail(&h->err, IDC_ERR_INVALID_ARG, "null tensor pointer");
     HIPCHK(h, hipSetDevice(h->device));
+    int rc = ensure_post_buffers(h);
+    if (rc) return rc;
     const size_t hw = (size_t)h->H * h->W;
     memcpy(h->h_in, L, (size_t)n * hw * 4);
     memcpy(h->h_in + (size_t)n * hw, ab, (size_t)n * hw * 2 * 4);
-    HIPCHK(h, hipMemcpyAsync(h->d_L, h->h_in, (size_t)n * hw * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_out, h->h_in + (size_t)n * hw, (size_t)n * hw * 2 * 4, hipMemcpyHostToDevice, h->stream));
-    return run_lab_post(h, n, h->d_L, 0.f, h->d_out, rgb, lab_q);
+    HIPCHK(h, hipMemcpyAsync(h->d_post_in, h->h_in, (size_t)n * hw * 3 * 4, hipMemcpyHostToDevice, h->stream));
+    return run_lab_post(h, n, h->d_post_in, 0.f, h->d_post_in + (size_t)n * hw, rgb, lab_q);
 }
 
 int idc_forward_rgb(idc_handle h, int n, const float* L_mc, const float* ab, const float* mask, float maskcent,
@@ -987,6 +995,167 @@ int idc_forward_rgb(idc_handle h, int n, const float* L_mc, const float* ab, con
     rc = forward_host(h, n, L_mc, ab, mask, maskcent, out_ab ? out_ab : h->h_out, nullptr);
     if (rc) return rc;
     return run_lab_post(h, n, h->d_L, l_cent, h->d_out, rgb, lab_q);
+}
+
+// ---------------------------------------------------------------------------------------------- click session
+static int check_img(idc_context* h, int img) {
+    if (!h) return fail(nullptr, IDC_ERR_INVALID_ARG, "null handle");
+    if (img < 0 || img >= h->max_batch) return fail(&h->err, IDC_ERR_BATCH, "image %d outside 0..%d", img, h->max_batch - 1);
+    return IDC_OK;
+}
+
+int idc_set_image_l(idc_handle h, int img, const float* L_mc) {
+    int rc = check_img(h, img);
+    if (rc) return rc;
+    if (!L_mc) return fail(&h->err, IDC_ERR_INVALID_ARG, "null L_mc");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t hw = (size_t)h->H * h->W;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(h->d_L + (size_t)img * hw, L_mc, hw * 4, hipMemcpyHostToDevice));
+    return IDC_OK;
+}
+
+int idc_set_hints(idc_handle h, int img, int n_hints, const idc_hint* hints, int mode, float mask_value) {
+    int rc = check_img(h, img);
+    if (rc) return rc;
+    if (n_hints < 0 || (n_hints > 0 && !hints)) return fail(&h->err, IDC_ERR_INVALID_ARG, "bad hint list");
+    if (mode != IDC_HINT_AB && mode != IDC_HINT_RGB) return fail(&h->err, IDC_ERR_INVALID_ARG, "hint mode %d", mode);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));            // the pinned list of the previous call may still be in flight
+    if (n_hints > h->hints_cap) {
+        const int cap = n_hints < 256 ? 256 : 2 * n_hints;
+        if (h->d_hints) (void)hipFree(h->d_hints);
+        if (h->h_hints) (void)hipHostFree(h->h_hints);
+        h->d_hints = nullptr; h->h_hints = nullptr; h->hints_cap = 0;
+        HIPCHK(h, hipMalloc((void**)&h->d_hints, (size_t)cap * sizeof(HintRect)));
+        HIPCHK(h, hipHostMalloc((void**)&h->h_hints, (size_t)cap * sizeof(HintRect), hipHostMallocDefault));
+        h->hints_cap = cap;
+    }
+    int kept = 0;
+    for (int i = 0; i < n_hints; ++i) {                    // cv2.rectangle: corners in either order, inclusive, clipped
+        HintRect r;
+        r.y0 = hints[i].y0 < hints[i].y1 ? hints[i].y0 : hints[i].y1; r.y1 = hints[i].y0 < hints[i].y1 ? hints[i].y1 : hints[i].y0;
+        r.x0 = hints[i].x0 < hints[i].x1 ? hints[i].x0 : hints[i].x1; r.x1 = hints[i].x0 < hints[i].x1 ? hints[i].x1 : hints[i].x0;
+        if (r.y0 < 0) r.y0 = 0;
+        if (r.x0 < 0) r.x0 = 0;
+        if (r.y1 > h->H - 1) r.y1 = h->H - 1;
+        if (r.x1 > h->W - 1) r.x1 = h->W - 1;
+        if (r.y0 > r.y1 || r.x0 > r.x1) continue;          // entirely outside
+        r.c0 = hints[i].c0; r.c1 = hints[i].c1; r.c2 = hints[i].c2;
+        if (mode == IDC_HINT_RGB)
+            if (!(r.c0 >= 0.f && r.c0 <= 255.f && r.c1 >= 0.f && r.c1 <= 255.f && r.c2 >= 0.f && r.c2 <= 255.f))
+                return fail(&h->err, IDC_ERR_INVALID_ARG, "hint %d: RGB outside 0..255", i);
+        h->h_hints[kept++] = r;
+    }
+    const size_t hw = (size_t)h->H * h->W;
+    if (kept) HIPCHK(h, hipMemcpyAsync(h->d_hints, h->h_hints, (size_t)kept * sizeof(HintRect), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, launch_raster_hints(h->d_hints, kept, mode, mask_value, h->d_ab + (size_t)img * hw * 2, h->d_mask + (size_t)img * hw,
+                                  h->H, h->W, h->stream));
+    return IDC_OK;
+}
+
+int idc_get_hint_planes(idc_handle h, int img, float* ab, float* mask) {
+    int rc = check_img(h, img);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t hw = (size_t)h->H * h->W;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (ab) HIPCHK(h, hipMemcpy(ab, h->d_ab + (size_t)img * hw * 2, hw * 2 * 4, hipMemcpyDeviceToHost));
+    if (mask) HIPCHK(h, hipMemcpy(mask, h->d_mask + (size_t)img * hw, hw * 4, hipMemcpyDeviceToHost));
+    return IDC_OK;
+}
+
+int idc_forward_resident(idc_handle h, int n, float maskcent, float l_cent, float* out_ab, uint8_t* rgb, double* lab_q) {
+    int rc = check_forward_args(h, n);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t hw = (size_t)h->H * h->W;
+    rc = run_graph(h, n, h->d_L, h->d_ab, h->d_mask, maskcent, h->d_out, (h->flags & IDC_FLAG_DIST_HEAD) ? h->d_dist : nullptr);
+    if (rc) return rc;
+    if (out_ab) HIPCHK(h, hipMemcpyAsync(h->h_out, h->d_out, (size_t)n * hw * 2 * 4, hipMemcpyDeviceToHost, h->stream));
+    if (rgb) {
+        rc = run_lab_post(h, n, h->d_L, l_cent, h->d_out, rgb, lab_q);      // synchronises the stream
+        if (rc) return rc;
+    } else {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    if (out_ab) memcpy(out_ab, h->h_out, (size_t)n * hw * 2 * 4);
+    return IDC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- colour suggestions
+int idc_keep_dist(idc_handle h, int on) {
+    if (!h) return fail(nullptr, IDC_ERR_INVALID_ARG, "null handle");
+    if (!(h->flags & IDC_FLAG_DIST313)) return fail(&h->err, IDC_ERR_UNSUPPORTED, "handle was created without IDC_FLAG_DIST313");
+    h->keep_dist313 = on != 0;
+    return IDC_OK;
+}
+
+// where the resident distribution of image `img` lives: bins, element stride between bins, pointer to bin 0 at (y, x)
+static int dist_locate(idc_context* h, int img, int y, int x, int* B, long long* stride, const float** p) {
+    if (!h) return fail(nullptr, IDC_ERR_INVALID_ARG, "null handle");
+    if (h->dist_n <= 0) return fail(&h->err, IDC_ERR_UNSUPPORTED, "Need to set prediction first (no resident distribution)");
+    if (img < 0 || img >= h->dist_n) return fail(&h->err, IDC_ERR_BATCH, "image %d outside 0..%d", img, h->dist_n - 1);
+    if (y < 0 || y >= h->H || x < 0 || x >= h->W) return fail(&h->err, IDC_ERR_INVALID_ARG, "pixel (%d,%d) outside the image", y, x);
+    if (h->flags & IDC_FLAG_DIST313) {
+        *B = 313; *stride = (long long)h->H * h->W;
+        *p = h->d_dist313 + (size_t)img * 313 * (*stride) + (size_t)y * h->W + x;
+    } else {                                               // 529 bins at H/4 x W/4; out_cl is its nearest x4 upsample (model.py:131)
+        const int h4 = h->H / 4, w4 = h->W / 4;
+        *B = 529; *stride = (long long)h4 * w4;
+        *p = h->d_dist + (size_t)img * 529 * (*stride) + (size_t)(y / 4) * w4 + (x / 4);
+    }
+    return IDC_OK;
+}
+
+int idc_dist_bins(idc_handle h) { return !h ? 0 : (h->flags & IDC_FLAG_DIST313) ? 313 : (h->flags & IDC_FLAG_DIST_HEAD) ? 529 : 0; }
+
+int idc_dist_at(idc_handle h, int img, int y, int x, float* pdf) {
+    int B; long long stride; const float* p;
+    int rc = dist_locate(h, img, y, x, &B, &stride, &p);
+    if (rc) return rc;
+    if (!pdf) return fail(&h->err, IDC_ERR_INVALID_ARG, "null pdf");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy2D(pdf, 4, p, (size_t)stride * 4, 4, (size_t)B, hipMemcpyDeviceToHost));
+    return IDC_OK;
+}
+
+int idc_get_dist(idc_handle h, int n, float* dist) {
+    if (!h) return fail(nullptr, IDC_ERR_INVALID_ARG, "null handle");
+    if (h->dist_n <= 0) return fail(&h->err, IDC_ERR_UNSUPPORTED, "Need to set prediction first (no resident distribution)");
+    if (n <= 0 || n > h->dist_n) return fail(&h->err, IDC_ERR_BATCH, "batch %d outside 1..%d", n, h->dist_n);
+    if (!dist) return fail(&h->err, IDC_ERR_INVALID_ARG, "null dist");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t hw = (size_t)h->H * h->W;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->flags & IDC_FLAG_DIST313) HIPCHK(h, hipMemcpy(dist, h->d_dist313, (size_t)n * 313 * hw * 4, hipMemcpyDeviceToHost));
+    else HIPCHK(h, hipMemcpy(dist, h->d_dist, (size_t)n * 529 * (hw / 16) * 4, hipMemcpyDeviceToHost));
+    return IDC_OK;
+}
+
+int idc_suggest_colors(idc_handle h, int img, int y, int x, int K, int N, unsigned seed, const float* centres,
+                       double* out_centres, double* out_conf, unsigned* out_counts) {
+    int B; long long stride; const float* p;
+    int rc = dist_locate(h, img, y, x, &B, &stride, &p);
+    if (rc) return rc;
+    if (!centres || !out_centres || !out_conf) return fail(&h->err, IDC_ERR_INVALID_ARG, "null pointer");
+    if (K < 1 || K > kSuggestMaxK) return fail(&h->err, IDC_ERR_INVALID_ARG, "K %d outside 1..%d", K, kSuggestMaxK);
+    if (N < 1) return fail(&h->err, IDC_ERR_INVALID_ARG, "N must be positive");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->d_centres) {
+        HIPCHK(h, hipMalloc((void**)&h->d_centres, (size_t)kSuggestMaxBins * 2 * 4));
+        HIPCHK(h, hipMalloc((void**)&h->d_sugg, (size_t)kSuggestMaxK * 3 * 8));
+        HIPCHK(h, hipMalloc((void**)&h->d_sugg_counts, (size_t)kSuggestMaxBins * 4));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(h->d_centres, centres, (size_t)B * 2 * 4, hipMemcpyHostToDevice));
+    HIPCHK(h, launch_suggest(p, stride, B, h->d_centres, K, N, seed, h->d_sugg, h->d_sugg + 2 * kSuggestMaxK, h->d_sugg_counts, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out_centres, h->d_sugg, (size_t)K * 2 * 8, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(out_conf, h->d_sugg + 2 * kSuggestMaxK, (size_t)K * 8, hipMemcpyDeviceToHost));
+    if (out_counts) HIPCHK(h, hipMemcpy(out_counts, h->d_sugg_counts, (size_t)B * 4, hipMemcpyDeviceToHost));
+    return IDC_OK;
 }
 
 int idc_global_histogram(idc_handle h, int n, const uint8_t* rgb, const float* centres, float* hist, float* s_avg) {

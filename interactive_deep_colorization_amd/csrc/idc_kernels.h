@@ -113,6 +113,19 @@ hipError_t launch_lab_post(const float* L, float l_add, const float* ab, unsigne
 hipError_t launch_global_stats(const unsigned char* rgb, const float* centres, unsigned* counts, double* sat_sum, int N,
                                int H, int W, hipStream_t s);
 
+// Click session (idc_session.hip).  HintRect = idc_hint of include/ideepcolor.h after clipping: inclusive rectangle,
+// (c0,c1) = ab (mode 0) or (c0,c1,c2) = RGB 0..255 (mode 1).  raster_hints fills ab [2,H,W] and mask [1,H,W] of ONE
+// image: the last covering hint wins; uncovered pixels get ab = 0, mask = 0 (a black canvas is Lab (0,0,0)).
+struct HintRect { int y0, x0, y1, x1; float c0, c1, c2; };
+hipError_t launch_raster_hints(const HintRect* hints, int n_hints, int mode, float mask_value, float* ab, float* mask,
+                               int H, int W, hipStream_t s);
+
+// Colour suggestions at one pixel (get_ab_reccs, colorize_image.py:322-354): see idc_session.hip for the algorithm.
+// pdf bin b at pdf[b*stride]; centres [B][2]; out_centres [K][2], out_conf [K] (f64); out_counts [B] or nullptr.
+constexpr int kSuggestMaxBins = 1024, kSuggestMaxK = 16;
+hipError_t launch_suggest(const float* pdf, long long stride, int B, const float* centres, int K, int N, unsigned seed,
+                          double* out_centres, double* out_conf, unsigned* out_counts, hipStream_t s);
+
 // layout converters for the single-operator test entry points and idc_get_activation
 hipError_t launch_nchw_to_nhwc(int precision, const float* src, void* dst, int N, int C, int H, int W,
                                int Cpad, hipStream_t s);

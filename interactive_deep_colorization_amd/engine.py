@@ -179,14 +179,82 @@ class HipColorizer(object):
         self._chk(self.lib.idc_forward(self._h, n, _fptr(L), _fptr(A), _fptr(M), float(maskcent), _fptr(out)))
         return out
 
-    def forward_dist(self, L_mc, ab, mask, maskcent=0.0):
-        """Also returns the 529-bin distribution at quarter resolution (N,529,H/4,W/4)."""
+    def forward_dist(self, L_mc, ab, mask, maskcent=0.0, want_dist=True):
+        """Also returns the 529-bin distribution at quarter resolution (N,529,H/4,W/4); ``want_dist=False`` leaves it
+        on the device (``dist_at`` / ``suggest_colors`` / ``get_dist``) and returns None in its place."""
         n, L, A, M = self._prep(L_mc, ab, mask)
         out = np.empty((n, 2, self.H, self.W), np.float32)
-        dq = np.empty((n, 529, self.H // 4, self.W // 4), np.float32)
+        dq = np.empty((n, 529, self.H // 4, self.W // 4), np.float32) if want_dist else None
         self._chk(self.lib.idc_forward_dist(self._h, n, _fptr(L), _fptr(A), _fptr(M), float(maskcent),
-                                            _fptr(out), _fptr(dq)))
+                                            _fptr(out), _fptr(dq) if want_dist else None))
         return out, dq
+
+    # ---- click session: resident L plane + device-side hint rasterisation (SURVEY.md 8f rank 4) ------------
+    def set_image_l(self, L_mc, img=0):
+        """Upload L-50 of one image slot ((H,W) or (1,H,W)); stays resident for ``forward_resident``."""
+        L = _f32c(np.asarray(L_mc).reshape(self.H, self.W))
+        self._chk(self.lib.idc_set_image_l(self._h, int(img), _fptr(L)))
+
+    def set_hints(self, hints, mode="ab", img=0, mask_value=1.0):
+        """Rasterise a hint list on the device.  hints: rows (y0, x0, y1, x1, c0, c1[, c2]) -- inclusive rectangle and
+        its (a, b) [mode 'ab', the notebook's put_point] or uint8 (r, g, b) [mode 'rgb', UIControl.get_input +
+        rgb2lab]; later rows paint over earlier ones."""
+        rows = [tuple(r) for r in hints]
+        arr = (N.Hint * max(len(rows), 1))()
+        for i, r in enumerate(rows):
+            arr[i].y0, arr[i].x0, arr[i].y1, arr[i].x1 = int(r[0]), int(r[1]), int(r[2]), int(r[3])
+            arr[i].c0, arr[i].c1, arr[i].c2 = float(r[4]), float(r[5]), float(r[6]) if len(r) > 6 else 0.0
+        self._chk(self.lib.idc_set_hints(self._h, int(img), len(rows), arr, {"ab": N.IDC_HINT_AB, "rgb": N.IDC_HINT_RGB}[mode],
+                                         float(mask_value)))
+
+    def hint_planes(self, img=0):
+        """(ab (2,H,W), mask (1,H,W)) float32 copies of the resident hint planes of one slot."""
+        ab = np.empty((2, self.H, self.W), np.float32)
+        mask = np.empty((1, self.H, self.W), np.float32)
+        self._chk(self.lib.idc_get_hint_planes(self._h, int(img), _fptr(ab), _fptr(mask)))
+        return ab, mask
+
+    def forward_resident(self, n=1, maskcent=0.0, l_cent=50.0, want_ab=True, want_rgb=True, want_lab=True):
+        """Forward of slots 0..n-1 from the resident planes -> (out_ab | None, rgb | None, lab_q | None)."""
+        out = np.empty((n, 2, self.H, self.W), np.float32) if want_ab else None
+        rgb = np.empty((n, self.H, self.W, 3), np.uint8) if want_rgb else None
+        labq = np.empty((n, 3, self.H, self.W), np.float64) if (want_rgb and want_lab) else None
+        self._chk(self.lib.idc_forward_resident(self._h, int(n), float(maskcent), float(l_cent), _fptr(out) if want_ab else None,
+                                                rgb.ctypes.data_as(ctypes.c_void_p) if want_rgb else None,
+                                                labq.ctypes.data_as(ctypes.c_void_p) if labq is not None else None))
+        return out, rgb, labq
+
+    # ---- colour suggestions on the resident distribution (SURVEY.md 8f rank 2) ---------------------------
+    def dist_bins(self):
+        return int(self.lib.idc_dist_bins(self._h))
+
+    def keep_dist(self, on=True):
+        self._chk(self.lib.idc_keep_dist(self._h, 1 if on else 0))
+
+    def dist_at(self, y, x, img=0):
+        """The predicted distribution (529 or 313 probabilities, float32) of pixel (y, x) from the last forward."""
+        pdf = np.empty(self.dist_bins(), np.float32)
+        self._chk(self.lib.idc_dist_at(self._h, int(img), int(y), int(x), _fptr(pdf)))
+        return pdf
+
+    def get_dist(self, n=1):
+        """The whole resident distribution: (n,529,H/4,W/4) or (n,313,H,W) float32."""
+        shape = (n, 313, self.H, self.W) if self.dist_bins() == 313 else (n, 529, self.H // 4, self.W // 4)
+        d = np.empty(shape, np.float32)
+        self._chk(self.lib.idc_get_dist(self._h, int(n), _fptr(d)))
+        return d
+
+    def suggest_colors(self, y, x, centres, K=5, N_draws=25000, seed=0, img=0, want_counts=False):
+        """``get_ab_reccs`` on the device: (centres (K,2) f64, conf (K,) f64[, counts (B,) uint32]) ordered by occupancy."""
+        B = self.dist_bins()
+        c = _f32c(centres, (B, 2))
+        oc, of = np.empty((K, 2), np.float64), np.empty(K, np.float64)
+        cnt = np.empty(B, np.uint32) if want_counts else None
+        vp = ctypes.c_void_p
+        self._chk(self.lib.idc_suggest_colors(self._h, int(img), int(y), int(x), int(K), int(N_draws), int(seed) & 0xFFFFFFFF, _fptr(c),
+                                              oc.ctypes.data_as(vp), of.ctypes.data_as(vp),
+                                              cnt.ctypes.data_as(vp) if want_counts else None))
+        return (oc, of, cnt) if want_counts else (oc, of)
 
     def global_histogram(self, rgb, centres, want_sat=True):
         """Global statistics of reference image(s) (the reference's global_stats.prototxt): rgb (n,H,W,3) or (H,W,3)

@@ -1,0 +1,94 @@
+"""CPU checks of oracle/session.py: the hint rasteriser against the notebook's put_point and against rgb2lab of a
+painted canvas; the deterministic colour-suggestion restatement against the reference's own (stochastic)
+get_ab_reccs (data/colorize_image.py:322-354) on mixtures whose clusters are unambiguous."""
+import numpy as np
+
+from interactive_deep_colorization_amd import workloads
+from oracle import colorspace, session
+
+
+def _grid529():
+    axis = np.arange(-110, 120, 10)
+    return np.array(np.meshgrid(axis, axis)).reshape((2, 529)).T.astype(np.float32)
+
+
+def _mixture(centres, modes, weights, sigma=6.0):
+    p = np.zeros(len(centres))
+    for (a, b), w in zip(modes, weights):
+        p += w * np.exp(-((centres[:, 0] - a) ** 2 + (centres[:, 1] - b) ** 2) / (2 * sigma ** 2))
+    return (p / p.sum()).astype(np.float32)
+
+
+def test_raster_ab_matches_put_point():
+    H = W = 64
+    pts = [((10, 12), 3, (25.0, -40.0)), ((30, 50), 2, (-60.0, 10.0)), ((11, 13), 1, (5.0, 5.0)), ((62, 62), 4, (70.0, 70.0))]
+    ab = np.zeros((2, H, W), np.float32); mask = np.zeros((1, H, W), np.float32)
+    for loc, p, val in pts:
+        workloads.put_point(ab, mask, loc, p, val)
+    hints = [(loc[0] - p, loc[1] - p, loc[0] + p, loc[1] + p, val[0], val[1]) for loc, p, val in pts]
+    ab2, mask2 = session.raster_hints(hints, H, W, "ab")
+    np.testing.assert_array_equal(ab, ab2)
+    np.testing.assert_array_equal(mask, mask2)
+
+
+def test_raster_rgb_is_rgb2lab_of_the_canvas():
+    H, W = 48, 40
+    hints = [(5, 5, 9, 9, 255, 0, 0), (7, 7, 20, 12, 0, 128, 255), (-3, 30, 4, 60, 10, 200, 30), (40, 2, 38, 6, 90, 90, 90),
+             (100, 100, 120, 120, 1, 2, 3)]
+    canvas = np.zeros((H, W, 3), np.uint8); m = np.zeros((H, W), np.uint8)
+    for y0, x0, y1, x1, r, g, b in hints:
+        ya, yb = sorted((y0, y1)); xa, xb = sorted((x0, x1))
+        ya, xa = max(ya, 0), max(xa, 0)
+        if ya > min(yb, H - 1) or xa > min(xb, W - 1):
+            continue
+        canvas[ya:yb + 1, xa:xb + 1] = (r, g, b); m[ya:yb + 1, xa:xb + 1] = 255
+    lab = colorspace.rgb2lab(canvas)
+    ab, mask = session.raster_hints(hints, H, W, "rgb", mask_value=110.0)
+    np.testing.assert_allclose(ab, lab[:, :, 1:].transpose(2, 0, 1), atol=1e-5)
+    np.testing.assert_array_equal(mask[0], (m > 0) * np.float32(110.0))
+    assert mask[0, 39, 4] == 110.0 and mask[0, 0, 35] == 110.0 and ab[:, 47, 39].tolist() == [0.0, 0.0]
+
+
+def test_draws_are_uniform_and_seeded():
+    u = session.draws(200000, 7)
+    assert u.dtype == np.float32 and u.min() >= 0.0 and u.max() < 1.0
+    assert abs(u.mean() - 0.5) < 5e-3 and abs(u.var() - 1.0 / 12) < 2e-3
+    hist = np.histogram(u, bins=64, range=(0, 1))[0]
+    assert hist.min() > 0.9 * 200000 / 64 and hist.max() < 1.1 * 200000 / 64
+    np.testing.assert_array_equal(u, session.draws(200000, 7))
+    assert np.mean(session.draws(1000, 8) == u[:1000]) < 0.01
+
+
+def test_draw_counts_follow_the_pdf():
+    c = _grid529()
+    pdf = _mixture(c, [(-60, 40), (50, -30)], [0.7, 0.3])
+    cnt = session.draw_counts(pdf, 100000, 3)
+    assert cnt.sum() == 100000
+    assert np.abs(cnt / 1e5 - pdf).max() < 6e-3
+
+
+def test_suggest_colors_agrees_with_reference_get_ab_reccs():
+    c = _grid529()
+    modes = [(-70, 50), (60, -40), (0, 90), (80, 80)]
+    w = [0.4, 0.3, 0.2, 0.1]
+    pdf = _mixture(c, modes, w)
+    cen, conf = session.suggest_colors(pdf, c, K=4, N=25000, seed=11)
+    ref_cen, ref_conf = session.get_ab_reccs_reference(pdf, c, K=4, N=25000, rng=np.random.RandomState(0))
+    assert np.all(np.diff(conf) <= 0) and abs(conf.sum() - 1.0) < 1e-12
+    np.testing.assert_allclose(cen, ref_cen, atol=1.5)          # same clusters, same order (by occupancy)
+    np.testing.assert_allclose(conf, ref_conf, atol=0.015)
+    np.testing.assert_allclose(cen, np.array(modes, float), atol=2.5)
+    np.testing.assert_allclose(conf, w, atol=0.015)
+    # deterministic in the seed
+    cen2, conf2 = session.suggest_colors(pdf, c, K=4, N=25000, seed=11)
+    np.testing.assert_array_equal(cen, cen2); np.testing.assert_array_equal(conf, conf2)
+
+
+def test_suggest_colors_degenerate_inputs():
+    c = _grid529()
+    pdf = np.zeros(529, np.float32); pdf[100] = 1.0              # one possible colour, K = 3
+    cen, conf = session.suggest_colors(pdf, c, K=3, N=1000, seed=0)
+    np.testing.assert_array_equal(cen[0], c[100]); assert conf[0] == 1.0 and conf[1] == 0.0 and conf[2] == 0.0
+    pdf = np.full(529, 1.0 / 529, np.float32)                   # flat: K clusters, all populated
+    cen, conf = session.suggest_colors(pdf, c, K=5, N=25000, seed=1)
+    assert (conf > 0.05).all() and abs(conf.sum() - 1) < 1e-12
