@@ -532,9 +532,6 @@ hipError_t launch_splitk_epilogue(int precision, const ConvArgs& a, hipStream_t 
 //   * swizzle (row>>1)&7: conflict-free for 32-row x 2-k-group fragments (tools/bank model).
 // ================================================================================================
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-#ifdef IDC_PRIO_SLOTS
-__device__ int g_prio_slots[4096];
-#endif
 #ifdef IDC_TIMING
 __device__ long long* g_idc_dbg;
 #define IDC_STAMP(i) do { if (tid == 0) g_idc_dbg[(size_t)blockIdx.x * 16 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -563,29 +560,6 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wco = wave % WCO, wpx = wave / WCO;
     const int px = lane & 31, h = lane >> 5;
-#ifdef IDC_PRIO_SLOTS
-    // experiment: the two workgroups that share a CU get different wave priorities (arrival parity per CU), so
-    // that they do not settle into lock-step (same phase = both in prologue / both in epilogue)
-    {
-        __shared__ int s_par;
-        if (tid == 0) {
-            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_ID
-            const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
-            const unsigned key = ((xcc & 15u) << 8) | ((hw >> 8) & 0xffu);
-            s_par = atomicAdd(&g_prio_slots[key], 1) & 1;
-        }
-        __syncthreads();
-        if (s_par) __builtin_amdgcn_s_setprio(IDC_PRIO_SLOTS);
-    }
-#endif
-#ifdef IDC_STAGGER
-    // experiment: first-round workgroups on odd XCDs start late, so that the memory phases (prologue / epilogue) of
-    // one half of the chip fall into the MFMA phase of the other half
-    if (blockIdx.x < 256 && (blockIdx.x & 1)) {
-#pragma unroll 1
-        for (int i = 0; i < IDC_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     IDC_STAMP(0);
 
     // tile order: (deconv phase, cout tile) vary fastest, so the workgroups that share an input halo run
@@ -642,23 +616,13 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
     };
     constexpr int nstage = FUSED ? 5 : 1;
 
-    // accumulators start at the bias (bf16-output launches; the fp32-output epilogue adds it itself): lane
-    // (pixel px, half h) register r of acc[mi][.] is cout h*32 + mi*16 + r of the wave's 64 (idc_layout.h layout 2)
     f32x16 acc[2][4];
-    {
-        const float* const bp = a.bias + (ct * WCO + wco) * kCoutGroup + h * 32;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            f32x16 b16;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 bq = a.out_f32 ? float4{0.f, 0.f, 0.f, 0.f} : *(const float4*)(bp + i * 16 + q * 4);
-                b16[q * 4 + 0] = bq.x; b16[q * 4 + 1] = bq.y; b16[q * 4 + 2] = bq.z; b16[q * 4 + 3] = bq.w;
-            }
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = b16;
-        }
-    }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // LDS-DMA of one weight tile: lane-linear destination (wave-uniform base + lane*16)
     auto dma_w = [&](const Stage& st, int tw, int kc, int buf) {
@@ -688,14 +652,12 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
     };
 
     Stage cur = make_stage(0);
-    IDC_STAMP(5);
     load_halo(cur, 0);
     {
         int dy0, dx0, tw0;
         tap_of(0, 0, dy0, dx0, tw0);
         dma_w(cur, tw0, 0, 0);
     }
-    IDC_STAMP(6);
 
     const int wrow_byte = (wco * 64 + px) * kRowBytes;         // + mi*32 rows
     // swz2(row) = (row>>1)&7 is the same for rows px and px+32 (and +64*wco): one slot term serves both
@@ -707,7 +669,6 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
             __syncthreads();                   // previous chunk's halo reads are done
 #pragma unroll
             for (int j = 0; j < N_HITEMS; ++j) *(u32x4*)(halo + (tid + j * NT) * kSlotBytes) = hreg[j];
-            if (first) IDC_STAMP(7);
             const bool last_kc = kc + 1 == cur.nkc;
             for (int t = 0; t < cur.ntaps; ++t) {
                 const char* const wcur = wbuf + buf * W_BYTES;
@@ -832,7 +793,11 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
         float* const part = (float*)(smem + (NT / 64) * 8192);  // fused head: [wave][pj][32 px][2]
         const int rr = lane >> 3, cc = lane & 7;
         const int co8 = cow + cc * 8;
-        float cs[8], ct[8], hw0[8], hw1[8];
+        float cb[8], cs[8], ct[8], hw0[8], hw1[8];
+        {
+            const float4 b0 = *(const float4*)(a.bias + co8), b1 = *(const float4*)(a.bias + co8 + 4);
+            cb[0] = b0.x; cb[1] = b0.y; cb[2] = b0.z; cb[3] = b0.w; cb[4] = b1.x; cb[5] = b1.y; cb[6] = b1.z; cb[7] = b1.w;
+        }
         if (has_bn) {
             const float4 s0 = *(const float4*)(a.bn_scale + co8), s1 = *(const float4*)(a.bn_scale + co8 + 4);
             const float4 t0 = *(const float4*)(a.bn_shift + co8), t1 = *(const float4*)(a.bn_shift + co8 + 4);
@@ -844,73 +809,6 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
             const float4 q0 = *(const float4*)(a.head_w + 128 + co8), q1 = *(const float4*)(a.head_w + 128 + co8 + 4);
             hw0[0] = u0.x; hw0[1] = u0.y; hw0[2] = u0.z; hw0[3] = u0.w; hw0[4] = u1.x; hw0[5] = u1.y; hw0[6] = u1.z; hw0[7] = u1.w;
             hw1[0] = q0.x; hw1[1] = q0.y; hw1[2] = q0.z; hw1[3] = q0.w; hw1[4] = q1.x; hw1[5] = q1.y; hw1[6] = q1.z; hw1[7] = q1.w;
-        }
-        // bf16 shortcut partials: all 16 loads of the lane go out before the first store (gfx9 counts loads and
-        // stores in one in-order vmcnt, so a load issued after a store cannot be waited for without also waiting
-        // for that store's L2 acknowledgement -- once per pixel row otherwise)
-        // Layers whose epilogue is only (ReLU +) rounding -- no BN, shortcut sum, LeakyReLU, per-image shift or head
-        // (15 of the 27 large-tile launches) -- round in the MFMA layout and transpose bf16 instead of fp32: half the
-        // LDS traffic, ReLU as one v_pk_max_i16 per pair (a bf16 is negative iff its int16 pattern is), no per-lane
-        // constants.  [32 px][64 couts] bf16 = 128-B rows, 16-B slot ^ (px & 7): conflict-free both ways.
-        const bool cheap = !has_bn && a.resid == nullptr && a.act != 2 && a.img_shift == nullptr && !fuse_head;
-        if (cheap) {
-            char* const tb16 = smem + wave * 4096;
-            typedef short s16x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-            for (int pj = 0; pj < 4; ++pj) {
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    unsigned pk[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        pk[e] = pack_bf16x2(acc[mi][pj][2 * e], acc[mi][pj][2 * e + 1]);
-                        if (a.act == 1)
-                            pk[e] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk[e]), s16x2{0, 0}));
-                    }
-                    const int s0 = h * 4 + mi * 2;
-                    *(uint4*)(tb16 + px * 128 + ((s0 ^ (px & 7)) * 16)) = uint4{pk[0], pk[1], pk[2], pk[3]};
-                    *(uint4*)(tb16 + px * 128 + (((s0 + 1) ^ (px & 7)) * 16)) = uint4{pk[4], pk[5], pk[6], pk[7]};
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                const int sy = ty0 + wpx * 4 + pj;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = i * 8 + rr;
-                    const uint4 o = *(const uint4*)(tb16 + row * 128 + ((cc ^ (row & 7)) * 16));
-                    const int sx = tx0 + row;
-                    if (sy < Hs && sx < Ws) {
-                        const size_t oidx = (((size_t)n * Hout + (sy * so + ro)) * Wout + (sx * so + cof)) * CoutPad + co8;
-                        *(uint4*)((unsigned short*)a.out + oidx) = o;
-                    }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-            IDC_STAMP(3);
-#ifdef IDC_TIMING
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            IDC_STAMP(4);
-#endif
-            return;
-        }
-        const bool pre_resid = a.resid != nullptr && a.resid_bf16;
-        // two instantiations of the row loop: shortcut launches never carry the fused head, so neither version
-        // holds both the 64 prefetched registers and the head weights
-        auto epi_rows = [&](auto res_tag) {
-        constexpr bool PRE = decltype(res_tag)::value;
-        const bool fh = !PRE && fuse_head;
-        uint4 rres[PRE ? 4 : 1][4];
-        if constexpr (PRE) {
-#pragma unroll
-            for (int pj = 0; pj < 4; ++pj) {
-                const int sy = ty0 + wpx * 4 + pj;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int sx = tx0 + i * 8 + rr;
-                    const bool inside = sy < Hs && sx < Ws;
-                    const size_t oidx = (((size_t)n * Hout + (sy * so + ro)) * Wout + (sx * so + cof)) * CoutPad + co8;
-                    rres[pj][i] = inside ? *(const uint4*)((const unsigned short*)a.resid + oidx) : uint4{0u, 0u, 0u, 0u};
-                }
-            }
         }
 #pragma unroll
         for (int pj = 0; pj < 4; ++pj) {
@@ -933,19 +831,23 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
                 const int sx = tx0 + row;
                 const bool inside = sy < Hs && sx < Ws;
                 const size_t oidx = (((size_t)n * Hout + (sy * so + ro)) * Wout + (sx * so + cof)) * CoutPad + co8;
-                if constexpr (PRE) {
-                    const uint4 r4 = rres[pj][i];                   // zeros outside the image
-                    const unsigned rw[4] = {r4.x, r4.y, r4.z, r4.w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[2 * e] += __uint_as_float(rw[e] << 16);
-                        v[2 * e + 1] += __uint_as_float(rw[e] & 0xffff0000u);
+                for (int e = 0; e < 8; ++e) v[e] += cb[e];
+                if (a.resid != nullptr && inside) {
+                    if (a.resid_bf16) {
+                        const uint4 r4 = *(const uint4*)((const unsigned short*)a.resid + oidx);
+                        const unsigned rw[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[2 * e] += __uint_as_float(rw[e] << 16);
+                            v[2 * e + 1] += __uint_as_float(rw[e] & 0xffff0000u);
+                        }
+                    } else {
+                        const float4 r0 = *(const float4*)((const float*)a.resid + oidx);
+                        const float4 r1 = *(const float4*)((const float*)a.resid + oidx + 4);
+                        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+                        v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
                     }
-                } else if (a.resid != nullptr && inside) {          // fp32 partial sums (313 head hyper-column)
-                    const float4 r0 = *(const float4*)((const float*)a.resid + oidx);
-                    const float4 r1 = *(const float4*)((const float*)a.resid + oidx + 4);
-                    v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
-                    v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
                 }
                 if (a.act == 1) {
 #pragma unroll
@@ -964,7 +866,7 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
                     v[0] += g0.x; v[1] += g0.y; v[2] += g0.z; v[3] += g0.w;
                     v[4] += g1.x; v[5] += g1.y; v[6] += g1.z; v[7] += g1.w;
                 }
-                if (fh) {
+                if (fuse_head) {
                     // model_out (1x1, 128 -> 2): 8 couts per lane, the pixel's other 56 in the 7 neighbour lanes
                     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
@@ -981,8 +883,6 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads retired before the tile is rewritten
         }
-        };
-        if (pre_resid) epi_rows(std::true_type{}); else epi_rows(std::false_type{});
         if (fuse_head) {
             // the two cout waves of a pixel row meet in LDS; wave wco == 0 finishes: lane (px, h) = channel h
             __syncthreads();
@@ -1031,11 +931,7 @@ static hipError_t launch_conv_v2_t(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-#ifdef IDC_V2_22
-#define IDC_FOR_EACH_CONV_V2(X) X(4, 2, 0) X(4, 2, 1) X(4, 2, 2) X(2, 4, 0) X(2, 4, 1) X(2, 4, 2) X(2, 2, 1)
-#else
 #define IDC_FOR_EACH_CONV_V2(X) X(4, 2, 0) X(4, 2, 1) X(4, 2, 2) X(2, 4, 0) X(2, 4, 1) X(2, 4, 2)
-#endif
 
 hipError_t init_kernels_v2() {
     hipError_t e;

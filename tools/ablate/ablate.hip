@@ -6,7 +6,10 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
-#include "../../interactive_deep_colorization_amd/csrc/idc_kernels.hip"
+#ifndef ABL_KERNELS
+#define ABL_KERNELS "../../interactive_deep_colorization_amd/csrc/idc_kernels.hip"
+#endif
+#include ABL_KERNELS
 
 __global__ void fill_bf16(unsigned short* p, size_t n, unsigned seed) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -52,6 +55,17 @@ int main(int argc, char** argv) {
         for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) { int ph = r * 2 + c; a.ro[ph] = r; a.co[ph] = c;
             for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) { int t = ph * 9 + i * 2 + j; a.dy[t] = T_d[r][i]; a.dx[t] = T_d[c][j]; a.tw[t] = T_k[r][i] * 4 + T_k[c][j]; } }
     }
+    if (v2 == 3) {      // 4-phase deconv of `in` (C ch @ HW) -> C ch @ 2HW, + bf16 shortcut partial sums (conv8_1/9_1/10_1)
+        void* resid;
+        CK(hipFree(out)); CK(hipMalloc(&out, act * 4)); CK(hipMalloc(&resid, act * 4));
+        hipLaunchKernelGGL(fill_bf16, dim3(2048), dim3(256), 0, 0, (unsigned short*)resid, act * 4 / 2, 5u);
+        CK(hipFree(w)); CK(hipMalloc(&w, (size_t)16 * (C / 64) * (C / 64) * 8192));
+        hipLaunchKernelGGL(fill_bf16, dim3(2048), dim3(256), 0, 0, (unsigned short*)w, (size_t)16 * (C / 64) * (C / 64) * 8192 / 2, 7u);
+        a.out = out; a.wgt = w; a.resid = resid; a.resid_bf16 = 1; a.nphase = 4; a.ntaps = 4; a.so = 2; ntaps = 4;
+        static const int T_k[2][2] = {{1, 3}, {0, 2}}, T_d[2][2] = {{0, -1}, {1, 0}};
+        for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) { int ph = r * 2 + c; a.ro[ph] = r; a.co[ph] = c;
+            for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) { int t = ph * 9 + i * 2 + j; a.dy[t] = T_d[r][i]; a.dx[t] = T_d[c][j]; a.tw[t] = T_k[r][i] * 4 + T_k[c][j]; } }
+    }
     idc::ConvConfig cfg{wm, wp};
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 #define LAUNCH() (v2 ? idc::launch_conv_v2(cfg, halo, a, 0) : idc::launch_conv(prec, cfg, halo, a, 0))
@@ -67,7 +81,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < reps; ++i) CK(LAUNCH());
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
-    double flops = v2 == 2 ? 2.0 * N * 4 * HW * HW * (double)C * (4.0 * C + 9.0 * (argc > 10 ? atoi(argv[10]) : C)) : 2.0 * N * HW * HW * (double)C * C * ntaps;
+    double flops = v2 == 3 ? 2.0 * N * 4 * HW * HW * (double)C * C * 4 : v2 == 2 ? 2.0 * N * 4 * HW * HW * (double)C * (4.0 * C + 9.0 * (argc > 10 ? atoi(argv[10]) : C)) : 2.0 * N * HW * HW * (double)C * C * ntaps;
 #ifdef IDC_TIMING
     {
         CK(LAUNCH()); CK(hipDeviceSynchronize());
@@ -79,6 +93,8 @@ int main(int argc, char** argv) {
             printf("  stage spans (mean ticks): deconv %.0f | p00 %.0f | p01 %.0f | p10 %.0f | p11 %.0f\n", st[0] / nb, st[1] / nb, st[2] / nb, st[3] / nb, st[4] / nb); }
         printf("  timing (ticks, mean over %d blocks): start-offset %.0f | prologue %.0f | mainloop %.0f | epilogue-issue %.0f | store-drain %.0f | kernel span %lld\n",
                nb, s[0] / nb, s[1] / nb, s[2] / nb, s[3] / nb, s[4] / nb, tend - t0);
+        { double u[3] = {0, 0, 0}; for (int b = 0; b < nb; ++b) { u[0] += (double)(h[b * 16 + 5] - h[b * 16]); u[1] += (double)(h[b * 16 + 6] - h[b * 16 + 5]); u[2] += (double)(h[b * 16 + 7] - h[b * 16 + 6]); }
+          printf("  prologue split: setup(to first load issue) %.0f | issue halo+dma %.0f | wait loads + LDS write %.0f | to first tap barrier %.0f\n", u[0] / nb, u[1] / nb, u[2] / nb, s[1] / nb - (u[0] + u[1] + u[2]) / nb); }
         for (int b : {0, 1, 8, nb / 2, nb - 1}) printf("   block %5d: start %lld pro %lld main %lld epi %lld drain %lld\n", b, h[b * 16] - t0, h[b * 16 + 1] - h[b * 16], h[b * 16 + 2] - h[b * 16 + 1], h[b * 16 + 3] - h[b * 16 + 2], h[b * 16 + 4] - h[b * 16 + 3]);
     }
 #endif
