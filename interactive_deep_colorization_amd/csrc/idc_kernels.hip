@@ -532,14 +532,16 @@ hipError_t launch_splitk_epilogue(int precision, const ConvArgs& a, hipStream_t 
 //   * swizzle (row>>1)&7: conflict-free for 32-row x 2-k-group fragments (tools/bank model).
 // ================================================================================================
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-#ifdef IDC_PRIO_SLOTS
-__device__ int g_prio_slots[4096];
-#endif
 #ifdef IDC_TIMING
 __device__ long long* g_idc_dbg;
 #define IDC_STAMP(i) do { if (tid == 0) g_idc_dbg[(size_t)blockIdx.x * 16 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define IDC_STAMP(i) do {} while (0)
+#endif
+#ifdef IDC_TIMING_FINE
+#define IDC_STAMP_FINE(i) IDC_STAMP(i)
+#else
+#define IDC_STAMP_FINE(i) do {} while (0)
 #endif
 
 template <int WCO, int WPX, int HALO, bool FUSED>
@@ -563,29 +565,6 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wco = wave % WCO, wpx = wave / WCO;
     const int px = lane & 31, h = lane >> 5;
-#ifdef IDC_PRIO_SLOTS
-    // experiment: the two workgroups that share a CU get different wave priorities (arrival parity per CU), so
-    // that they do not settle into lock-step (same phase = both in prologue / both in epilogue)
-    {
-        __shared__ int s_par;
-        if (tid == 0) {
-            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_ID
-            const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
-            const unsigned key = ((xcc & 15u) << 8) | ((hw >> 8) & 0xffu);
-            s_par = atomicAdd(&g_prio_slots[key], 1) & 1;
-        }
-        __syncthreads();
-        if (s_par) __builtin_amdgcn_s_setprio(IDC_PRIO_SLOTS);
-    }
-#endif
-#ifdef IDC_STAGGER
-    // experiment: first-round workgroups on odd XCDs start late, so that the memory phases (prologue / epilogue) of
-    // one half of the chip fall into the MFMA phase of the other half
-    if (blockIdx.x < 256 && (blockIdx.x & 1)) {
-#pragma unroll 1
-        for (int i = 0; i < IDC_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     IDC_STAMP(0);
 
     // tile order: (deconv phase, cout tile) vary fastest, so the workgroups that share an input halo run
@@ -688,14 +667,52 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
     };
 
     Stage cur = make_stage(0);
-    IDC_STAMP(5);
+    IDC_STAMP_FINE(5);
     load_halo(cur, 0);
     {
         int dy0, dx0, tw0;
         tap_of(0, 0, dy0, dx0, tw0);
         dma_w(cur, tw0, 0, 0);
     }
-    IDC_STAMP(6);
+    IDC_STAMP_FINE(6);
+    // bf16 shortcut partial sums (model.py:156,170,172) are added into the accumulators here, in the MFMA layout
+    // (2 x 32 B per lane and pixel row): their latency hides behind the halo fetch that is already in flight, and the
+    // epilogue of a deconv + shortcut launch becomes the plain one
+    const bool resid_in_acc = !a.out_f32 && a.resid != nullptr && a.resid_bf16;
+    if (resid_in_acc) {
+        const int so_ = a.so, Wout_ = Ws * so_, Hout_ = Hs * so_, cpad_ = a.ncg * kCoutGroup;
+        const int sx = tx0 + px;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            uint4 rv[2][2][2];
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const int sy = ty0 + wpx * 4 + half * 2 + pp;
+                const bool inside = sy < Hs && sx < Ws;
+                const size_t ridx = (((size_t)n * Hout_ + (sy * so_ + ro)) * Wout_ + (sx * so_ + cof)) * cpad_ +
+                                    (ct * WCO + wco) * kCoutGroup + h * 32;
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        rv[pp][mi][q] = inside ? *(const uint4*)((const unsigned short*)a.resid + ridx + mi * 16 + q * 8)
+                                               : uint4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const unsigned rw[4] = {rv[pp][mi][q].x, rv[pp][mi][q].y, rv[pp][mi][q].z, rv[pp][mi][q].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            acc[mi][half * 2 + pp][q * 8 + 2 * e] += __uint_as_float(rw[e] << 16);
+                            acc[mi][half * 2 + pp][q * 8 + 2 * e + 1] += __uint_as_float(rw[e] & 0xffff0000u);
+                        }
+                    }
+        }
+    }
 
     const int wrow_byte = (wco * 64 + px) * kRowBytes;         // + mi*32 rows
     // swz2(row) = (row>>1)&7 is the same for rows px and px+32 (and +64*wco): one slot term serves both
@@ -707,7 +724,7 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
             __syncthreads();                   // previous chunk's halo reads are done
 #pragma unroll
             for (int j = 0; j < N_HITEMS; ++j) *(u32x4*)(halo + (tid + j * NT) * kSlotBytes) = hreg[j];
-            if (first) IDC_STAMP(7);
+            if (first) IDC_STAMP_FINE(7);
             const bool last_kc = kc + 1 == cur.nkc;
             for (int t = 0; t < cur.ntaps; ++t) {
                 const char* const wcur = wbuf + buf * W_BYTES;
@@ -852,20 +869,41 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
         // (15 of the 27 large-tile launches) -- round in the MFMA layout and transpose bf16 instead of fp32: half the
         // LDS traffic, ReLU as one v_pk_max_i16 per pair (a bf16 is negative iff its int16 pattern is), no per-lane
         // constants.  [32 px][64 couts] bf16 = 128-B rows, 16-B slot ^ (px & 7): conflict-free both ways.
-        const bool cheap = !has_bn && a.resid == nullptr && a.act != 2 && a.img_shift == nullptr && !fuse_head;
+        const bool cheap = (a.resid == nullptr || resid_in_acc) && a.act != 2 && a.img_shift == nullptr && !fuse_head;
         if (cheap) {
             char* const tb16 = smem + wave * 4096;
             typedef short s16x2 __attribute__((ext_vector_type(2)));
+            f32x16 bsc[2], bsh[2];                              // eval-BN affine of the lane's 32 couts (after the ReLU)
+            if (has_bn) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 s4 = *(const float4*)(a.bn_scale + cow + h * 32 + mi * 16 + q * 4);
+                        const float4 t4 = *(const float4*)(a.bn_shift + cow + h * 32 + mi * 16 + q * 4);
+                        bsc[mi][q * 4 + 0] = s4.x; bsc[mi][q * 4 + 1] = s4.y; bsc[mi][q * 4 + 2] = s4.z; bsc[mi][q * 4 + 3] = s4.w;
+                        bsh[mi][q * 4 + 0] = t4.x; bsh[mi][q * 4 + 1] = t4.y; bsh[mi][q * 4 + 2] = t4.z; bsh[mi][q * 4 + 3] = t4.w;
+                    }
+            }
 #pragma unroll
             for (int pj = 0; pj < 4; ++pj) {
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi) {
                     unsigned pk[8];
+                    if (has_bn) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        pk[e] = pack_bf16x2(acc[mi][pj][2 * e], acc[mi][pj][2 * e + 1]);
-                        if (a.act == 1)
-                            pk[e] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk[e]), s16x2{0, 0}));
+                        for (int e = 0; e < 8; ++e) {
+                            float v0 = acc[mi][pj][2 * e], v1 = acc[mi][pj][2 * e + 1];
+                            if (a.act == 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                            pk[e] = pack_bf16x2(fmaf(v0, bsc[mi][2 * e], bsh[mi][2 * e]), fmaf(v1, bsc[mi][2 * e + 1], bsh[mi][2 * e + 1]));
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            pk[e] = pack_bf16x2(acc[mi][pj][2 * e], acc[mi][pj][2 * e + 1]);
+                            if (a.act == 1)
+                                pk[e] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk[e]), s16x2{0, 0}));
+                        }
                     }
                     const int s0 = h * 4 + mi * 2;
                     *(uint4*)(tb16 + px * 128 + ((s0 ^ (px & 7)) * 16)) = uint4{pk[0], pk[1], pk[2], pk[3]};
@@ -892,26 +930,9 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
 #endif
             return;
         }
-        const bool pre_resid = a.resid != nullptr && a.resid_bf16;
-        // two instantiations of the row loop: shortcut launches never carry the fused head, so neither version
-        // holds both the 64 prefetched registers and the head weights
-        auto epi_rows = [&](auto res_tag) {
-        constexpr bool PRE = decltype(res_tag)::value;
-        const bool fh = !PRE && fuse_head;
-        uint4 rres[PRE ? 4 : 1][4];
-        if constexpr (PRE) {
-#pragma unroll
-            for (int pj = 0; pj < 4; ++pj) {
-                const int sy = ty0 + wpx * 4 + pj;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int sx = tx0 + i * 8 + rr;
-                    const bool inside = sy < Hs && sx < Ws;
-                    const size_t oidx = (((size_t)n * Hout + (sy * so + ro)) * Wout + (sx * so + cof)) * CoutPad + co8;
-                    rres[pj][i] = inside ? *(const uint4*)((const unsigned short*)a.resid + oidx) : uint4{0u, 0u, 0u, 0u};
-                }
-            }
-        }
+        // transposed fp32 path: LeakyReLU + fused head (conv10_2), per-image shift (global hints), fp32 partial sums
+        {
+        const bool fh = fuse_head;
 #pragma unroll
         for (int pj = 0; pj < 4; ++pj) {
 #pragma unroll
@@ -933,15 +954,7 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
                 const int sx = tx0 + row;
                 const bool inside = sy < Hs && sx < Ws;
                 const size_t oidx = (((size_t)n * Hout + (sy * so + ro)) * Wout + (sx * so + cof)) * CoutPad + co8;
-                if constexpr (PRE) {
-                    const uint4 r4 = rres[pj][i];                   // zeros outside the image
-                    const unsigned rw[4] = {r4.x, r4.y, r4.z, r4.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[2 * e] += __uint_as_float(rw[e] << 16);
-                        v[2 * e + 1] += __uint_as_float(rw[e] & 0xffff0000u);
-                    }
-                } else if (a.resid != nullptr && inside) {          // fp32 partial sums (313 head hyper-column)
+                if (a.resid != nullptr && !resid_in_acc && inside) {   // fp32 partial sums (313 head hyper-column)
                     const float4 r0 = *(const float4*)((const float*)a.resid + oidx);
                     const float4 r1 = *(const float4*)((const float*)a.resid + oidx + 4);
                     v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
@@ -981,8 +994,7 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads retired before the tile is rewritten
         }
-        };
-        if (pre_resid) epi_rows(std::true_type{}); else epi_rows(std::false_type{});
+        }
         if (fuse_head) {
             // the two cout waves of a pixel row meet in LDS; wave wco == 0 finishes: lane (px, h) = channel h
             __syncthreads();
@@ -1031,11 +1043,7 @@ static hipError_t launch_conv_v2_t(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-#ifdef IDC_V2_22
-#define IDC_FOR_EACH_CONV_V2(X) X(4, 2, 0) X(4, 2, 1) X(4, 2, 2) X(2, 4, 0) X(2, 4, 1) X(2, 4, 2) X(2, 2, 1)
-#else
 #define IDC_FOR_EACH_CONV_V2(X) X(4, 2, 0) X(4, 2, 1) X(4, 2, 2) X(2, 4, 0) X(2, 4, 1) X(2, 4, 2)
-#endif
 
 hipError_t init_kernels_v2() {
     hipError_t e;
@@ -1059,6 +1067,7 @@ hipError_t launch_conv_v2(ConvConfig cfg, int halo, const ConvArgs& a, hipStream
 #undef X
     return hipErrorInvalidConfiguration;
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // head: model_out = Conv1x1(128->2) -> Tanh, then *110 (model.py:108-109,174-175).

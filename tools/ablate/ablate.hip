@@ -93,8 +93,10 @@ int main(int argc, char** argv) {
             printf("  stage spans (mean ticks): deconv %.0f | p00 %.0f | p01 %.0f | p10 %.0f | p11 %.0f\n", st[0] / nb, st[1] / nb, st[2] / nb, st[3] / nb, st[4] / nb); }
         printf("  timing (ticks, mean over %d blocks): start-offset %.0f | prologue %.0f | mainloop %.0f | epilogue-issue %.0f | store-drain %.0f | kernel span %lld\n",
                nb, s[0] / nb, s[1] / nb, s[2] / nb, s[3] / nb, s[4] / nb, tend - t0);
+#ifdef IDC_TIMING_FINE
         { double u[3] = {0, 0, 0}; for (int b = 0; b < nb; ++b) { u[0] += (double)(h[b * 16 + 5] - h[b * 16]); u[1] += (double)(h[b * 16 + 6] - h[b * 16 + 5]); u[2] += (double)(h[b * 16 + 7] - h[b * 16 + 6]); }
           printf("  prologue split: setup(to first load issue) %.0f | issue halo+dma %.0f | wait loads + LDS write %.0f | to first tap barrier %.0f\n", u[0] / nb, u[1] / nb, u[2] / nb, s[1] / nb - (u[0] + u[1] + u[2]) / nb); }
+#endif
         for (int b : {0, 1, 8, nb / 2, nb - 1}) printf("   block %5d: start %lld pro %lld main %lld epi %lld drain %lld\n", b, h[b * 16] - t0, h[b * 16 + 1] - h[b * 16], h[b * 16 + 2] - h[b * 16 + 1], h[b * 16 + 3] - h[b * 16 + 2], h[b * 16 + 4] - h[b * 16 + 3]);
     }
 #endif

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Per-layer times of the bench workload (bf16, N=32, 256x256) for the build under <root> (default: this tree), as
+one JSON line -- for same-box A/B of two worktrees:  python tools/quick_layers.py _ab ; python tools/quick_layers.py ."""
+import json
+import os
+import sys
+
+import numpy as np
+
+root = os.path.abspath(sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, root)
+import torch                                                           # noqa: E402
+from interactive_deep_colorization_amd import engine, workloads        # noqa: E402
+from oracle import weights                                             # noqa: E402  (seeded weights only)
+
+nb = 32
+e = engine.HipColorizer(256, 256, max_batch=nb, precision="bf16")
+e.load_state_dict(weights.make_state_dict(0, "he"))
+L, ab, m = workloads.random_batch(nb, 256, seed=0)
+dev = torch.device("cuda", 0)
+dL, dab, dm = (torch.from_numpy(x).to(dev) for x in (L, ab, m))
+dout = torch.empty((nb, 2, 256, 256), dtype=torch.float32, device=dev)
+for _ in range(5):
+    e.forward_device(nb, dL, dab, dm, dout, 0.0, sync=True)
+import time                                                            # noqa: E402
+t0 = time.perf_counter()
+for _ in range(30):
+    e.forward_device(nb, dL, dab, dm, dout, 0.0, sync=False)
+e.sync()
+whole = (time.perf_counter() - t0) / 30 * 1e3
+e.set_profiling(True)
+for _ in range(10):
+    e.forward_device(nb, dL, dab, dm, dout, 0.0, sync=False)
+e.sync()
+ms = e.layer_times_ms()
+rows = {r["name"]: round(float(ms[r["index"]]), 4) for r in e.layer_table() if ms[r["index"]] > 0}
+print(json.dumps({"root": os.path.basename(root), "ms_per_forward": round(whole, 4), "img_s": round(nb / whole * 1e3, 1), "layers": rows}))
