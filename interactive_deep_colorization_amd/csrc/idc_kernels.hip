@@ -869,6 +869,57 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
         // (15 of the 27 large-tile launches) -- round in the MFMA layout and transpose bf16 instead of fp32: half the
         // LDS traffic, ReLU as one v_pk_max_i16 per pair (a bf16 is negative iff its int16 pattern is), no per-lane
         // constants.  [32 px][64 couts] bf16 = 128-B rows, 16-B slot ^ (px & 7): conflict-free both ways.
+        // Fused tanh head (conv10_2 -> model_out, model.py:101-109): the activation and the 128 -> 2 dot product run in
+        // the MFMA layout (32 couts of one pixel per lane); the four partial sums of a pixel (2 lane halves x 2 cout
+        // waves) meet in LDS.  conv10_2 itself is never rounded or stored, and nothing is transposed.
+        if (fuse_head && !has_bn && a.img_shift == nullptr && (a.resid == nullptr || resid_in_acc)) {
+            f32x16 w0[2], w1[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 u = *(const float4*)(a.head_w + cow + h * 32 + mi * 16 + q * 4);
+                    const float4 v = *(const float4*)(a.head_w + 128 + cow + h * 32 + mi * 16 + q * 4);
+                    w0[mi][q * 4 + 0] = u.x; w0[mi][q * 4 + 1] = u.y; w0[mi][q * 4 + 2] = u.z; w0[mi][q * 4 + 3] = u.w;
+                    w1[mi][q * 4 + 0] = v.x; w1[mi][q * 4 + 1] = v.y; w1[mi][q * 4 + 2] = v.z; w1[mi][q * 4 + 3] = v.w;
+                }
+            float* const hp = (float*)smem;                     // [wave][pj][half][32 px][2]
+#pragma unroll
+            for (int pj = 0; pj < 4; ++pj) {
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[mi][pj][r];
+                        if (a.act == 1) v = fmaxf(v, 0.f);
+                        else if (a.act == 2) v = fmaxf(v, 0.2f * v);
+                        s0 = fmaf(v, w0[mi][r], s0);
+                        s1 = fmaf(v, w1[mi][r], s1);
+                    }
+                *(float2*)(hp + ((((wave * 4 + pj) * 2 + h) * 32 + px) * 2)) = float2{s0, s1};
+            }
+            __syncthreads();
+            if (wco == 0) {                                     // waves wave, wave+1 hold the two cout halves of these pixels
+                const float hb = a.head_b[h];
+#pragma unroll
+                for (int pj = 0; pj < 4; ++pj) {
+                    float p = hb;
+#pragma unroll
+                    for (int w2 = 0; w2 < 2; ++w2)
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) p += hp[((((wave + w2) * 4 + pj) * 2 + hh) * 32 + px) * 2 + h];
+                    const int sy = ty0 + wpx * 4 + pj, sx = tx0 + px;
+                    if (sy < Hs && sx < Ws) a.head_out[(((size_t)n * 2 + h) * Hs + sy) * Ws + sx] = tanhf(p) * a.head_mul;
+                }
+            }
+            IDC_STAMP(3);
+#ifdef IDC_TIMING
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            IDC_STAMP(4);
+#endif
+            return;
+        }
         const bool cheap = (a.resid == nullptr || resid_in_acc) && a.act != 2 && a.img_shift == nullptr && !fuse_head;
         if (cheap) {
             char* const tb16 = smem + wave * 4096;
