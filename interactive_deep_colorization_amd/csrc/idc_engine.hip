@@ -640,7 +640,18 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             a.partial = c->d_partial;
         }
         tic();
-        HIPCHK(c, L.v2 ? launch_conv_v2(L.cfg, L.halo, a, s) : launch_conv(c->precision, L.cfg, L.halo, a, s));
+        {
+            hipError_t le = hipErrorInvalidConfiguration;
+            // conv1_1 with >= 128 big tiles: the 32x32-tile form (the small-tile kernel keeps the batch-1 click path).
+            // Chosen by the handle's max_batch like every other kernel variant, so a result never depends on how many
+            // images share the call.
+            if (L.spec->kind == kConvIm2col && c->precision == IDC_BF16 && a.ksplit <= 1 &&
+                (long long)((a.Ws + 31) / 32) * ((a.Hs + 31) / 32) * c->max_batch >= 128)
+                le = launch_conv1_1_bf16(a, s);
+            if (le == hipErrorInvalidConfiguration)
+                le = L.v2 ? launch_conv_v2(L.cfg, L.halo, a, s) : launch_conv(c->precision, L.cfg, L.halo, a, s);
+            HIPCHK(c, le);
+        }
         if (a.ksplit > 1) HIPCHK(c, launch_splitk_epilogue(c->precision, a, s));
         toc();
     }

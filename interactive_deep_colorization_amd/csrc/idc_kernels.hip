@@ -1121,6 +1121,134 @@ hipError_t launch_conv_v2(ConvConfig cfg, int halo, const ConvArgs& a, hipStream
 
 
 // ------------------------------------------------------------------------------------------------
+// conv1_1_bf16_kernel: model1.0 (4 -> 64 channels, 3x3, model.py:13) with the input pack (model.py:139-148) fused,
+// throughput form.  One workgroup = a 32x32 tile of one image x all 64 output channels; 8 waves x 4 pixel rows.
+// The (32+2)^2 input patch is normalised once into LDS as float4 (L, a, b, mask); every lane builds its own MFMA B
+// fragments from it (K index = tap*4 + channel, 36 of 64 used: three k16 steps), the A fragments come straight from
+// the packed weights (layout 1 rows, read in the row order of the 32x32 D layout so that a lane ends up with 32
+// consecutive couts), so there is no im2col buffer, one barrier, and the 268 MB output is the only HBM stream that
+// matters.  Epilogue = the bf16-transpose one of conv_igemm_v2.  (The small-tile conv_igemm path keeps the batch-1 case.)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void conv1_1_bf16_kernel(const ConvArgs a) {
+    constexpr int PW = 34;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* const patch = (float4*)smem;                       // [34][34]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 31, h = lane >> 5;
+    const int Hs = a.Hs, Ws = a.Ws;
+    const int ntx = (Ws + 31) >> 5, nty = (Hs + 31) >> 5;
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int txi = b % ntx; b /= ntx;
+    const int tyi = b % nty;
+    const int n = b / nty;
+    const int ty0 = tyi * 32, tx0 = txi * 32;
+    {
+        const size_t hw = (size_t)Hs * Ws;
+        const float* const pL = a.pk_L + (size_t)n * hw;
+        const float* const pA = a.pk_ab + (size_t)n * 2 * hw;
+        const float* const pM = a.pk_mask + (size_t)n * hw;
+        const float rl = 1.0f / a.pk_ldiv, ra = 1.0f / a.pk_abdiv;
+        for (int idx = tid; idx < PW * PW; idx += 512) {
+            const int py = idx / PW, pxx = idx - py * PW;
+            const int yy = ty0 - 1 + py, xx = tx0 - 1 + pxx;
+            float4 c = float4{0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)yy < (unsigned)Hs && (unsigned)xx < (unsigned)Ws) {
+                const size_t p = (size_t)yy * Ws + xx;
+                c = float4{pL[p] / a.pk_ldiv, pA[p] / a.pk_abdiv, pA[hw + p] / a.pk_abdiv, pM[p] * a.pk_mmul - a.pk_mcent};
+            }
+            patch[idx] = c;
+        }
+        (void)rl; (void)ra;
+    }
+    // A fragments: MFMA row rho = px of block mi is cout hh*32 + mi*16 + r with r = (rho>>3)*4 + (rho&3), hh = (rho>>2)&1
+    u32x4 wf[3][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int c = ((px >> 2) & 1) * 32 + mi * 16 + (px >> 3) * 4 + (px & 3);
+        const int lam = ((c >> 2) & 3) * 16 + (c >> 4) * 4 + (c & 3);          // layout-1 row of cout c (idc_layout.h)
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk)
+            wf[kk][mi] = *(const u32x4*)((const char*)a.wgt + lam * kRowBytes + (((kk * 2 + h) ^ swz(lam)) * kSlotBytes));
+    }
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        f32x16 b16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 bq = *(const float4*)(a.bias + h * 32 + mi * 16 + q * 4);
+            b16[q * 4 + 0] = bq.x; b16[q * 4 + 1] = bq.y; b16[q * 4 + 2] = bq.z; b16[q * 4 + 3] = bq.w;
+        }
+#pragma unroll
+        for (int pj = 0; pj < 4; ++pj) acc[mi][pj] = b16;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pj = 0; pj < 4; ++pj) {
+        const int base = (wave * 4 + pj) * PW + px;            // patch index of tap (ky=0, kx=0) for this site
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+            // lane half h holds K = kk*16 + h*8 .. +7 = taps 4kk+2h, 4kk+2h+1 (x 4 channels); taps >= 9 are zero padding
+            const int t0a = 4 * kk, t0b = 4 * kk + 2;          // first tap for h = 0 / h = 1
+            const int o0 = h ? (t0b / 3) * PW + t0b % 3 : (t0a / 3) * PW + t0a % 3;
+            const int o1 = h ? ((t0b + 1) / 3) * PW + (t0b + 1) % 3 : ((t0a + 1) / 3) * PW + (t0a + 1) % 3;
+            const bool z0 = h ? t0b >= 9 : t0a >= 9, z1 = h ? t0b + 1 >= 9 : t0a + 1 >= 9;
+            const float4 c0 = z0 ? float4{0.f, 0.f, 0.f, 0.f} : patch[base + o0];
+            const float4 c1 = z1 ? float4{0.f, 0.f, 0.f, 0.f} : patch[base + o1];
+            const u32x4 xf = u32x4{pack_bf16x2(c0.x, c0.y), pack_bf16x2(c0.z, c0.w), pack_bf16x2(c1.x, c1.y), pack_bf16x2(c1.z, c1.w)};
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+                acc[mi][pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[kk][mi]),
+                                                                      __builtin_bit_cast(bf16x8, xf), acc[mi][pj], 0, 0, 0);
+        }
+    }
+    // epilogue: (ReLU,) round, transpose [32 px][64 couts] bf16 through a wave-private LDS tile, whole-line stores
+    char* const tb16 = smem + PW * PW * 16 + wave * 4096;
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    const int rr = lane >> 3, cc = lane & 7;
+    const int CoutPad = a.ncg * kCoutGroup;
+#pragma unroll
+    for (int pj = 0; pj < 4; ++pj) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            unsigned pk[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                pk[e] = pack_bf16x2(acc[mi][pj][2 * e], acc[mi][pj][2 * e + 1]);
+                if (a.act == 1)
+                    pk[e] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk[e]), s16x2{0, 0}));
+            }
+            const int s0 = h * 4 + mi * 2;
+            *(uint4*)(tb16 + px * 128 + ((s0 ^ (px & 7)) * 16)) = uint4{pk[0], pk[1], pk[2], pk[3]};
+            *(uint4*)(tb16 + px * 128 + (((s0 + 1) ^ (px & 7)) * 16)) = uint4{pk[4], pk[5], pk[6], pk[7]};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int sy = ty0 + wave * 4 + pj;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = i * 8 + rr;
+            const uint4 o = *(const uint4*)(tb16 + row * 128 + ((cc ^ (row & 7)) * 16));
+            const int sx = tx0 + row;
+            if (sy < Hs && sx < Ws)
+                *(uint4*)((unsigned short*)a.out + (((size_t)n * Hs + sy) * Ws + sx) * CoutPad + cc * 8) = o;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+// conv1_1 (kConvIm2col) in its throughput form; needs bf16, the fused-pack planes, ReLU/none and no BN / shortcut
+hipError_t launch_conv1_1_bf16(const ConvArgs& a, hipStream_t s) {
+    if (a.pk_L == nullptr || a.bn_scale != nullptr || a.resid != nullptr || a.out_f32 || a.act == 2 || a.ncg != 1 || a.ksplit > 1)
+        return hipErrorInvalidConfiguration;
+    const long long blocks = (long long)((a.Ws + 31) / 32) * ((a.Hs + 31) / 32) * a.N;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(conv1_1_bf16_kernel, dim3((unsigned)blocks), dim3(512), 34 * 34 * 16 + 8 * 4096, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // head: model_out = Conv1x1(128->2) -> Tanh, then *110 (model.py:108-109,174-175).
 // 16 lanes per pixel, 8 channels each, xor-shuffle reduction inside the 16-lane group.
 // ------------------------------------------------------------------------------------------------

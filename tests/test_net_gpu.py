@@ -290,3 +290,33 @@ def test_ragged_geometry_40x72_batch3(make_sd, precision, tiles):
         assert d.max() <= BF16_MAX["he"] and d.mean() <= BF16_MEAN["he"], (d.max(), d.mean())
     np.testing.assert_array_equal(e.forward(L[2:3], ab[2:3], m[2:3], 0.5)[0], out[2])
     e.close()
+
+
+def test_conv1_1_throughput_kernel(make_sd):
+    """conv1_1's 32x32-tile form (conv1_1_bf16_kernel, used from 128 tiles up) against a float64 conv of the packed
+    input (model.py:139-148, :13) and against the small-tile path that single-image forwards take.  72 x 104: partial
+    tiles on both axes, 3 x 4 tiles x 12 images = 144 workgroups.  Tolerance = one bf16 ulp of the largest value (both
+    the operands and the stored result are bf16)."""
+    import torch
+    H, W, N = 72, 104, 12
+    L, ab, m = workloads.random_batch(N, H, W, seed=17, max_points=6, max_p=3)
+    sd = make_sd(4, "he")
+    e = engine.HipColorizer(H, W, max_batch=N, precision="bf16")
+    e.load_state_dict(sd)
+    e.forward(L, ab, m, 0.5)
+    big = e.activation("conv1_1", N)
+    x = np.concatenate([L / 100.0, ab / 110.0, m - 0.5], axis=1).astype(np.float64)
+    ref = torch.relu(torch.nn.functional.conv2d(torch.from_numpy(x), torch.from_numpy(sd["model1.0.weight"].astype(np.float64)),
+                                                torch.from_numpy(sd["model1.0.bias"].astype(np.float64)), padding=1)).numpy()
+    tol = 2.0 ** -7 * max(1.0, np.abs(ref).max())
+    assert np.abs(big - ref).max() <= tol, (np.abs(big - ref).max(), tol)
+    e.forward(L[5:6], ab[5:6], m[5:6], 0.5)                    # same handle: same kernel whatever the batch
+    np.testing.assert_array_equal(e.activation("conv1_1", 1)[0], big[5])
+    e.close()
+    e1 = engine.HipColorizer(H, W, max_batch=1, precision="bf16")   # 12 tiles: the small-tile kernel
+    e1.load_state_dict(sd)
+    e1.forward(L[5:6], ab[5:6], m[5:6], 0.5)
+    small = e1.activation("conv1_1", 1)
+    assert np.abs(small[0] - big[5]).max() <= tol
+    assert (small[0] == big[5]).mean() > 0.98                   # same operands, same fp32 sums up to their order
+    e1.close()
