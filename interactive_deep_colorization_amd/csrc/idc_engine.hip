@@ -380,7 +380,12 @@ static int g_splitk_policy = 0;
 // Shortcut fusion (conv_igemm_v2<.,.,1,true>) is correct (parity-tested under tile policy 2) but measured slower
 // than two launches on MI355X (4x re-reads of the skip tensor by the four phase workgroups, VGPR spills around
 // the staged K loop): 0.87 ms -> 1.25 ms at level 1.  Off unless the tile policy forces every variant on.
-static bool fuse_shortcut_enabled() { return g_tile_policy == 2 || getenv("IDC_FUSE_SHORTCUT") != nullptr; }          // large-tile deconv launches also run the shortcut conv they are summed with
+// large-tile deconv launches also run the shortcut conv they are summed with (conv_ds_fused); IDC_FUSE_SHORTCUT=0 keeps
+// the two launches apart (A/B)
+static bool fuse_shortcut_enabled() {
+    static const bool off = getenv("IDC_FUSE_SHORTCUT") != nullptr && atoi(getenv("IDC_FUSE_SHORTCUT")) == 0;
+    return !off;
+}
 
 // Small-tile kernel shape.  cout<=64 layers can only use one 64-wide cout group per wave column;
 // otherwise prefer 128 couts x 128 pixels and fall back to smaller pixel tiles when the launch would
@@ -648,6 +653,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             if (L.spec->kind == kConvIm2col && c->precision == IDC_BF16 && a.ksplit <= 1 &&
                 (long long)((a.Ws + 31) / 32) * ((a.Hs + 31) / 32) * c->max_batch >= 128)
                 le = launch_conv1_1_bf16(a, s);
+            if (L.fused_short >= 0) le = launch_conv_ds(a, s);    // deconv + its shortcut conv in one K loop
             if (le == hipErrorInvalidConfiguration)
                 le = L.v2 ? launch_conv_v2(L.cfg, L.halo, a, s) : launch_conv(c->precision, L.cfg, L.halo, a, s);
             HIPCHK(c, le);

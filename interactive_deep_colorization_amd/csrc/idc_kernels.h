@@ -72,6 +72,10 @@ hipError_t launch_conv(int precision, ConvConfig cfg, int halo, const ConvArgs& 
 // {4,2} = 256 couts x (32x8 sites), {2,4} = 128 couts x (32x16 sites).  a.wgt must point at the
 // layer's layout-2 weight image (idc_layout.h); tiles_x/tiles_y count 32 x 4*WPX tiles.
 hipError_t launch_conv_v2(ConvConfig cfg, int halo, const ConvArgs& a, hipStream_t s);
+// ConvTranspose 4x4 s2 + the 3x3 shortcut conv it is summed with, one K loop (conv_ds_fused); a.in2 / wgt2 / nkc2 = the
+// shortcut's input, layout-2 weights and channel chunks, a.bias = the two biases added.  hipErrorInvalidConfiguration if
+// the launch does not qualify.
+hipError_t launch_conv_ds(const ConvArgs& a, hipStream_t s);
 // conv1_1 (4 -> 64, input pack fused) as one 32x32 tile per workgroup, bf16; hipErrorInvalidConfiguration if the
 // launch does not qualify (the caller then uses launch_conv)
 hipError_t launch_conv1_1_bf16(const ConvArgs& a, hipStream_t s);

@@ -1120,6 +1120,281 @@ hipError_t launch_conv_v2(ConvConfig cfg, int halo, const ConvArgs& a, hipStream
 }
 
 
+// ================================================================================================
+// conv_ds_fused -- ConvTranspose2d 4x4 s2 (model8up / model9up / model10up) and the 3x3 shortcut conv it is summed
+// with (model3short8 / model2short9 / model1short10; model.py:156,170,172) in ONE K loop: the shortcut's 128-channel
+// partial sums never go to HBM (537 MB written + read back per forward at 256^2, N = 32, for model10 alone).
+//   * workgroup = 64 x 8 OUTPUT pixels x 128 couts: 2 cout waves x 4 PHASE waves.  Wave (wco, ph) owns the 32 x 4 sites
+//     whose output pixel is (2y + ro, 2x + cof) -- so the four deconv phases of a site tile share one workgroup, and the
+//     skip tensor's (10 x 66)-pixel halo is fetched once instead of once per phase launch;
+//   * S part (shortcut): K = 9 taps x Cs.  The halo tile is stored de-interleaved by x parity (LDS row = y*66 +
+//     (x&1)*33 + x/2): a phase wave reads pixels of one parity, i.e. 32 consecutive rows -> the same conflict-free
+//     ds_read_b128 pattern as conv_igemm_v2.  Weight tiles (128 couts) are shared, 2-deep LDS-DMA ring;
+//   * D part (deconv): K = 4 taps x Cd, taps and weight tiles depend on the phase, so every wave streams its own
+//     8 KiB tile (64 couts x 64 cin) through a wave-private 2-deep ring;
+//   * epilogue = the bf16-transpose one (bias in the accumulators, ReLU on packed pairs), per-wave output phase.
+// LDS: S part 90 KiB halo + 32 KiB ring; D part 32 KiB halo + 128 KiB rings = 160 KiB (the two parts reuse the space,
+// one drained hand-over in between).
+// ================================================================================================
+__global__ __launch_bounds__(512, 2) void conv_ds_fused(const ConvArgs a) {
+    constexpr int NT = 512;
+    constexpr int SW = 66, SROWS = 10 * SW, S_ITEMS = (SROWS * kSlots + NT - 1) / NT, S_HALO_BYTES = S_ITEMS * NT * kSlotBytes;
+    constexpr int DW = 34, DROWS = 6 * DW, D_ITEMS = (DROWS * kSlots + NT - 1) / NT, D_HALO_BYTES = D_ITEMS * NT * kSlotBytes;
+    constexpr int S_WB = 2 * kWBlockBytes, D_WB = kWBlockBytes;
+    static_assert(S_HALO_BYTES + 2 * S_WB <= 160 * 1024 && D_HALO_BYTES + 16 * D_WB <= 160 * 1024, "LDS budget");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const halo = smem;
+    char* const ringS = smem + S_HALO_BYTES;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave & 1, ph = wave >> 1;
+    char* const ringD = smem + D_HALO_BYTES + wave * 2 * D_WB;
+    const int px = lane & 31, h = lane >> 5;
+    const int Hs = a.Hs, Ws = a.Ws;                            // deconv input (= site) resolution; output is 2x
+    const int ntx = (Ws + 31) >> 5, nty = (Hs + 3) >> 2, nct = a.ncg >> 1;
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int ct = b % nct; b /= nct;
+    const int txi = b % ntx; b /= ntx;
+    const int tyi = b % nty;
+    const int n = b / nty;
+    const int y0 = tyi * 4, x0 = txi * 32;
+    const int ro = a.ro[ph], cof = a.co[ph];
+    const int nkc = a.nkc, nkc2 = a.nkc2, ncg = a.ncg;
+    const int pixD = nkc * kRowBytes, pixS = nkc2 * kRowBytes;
+    const char* const imgD = (const char*)a.in + (size_t)n * Hs * Ws * pixD;
+    const char* const imgS = (const char*)a.in2 + (size_t)n * (4 * (size_t)Hs * Ws) * pixS;
+    const int cg0 = ct * 2;
+
+    f32x16 acc[2][4];
+    {
+        const float* const bp = a.bias + (cg0 + wco) * kCoutGroup + h * 32;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f32x16 b16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bq = *(const float4*)(bp + i * 16 + q * 4);
+                b16[q * 4 + 0] = bq.x; b16[q * 4 + 1] = bq.y; b16[q * 4 + 2] = bq.z; b16[q * 4 + 3] = bq.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = b16;
+        }
+    }
+
+    u32x4 hreg[S_ITEMS];
+    auto load_halo_S = [&](int kc2) {
+#pragma unroll
+        for (int j = 0; j < S_ITEMS; ++j) {
+            const int item = tid + j * NT;
+            const int hr = item >> 3, sig = item & 7;          // LDS row (de-interleaved order) and physical slot
+            const int hy = hr / SW, rem = hr - hy * SW;
+            const int par = rem >= 33 ? 1 : 0, hx = 2 * (rem - par * 33) + par;
+            const int Y = 2 * y0 - 1 + hy, X = 2 * x0 - 1 + hx;
+            const bool inside = (unsigned)Y < (unsigned)(2 * Hs) && (unsigned)X < (unsigned)(2 * Ws) && hr < SROWS;
+            const int off = (Y * (2 * Ws) + X) * pixS + ((sig ^ swz2(hr)) + kc2 * kSlots) * kSlotBytes;
+            const u32x4 v = *(const u32x4*)(imgS + (inside ? off : 0));
+            hreg[j] = inside ? v : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto load_halo_D = [&](int kc) {
+#pragma unroll
+        for (int j = 0; j < D_ITEMS; ++j) {
+            const int item = tid + j * NT;
+            const int hr = item >> 3, sig = item & 7;
+            const int hy = hr / DW, hx = hr - hy * DW;
+            const int Y = y0 - 1 + hy, X = x0 - 1 + hx;
+            const bool inside = (unsigned)Y < (unsigned)Hs && (unsigned)X < (unsigned)Ws && hr < DROWS;
+            const int off = (Y * Ws + X) * pixD + ((sig ^ swz2(hr)) + kc * kSlots) * kSlotBytes;
+            const u32x4 v = *(const u32x4*)(imgD + (inside ? off : 0));
+            hreg[j] = inside ? v : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto dma_S = [&](int tap, int kc2, int buf) {              // 128 couts x 64 cin, shared: every wave brings 2 KiB
+        const char* src = (const char*)a.wgt2 + (((size_t)tap * nkc2 + kc2) * ncg + cg0) * kWBlockBytes + (size_t)tid * kSlotBytes;
+        char* dst = ringS + buf * S_WB + wave * 64 * kSlotBytes;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)j * NT * kSlotBytes),
+                                             (__attribute__((address_space(3))) void*)(dst + j * NT * kSlotBytes), 16, 0, 0);
+    };
+    auto dma_D = [&](int tw, int kc, int buf) {                // this wave's 64 couts x 64 cin of its phase's tap
+        const char* src = (const char*)a.wgt + (((size_t)tw * nkc + kc) * ncg + cg0 + wco) * kWBlockBytes + (size_t)lane * kSlotBytes;
+        char* dst = ringD + buf * D_WB;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 64 * kSlotBytes),
+                                             (__attribute__((address_space(3))) void*)(dst + j * 64 * kSlotBytes), 16, 0, 0);
+    };
+    // one K step of 64 channels: 4 k16 steps x 8 MFMAs, fragments of step kk+1 in flight under step kk (as conv_igemm_v2)
+    auto stage = [&](const char* const wcur, const int wrow_byte, const int (&xaddr)[4]) {
+        const int wslot0 = (h ^ swz2(px)) * kSlotBytes;
+        u32x4 wfA[2], xfA[4], wfB[2], xfB[4];
+        auto read_frags = [&](int kk, u32x4 (&wf)[2], u32x4 (&xf)[4]) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+                wf[mi] = *(const u32x4*)(wcur + ((wrow_byte + mi * 32 * kRowBytes + wslot0) ^ (kk * 2 * kSlotBytes)));
+#pragma unroll
+            for (int pj = 0; pj < 4; ++pj)
+                xf[pj] = *(const u32x4*)(halo + (xaddr[pj] ^ (kk * 2 * kSlotBytes)));
+        };
+        auto mma8 = [&](const u32x4 (&wf)[2], const u32x4 (&xf)[4]) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int pj = 0; pj < 4; ++pj)
+                    acc[mi][pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[mi]),
+                                                                          __builtin_bit_cast(bf16x8, xf[pj]),
+                                                                          acc[mi][pj], 0, 0, 0);
+        };
+#define IDC_STAGE_INTERLEAVE()                                                        \
+    _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) {                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
+    }                                                                                 \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        read_frags(0, wfA, xfA);
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        read_frags(1, wfB, xfB);
+        mma8(wfA, xfA);
+        IDC_STAGE_INTERLEAVE()
+        read_frags(2, wfA, xfA);
+        mma8(wfB, xfB);
+        IDC_STAGE_INTERLEAVE()
+        read_frags(3, wfB, xfB);
+        mma8(wfA, xfA);
+        IDC_STAGE_INTERLEAVE()
+        mma8(wfB, xfB);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+#undef IDC_STAGE_INTERLEAVE
+    };
+
+    // ---------------------------------------------------------------- S part: 3x3 conv of the skip tensor
+    load_halo_S(0);
+    dma_S(0, 0, 0);
+    int buf = 0;
+    for (int kc2 = 0; kc2 < nkc2; ++kc2) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < S_ITEMS; ++j) *(u32x4*)(halo + (tid + j * NT) * kSlotBytes) = hreg[j];
+        const bool last_kc = kc2 + 1 == nkc2;
+        for (int t = 0; t < 9; ++t) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t + 1 < 9) {
+                dma_S(t + 1, kc2, buf ^ 1);
+            } else if (!last_kc) {
+                dma_S(0, kc2 + 1, buf ^ 1);
+                load_halo_S(kc2 + 1);
+            } else {
+                load_halo_D(0);                                // the deconv input's first chunk: rows wait in registers
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const int ky = t / 3, kx = t - ky * 3;             // 0..2 (= tap offset + 1)
+            const int c = cof + kx, par = c & 1, sh = c >> 1;  // output x = 2*xs + cof reads skip x + kx - 1: halo col 2*xs + c
+            int xaddr[4];
+#pragma unroll
+            for (int pj = 0; pj < 4; ++pj) {
+                const int xr = (2 * pj + ro + ky) * SW + par * 33 + px + sh;
+                xaddr[pj] = xr * kRowBytes + ((h ^ swz2(xr)) * kSlotBytes);
+            }
+            stage(ringS + buf * S_WB, (wco * 64 + px) * kRowBytes, xaddr);
+            buf ^= 1;
+        }
+    }
+    // ---------------------------------------------------------------- hand-over: the D part reuses the whole LDS
+    const int* const tdy = a.dy + ph * 9;
+    const int* const tdx = a.dx + ph * 9;
+    const int* const ttw = a.tw + ph * 9;
+    __syncthreads();                                           // every wave left the S halo and ring
+#pragma unroll
+    for (int j = 0; j < D_ITEMS; ++j) *(u32x4*)(halo + (tid + j * NT) * kSlotBytes) = hreg[j];
+    dma_D(ttw[0], 0, 0);
+    buf = 0;
+    // ---------------------------------------------------------------- D part: the wave's deconv phase, 2x2 taps
+    for (int kc = 0; kc < nkc; ++kc) {
+        if (kc > 0) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < D_ITEMS; ++j) *(u32x4*)(halo + (tid + j * NT) * kSlotBytes) = hreg[j];
+        }
+        const bool last_kc = kc + 1 == nkc;
+        for (int t = 0; t < 4; ++t) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t + 1 < 4) {
+                dma_D(ttw[t + 1], kc, buf ^ 1);
+            } else if (!last_kc) {
+                dma_D(ttw[0], kc + 1, buf ^ 1);
+                load_halo_D(kc + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const int dy = tdy[t], dx = tdx[t];
+            int xaddr[4];
+#pragma unroll
+            for (int pj = 0; pj < 4; ++pj) {
+                const int xr = (pj + 1 + dy) * DW + (px + 1 + dx);
+                xaddr[pj] = xr * kRowBytes + ((h ^ swz2(xr)) * kSlotBytes);
+            }
+            stage(ringD + buf * D_WB, px * kRowBytes, xaddr);
+            buf ^= 1;
+        }
+    }
+    // ---------------------------------------------------------------- epilogue: (ReLU,) round, transpose, whole-line stores
+    __syncthreads();
+    char* const tb16 = smem + wave * 4096;
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    const int rr = lane >> 3, cc = lane & 7;
+    const int CoutPad = ncg * kCoutGroup;
+    const int co8 = (cg0 + wco) * kCoutGroup + cc * 8;
+    const int Wout = 2 * Ws, Hout = 2 * Hs;
+#pragma unroll
+    for (int pj = 0; pj < 4; ++pj) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            unsigned pk[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                pk[e] = pack_bf16x2(acc[mi][pj][2 * e], acc[mi][pj][2 * e + 1]);
+                if (a.act == 1)
+                    pk[e] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk[e]), s16x2{0, 0}));
+            }
+            const int s0 = h * 4 + mi * 2;
+            *(uint4*)(tb16 + px * 128 + ((s0 ^ (px & 7)) * 16)) = uint4{pk[0], pk[1], pk[2], pk[3]};
+            *(uint4*)(tb16 + px * 128 + (((s0 + 1) ^ (px & 7)) * 16)) = uint4{pk[4], pk[5], pk[6], pk[7]};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int sy = y0 + pj;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = i * 8 + rr;
+            const uint4 o = *(const uint4*)(tb16 + row * 128 + ((cc ^ (row & 7)) * 16));
+            const int sx = x0 + row;
+            if (sy < Hs && sx < Ws)
+                *(uint4*)((unsigned short*)a.out + (((size_t)n * Hout + (2 * sy + ro)) * Wout + (2 * sx + cof)) * CoutPad + co8) = o;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+// deconv 4x4 s2 + its 3x3 shortcut conv in one launch: bf16, Cout a multiple of 128, (ReLU | none), no BN
+hipError_t launch_conv_ds(const ConvArgs& a, hipStream_t s) {
+    if (a.in2 == nullptr || a.wgt2 == nullptr || a.nphase != 4 || a.so != 2 || a.si != 1 || (a.ncg & 1) || a.out_f32 ||
+        a.bn_scale != nullptr || a.act == 2 || a.img_shift != nullptr || a.resid != nullptr || a.head_w != nullptr)
+        return hipErrorInvalidConfiguration;
+    const long long blocks = (long long)((a.Ws + 31) / 32) * ((a.Hs + 3) / 4) * a.N * (a.ncg / 2);
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_ds_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_ds_fused, dim3((unsigned)blocks), dim3(512), 160 * 1024, s, a);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // conv1_1_bf16_kernel: model1.0 (4 -> 64 channels, 3x3, model.py:13) with the input pack (model.py:139-148) fused,
 // throughput form.  One workgroup = a 32x32 tile of one image x all 64 output channels; 8 waves x 4 pixel rows.
