@@ -586,6 +586,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
     }
     for (auto& L : c->layers) {
         if (L.spec->kind != kDeconv4x4 || L.resid < 0 || !L.v2 || !fuse_shortcut_enabled()) continue;
+        if (L.spec->cout % 128 != 0 || L.spec->bnkey || L.spec->act == 2 || c->tensors[L.dst].is_f32) continue;   // conv_ds_fused's domain
         for (size_t j = 0; j < c->layers.size(); ++j) {
             Layer& P = c->layers[j];
             const LayerSpec& ps = *P.spec;

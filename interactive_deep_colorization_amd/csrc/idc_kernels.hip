@@ -544,7 +544,7 @@ __device__ long long* g_idc_dbg;
 #define IDC_STAMP_FINE(i) do {} while (0)
 #endif
 
-template <int WCO, int WPX, int HALO, bool FUSED>
+template <int WCO, int WPX, int HALO>
 __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs a) {
     constexpr int NT = WCO * WPX * 64;
     constexpr int TW = 32, TH = 4 * WPX;
@@ -585,41 +585,18 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
     const size_t w_kc_stride = (size_t)a.ncg * kWBlockBytes;   // next cin chunk (both sources: same couts)
     const size_t w_lane = (size_t)(ct * WCO) * kWBlockBytes + (size_t)tid * kSlotBytes;
 
-    // ---- K loop = a list of stages, all accumulating into the same output sites -------------------
-    // stage 0: the layer itself (a.in / a.wgt / tap tables: 3x3 conv, 1x1 conv or one deconv phase);
-    // stages 1..4 (only with a.in2, deconv launches): the fused shortcut 3x3 conv of in2 at the output
-    // resolution (model.py:156,170,172: model8up(.) + model3short8(.)).  Output pixel (2m+r, 2n+s)
-    // reads in2 at (2m+r+ky, 2n+s+kx): taps whose row/col parity is (pa,pb) form a stride-2 gather of
-    // in2 with offset (pa,pb) and site shifts in {-1,0,+1} -- same halo machinery, four more stages.
+    // ---- K loop: one source (a.in / a.wgt / tap tables: 3x3 conv, 1x1 conv or one deconv phase) --------------
     struct Stage { const char* img; const char* wb; int nkc, ntaps, si, oy, ox; };
-    auto make_stage = [&](int q) -> Stage {
+    auto make_stage = [&](int) -> Stage {
         Stage st;
-        if (!FUSED || q == 0) {
-            const size_t pix = (size_t)a.nkc * kRowBytes;
-            st.img = (const char*)a.in + (size_t)n * (size_t)(Hs * a.si) * (Ws * a.si) * pix;
-            st.wb = (const char*)a.wgt + w_lane;
-            st.nkc = a.nkc; st.ntaps = a.ntaps; st.si = a.si; st.oy = 0; st.ox = 0;
-        } else {
-            const int pa = (q - 1) >> 1, pb = (q - 1) & 1;
-            const size_t pix = (size_t)a.nkc2 * kRowBytes;
-            st.img = (const char*)a.in2 + (size_t)n * (size_t)(Hs * 2) * (Ws * 2) * pix;
-            st.wb = (const char*)a.wgt2 + w_lane;
-            st.nkc = a.nkc2; st.ntaps = (pa == ro ? 1 : 2) * (pb == cof ? 1 : 2); st.si = 2; st.oy = pa; st.ox = pb;
-        }
+        const size_t pix = (size_t)a.nkc * kRowBytes;
+        st.img = (const char*)a.in + (size_t)n * (size_t)(Hs * a.si) * (Ws * a.si) * pix;
+        st.wb = (const char*)a.wgt + w_lane;
+        st.nkc = a.nkc; st.ntaps = a.ntaps; st.si = a.si; st.oy = 0; st.ox = 0;
         return st;
     };
-    // tap t of stage q: site shift (dy, dx) and index of its packed weight tile
-    auto tap_of = [&](int q, int t, int& dy, int& dx, int& tw) {
-        if (!FUSED || q == 0) { dy = tap_dy[t]; dx = tap_dx[t]; tw = tap_tw[t]; return; }
-        const int pa = (q - 1) >> 1, pb = (q - 1) & 1;
-        const int nx = pb == cof ? 1 : 2;
-        const int iy = nx == 2 ? (t >> 1) : t, ix = nx == 2 ? (t & 1) : 0;
-        const int ky = pa == ro ? 0 : (iy ? 1 : -1), kx = pb == cof ? 0 : (ix ? 1 : -1);
-        dy = pa == ro ? 0 : (iy ? ro : ro - 1);                 // (r + ky - pa) / 2
-        dx = pb == cof ? 0 : (ix ? cof : cof - 1);
-        tw = (ky + 1) * 3 + (kx + 1);
-    };
-    constexpr int nstage = FUSED ? 5 : 1;
+    auto tap_of = [&](int, int t, int& dy, int& dx, int& tw) { dy = tap_dy[t]; dx = tap_dx[t]; tw = tap_tw[t]; };
+    constexpr int nstage = 1;
 
     // accumulators start at the bias (bf16-output launches; the fp32-output epilogue adds it itself): lane
     // (pixel px, half h) register r of acc[mi][.] is cout h*32 + mi*16 + r of the wave's 64 (idc_layout.h layout 2)
@@ -1081,16 +1058,8 @@ static hipError_t launch_conv_v2_t(const ConvArgs& a, hipStream_t s) {
     const int nct = a.ncg / WCO;
     const long long blocks = (long long)a.tiles_x * a.tiles_y * a.N * nct * a.nphase;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (a.in2 != nullptr) {
-        if constexpr (HALO == 1) {           // fused shortcut: 4-phase deconv launches only
-            if (a.nphase != 4 || a.so != 2 || a.si != 1 || a.wgt2 == nullptr) return hipErrorInvalidValue;
-            hipLaunchKernelGGL((conv_igemm_v2<WCO, WPX, 1, true>), dim3((unsigned)blocks), dim3(WCO * WPX * 64), lds, s, a);
-        } else {
-            return hipErrorInvalidValue;
-        }
-    } else {
-        hipLaunchKernelGGL((conv_igemm_v2<WCO, WPX, HALO, false>), dim3((unsigned)blocks), dim3(WCO * WPX * 64), lds, s, a);
-    }
+    if (a.in2 != nullptr) return hipErrorInvalidConfiguration;      // fused shortcut launches are conv_ds_fused's
+    hipLaunchKernelGGL((conv_igemm_v2<WCO, WPX, HALO>), dim3((unsigned)blocks), dim3(WCO * WPX * 64), lds, s, a);
     return hipGetLastError();
 }
 
@@ -1099,11 +1068,8 @@ static hipError_t launch_conv_v2_t(const ConvArgs& a, hipStream_t s) {
 hipError_t init_kernels_v2() {
     hipError_t e;
 #define X(WCO, WPX, HL)                                                                                     \
-    e = hipFuncSetAttribute((const void*)conv_igemm_v2<WCO, WPX, HL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+    e = hipFuncSetAttribute((const void*)conv_igemm_v2<WCO, WPX, HL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                             (int)conv_v2_lds_bytes_c(WCO, WPX, HL));                                        \
-    if (e != hipSuccess) return e;                                                                          \
-    if (HL == 1) e = hipFuncSetAttribute((const void*)conv_igemm_v2<WCO, WPX, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                         (int)conv_v2_lds_bytes_c(WCO, WPX, 1));                            \
     if (e != hipSuccess) return e;
     IDC_FOR_EACH_CONV_V2(X)
 #undef X

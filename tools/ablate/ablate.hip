@@ -68,7 +68,7 @@ int main(int argc, char** argv) {
     }
     idc::ConvConfig cfg{wm, wp};
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-#define LAUNCH() (v2 ? idc::launch_conv_v2(cfg, halo, a, 0) : idc::launch_conv(prec, cfg, halo, a, 0))
+#define LAUNCH() (v2 == 2 ? idc::launch_conv_ds(a, 0) : v2 ? idc::launch_conv_v2(cfg, halo, a, 0) : idc::launch_conv(prec, cfg, halo, a, 0))
 #ifdef IDC_TIMING
     int nb = a.tiles_x * a.tiles_y * N * (a.ncg / wm) * a.nphase;
     long long* dbg; CK(hipMalloc(&dbg, (size_t)nb * 128)); CK(hipMemset(dbg, 0, (size_t)nb * 128));
