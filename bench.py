@@ -14,7 +14,7 @@ With N ranks every rank runs its own 32 images (weak scaling, no data-path colle
 weights are packed on rank 0 and broadcast once over RCCL before the timed region.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      : the conv stack (kernel family conv_igemm<bf16>) against the dense bf16 MFMA peak,
+  roofline      : the conv stack (kernels conv_igemm_v2 / conv_ds_fused / conv_igemm / conv1_1_bf16) against the dense bf16 MFMA peak,
                   from per-layer HIP events recorded on the engine's stream inside the timed region;
   cpu_baseline  : the torch-CPU oracle (same ATen kernels as the reference's PyTorch backend)
                   timed on this box's host cores on a bounded sample (rank 0, N=1 only);
@@ -251,7 +251,7 @@ def main():
                    "weights_broadcast_ms": sc.weights_broadcast_ms},
         "roofline": {"bound": "mfma", "achieved": round(achieved_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved_tflops / peak, 4), "traffic": traffic.get("conv_family_bytes_per_forward"),
-                     "kernel": "conv_igemm family (conv_igemm_v2 / conv_igemm, %s): the %d conv/deconv launches of one "
+                     "kernel": "conv kernel family (conv_igemm_v2 / conv_ds_fused / conv_igemm / conv1_1, %s): the %d conv/deconv launches of one "
                                "forward taken together" % (args.precision, len(conv_rows)),
                      "launches_per_forward": len(conv_rows),
                      "algorithmic_flop_per_forward": conv_flops,

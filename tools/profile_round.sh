@@ -18,7 +18,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT
 cd $R
 for p in stats pmc_fetch pmc_write pmc_sq; do
   f=$(find $OUT/$p -name "*.db" | head -1)
-  [ -n "$f" ] && python tools/rocpd_summary.py $f > $OUT/${p}_summary.txt
+  [ -n "$f" ] && python tools/rocpd_summary.py $f --family conv > $OUT/${p}_summary.txt
   grep -h '"metric"' $OUT/$p.log | tail -1 > $OUT/${p}_benchline.json
 done
 python tools/pmc_traffic.py $(find $OUT/pmc_fetch -name "*.db" | head -1) $(find $OUT/pmc_write -name "*.db" | head -1) 12 $OUT/pmc_traffic.json
