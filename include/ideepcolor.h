@@ -60,6 +60,10 @@ int idc_version(void);
  * (conv_igemm_v2) wherever it applies.  Exists so that the parity tests can drive every kernel
  * variant at small sizes.  No reference counterpart. */
 int idc_set_tile_policy(int policy);
+/* Process-wide switches for the parity tests (speed only).  "fuse_conv1" (default 1): model1 = conv1_1 + conv1_2 as one
+ * launch on the bf16 throughput path -- 0 keeps the two launches apart, so that conv1_1's own output exists and can be
+ * read with idc_get_activation.  Takes effect on the next forward. */
+int idc_set_option(const char* name, int value);
 /* Split-K policy of the small-tile kernels (speed only): 0 automatic (launches too small to fill the chip: the
  * batch-1 click path), 1 never, 2 always (tests).  The slice sums are added in a fixed order: results stay
  * deterministic and independent of how many images a call carries. */

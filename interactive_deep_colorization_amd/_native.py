@@ -20,7 +20,7 @@ STATUS_NAMES = {0: "IDC_OK", -1: "IDC_ERR_INVALID_ARG", -2: "IDC_ERR_NO_DEVICE",
 
 # every symbol include/ideepcolor.h declares (tests check the .so exports all of them)
 EXPORTED_SYMBOLS = [
-    "idc_version", "idc_set_tile_policy", "idc_set_splitk_policy", "idc_device_count", "idc_last_error", "idc_create", "idc_destroy", "idc_set_io_scales",
+    "idc_version", "idc_set_tile_policy", "idc_set_option", "idc_set_splitk_policy", "idc_device_count", "idc_last_error", "idc_create", "idc_destroy", "idc_set_io_scales",
     "idc_weights_blob_bytes", "idc_pack_weights", "idc_set_weights_host", "idc_set_weights_device",
     "idc_load_weights", "idc_weights_device_ptr", "idc_forward", "idc_forward_device", "idc_forward_dist",
     "idc_lab2rgb", "idc_forward_rgb", "idc_global_histogram", "idc_forward_dist313", "idc_set_dist_temperature", "idc_set_global_hints", "idc_clear_global_hints", "idc_sync", "idc_stream", "idc_num_layers", "idc_layer_info_get", "idc_set_profiling",
@@ -77,6 +77,7 @@ def load():
 
     proto("idc_version", ci, [])
     proto("idc_set_tile_policy", ci, [ci])
+    proto("idc_set_option", ci, [ctypes.c_char_p, ci])
     proto("idc_set_splitk_policy", ci, [ci])
     proto("idc_device_count", ci, [])
     proto("idc_last_error", ctypes.c_char_p, [vp])

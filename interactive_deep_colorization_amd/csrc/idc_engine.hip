@@ -310,7 +310,8 @@ struct Layer {
     bool v2 = false;                     // bf16 large-tile kernel (layout-2 weights)
     bool fused_head = false;             // conv10_2 only: model_out + tanh run in this layer's epilogue
     int fused_short = -1;                // deconv layers: index of the shortcut conv layer riding in this launch's K loop
-    bool skip = false;                   // shortcut conv layer fused into its consumer: not launched
+    bool skip = false;                   // layer fused into another launch: not launched itself
+    int fused_next = -1;                 // conv1_1 only: index of conv1_2 when model1 runs as one launch (conv1_block_fused)
     ConvArgs args{};                     // zero-initialised; pointers patched per forward where they depend on weights
     double flops = 0, min_bytes = 0;
 };
@@ -374,6 +375,7 @@ static int find_tensor(idc_context* c, const char* name) {
 // Tile policy (speed only; every choice computes the same result): 0 = automatic, 1 = always the
 // small-tile kernels (conv_igemm), 2 = the large-tile bf16 kernel (conv_igemm_v2) wherever it applies.
 static int g_tile_policy = 0;
+static int g_fuse_conv1 = !(getenv("IDC_FUSE_CONV1") && atoi(getenv("IDC_FUSE_CONV1")) == 0);   // model1 (conv1_1 + conv1_2) as one launch on the bf16 throughput path (idc_set_option / env IDC_FUSE_CONV1=0 for A/B)
 // Split-K policy of the small-tile kernels (speed only): 0 = automatic (launches that would leave most CUs idle,
 // i.e. the batch-1 click path), 1 = never, 2 = always split as far as the cin chunks allow (tests).
 static int g_splitk_policy = 0;
@@ -582,7 +584,22 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
         const int Hs = L.spec->kind == kDeconv4x4 ? ti.H : to.H;
         const int Ws = L.spec->kind == kDeconv4x4 ? ti.W : to.W;
         set_geometry(L, c->precision, n, c->max_batch, Hs, Ws);
-        L.fused_short = -1; L.skip = false;
+        L.fused_short = -1; L.skip = false; L.fused_next = -1;
+    }
+    // model1 in one launch: conv1_1 (input pack fused) followed by conv1_2 on the small-tile bf16 path, >= 128 big tiles
+    for (size_t i = 0; i + 1 < c->layers.size(); ++i) {
+        Layer& L = c->layers[i];
+        if (L.spec->kind != kConvIm2col || c->precision != IDC_BF16 || !g_fuse_conv1 || L.spec->act != 1 || L.spec->bnkey) continue;
+        if ((long long)((c->W + 31) / 32) * ((c->H + 31) / 32) * c->max_batch < 128) continue;
+        for (size_t j = 0; j < c->layers.size(); ++j) {
+            Layer& P = c->layers[j];
+            const LayerSpec& ps = *P.spec;
+            if (P.src != L.dst || P.v2 || ps.kind != kConv3x3 || ps.cin != 64 || ps.cout != 64 || ps.dilation != 1 ||
+                ps.in_stride != 1 || ps.act != 1 || ps.resid || c->tensors[P.dst].is_f32 || P.args.ksplit > 1) continue;
+            bool only_consumer = true;
+            for (const Layer& Q : c->layers) if (&Q != &P && (Q.src == L.dst || Q.resid == L.dst)) only_consumer = false;
+            if (only_consumer) { L.fused_next = (int)j; P.skip = true; }
+        }
     }
     for (auto& L : c->layers) {
         if (L.spec->kind != kDeconv4x4 || L.resid < 0 || !L.v2 || !fuse_shortcut_enabled()) continue;
@@ -634,6 +651,15 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
         a.head_b = (const float*)(c->d_blob + c->plan.head_b_off);
         a.head_out = dout; a.head_mul = c->out_mul;
         head_done = head_done || L.fused_head;
+        if (L.fused_next >= 0) {             // conv1_2 rides in conv1_1's launch (launch_conv1_block's argument convention)
+            const Layer& P = c->layers[L.fused_next];
+            a.wgt2 = c->d_blob + P.blob.w_off;
+            a.head_b = (const float*)(c->d_blob + P.blob.bias_off);
+            a.bn_scale = P.blob.bn_scale_off != (size_t)-1 ? (const float*)(c->d_blob + P.blob.bn_scale_off) : nullptr;
+            a.bn_shift = P.blob.bn_shift_off != (size_t)-1 ? (const float*)(c->d_blob + P.blob.bn_shift_off) : nullptr;
+            a.out = c->tensors[P.dst].ptr;
+            a.head_w = nullptr;
+        }
         if (a.ksplit > 1) {
             const size_t need = (size_t)a.ksplit * n * to.H * to.W * to.Cpad * 4;
             if (c->partial_bytes < need) {
@@ -651,7 +677,8 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             // conv1_1 with >= 128 big tiles: the 32x32-tile form (the small-tile kernel keeps the batch-1 click path).
             // Chosen by the handle's max_batch like every other kernel variant, so a result never depends on how many
             // images share the call.
-            if (L.spec->kind == kConvIm2col && c->precision == IDC_BF16 && a.ksplit <= 1 &&
+            if (L.fused_next >= 0) le = launch_conv1_block(a, s);
+            else if (L.spec->kind == kConvIm2col && c->precision == IDC_BF16 && a.ksplit <= 1 &&
                 (long long)((a.Ws + 31) / 32) * ((a.Hs + 31) / 32) * c->max_batch >= 128)
                 le = launch_conv1_1_bf16(a, s);
             if (L.fused_short >= 0) le = launch_conv_ds(a, s);    // deconv + its shortcut conv in one K loop
@@ -762,6 +789,12 @@ int idc_set_tile_policy(int policy) {
     if (policy < 0 || policy > 2) return fail(nullptr, IDC_ERR_INVALID_ARG, "tile policy %d not in 0..2", policy);
     g_tile_policy = policy;
     return IDC_OK;
+}
+
+int idc_set_option(const char* name, int value) {
+    if (!name) return fail(nullptr, IDC_ERR_INVALID_ARG, "null option name");
+    if (strcmp(name, "fuse_conv1") == 0) { g_fuse_conv1 = value != 0; return IDC_OK; }
+    return fail(nullptr, IDC_ERR_INVALID_ARG, "unknown option '%s'", name);
 }
 
 int idc_device_count(void) {
@@ -1231,7 +1264,7 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
         snprintf(out->name, sizeof(out->name), "%s", L.spec->name);
         if (L.skip) {                        // its MACs and bytes are accounted to the launch that runs them
             for (const Layer& C : h->layers)
-                if (C.fused_short == layer - 1) snprintf(out->kernel, sizeof(out->kernel), "fused into %s", C.spec->name);
+                if (C.fused_short == layer - 1 || C.fused_next == layer - 1) snprintf(out->kernel, sizeof(out->kernel), "fused into %s", C.spec->name);
             out->flops = 0; out->min_bytes = 0; out->launches = 0;
         } else {
             snprintf(out->kernel, sizeof(out->kernel), L.v2 ? "conv_igemm_v2<%d,%d>" : (h->precision == IDC_BF16 ? "conv_igemm<bf16,%d,%d>" : "conv_igemm<f32,%d,%d>"),
@@ -1242,6 +1275,12 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
                 strncat(out->kernel, sk, sizeof(out->kernel) - strlen(out->kernel) - 1);
             }
             out->flops = L.flops; out->min_bytes = L.min_bytes; out->launches = 1;
+            if (L.fused_next >= 0) {
+                const Layer& P = h->layers[L.fused_next];
+                snprintf(out->kernel, sizeof(out->kernel), "conv1_block_fused");
+                out->flops += P.flops;
+                out->min_bytes += P.min_bytes - 2.0 * (double)h->tensors[L.dst].H * h->tensors[L.dst].W * h->tensors[L.dst].Cpad * eb;
+            }
             if (L.fused_short >= 0) {
                 const Layer& P = h->layers[L.fused_short];
                 strncat(out->kernel, "+shortcut", sizeof(out->kernel) - strlen(out->kernel) - 1);

@@ -76,6 +76,9 @@ hipError_t launch_conv_v2(ConvConfig cfg, int halo, const ConvArgs& a, hipStream
 // shortcut's input, layout-2 weights and channel chunks, a.bias = the two biases added.  hipErrorInvalidConfiguration if
 // the launch does not qualify.
 hipError_t launch_conv_ds(const ConvArgs& a, hipStream_t s);
+// model1 = conv1_1 + conv1_2 of a 32x32 tile in one workgroup (conv1_block_fused): `a` = conv1_1's arguments with conv1_2's
+// riding in (wgt2 = its layout-1 weights, head_b = its bias, bn_scale/bn_shift, out = its output)
+hipError_t launch_conv1_block(const ConvArgs& a, hipStream_t s);
 // conv1_1 (4 -> 64, input pack fused) as one 32x32 tile per workgroup, bf16; hipErrorInvalidConfiguration if the
 // launch does not qualify (the caller then uses launch_conv)
 hipError_t launch_conv1_1_bf16(const ConvArgs& a, hipStream_t s);

@@ -1490,6 +1490,237 @@ hipError_t launch_conv1_1_bf16(const ConvArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv1_block_fused: model1 = conv1_1 (4 -> 64, ReLU) -> conv1_2 (64 -> 64, ReLU, eval-BN) of one 32x32 tile in one
+// workgroup (model.py:13-17): conv1_1's 268 MB output never exists in HBM.
+//   phase 0: the 36x36 input patch, normalised (model.py:139-148) and rounded to bf16, 8 B per pixel, into LDS;
+//   phase 1: conv1_1 on the 34x34 halo sites conv1_2 needs: a wave takes 32 consecutive halo sites per MFMA column
+//            block, builds its B fragments from the patch (K = tap*4 + channel), and writes ReLU(.) as bf16 straight
+//            into the halo tile in the layout conv_igemm_v2 reads (128-B rows, slot ^ swz2(row)); sites outside the
+//            image are conv1_2's zero padding and are written as zeros;
+//   phase 2: conv1_2 = 9 taps x 4 k16 steps x 8 MFMAs per wave over the static halo tile, A fragments straight from
+//            the packed weights (global -> registers, one tap ahead): no weights in LDS, no barrier in the K loop;
+//   phase 3: ReLU + eval-BN in the MFMA layout, bf16 LDS transpose, whole-line stores.
+// LDS: 34*34*128 B halo + 36*36*8 B patch = 154.6 KiB, one workgroup (8 waves) per CU.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void conv1_block_fused(const ConvArgs a) {
+    constexpr int HW_ = 34, PW = 36, NSITE = HW_ * HW_;
+    constexpr int HALO_BYTES = NSITE * kRowBytes;              // 147,968
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const halo = smem;
+    uint2* const patch = (uint2*)(smem + HALO_BYTES);          // [36][36] x 4 bf16
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 31, h = lane >> 5;
+    const int Hs = a.Hs, Ws = a.Ws;
+    const int ntx = (Ws + 31) >> 5, nty = (Hs + 31) >> 5;
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int txi = b % ntx; b /= ntx;
+    const int tyi = b % nty;
+    const int n = b / nty;
+    const int ty0 = tyi * 32, tx0 = txi * 32;
+    // ---- phase 0 -------------------------------------------------------------------------------
+    {
+        const size_t hw = (size_t)Hs * Ws;
+        const float* const pL = a.pk_L + (size_t)n * hw;
+        const float* const pA = a.pk_ab + (size_t)n * 2 * hw;
+        const float* const pM = a.pk_mask + (size_t)n * hw;
+        for (int idx = tid; idx < PW * PW; idx += 512) {
+            const int py = idx / PW, pxx = idx - py * PW;
+            const int yy = ty0 - 2 + py, xx = tx0 - 2 + pxx;
+            uint2 c = uint2{0u, 0u};
+            if ((unsigned)yy < (unsigned)Hs && (unsigned)xx < (unsigned)Ws) {
+                const size_t p = (size_t)yy * Ws + xx;
+                c = uint2{pack_bf16x2(pL[p] / a.pk_ldiv, pA[p] / a.pk_abdiv),
+                          pack_bf16x2(pA[hw + p] / a.pk_abdiv, pM[p] * a.pk_mmul - a.pk_mcent)};
+            }
+            patch[idx] = c;
+        }
+    }
+    // A-fragment row of this lane: MFMA row rho = px of block mi is cout hh*32 + mi*16 + r (see conv1_1_bf16_kernel)
+    int lam[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int c = ((px >> 2) & 1) * 32 + mi * 16 + (px >> 3) * 4 + (px & 3);
+        lam[mi] = ((c >> 2) & 3) * 16 + (c >> 4) * 4 + (c & 3);
+    }
+    // ---- phase 1 -------------------------------------------------------------------------------
+    {
+        u32x4 wf[3][2];
+        f32x16 b1[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk)
+                wf[kk][mi] = *(const u32x4*)((const char*)a.wgt + lam[mi] * kRowBytes + (((kk * 2 + h) ^ swz(lam[mi])) * kSlotBytes));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bq = *(const float4*)(a.bias + h * 32 + mi * 16 + q * 4);
+                b1[mi][q * 4 + 0] = bq.x; b1[mi][q * 4 + 1] = bq.y; b1[mi][q * 4 + 2] = bq.z; b1[mi][q * 4 + 3] = bq.w;
+            }
+        }
+        __syncthreads();                                       // patch complete
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        for (int g = wave; g * 32 < NSITE; g += 8) {
+            const int sidx = g * 32 + px;                      // halo site = halo row of the tile
+            const int hy = sidx / HW_, hx = sidx - hy * HW_;
+            const bool live = sidx < NSITE;
+            const int yy = ty0 - 1 + hy, xx = tx0 - 1 + hx;
+            const bool inimg = live && (unsigned)yy < (unsigned)Hs && (unsigned)xx < (unsigned)Ws;
+            const int pbase = live ? hy * PW + hx : 0;         // patch index of tap (0,0)
+            f32x16 c1[2] = {b1[0], b1[1]};
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                const int t0a = 4 * kk, t0b = 4 * kk + 2;
+                const int o0 = h ? (t0b / 3) * PW + t0b % 3 : (t0a / 3) * PW + t0a % 3;
+                const int o1 = h ? ((t0b + 1) / 3) * PW + (t0b + 1) % 3 : ((t0a + 1) / 3) * PW + (t0a + 1) % 3;
+                const bool z0 = h ? t0b >= 9 : t0a >= 9, z1 = h ? t0b + 1 >= 9 : t0a + 1 >= 9;
+                const uint2 q0 = z0 ? uint2{0u, 0u} : patch[pbase + o0];
+                const uint2 q1 = z1 ? uint2{0u, 0u} : patch[pbase + o1];
+                const u32x4 xf = u32x4{q0.x, q0.y, q1.x, q1.y};
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    c1[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[kk][mi]),
+                                                                     __builtin_bit_cast(bf16x8, xf), c1[mi], 0, 0, 0);
+            }
+            if (live) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    unsigned pk[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        pk[e] = pack_bf16x2(c1[mi][2 * e], c1[mi][2 * e + 1]);
+                        if (a.act == 1)
+                            pk[e] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk[e]), s16x2{0, 0}));
+                        if (!inimg) pk[e] = 0u;
+                    }
+                    const int s0 = h * 4 + mi * 2;
+                    *(uint4*)(halo + sidx * kRowBytes + ((s0 ^ swz2(sidx)) * kSlotBytes)) = uint4{pk[0], pk[1], pk[2], pk[3]};
+                    *(uint4*)(halo + sidx * kRowBytes + (((s0 + 1) ^ swz2(sidx)) * kSlotBytes)) = uint4{pk[4], pk[5], pk[6], pk[7]};
+                }
+            }
+        }
+    }
+    // ---- phase 2 -------------------------------------------------------------------------------
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        f32x16 b16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 bq = *(const float4*)(a.head_b + h * 32 + mi * 16 + q * 4);      // conv1_2's bias rides in head_b
+            b16[q * 4 + 0] = bq.x; b16[q * 4 + 1] = bq.y; b16[q * 4 + 2] = bq.z; b16[q * 4 + 3] = bq.w;
+        }
+#pragma unroll
+        for (int pj = 0; pj < 4; ++pj) acc[mi][pj] = b16;
+    }
+    u32x4 wcur[4][2], wnxt[4][2];
+    auto load_w = [&](int t, u32x4 (&w)[4][2]) {
+        const char* const base = (const char*)a.wgt2 + (size_t)t * kWBlockBytes;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+                w[kk][mi] = *(const u32x4*)(base + lam[mi] * kRowBytes + (((kk * 2 + h) ^ swz(lam[mi])) * kSlotBytes));
+    };
+    load_w(0, wcur);
+    __syncthreads();                                           // conv1_1 tile complete
+#pragma unroll 1
+    for (int t = 0; t < 9; ++t) {
+        if (t + 1 < 9) load_w(t + 1, wnxt);
+        const int dy = t / 3 - 1, dx = t - (t / 3) * 3 - 1;
+        int xaddr[4];
+#pragma unroll
+        for (int pj = 0; pj < 4; ++pj) {
+            const int xr = (wave * 4 + pj + 1 + dy) * HW_ + (px + 1 + dx);
+            xaddr[pj] = xr * kRowBytes + ((h ^ swz2(xr)) * kSlotBytes);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            u32x4 xf[4];
+#pragma unroll
+            for (int pj = 0; pj < 4; ++pj) xf[pj] = *(const u32x4*)(halo + (xaddr[pj] ^ (kk * 2 * kSlotBytes)));
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int pj = 0; pj < 4; ++pj)
+                    acc[mi][pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wcur[kk][mi]),
+                                                                          __builtin_bit_cast(bf16x8, xf[pj]), acc[mi][pj], 0, 0, 0);
+        }
+        if (t + 1 < 9) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) wcur[kk][mi] = wnxt[kk][mi];
+        }
+    }
+    // ---- phase 3 -------------------------------------------------------------------------------
+    __syncthreads();                                           // every wave left the halo tile
+    char* const tb16 = smem + wave * 4096;
+    const int rr = lane >> 3, cc = lane & 7;
+    const int CoutPad = a.ncg * kCoutGroup;
+    const bool has_bn = a.bn_scale != nullptr;
+    f32x16 bsc[2], bsh[2];
+    if (has_bn) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 s4 = *(const float4*)(a.bn_scale + h * 32 + mi * 16 + q * 4);
+                const float4 t4 = *(const float4*)(a.bn_shift + h * 32 + mi * 16 + q * 4);
+                bsc[mi][q * 4 + 0] = s4.x; bsc[mi][q * 4 + 1] = s4.y; bsc[mi][q * 4 + 2] = s4.z; bsc[mi][q * 4 + 3] = s4.w;
+                bsh[mi][q * 4 + 0] = t4.x; bsh[mi][q * 4 + 1] = t4.y; bsh[mi][q * 4 + 2] = t4.z; bsh[mi][q * 4 + 3] = t4.w;
+            }
+    }
+#pragma unroll
+    for (int pj = 0; pj < 4; ++pj) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            unsigned pk[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v0 = fmaxf(acc[mi][pj][2 * e], 0.f), v1 = fmaxf(acc[mi][pj][2 * e + 1], 0.f);
+                if (has_bn) { v0 = fmaf(v0, bsc[mi][2 * e], bsh[mi][2 * e]); v1 = fmaf(v1, bsc[mi][2 * e + 1], bsh[mi][2 * e + 1]); }
+                pk[e] = pack_bf16x2(v0, v1);
+            }
+            const int s0 = h * 4 + mi * 2;
+            *(uint4*)(tb16 + px * 128 + ((s0 ^ (px & 7)) * 16)) = uint4{pk[0], pk[1], pk[2], pk[3]};
+            *(uint4*)(tb16 + px * 128 + (((s0 + 1) ^ (px & 7)) * 16)) = uint4{pk[4], pk[5], pk[6], pk[7]};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int sy = ty0 + wave * 4 + pj;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = i * 8 + rr;
+            const uint4 o = *(const uint4*)(tb16 + row * 128 + ((cc ^ (row & 7)) * 16));
+            const int sx = tx0 + row;
+            if (sy < Hs && sx < Ws)
+                *(uint4*)((unsigned short*)a.out + (((size_t)n * Hs + sy) * Ws + sx) * CoutPad + cc * 8) = o;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+// model1 (conv1_1 + conv1_2) in one launch.  `a` = conv1_1's arguments (fused-pack planes, layout-1 weights, bias, act)
+// with conv1_2's riding in: wgt2 = its layout-1 weights (9 taps x 8 KiB), head_b = its bias, bn_scale/bn_shift = its
+// eval-BN affine, out = its output.  conv1_2 is ReLU + (optional) BN, 64 -> 64.
+hipError_t launch_conv1_block(const ConvArgs& a, hipStream_t s) {
+    if (a.pk_L == nullptr || a.wgt2 == nullptr || a.head_b == nullptr || a.ncg != 1 || a.out_f32 || a.resid != nullptr)
+        return hipErrorInvalidConfiguration;
+    const long long blocks = (long long)((a.Ws + 31) / 32) * ((a.Hs + 31) / 32) * a.N;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    constexpr int lds = 34 * 34 * 128 + 36 * 36 * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv1_block_fused, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv1_block_fused, dim3((unsigned)blocks), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // head: model_out = Conv1x1(128->2) -> Tanh, then *110 (model.py:108-109,174-175).
 // 16 lanes per pixel, 8 channels each, xor-shuffle reduction inside the 16-lane group.
 // ------------------------------------------------------------------------------------------------

@@ -76,6 +76,11 @@ def _flags(dist=False, global_hints=False, dist313=False):
 SPLITK_POLICIES = {"auto": 0, "never": 1, "always": 2}
 
 
+def set_option(name, value):
+    """Process-wide test switch (``idc_set_option``): 'fuse_conv1' 0/1."""
+    N.check(N.load().idc_set_option(name.encode(), int(value)))
+
+
 def set_splitk_policy(policy="auto"):
     """Process-wide split-K policy of the small-tile kernels (speed only): "auto", "never" or "always"."""
     N.check(N.load().idc_set_splitk_policy(SPLITK_POLICIES[policy] if isinstance(policy, str) else int(policy)))

@@ -64,6 +64,12 @@ def test_fp32_matches_reference_golden_layer_by_layer(golden, make_sd, name):
 
 
 @pytest.fixture(autouse=True)
+def _reset_options():
+    yield
+    engine.set_option("fuse_conv1", 1)
+
+
+@pytest.fixture(autouse=True)
 def _reset_tile_policy():
     yield
     engine.set_tile_policy("auto")
@@ -301,10 +307,12 @@ def test_conv1_1_throughput_kernel(make_sd):
     H, W, N = 72, 104, 12
     L, ab, m = workloads.random_batch(N, H, W, seed=17, max_points=6, max_p=3)
     sd = make_sd(4, "he")
+    engine.set_option("fuse_conv1", 0)                         # conv1_1 as its own launch, so that its output exists
     e = engine.HipColorizer(H, W, max_batch=N, precision="bf16")
     e.load_state_dict(sd)
     e.forward(L, ab, m, 0.5)
     big = e.activation("conv1_1", N)
+    c12_two = e.activation("conv1_2", N)
     x = np.concatenate([L / 100.0, ab / 110.0, m - 0.5], axis=1).astype(np.float64)
     ref = torch.relu(torch.nn.functional.conv2d(torch.from_numpy(x), torch.from_numpy(sd["model1.0.weight"].astype(np.float64)),
                                                 torch.from_numpy(sd["model1.0.bias"].astype(np.float64)), padding=1)).numpy()
@@ -320,3 +328,16 @@ def test_conv1_1_throughput_kernel(make_sd):
     assert np.abs(small[0] - big[5]).max() <= tol
     assert (small[0] == big[5]).mean() > 0.98                   # same operands, same fp32 sums up to their order
     e1.close()
+    # model1 as one launch (conv1_block_fused): same operands and the same fp32 sums up to their order, so conv1_2
+    # agrees with the two-launch result to one bf16 ulp and is identical almost everywhere
+    engine.set_option("fuse_conv1", 1)
+    e2 = engine.HipColorizer(H, W, max_batch=N, precision="bf16")
+    e2.load_state_dict(sd)
+    out2 = e2.forward(L, ab, m, 0.5)
+    c12 = e2.activation("conv1_2", N)
+    assert "conv1_block_fused" in [r["kernel"] for r in e2.layer_table()]
+    tol2 = 2.0 ** -7 * max(1.0, np.abs(c12_two).max())
+    assert np.abs(c12 - c12_two).max() <= tol2, (np.abs(c12 - c12_two).max(), tol2)
+    assert (c12 == c12_two).mean() > 0.97
+    assert np.isfinite(out2).all()
+    e2.close()
