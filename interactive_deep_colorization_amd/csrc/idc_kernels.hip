@@ -1635,18 +1635,41 @@ __global__ __launch_bounds__(512, 2) void conv1_block_fused(const ConvArgs a) {
             const int xr = (wave * 4 + pj + 1 + dy) * HW_ + (px + 1 + dx);
             xaddr[pj] = xr * kRowBytes + ((h ^ swz2(xr)) * kSlotBytes);
         }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            u32x4 xf[4];
+        // 2-stage software pipeline over the four k16 steps, issue order pinned as in conv_igemm_v2 (only B comes from LDS)
+        u32x4 xfA[4], xfB[4];
+        auto read_x = [&](int kk, u32x4 (&xf)[4]) {
 #pragma unroll
             for (int pj = 0; pj < 4; ++pj) xf[pj] = *(const u32x4*)(halo + (xaddr[pj] ^ (kk * 2 * kSlotBytes)));
+        };
+        auto mma8 = [&](int kk, const u32x4 (&xf)[4]) {
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int pj = 0; pj < 4; ++pj)
                     acc[mi][pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wcur[kk][mi]),
                                                                           __builtin_bit_cast(bf16x8, xf[pj]), acc[mi][pj], 0, 0, 0);
-        }
+        };
+#define IDC_C1_INTERLEAVE()                                                           \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
+    }                                                                                 \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_x(0, xfA);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        read_x(1, xfB);
+        mma8(0, xfA);
+        IDC_C1_INTERLEAVE()
+        read_x(2, xfA);
+        mma8(1, xfB);
+        IDC_C1_INTERLEAVE()
+        read_x(3, xfB);
+        mma8(2, xfA);
+        IDC_C1_INTERLEAVE()
+        mma8(3, xfB);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+#undef IDC_C1_INTERLEAVE
         if (t + 1 < 9) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
