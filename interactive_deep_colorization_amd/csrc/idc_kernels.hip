@@ -1065,6 +1065,9 @@ static hipError_t launch_conv_v2_t(const ConvArgs& a, hipStream_t s) {
 
 #define IDC_FOR_EACH_CONV_V2(X) X(4, 2, 0) X(4, 2, 1) X(4, 2, 2) X(2, 4, 0) X(2, 4, 1) X(2, 4, 2)
 
+__global__ void conv_ds_fused(const ConvArgs a);
+__global__ void conv1_block_fused(const ConvArgs a);
+
 hipError_t init_kernels_v2() {
     hipError_t e;
 #define X(WCO, WPX, HL)                                                                                     \
@@ -1073,7 +1076,10 @@ hipError_t init_kernels_v2() {
     if (e != hipSuccess) return e;
     IDC_FOR_EACH_CONV_V2(X)
 #undef X
-    return hipSuccess;
+    // the two fused kernels use more than the default 64 KiB of dynamic LDS (set per device: this runs for every handle)
+    e = hipFuncSetAttribute((const void*)conv_ds_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)conv1_block_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 34 * 34 * 128 + 36 * 36 * 8);
 }
 
 // v2 tile = 32 sites wide, 4*wpx rows; cfg.wm = WCO (x64 couts), cfg.wp = WPX.
@@ -1351,12 +1357,6 @@ hipError_t launch_conv_ds(const ConvArgs& a, hipStream_t s) {
         return hipErrorInvalidConfiguration;
     const long long blocks = (long long)((a.Ws + 31) / 32) * ((a.Hs + 3) / 4) * a.N * (a.ncg / 2);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_ds_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
     hipLaunchKernelGGL(conv_ds_fused, dim3((unsigned)blocks), dim3(512), 160 * 1024, s, a);
     return hipGetLastError();
 }
@@ -1733,12 +1733,6 @@ hipError_t launch_conv1_block(const ConvArgs& a, hipStream_t s) {
     const long long blocks = (long long)((a.Ws + 31) / 32) * ((a.Hs + 31) / 32) * a.N;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     constexpr int lds = 34 * 34 * 128 + 36 * 36 * 8;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv1_block_fused, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
     hipLaunchKernelGGL(conv1_block_fused, dim3((unsigned)blocks), dim3(512), lds, s, a);
     return hipGetLastError();
 }
