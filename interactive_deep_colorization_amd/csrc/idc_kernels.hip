@@ -14,6 +14,8 @@
 //     fp32 = an fmaf chain) on the same 16-byte fragments;
 //   * fused epilogue: +bias, +fp32 shortcut sum, ReLU/LeakyReLU, eval-BN affine AFTER the
 //     activation (model.py:13-17 order), 32/64-byte stores of 16 consecutive channels per lane.
+#include <type_traits>
+
 #include "idc_kernels.h"
 
 #include "idc_layout.h"
@@ -703,7 +705,11 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
             for (int j = 0; j < N_HITEMS; ++j) *(u32x4*)(halo + (tid + j * NT) * kSlotBytes) = hreg[j];
             if (first) IDC_STAMP_FINE(7);
             const bool last_kc = kc + 1 == cur.nkc;
-            for (int t = 0; t < cur.ntaps; ++t) {
+            // the tap body exists twice: taps 0 .. ntaps-2 only stream the next weight tile; the chunk's last tap also
+            // fetches the next chunk's halo rows.  (As one loop with a branch, hipcc merges the 24-40 halo registers of the
+            // two paths with v_mov_b64 copies on EVERY tap.)
+            auto tap_body = [&](int t, auto last_tag) {
+                constexpr bool LAST = decltype(last_tag)::value;
                 const char* const wcur = wbuf + buf * W_BYTES;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // my pieces of this tap's weight tile landed
                 __syncthreads();               // everybody's landed; everybody left the other buffer
@@ -713,7 +719,7 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
                 // issue the NEXT step's loads: its weight tile (LDS-DMA into the other buffer) and, when
                 // it opens a new chunk / stage, that chunk's halo rows (to registers, written after the
                 // chunk-end barrier) -- they land under this tap's 32 MFMAs per wave
-                if (t + 1 < cur.ntaps) {
+                if constexpr (!LAST) {
                     int dy2, dx2, tw2;
                     tap_of(q, t + 1, dy2, dx2, tw2);
                     dma_w(cur, tw2, kc, buf ^ 1);
@@ -722,12 +728,6 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
                     tap_of(q, 0, dy2, dx2, tw2);
                     dma_w(cur, tw2, kc + 1, buf ^ 1);
                     load_halo(cur, kc + 1);
-                } else if (q + 1 < nstage) {
-                    const Stage nxt = make_stage(q + 1);
-                    int dy2, dx2, tw2;
-                    tap_of(q + 1, 0, dy2, dx2, tw2);
-                    dma_w(nxt, tw2, 0, buf ^ 1);
-                    load_halo(nxt, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 int xaddr[4];
@@ -779,7 +779,9 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
                 __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
 #undef IDC_STAGE_INTERLEAVE
                 buf ^= 1;
-            }
+            };
+            for (int t = 0; t + 1 < cur.ntaps; ++t) tap_body(t, std::false_type{});
+            tap_body(cur.ntaps - 1, std::true_type{});
         }
         IDC_STAMP(8 + q);
         if (q + 1 < nstage) cur = make_stage(q + 1);
