@@ -698,6 +698,21 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
     const int wslot0 = (h ^ swz2(px)) * kSlotBytes;
     int buf = 0;
     bool first = true;
+    // LDS byte address of the lane's B-operand row for each of the wave's 4 pixel rows, for the tap about to run.  It is
+    // computed under the previous tap's last MFMAs, so that a tap starts with its fragment reads, not with ~35 VALU.
+    int xa[4];
+    auto set_xa = [&](int dy, int dx) {
+#pragma unroll
+        for (int pj = 0; pj < 4; ++pj) {
+            const int xr = (wpx * 4 + pj + HALO + dy) * HWP + (px + HALO + dx);
+            xa[pj] = xr * kRowBytes + ((h ^ swz2(xr)) * kSlotBytes);              // slot = kk*2 + h: kk*2 flips bits 1,2 only
+        }
+    };
+    set_xa(tap_dy[0], tap_dx[0]);
+    // weight-tile index the NEXT tap will request right after its barrier (tap t+1 requests tap t+2's tile, the chunk's
+    // last tap the first tile of the next chunk): read from the tap table one tap early, so that no scalar load sits
+    // between the barrier and the first fragment reads
+    int tw_dma = a.ntaps > 1 ? tap_tw[1] : tap_tw[0];
     for (int q = 0; q < nstage; ++q) {
         for (int kc = 0; kc < cur.nkc; ++kc) {
             __syncthreads();                   // previous chunk's halo reads are done
@@ -714,28 +729,7 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // my pieces of this tap's weight tile landed
                 __syncthreads();               // everybody's landed; everybody left the other buffer
                 if (first) { IDC_STAMP(1); first = false; }
-                int dy, dx, tw;
-                tap_of(q, t, dy, dx, tw);
-                // issue the NEXT step's loads: its weight tile (LDS-DMA into the other buffer) and, when
-                // it opens a new chunk / stage, that chunk's halo rows (to registers, written after the
-                // chunk-end barrier) -- they land under this tap's 32 MFMAs per wave
-                if constexpr (!LAST) {
-                    int dy2, dx2, tw2;
-                    tap_of(q, t + 1, dy2, dx2, tw2);
-                    dma_w(cur, tw2, kc, buf ^ 1);
-                } else if (!last_kc) {
-                    int dy2, dx2, tw2;
-                    tap_of(q, 0, dy2, dx2, tw2);
-                    dma_w(cur, tw2, kc + 1, buf ^ 1);
-                    load_halo(cur, kc + 1);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                int xaddr[4];
-#pragma unroll
-                for (int pj = 0; pj < 4; ++pj) {
-                    const int xr = (wpx * 4 + pj + HALO + dy) * HWP + (px + HALO + dx);
-                    xaddr[pj] = xr * kRowBytes + ((h ^ swz2(xr)) * kSlotBytes);      // slot = kk*2 + h: kk*2 flips bits 1,2 only
-                }
+                const int xaddr[4] = {xa[0], xa[1], xa[2], xa[3]};
                 // explicit 2-stage software pipeline over the four k16 steps of the chunk: fragments of
                 // step kk+1 are in flight while the 8 MFMAs of step kk issue
                 u32x4 wfA[2], xfA[4], wfB[2], xfB[4];
@@ -765,7 +759,17 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
     }                                                                                 \
     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 read_frags(0, wfA, xfA);
-                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // the NEXT step's loads, behind this tap's first fragment reads: its weight tile (LDS-DMA into the other
+                // buffer) and, when it opens a new chunk, that chunk's halo rows (to registers, written after the
+                // chunk-end barrier) -- they land under this tap's 32 MFMAs per wave
+                if constexpr (!LAST) {
+                    dma_w(cur, tw_dma, kc, buf ^ 1);
+                } else if (!last_kc) {
+                    dma_w(cur, tw_dma, kc + 1, buf ^ 1);
+                    load_halo(cur, kc + 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 read_frags(1, wfB, xfB);
                 mma8(wfA, xfA);
                 IDC_STAGE_INTERLEAVE()
@@ -775,6 +779,11 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
                 read_frags(3, wfB, xfB);
                 mma8(wfA, xfA);
                 IDC_STAGE_INTERLEAVE()
+                {
+                    const int tn = LAST ? 0 : t + 1;            // the tap that runs next
+                    set_xa(tap_dy[tn], tap_dx[tn]);
+                    tw_dma = tn + 1 < cur.ntaps ? tap_tw[tn + 1] : tap_tw[0];    // what tap tn requests: tap tn+1's tile, or the next chunk's first
+                }
                 mma8(wfB, xfB);
                 __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
 #undef IDC_STAGE_INTERLEAVE
