@@ -1335,6 +1335,15 @@ int idc_get_activation(idc_handle h, const char* name, int n, float* out, size_t
     if (ti < 0) return fail(&h->err, IDC_ERR_INVALID_ARG, "no activation named '%s'", name);
     const Tensor& t = h->tensors[ti];
     if (n <= 0 || n > h->max_batch) return fail(&h->err, IDC_ERR_BATCH, "bad n");
+    for (size_t li = 0; li < h->layers.size(); ++li) {      // a tensor the last forward never wrote: say so, do not return stale data
+        const Layer& L = h->layers[li];
+        if (L.dst != ti) continue;
+        bool fused_away = L.fused_next >= 0;                 // conv1_1 inside conv1_block_fused
+        for (const Layer& C : h->layers) fused_away = fused_away || C.fused_short == (int)li;   // shortcut conv inside conv_ds_fused
+        if (fused_away)
+            return fail(&h->err, IDC_ERR_UNSUPPORTED, "activation '%s' is not materialised: its layer runs fused inside another "
+                        "launch (idc_set_option(\"fuse_conv1\", 0) / IDC_FUSE_SHORTCUT=0 keep the launches apart)", name);
+    }
     const size_t need = (size_t)n * t.C * t.H * t.W;
     if (capacity_floats < need) return fail(&h->err, IDC_ERR_INVALID_ARG, "need %zu floats", need);
     HIPCHK(h, hipSetDevice(h->device));

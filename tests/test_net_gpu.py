@@ -336,6 +336,8 @@ def test_conv1_1_throughput_kernel(make_sd):
     out2 = e2.forward(L, ab, m, 0.5)
     c12 = e2.activation("conv1_2", N)
     assert "conv1_block_fused" in [r["kernel"] for r in e2.layer_table()]
+    with pytest.raises(Exception):                             # conv1_1 itself is never written now: refused, not stale
+        e2.activation("conv1_1", N)
     tol2 = 2.0 ** -7 * max(1.0, np.abs(c12_two).max())
     assert np.abs(c12 - c12_two).max() <= tol2, (np.abs(c12 - c12_two).max(), tol2)
     assert (c12 == c12_two).mean() > 0.97
