@@ -30,4 +30,9 @@ Pinning status
   reference ships no weights or outputs for them; they follow the published
   formulas / the prototxt line by line (fixtures:
   ``oracle/make_golden_caffe_branches.py``).
+* ``session`` (hint rasterisation = ``UIControl.get_input`` + ``rgb2lab``; colour suggestions =
+  ``get_ab_reccs``): the rasteriser is PARITY UNPINNED (cv2 absent; ``cv2.rectangle`` semantics restated) and checked
+  against the notebook's ``put_point`` run here; the suggestion step of the reference is stochastic (numpy global RNG +
+  sklearn's randomly seeded KMeans), so ``session.get_ab_reccs_reference`` restates it AS WRITTEN and
+  ``tests/test_session_cpu.py`` checks the deterministic form the device implements against it statistically.
 """
