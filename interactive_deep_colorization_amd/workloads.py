@@ -88,3 +88,99 @@ def shard_bounds(n_items, world_size, rank):
     base, rem = divmod(int(n_items), int(world_size))
     start = rank * base + min(rank, rem)
     return start, start + base + (1 if rank < rem else 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Seeded random-init weights of the reference architecture (the reference ships no trained weights:
+# ``models/fetch_models.sh:2-6`` needs the network).  ``numpy.random.RandomState`` only, so a seed gives the same bytes
+# on any box and any torch version.  Key names / layouts are exactly the reference ``state_dict`` (SURVEY.md Appendix B;
+# ``models/pytorch/model.py:13-109``): Conv2d.weight (Cout, Cin, kh, kw); ConvTranspose2d.weight (Cin, Cout, 4, 4);
+# BatchNorm2d weight, bias, running_mean, running_var, num_batches_tracked -- randomised too (the default init makes
+# eval-BN an identity and would hide epilogue bugs).  bench.py's synthetic weights and the parity tests' weights
+# (``oracle.weights.make_state_dict`` is this function) come from here.
+# ---------------------------------------------------------------------------------------------------------------
+# (key prefix, kind, Cin, Cout, k)   kind: 'conv' | 'deconv' | 'bn'
+LAYER_SPECS = [
+    ("model1.0", "conv", 4, 64, 3), ("model1.2", "conv", 64, 64, 3), ("model1.4", "bn", 64, 64, 0),
+    ("model2.0", "conv", 64, 128, 3), ("model2.2", "conv", 128, 128, 3), ("model2.4", "bn", 128, 128, 0),
+    ("model3.0", "conv", 128, 256, 3), ("model3.2", "conv", 256, 256, 3), ("model3.4", "conv", 256, 256, 3),
+    ("model3.6", "bn", 256, 256, 0),
+    ("model4.0", "conv", 256, 512, 3), ("model4.2", "conv", 512, 512, 3), ("model4.4", "conv", 512, 512, 3),
+    ("model4.6", "bn", 512, 512, 0),
+    ("model5.0", "conv", 512, 512, 3), ("model5.2", "conv", 512, 512, 3), ("model5.4", "conv", 512, 512, 3),
+    ("model5.6", "bn", 512, 512, 0),
+    ("model6.0", "conv", 512, 512, 3), ("model6.2", "conv", 512, 512, 3), ("model6.4", "conv", 512, 512, 3),
+    ("model6.6", "bn", 512, 512, 0),
+    ("model7.0", "conv", 512, 512, 3), ("model7.2", "conv", 512, 512, 3), ("model7.4", "conv", 512, 512, 3),
+    ("model7.6", "bn", 512, 512, 0),
+    ("model8up.0", "deconv", 512, 256, 4), ("model3short8.0", "conv", 256, 256, 3),
+    ("model8.1", "conv", 256, 256, 3), ("model8.3", "conv", 256, 256, 3), ("model8.5", "bn", 256, 256, 0),
+    ("model9up.0", "deconv", 256, 128, 4), ("model2short9.0", "conv", 128, 128, 3),
+    ("model9.1", "conv", 128, 128, 3), ("model9.3", "bn", 128, 128, 0),
+    ("model10up.0", "deconv", 128, 128, 4), ("model1short10.0", "conv", 64, 128, 3),
+    ("model10.1", "conv", 128, 128, 3),
+    ("model_class.0", "conv", 256, 529, 1),
+    ("model_out.0", "conv", 128, 2, 1),
+]
+
+
+def random_state_dict(seed=0, style="he", include_class=True):
+    """Return ``{key: np.ndarray}`` with the reference key set.
+
+    style='he'     : N(0, gain/sqrt(fan_in)) conv weights so activations stay
+                     O(1) through all 30 layers and the tanh head is exercised
+                     over its whole range (the hard case for parity).
+    style='torch'  : U(+-1/sqrt(fan_in)) like ``torch.nn`` default init
+                     (activations shrink; |out| stays small).
+    """
+    rs = np.random.RandomState(seed)
+    sd = {}
+    for key, kind, cin, cout, k in LAYER_SPECS:
+        if key.startswith("model_class") and not include_class:
+            continue
+        if kind == "bn":
+            c = cout
+            sd[key + ".weight"] = rs.uniform(0.8, 1.2, c).astype(np.float32)
+            sd[key + ".bias"] = rs.uniform(-0.2, 0.2, c).astype(np.float32)
+            sd[key + ".running_mean"] = rs.uniform(0.2, 0.6, c).astype(np.float32)
+            sd[key + ".running_var"] = rs.uniform(0.25, 0.6, c).astype(np.float32)
+            sd[key + ".num_batches_tracked"] = np.array(1, dtype=np.int64)
+            continue
+        if kind == "deconv":
+            # every output pixel sees 2x2 taps of Cin channels
+            fan_in = cin * 4
+            shape = (cin, cout, k, k)
+        else:
+            fan_in = cin * k * k
+            shape = (cout, cin, k, k)
+        if style == "he":
+            gain = np.sqrt(2.0)
+            if key in ("model8up.0", "model3short8.0", "model9up.0", "model2short9.0",
+                       "model10up.0", "model1short10.0"):
+                gain = 1.0          # the two summed branches share the variance
+            if key == "model_out.0":
+                gain = 0.6          # keep most pre-tanh logits inside +-2
+            if key == "model_class.0":
+                gain = 4.0          # make the 0.2-tempered softmax non-flat
+            w = rs.standard_normal(shape) * (gain / np.sqrt(fan_in))
+            b = rs.uniform(-0.1, 0.1, cout)
+        elif style == "torch":
+            bound = 1.0 / np.sqrt(fan_in)
+            w = rs.uniform(-bound, bound, shape)
+            b = rs.uniform(-bound, bound, cout)
+        else:
+            raise ValueError("unknown style %r" % style)
+        sd[key + ".weight"] = w.astype(np.float32)
+        sd[key + ".bias"] = b.astype(np.float32)
+    return sd
+
+
+def param_count(sd, include_class=True):
+    n = 0
+    for k, v in sd.items():
+        if k.endswith("num_batches_tracked"):
+            continue
+        if not include_class and k.startswith("model_class"):
+            continue
+        n += int(np.prod(v.shape))
+    return n

@@ -11,11 +11,10 @@ root = os.path.abspath(sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.pat
 sys.path.insert(0, root)
 import torch                                                           # noqa: E402
 from interactive_deep_colorization_amd import engine, workloads        # noqa: E402
-from oracle import weights                                             # noqa: E402  (seeded weights only)
 
 nb = 32
 e = engine.HipColorizer(256, 256, max_batch=nb, precision="bf16")
-e.load_state_dict(weights.make_state_dict(0, "he"))
+e.load_state_dict(workloads.random_state_dict(0, "he"))
 L, ab, m = workloads.random_batch(nb, 256, seed=0)
 dev = torch.device("cuda", 0)
 dL, dab, dm = (torch.from_numpy(x).to(dev) for x in (L, ab, m))

@@ -11,7 +11,6 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from interactive_deep_colorization_amd import api, workloads          # noqa: E402
-from oracle import weights                                             # noqa: E402  (seeded weights only)
 
 
 def p50(fn, n=200, warm=20):
@@ -24,7 +23,7 @@ def p50(fn, n=200, warm=20):
 
 
 def main():
-    sd = weights.make_state_dict(0, "he")
+    sd = workloads.random_state_dict(0, "he")
     rgb = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
                                "mortar_pestle_256_rgb.npy"))
     hints = [(100 + 7 * i, 60 + 9 * i, 106 + 7 * i, 66 + 9 * i, 30 * i % 256, 200 - 20 * i, 40 + 15 * i) for i in range(8)]

@@ -6,9 +6,8 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from interactive_deep_colorization_amd import engine, workloads
-from oracle import weights
 
-sd = weights.make_state_dict(0, "he")
+sd = workloads.random_state_dict(0, "he")
 dev = torch.device("cuda", 0)
 def mk(nb, seed):
     e = engine.HipColorizer(256, 256, max_batch=nb, precision="bf16")
