@@ -25,7 +25,7 @@ import os
 import numpy as np
 from scipy.ndimage import zoom
 
-from . import colorspace
+from . import color_bins, colorspace
 from .colorspace import lab2rgb_transpose, rgb2lab_transpose  # same helper names as the reference
 from .engine import HipColorizer
 from .workloads import put_point  # noqa: F401  notebook helper (DemoInteractiveColorization.ipynb:131-139)
@@ -91,6 +91,20 @@ class ColorizeImageBase(object):
 
     def prep_net(self):
         raise Exception("Should be implemented by base class")
+
+    def _new_engine(self, net):
+        """A fresh engine handle replaces ``self.net``: nothing of the previous handle's device state (resident L plane,
+        rasterised hints, resident distribution) exists in it, so every "already on the device" flag is cleared."""
+        old = getattr(self, 'net', None)
+        self.net = net
+        self._l_resident = False
+        self._hints_on_device = False
+        if hasattr(self, '_dist_on_device'):
+            self._dist_on_device = False
+            self.dist_ab_set = False
+        if old is not None and old is not net and hasattr(old, 'close'):
+            old.close()
+        self.net_set = True
 
     # input_ab / input_mask: plain attributes after net_forward; after net_forward_hints they are read back from the
     # device planes only when something (get_input_img, get_sup_img, ...) asks for them
@@ -275,10 +289,10 @@ class ColorizeImageTorch(ColorizeImageBase):
         print('path = %s' % path)
         print('Model set! dist mode? ', dist)
         sd = read_state_dict(path) if state_dict is None else state_dict
-        self.net = HipColorizer(H=self.Xd, W=self.Xd, max_batch=1, precision=self.precision,
-                                device=0 if gpu_id is None else int(gpu_id), dist=dist)
-        self.net.load_state_dict(sd)
-        self.net_set = True
+        net = HipColorizer(H=self.Xd, W=self.Xd, max_batch=1, precision=self.precision,
+                           device=0 if gpu_id is None else int(gpu_id), dist=dist)
+        net.load_state_dict(sd)
+        self._new_engine(net)
 
     def net_forward(self, input_ab, input_mask):
         if ColorizeImageBase.net_forward(self, input_ab, input_mask) == -1:
@@ -335,9 +349,11 @@ class ColorizeImageTorchDist(ColorizeImageTorch):
                                           want_dist=False)
         self._dist_on_device = True
         self.dist_ab_set = True
-        # the reference returns out_reg*110*110 here (model.py:166-168), a value nothing reads;
-        # this returns the ab map itself
-        return out_ab[0]
+        # model.py:164-166: with dist=True the network returns ``out_reg * 110`` where out_reg is ALREADY the ab map
+        # (tanh * 110); the reference hands that doubly scaled array back (nothing reads it) -- so does this.  The
+        # ab map itself is ``output_ab_raw``.
+        self.output_ab_raw = out_ab[0]
+        return out_ab[0] * np.float32(110.)
 
     def net_forward_hints(self, hints, mode='rgb'):
         if self._stage_hints(hints, mode) == -1:
@@ -345,7 +361,8 @@ class ColorizeImageTorchDist(ColorizeImageTorch):
         out_ab, _, _ = self.net.forward_resident(1, self.mask_cent, want_rgb=False)
         self._dist_on_device = True
         self.dist_ab_set = True
-        return out_ab[0]
+        self.output_ab_raw = out_ab[0]
+        return out_ab[0] * np.float32(110.)
 
     def get_ab_reccs(self, h, w, K=5, N=25000, return_conf=False):
         """K suggested colours at pixel (h,w): N inverse-CDF draws from the predicted pdf, k-means, ordered by
@@ -387,7 +404,10 @@ class ColorizeImageCaffe(ColorizeImageBase):
     the torch key names (e.g. the reference's converted ``caffemodel.pth``),
     passed as ``caffemodel_path`` or ``state_dict``; ``prototxt_path`` is accepted and ignored."""
 
-    def __init__(self, Xd=256, precision='fp32'):
+    def __init__(self, Xd=256, precision='fp32', color_bins_dir=None):
+        """``color_bins_dir`` (not in the reference): a directory holding ``pts_in_hull.npy`` / ``pts_grid.npy`` /
+        ``in_hull.npy`` (the reference reads ``./data/color_bins``, ``:398-399,486-489``); ``None`` = the tables built
+        into :mod:`color_bins`.  A directory that lacks one of the files raises here, not at first use."""
         print('ColorizeImageCaffe instantiated')
         ColorizeImageBase.__init__(self, Xd)
         self.l_norm, self.ab_norm = 1., 1.
@@ -395,8 +415,8 @@ class ColorizeImageCaffe(ColorizeImageBase):
         self.mask_mult = 110.
         self.precision = precision
         self.pred_ab_layer = 'pred_ab'
-        self.pts_in_hull_path = os.path.join(_PKG_DIR, 'color_bins', 'pts_in_hull.npy')
-        self.pts_in_hull = np.load(self.pts_in_hull_path) if os.path.exists(self.pts_in_hull_path) else None
+        self.pts_in_hull_path = os.path.join(color_bins_dir, 'pts_in_hull.npy') if color_bins_dir else '<built in>'
+        self.pts_in_hull, self._pts_grid_table, self._in_hull_table = color_bins.load(color_bins_dir)
 
     _global_hints = False
     _dist313 = False
@@ -407,11 +427,11 @@ class ColorizeImageCaffe(ColorizeImageBase):
             raise RuntimeError('cpu mode is not available: this backend runs on gfx950 only')
         sd = read_state_dict(caffemodel_path) if state_dict is None else state_dict
         self.gpu_id = gpu_id
-        self.net = HipColorizer(H=self.Xd, W=self.Xd, max_batch=1, precision=self.precision, device=int(gpu_id),
-                                global_hints=self._global_hints, dist313=self._dist313)
-        self.net.set_io_scales(l_div=1., ab_div=1., mask_mul=1., out_mul=100.)
-        self.net.load_state_dict(sd)
-        self.net_set = True
+        net = HipColorizer(H=self.Xd, W=self.Xd, max_batch=1, precision=self.precision, device=int(gpu_id),
+                           global_hints=self._global_hints, dist313=self._dist313)
+        net.set_io_scales(l_div=1., ab_div=1., mask_mul=1., out_mul=100.)
+        net.load_state_dict(sd)
+        self._new_engine(net)
 
     def net_forward(self, input_ab, input_mask):
         if ColorizeImageBase.net_forward(self, input_ab, input_mask) == -1:
@@ -430,8 +450,8 @@ class ColorizeImageCaffeGlobDist(ColorizeImageCaffe):
     with one input channel (L only) is widened to four with zero ab/mask columns."""
     _global_hints = True
 
-    def __init__(self, Xd=256, precision='fp32'):
-        ColorizeImageCaffe.__init__(self, Xd, precision=precision)
+    def __init__(self, Xd=256, precision='fp32', color_bins_dir=None):
+        ColorizeImageCaffe.__init__(self, Xd, precision=precision, color_bins_dir=color_bins_dir)
         self.glob_mask_mult = 1.
         self.glob_layer = 'glob_ab_313_mask'
 
@@ -449,21 +469,35 @@ class ColorizeImageCaffeGlobDist(ColorizeImageCaffe):
         ``global_stats.prototxt`` net, on the device: an Xd x Xd RGB uint8 reference image -> the 313-bin global ab
         histogram to pass as ``glob_dist``.  ``pts_in_hull`` defaults to the table loaded like the reference does."""
         centres = self.pts_in_hull if pts_in_hull is None else pts_in_hull
-        if centres is None:
-            raise RuntimeError('pts_in_hull.npy was not found at %s; pass pts_in_hull' % self.pts_in_hull_path)
         hist, _ = self.net.global_histogram(ref_rgb, np.asarray(centres, np.float32))
         return hist[0]
 
-    def net_forward(self, input_ab, input_mask, glob_dist=-1):
-        # glob_dist is a 313 array, or -1 (reference :451-459)
-        if not self.net_set:
-            print('I need to have a net!')
-            return -1
+    def _set_glob(self, glob_dist):
+        # glob_dist is a 313 array, or -1 = "no global hint": histogram and flag all zero (reference :451-459)
         g = np.zeros((1, 314), np.float32)
         if np.array(glob_dist).flatten()[0] != -1:
             g[0, :313] = np.asarray(glob_dist, np.float32).ravel()
             g[0, 313] = self.glob_mask_mult
         self.net.set_global_hints(g)
+
+    def net_forward_hints(self, hints, mode='rgb', glob_dist=-1):
+        """Edit-list form; the global hint is an argument here too (default -1 = none), never a leftover of an earlier
+        call."""
+        if not self.net_set:
+            print('I need to have a net!')
+            return -1
+        self._set_glob(glob_dist)
+        ret = ColorizeImageCaffe.net_forward_hints(self, hints, mode)
+        if isinstance(ret, int):
+            return ret
+        self._set_out_ab_()
+        return ret
+
+    def net_forward(self, input_ab, input_mask, glob_dist=-1):
+        if not self.net_set:
+            print('I need to have a net!')
+            return -1
+        self._set_glob(glob_dist)
         self.output_rgb = ColorizeImageCaffe.net_forward(self, input_ab, input_mask)
         if isinstance(self.output_rgb, int):
             return self.output_rgb
@@ -480,17 +514,15 @@ class ColorizeImageCaffeDist(ColorizeImageCaffe):
     is absent it is set from ``pts_in_hull`` exactly as the reference does at load time (``:405-407``)."""
     _dist313 = True
 
-    def __init__(self, Xd=256, precision='fp32'):
-        ColorizeImageCaffe.__init__(self, Xd, precision=precision)
+    def __init__(self, Xd=256, precision='fp32', color_bins_dir=None):
+        ColorizeImageCaffe.__init__(self, Xd, precision=precision, color_bins_dir=color_bins_dir)
         self.dist_ab_set = False
         self._dist_on_device = False
         self.dist_ab = None
         self.scale_S_layer = 'scale_S'
         self.dist_ab_S_layer = 'dist_ab_S'
-        grid_path = os.path.join(os.path.dirname(self.pts_in_hull_path), 'pts_grid.npy')
-        hull_path = os.path.join(os.path.dirname(self.pts_in_hull_path), 'in_hull.npy')
-        self.pts_grid = np.load(grid_path) if os.path.exists(grid_path) else None      # 529x2, all points
-        self.in_hull = np.load(hull_path) if os.path.exists(hull_path) else None       # 529 bool
+        self.pts_grid = self._pts_grid_table          # 529x2, all points
+        self.in_hull = self._in_hull_table            # 529 bool
         self.AB, self.A, self.B = 529, 23, 23
         self.dist_ab_full = np.zeros((self.AB, self.Xd, self.Xd))
         self.dist_ab_grid = np.zeros((self.A, self.B, self.Xd, self.Xd))
@@ -499,9 +531,6 @@ class ColorizeImageCaffeDist(ColorizeImageCaffe):
     def prep_net(self, gpu_id, prototxt_path='', caffemodel_path='', S=.2, state_dict=None):
         sd = dict(read_state_dict(caffemodel_path) if state_dict is None else state_dict)
         if 'pred.pred_ab.weight' not in sd:
-            if self.pts_in_hull is None:
-                raise RuntimeError('pred.pred_ab.weight is absent and pts_in_hull.npy was not found at %s'
-                                   % self.pts_in_hull_path)
             print('Setting ab cluster centers in layer: %s' % self.pred_ab_layer)
             sd['pred.pred_ab.weight'] = np.ascontiguousarray(np.asarray(self.pts_in_hull, np.float32).T)[:, :, None, None]
         sd.setdefault('pred.pred_ab.bias', np.zeros(2, np.float32))
@@ -515,10 +544,9 @@ class ColorizeImageCaffeDist(ColorizeImageCaffe):
         if self._dist_on_device:
             self._dist_on_device = False
             self.dist_ab = self.net.get_dist(1)[0]               # in-gamut, 313 x X x X
-            if self.in_hull is not None:                         # full 529 grid, as the reference keeps it
-                full = self.__dict__['_lazy_dist_ab_full']
-                full[self.in_hull, :, :] = self.dist_ab
-                self.dist_ab_grid = full.reshape((self.A, self.B, self.Xd, self.Xd))
+            full = self.__dict__['_lazy_dist_ab_full']           # full 529 grid, as the reference keeps it (:496-499)
+            full[self.in_hull, :, :] = self.dist_ab
+            self.dist_ab_grid = full.reshape((self.A, self.B, self.Xd, self.Xd))
 
     dist_ab = _lazy('dist_ab', '_refresh_dist')
     dist_ab_full = _lazy('dist_ab_full', '_refresh_dist')
@@ -551,3 +579,6 @@ class ColorizeImageCaffeDist(ColorizeImageCaffe):
 
     def compute_entropy(self):
         self.dist_entropy = np.sum(self.dist_ab * np.log(self.dist_ab), axis=0)
+
+    plot_dist_grid = ColorizeImageTorchDist.plot_dist_grid            # same bodies as the reference's (:547-561)
+    plot_dist_entropy = ColorizeImageTorchDist.plot_dist_entropy

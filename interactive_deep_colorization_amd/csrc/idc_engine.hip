@@ -392,15 +392,34 @@ static bool fuse_shortcut_enabled() {
 // Small-tile kernel shape.  cout<=64 layers can only use one 64-wide cout group per wave column;
 // otherwise prefer 128 couts x 128 pixels and fall back to smaller pixel tiles when the launch would
 // not fill the 256 CUs.
+// Tuning knobs of the small-tile path (speed only), read once from the environment: tools/click_sweep.py walks them on
+// the GPU box and the defaults below are what it found best (profiles/r02_click_sweep.txt).
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+struct SmallTileTuning {
+    int tiles_goal = env_int("IDC_ST_TILES_GOAL", 512);         // shrink the pixel tile until this many workgroups exist
+    int force_wp = env_int("IDC_ST_FORCE_WP", 0);               // 1/2/4: fixed rows-of-4 per workgroup (0 = automatic)
+    int force_wm = env_int("IDC_ST_FORCE_WM", 0);               // 1/2: cout groups per workgroup (0 = automatic)
+    int sk_below[2] = {env_int("IDC_SK_BELOW_FP32", 256), env_int("IDC_SK_BELOW_BF16", 128)};   // split K when fewer tiles than this
+    int sk_goal[2] = {env_int("IDC_SK_GOAL_FP32", 512), env_int("IDC_SK_GOAL_BF16", 256)};      // ... until about this many workgroups
+    int v2_min_blocks = env_int("IDC_V2_MIN_BLOCKS", 128);      // large-tile bf16 kernel from this many workgroups on
+};
+static const SmallTileTuning& tuning() { static const SmallTileTuning t; return t; }
+
 static ConvConfig choose_config(int n, int Hs, int Ws, int coutpad, int nphase) {
-    const int wm = coutpad >= 128 ? 2 : 1;
+    const SmallTileTuning& tn = tuning();
+    int wm = coutpad >= 128 ? 2 : 1;
+    if (tn.force_wm && coutpad >= 64 * tn.force_wm && (coutpad / 64) % tn.force_wm == 0) wm = tn.force_wm;
+    if (tn.force_wp == 1 || tn.force_wp == 2 || tn.force_wp == 4) return ConvConfig{wm, tn.force_wp};
     const int cand_wp[3] = {wm == 1 ? 4 : 2, 2, 1};
     ConvConfig best{wm, cand_wp[0]};
     for (int i = 0; i < 3; ++i) {
         const int wp = cand_wp[i];
         const long long tiles = (long long)((Ws + 15) / 16) * ((Hs + 4 * wp - 1) / (4 * wp)) * n * (coutpad / (64 * wm)) * nphase;
         best = ConvConfig{wm, wp};
-        if (tiles >= 512) break;
+        if (tiles >= tn.tiles_goal) break;
     }
     return best;
 }
@@ -457,7 +476,7 @@ static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, i
         const ConvConfig c2 = (a.ncg % 4 == 0) ? ConvConfig{4, 2} : ConvConfig{2, 4};
         const int tx = (Ws + 31) / 32, ty = (Hs + 4 * c2.wp - 1) / (4 * c2.wp);
         const long long blocks = (long long)tx * ty * n_policy * (a.ncg / c2.wm) * a.nphase;
-        if (g_tile_policy == 2 || blocks >= 128) {
+        if (g_tile_policy == 2 || blocks >= tuning().v2_min_blocks) {
             L.v2 = true; L.cfg = c2; a.tiles_x = tx; a.tiles_y = ty;
             a.ksplit = 1; a.kc_per = a.nkc;
             return;
@@ -470,9 +489,10 @@ static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, i
     // 9*Cin/64 tap-steps alone; cut the cin chunks into slices until ~512 workgroups exist
     a.ksplit = 1; a.kc_per = a.nkc;
     const long long tiles = (long long)a.tiles_x * a.tiles_y * n_policy * (a.ncg / L.cfg.wm) * a.nphase;
-    if (g_splitk_policy != 1 && a.nkc >= 2 && (g_splitk_policy == 2 || tiles < (precision == IDC_FP32 ? 256 : 128))) {
+    const int pi = precision == IDC_FP32 ? 0 : 1;
+    if (g_splitk_policy != 1 && a.nkc >= 2 && (g_splitk_policy == 2 || tiles < tuning().sk_below[pi])) {
         // fp32 tap-steps are 16x longer than bf16 ones: worth twice as many slices (measured: 3.0 -> 2.0 ms at N=1)
-        long long want = g_splitk_policy == 2 ? a.nkc : ((precision == IDC_FP32 ? 512 : 256) + tiles - 1) / tiles;
+        long long want = g_splitk_policy == 2 ? a.nkc : (tuning().sk_goal[pi] + tiles - 1) / tiles;
         if (want > a.nkc) want = a.nkc;
         if (want >= 2) {
             a.kc_per = (int)((a.nkc + want - 1) / want);

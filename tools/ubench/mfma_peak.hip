@@ -1,56 +1,95 @@
-// MFMA issue-rate microbenchmark: waves/WG and accumulators per wave as parameters.
+// MFMA issue-rate microbenchmark for MI355X: what v_mfma_f32_32x32x16_bf16 sustains on this box, by operand data.
+//
+//   mfma_peak [seconds-per-arm]          (default 10)
+//
+// Arms: operand fill = zeros | constant 1.0 | uniform random [-1,1) bf16 (per lane, per register; the accumulators
+// see a random walk), each held for `seconds` of back-to-back launches of 256 CUs x 8 waves x 8 independent
+// accumulators (the issue-bound form: 2 waves/SIMD, no memory traffic at all).  Per second of wall time it prints
+// TFLOP/s and the shader clock the kernel saw (s_memtime ticks = shader cycles, against the 100 MHz wall_clock64),
+// so the DVFS give-back (MI355X_MICROARCH.md "DVFS give-back") is visible as a number: the nominal 2.5 PFLOP/s is
+// 256 CU x 4 SIMD x 1024 FLOP/cycle x 2.4 GHz; what a kernel can reach on REAL data is this figure at the clock
+// the chip sustains under that data.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <vector>
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 template <int NACC>
-__global__ __launch_bounds__(512) void k32(float* out, int iters, unsigned seed) {
+__global__ __launch_bounds__(512) void k32(const u32x4* __restrict__ ops, float* out, long long* clk, int iters) {
     f32x16 acc[NACC];
-    for (int i = 0; i < NACC; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    u32x4 a = {0x3f803f80u ^ (threadIdx.x * 2654435761u & 0x007f007fu), 0x3e803f00u, 0x3f003e80u, 0x3f803f00u ^ seed};
-    u32x4 b = {0x3f003f80u, 0x3e803f80u ^ (threadIdx.x * 40503u & 0x007f007fu), 0x3f803e80u, 0x3f003f00u};
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    u32x4 a[2], b[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = ops[t * 6 + i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = ops[t * 6 + 2 + i];
+    const long long c0 = clock64(), w0 = wall_clock64();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < NACC; ++i)
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i & 1]),
+                                                             __builtin_bit_cast(bf16x8, b[i & 3]), acc[i], 0, 0, 0);
     }
+    const long long c1 = clock64(), w1 = wall_clock64();
     float s = 0;
-    for (int i = 0; i < NACC; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
-    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-}
-template <int NACC>
-__global__ __launch_bounds__(512) void k16(float* out, int iters, unsigned seed) {
-    f32x4 acc[NACC];
-    for (int i = 0; i < NACC; ++i) for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
-    u32x4 a = {0x3f803f80u ^ (threadIdx.x * 2654435761u & 0x007f007fu), 0x3e803f00u, 0x3f003e80u, 0x3f803f00u ^ seed};
-    u32x4 b = {0x3f003f80u, 0x3e803f80u ^ (threadIdx.x * 40503u & 0x007f007fu), 0x3f803e80u, 0x3f003f00u};
-    for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int i = 0; i < NACC; ++i)
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc[i], 0, 0, 0);
-    }
-    float s = 0;
-    for (int i = 0; i < NACC; ++i) for (int r = 0; r < 4; ++r) s += acc[i][r];
-    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    out[t] = s;
+    if (threadIdx.x == 0) { clk[blockIdx.x * 2] = c1 - c0; clk[blockIdx.x * 2 + 1] = w1 - w0; }
 }
+
+static unsigned short bf16_of(float f) {
+    unsigned u; __builtin_memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
 int main(int argc, char** argv) {
-    float* out; hipMalloc(&out, 4096 * 512 * 4);
+    const double seconds = argc > 1 ? atof(argv[1]) : 10.0;
+    const int blocks = 256, threads = 512, iters = 20000;
+    const size_t nthr = (size_t)blocks * threads;
+    u32x4* d_ops; float* d_out; long long* d_clk;
+    hipMalloc(&d_ops, nthr * 6 * sizeof(u32x4)); hipMalloc(&d_out, nthr * 4); hipMalloc(&d_clk, blocks * 16);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const int iters = 4000;
-    for (int threads : {256, 512}) for (int blocks : {256, 512, 1024}) {
-        for (int variant = 0; variant < 2; ++variant) {
-            auto launch = [&]() { if (variant == 0) hipLaunchKernelGGL(k32<8>, dim3(blocks), dim3(threads), 0, 0, out, iters, 1u);
-                                  else hipLaunchKernelGGL(k16<16>, dim3(blocks), dim3(threads), 0, 0, out, iters, 1u); };
-            launch(); hipDeviceSynchronize();
-            hipEventRecord(e0, 0); for (int r = 0; r < 5; ++r) launch(); hipEventRecord(e1, 0); hipEventSynchronize(e1);
-            float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
-            double flops = (variant == 0 ? 8.0 * 2 * 32 * 32 * 16 : 16.0 * 2 * 16 * 16 * 32) * iters * (threads / 64) * blocks;
-            printf("%s threads=%d blocks=%d : %.3f ms  %.0f TFLOP/s\n", variant == 0 ? "32x32x16 x8acc " : "16x16x32 x16acc", threads, blocks, ms, flops / ms / 1e9);
+    const double flop_per_launch = 8.0 * 2 * 32 * 32 * 16 * (double)iters * (threads / 64) * blocks;
+    const char* names[3] = {"zeros", "constant 1.0", "uniform random [-1,1)"};
+    for (int fill = 0; fill < 3; ++fill) {
+        std::vector<unsigned short> h(nthr * 6 * 8);
+        unsigned long long st = 0x9e3779b97f4a7c15ull;
+        for (auto& v : h) {
+            st = st * 6364136223846793005ull + 1442695040888963407ull;
+            const float r = (float)((st >> 40) & 0xffffff) / 8388608.0f - 1.0f;       // [-1, 1)
+            v = fill == 0 ? 0 : fill == 1 ? 0x3f80 : bf16_of(r);
         }
+        hipMemcpy(d_ops, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(k32<8>, dim3(blocks), dim3(threads), 0, 0, d_ops, d_out, d_clk, iters);
+        hipDeviceSynchronize();
+        printf("== operands: %s, %.0f s sustained, %d x %d threads, 8 accumulators per wave\n", names[fill], seconds, blocks, threads);
+        double elapsed = 0, best = 0, sum_tf = 0; int nwin = 0;
+        while (elapsed < seconds) {
+            // one ~1 s window of back-to-back launches
+            int n = 0; float ms = 0;
+            hipEventRecord(e0, 0);
+            do { for (int k = 0; k < 8; ++k) hipLaunchKernelGGL(k32<8>, dim3(blocks), dim3(threads), 0, 0, d_ops, d_out, d_clk, iters);
+                 n += 8; hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); } while (ms < 1000.f);
+            long long hc[512]; hipMemcpy(hc, d_clk, blocks * 16, hipMemcpyDeviceToHost);
+            double cyc = 0, wall = 0; for (int b = 0; b < blocks; ++b) { cyc += hc[2 * b]; wall += hc[2 * b + 1]; }
+            const double ghz = cyc / wall * 0.1;                                        // wall_clock64 = 100 MHz
+            const double tf = flop_per_launch * n / ms / 1e9;
+            const double cyc_per_mfma = (cyc / blocks) / ((double)iters * 8 * 2);        // per SIMD: 2 waves share it
+            printf("  t=%5.1fs  %7.1f TFLOP/s  shader clock %.3f GHz  %.2f cycles per MFMA per SIMD\n", elapsed + ms / 1e3, tf, ghz, cyc_per_mfma);
+            elapsed += ms / 1e3; sum_tf += tf; ++nwin; if (tf > best) best = tf;
+        }
+        printf("  mean %.1f TFLOP/s (best window %.1f) = %.3f of the nominal 2500\n", sum_tf / nwin, best, sum_tf / nwin / 2500.0);
     }
     return 0;
 }
