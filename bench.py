@@ -51,6 +51,13 @@ def parse_args():
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="images per GPU per step")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-pointer (PCIe-inclusive) pipeline leg")
+    ap.add_argument("--no-peak-probe", action="store_true", help="skip the 3 s MFMA-peak probe (tools/ubench/mfma_peak)")
+    ap.add_argument("--dryrun-single-gpu", action="store_true",
+                    help="N>1 control flow on ONE GPU: every rank uses device 0, the process group is gloo (host "
+                         "broadcast of the packed blob -> idc_set_weights_host); for exercising barriers, the MAX-reduce "
+                         "and the sharded workload with the real HIP engine where only one GPU exists.  The number it "
+                         "prints is NOT a scaling result (ranks share the GPU) and says so.")
     return ap.parse_args()
 
 
@@ -156,7 +163,9 @@ def main():
     import torch.distributed as dist
     from interactive_deep_colorization_amd import engine, sharded, workloads
 
-    rank, local_rank, world = sharded.init_process_group()
+    rank, local_rank, world = sharded.init_process_group(backend="gloo" if args.dryrun_single_gpu else None)
+    if args.dryrun_single_gpu:
+        local_rank = 0
     if world != args.gpus:
         if rank == 0:
             print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run for N>1"
@@ -209,7 +218,7 @@ def main():
     e.set_profiling(False)
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank != 0:
@@ -253,6 +262,8 @@ def main():
                    "weights_broadcast_ms": sc.weights_broadcast_ms},
         "roofline": {"bound": "mfma", "achieved": round(achieved_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved_tflops / peak, 4), "traffic": traffic.get("conv_family_bytes_per_forward"),
+                     "traffic_source": "profiles/pmc_traffic.json: rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command run by "
+                                       "the builder (%s), replayed here -- not measured in this process" % traffic.get("tag", "r01j"),
                      "kernel": "conv kernel family (conv_igemm_v2 / conv_ds_fused / conv_igemm / conv1_1, %s): the %d conv/deconv launches of one "
                                "forward taken together" % (args.precision, len(conv_rows)),
                      "launches_per_forward": len(conv_rows),
@@ -267,7 +278,18 @@ def main():
         "layers_ms": {r["name"]: round(float(layer_ms[r["index"]]), 4) for r in table},
         "layers_ms_note": "separate untimed pass of 5 forwards with an event pair around every launch (these pairs cost ~4 %)",
     }
+    if world == 1 and not args.no_end_to_end:
+        result["end_to_end"] = measure_end_to_end(e, nb, args.steps, args.warmup, value)
     e.close()
+    if args.dryrun_single_gpu:
+        result["dryrun_single_gpu"] = ("%d ranks shared ONE GPU over a gloo group: control-flow check only, `value` is not a "
+                                       "scaling measurement" % world)
+    if world == 1 and not args.no_peak_probe and args.precision == "bf16":
+        probe = mfma_peak_probe()
+        if probe:
+            r = result["roofline"]
+            r["attainable_peak"] = probe
+            r["frac_of_attainable"] = round(r["achieved"] / probe["tflops_random_operands"], 4)
     if world == 1 and not args.no_latency:
         result["latency"] = measure_latency(sd, local_rank)
     if world == 1 and not args.no_cpu_baseline:
@@ -278,6 +300,70 @@ def main():
     sys.stdout.flush()
     if world > 1:
         dist.barrier()
+
+
+def measure_end_to_end(e, nb, steps, warmup, device_resident_value):
+    """SURVEY.md 8d config 3 "end-to-end": the same batches with HOST pointers in and out (33.5 MB in, 16.8 MB out per
+    batch over PCIe) through the two-slot pipeline (idc_forward_async / idc_wait: copy-in, compute and copy-out on
+    three streams), pinned host buffers (idc_alloc_host), two batches in flight.  Never `value`."""
+    bufs = []
+    for k in range(2):
+        Lh, abh, mh = __import__("interactive_deep_colorization_amd.workloads", fromlist=["x"]).random_batch(nb, H, seed=0, start=k * nb)
+        arrs = [e.pinned_empty(x.shape) for x in (Lh, abh, mh)] + [e.pinned_empty((nb, 2, H, W))]
+        for dst, src in zip(arrs[:3], (Lh, abh, mh)):
+            dst[...] = src
+        bufs.append(arrs)
+
+    def run(n_steps):
+        for i in range(n_steps):
+            k = i & 1
+            if i >= 2:
+                e.wait(k)
+            e.forward_async(k, bufs[k][0], bufs[k][1], bufs[k][2], bufs[k][3], 0.0)
+        e.wait(0); e.wait(1)
+
+    e.set_profiling(False)
+    run(max(warmup, 2))
+    t0 = time.perf_counter()
+    run(steps)
+    dt = time.perf_counter() - t0
+    v = nb * steps / dt
+    # the blocking single-slot call for comparison (serial H2D -> run -> D2H through the handle's own staging)
+    t0 = time.perf_counter()
+    for _ in range(max(3, steps // 4)):
+        e.forward(bufs[0][0], bufs[0][1], bufs[0][2], 0.0)
+    blocking = nb * max(3, steps // 4) / (time.perf_counter() - t0)
+    return {"value": round(v, 2), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 4),
+            "frac_of_device_resident": round(v / device_resident_value, 4),
+            "blocking_idc_forward_images_per_sec": round(blocking, 2),
+            "how": "host pointers, pinned buffers, idc_forward_async/idc_wait two-slot pipeline (H2D / compute / D2H on three "
+                   "streams), %d steps of %d images; 50.3 MB over PCIe per step" % (steps, nb)}
+
+
+def mfma_peak_probe(seconds=3.0):
+    """What the matrix pipes of THIS box sustain on full-range random bf16 operands (no memory traffic at all): the
+    chip clocks to its power budget, so the nominal 2.5 PFLOP/s (2.4 GHz) is not reachable on real data
+    (profiles/r02_mfma_peak.txt: zeros 2484, uniform random 1813 TFLOP/s at 1.78 GHz).  Runs tools/ubench/mfma_peak
+    (built by __graft_entry__.build()) for `seconds`; None when the binary is missing."""
+    import subprocess
+    exe = os.path.join(REPO, "tools", "ubench", "mfma_peak")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe, str(seconds), "random"], capture_output=True, text=True, timeout=60).stdout
+        tf = ghz = None
+        for line in out.splitlines():
+            if line.strip().startswith("mean"):
+                tf = float(line.split()[1])
+            if "shader clock" in line:
+                ghz = float(line.split("shader clock")[1].split()[0])
+        if tf is None:
+            return None
+        return {"tflops_random_operands": round(tf, 1), "shader_clock_ghz": ghz, "seconds": seconds,
+                "how": "tools/ubench/mfma_peak: 256 CUs x 8 waves x 8 independent v_mfma_f32_32x32x16_bf16 accumulators, uniform "
+                       "random [-1,1) bf16 operands, back-to-back launches; measured in this bench run"}
+    except Exception:
+        return None
 
 
 def _pmc_traffic():

@@ -46,8 +46,8 @@ typedef enum idc_precision { IDC_FP32 = 0, IDC_BF16 = 1 } idc_precision;
 
 /* idc_create flags */
 #define IDC_FLAG_DIST_HEAD   0x1u  /* also build model_class (529-bin) head: SIGGRAPHGenerator(dist=True), model.py:105,159-160 */
-/* (0x2 reserved: hipGraph replay was evaluated for the batch-1 path and left out -- every kernel of that path runs
- *  >= 5 us, above the ~3.5 us host launch cost, so the stream never starves) */
+/* (0x2 reserved: hipGraph replay was left out of the batch-1 path on measurement -- its 40 launches leave 6 us of gaps
+ *  in a 690 us forward, profiles/r02a_click_bf16_trace.txt) */
 #define IDC_FLAG_DIST313     0x8u  /* also build the 313-bin distribution / soft-decode head of
                                       models/reference_model/deploy_nopred.prototxt:650-850 (needs the pred.* tensors, see idc_forward_dist313) */
 #define IDC_FLAG_GLOBAL_HINTS 0x4u /* also build the Global-Hints branch of models/global_model/deploy_nodist.prototxt:37-172,
@@ -62,7 +62,9 @@ int idc_version(void);
 int idc_set_tile_policy(int policy);
 /* Process-wide switches for the parity tests (speed only).  "fuse_conv1" (default 1): model1 = conv1_1 + conv1_2 as one
  * launch on the bf16 throughput path -- 0 keeps the two launches apart, so that conv1_1's own output exists and can be
- * read with idc_get_activation.  Takes effect on the next forward. */
+ * read with idc_get_activation.  "click" (default -1 = on unless IDC_CLICK=0): small launches (the batch-1 click path) run
+ * conv_click, which requests a workgroup's whole K slice by LDS-DMA at entry; 0 keeps them on conv_igemm.  Take effect on
+ * the next forward. */
 int idc_set_option(const char* name, int value);
 /* Split-K policy of the small-tile kernels (speed only): 0 automatic (launches too small to fill the chip: the
  * batch-1 click path), 1 never, 2 always (tests).  The slice sums are added in a fixed order: results stay
@@ -121,7 +123,8 @@ const void* idc_weights_device_ptr(idc_handle h);
  * Host-pointer form: blocking; returns when out_ab is valid.                                    */
 int idc_forward(idc_handle h, int n, const float* L_mc, const float* ab, const float* mask,
                 float maskcent, float* out_ab);
-/* Device-pointer form (same layouts, device memory); enqueued on the handle's stream.
+/* Device-pointer form (same layouts, device memory); enqueued on the handle's stream (see STREAM ORDERING at
+ * idc_stream: inputs produced / outputs consumed on another stream need idc_stream_wait / idc_stream_signal).
  * sync!=0 waits for completion. */
 int idc_forward_device(idc_handle h, int n, const float* d_L_mc, const float* d_ab,
                        const float* d_mask, float maskcent, float* d_out_ab, int sync);
@@ -218,8 +221,60 @@ int idc_get_dist(idc_handle h, int n, float* dist);
 int idc_suggest_colors(idc_handle h, int img, int y, int x, int K, int N, unsigned seed, const float* centres,
                        double* out_centres, double* out_conf, unsigned* out_counts);
 int idc_sync(idc_handle h);
-/* The hipStream_t all work of this handle is enqueued on (as void*). */
+/* The hipStream_t all work of this handle is enqueued on (as void*): a stream of its own, created non-blocking.
+ * STREAM ORDERING: idc_forward_device / idc_forward_resident only ENQUEUE on that stream.  A caller that writes the
+ * device inputs or reads the device outputs on another stream (torch's current stream, say) must order the two --
+ * either synchronise fully (sync != 0 / idc_sync on this side, a stream/device synchronize on the producer's side),
+ * or use the two event helpers below:
+ *   idc_stream_wait(h, s)   : work enqueued on the handle AFTER this call waits for everything enqueued on s BEFORE it
+ *                             (call it after producing the inputs on s, before idc_forward_device);
+ *   idc_stream_signal(h, s) : work enqueued on s AFTER this call waits for everything the handle enqueued BEFORE it
+ *                             (call it after idc_forward_device, before consuming d_out_ab on s).
+ * The host-pointer entry points (idc_forward, ...) block and need none of this. */
 void* idc_stream(idc_handle h);
+int idc_stream_wait(idc_handle h, void* caller_stream);
+int idc_stream_signal(idc_handle h, void* caller_stream);
+
+/* ---- end-to-end batches: overlapped transfers.  The reference has no counterpart (it
+ *      runs one image per call on the host); this is the serving form of idc_forward.  Two slots (0, 1): while slot k
+ *      computes, slot 1-k's inputs travel host -> device on a copy stream and its previous result travels back on a third.
+ *          idc_forward_async(h, 0, ...batch 0...); idc_forward_async(h, 1, ...batch 1...);
+ *          idc_wait(h, 0) -> out of batch 0 valid; idc_forward_async(h, 0, ...batch 2...); idc_wait(h, 1); ...
+ *      Host buffers stay caller-owned and must stay untouched until the slot's idc_wait.  Pinned memory (idc_alloc_host,
+ *      or the caller's own hipHostMalloc / hipHostRegister) is transferred in place; pageable memory is staged through
+ *      pinned buffers with a host memcpy on the calling thread (correct, but the memcpy then bounds the rate).
+ *      The blocking entry points drain both slots first. */
+void* idc_alloc_host(size_t bytes);
+int idc_free_host(void* p);
+int idc_forward_async(idc_handle h, int slot, int n, const float* L_mc, const float* ab, const float* mask, float maskcent,
+                      float* out_ab);
+int idc_wait(idc_handle h, int slot);
+
+/* ---- multi-GPU weight distribution (SURVEY.md 8b export list, 8e): one RCCL broadcast of the packed blob over xGMI.
+ *      Every rank (one process per GPU) creates its handle; the root also loads the weights.  idc_comm_unique_id
+ *      (root only) fills 128 bytes that the caller ships to the other ranks by any side channel (a file, a socket,
+ *      torch.distributed's store); then EVERY rank calls idc_broadcast_weights(h, id, rank, world, root).  Non-root
+ *      handles receive into their own device allocation, verify header + checksum and become ready.  librccl.so is
+ *      opened on first use; IDC_ERR_UNSUPPORTED if it cannot be found.  No data-path collective exists: images are
+ *      independent (colorize_image.py:232 eval-mode BN), each rank runs its own shard. */
+#define IDC_UNIQUE_ID_BYTES 128
+int idc_comm_unique_id(void* id128);
+int idc_broadcast_weights(idc_handle h, const void* unique_id, int rank, int world, int root);
+
+/* ---- display / full-resolution step on the device: what follows every net_forward in the GUI,
+ *          ab_win = cv2.resize(output_ab, (win_w, win_h), interpolation=cv2.INTER_CUBIC)
+ *          pred_rgb = (clip(lab2rgb(concat(l_win, ab_win)), 0, 1) * 255).astype('uint8')          ui/gui_draw.py:280-283
+ *      and the full-resolution getters get_img_fullres / get_input_img_fullres / get_sup_fullres
+ *      (scipy.ndimage.zoom(ab, order=1 | 0) + lab2rgb with img_l_fullres, colorize_image.py:123-158).
+ *      source: which resident [2,H,W] ab planes of image slot img -- IDC_SRC_OUTPUT_AB the refreshed (uint8-quantised)
+ *      output_ab of the last idc_forward_rgb / idc_forward_resident (float64, what the GUI resizes), IDC_SRC_OUTPUT_AB_RAW
+ *      the network's own output, IDC_SRC_INPUT_AB the resident hint planes.  interp: IDC_INTERP_CUBIC = cv2 INTER_CUBIC
+ *      (a = -0.75, half-pixel centres, replicated border), IDC_INTERP_LINEAR / IDC_INTERP_NEAREST = scipy zoom order 1 / 0
+ *      (corner-aligned).  L [out_h,out_w] float64 = the L channel at the output size (l_win / img_l_fullres);
+ *      rgb [out_h,out_w,3] uint8. */
+enum { IDC_INTERP_CUBIC = 0, IDC_INTERP_LINEAR = 1, IDC_INTERP_NEAREST = 2 };
+enum { IDC_SRC_OUTPUT_AB = 0, IDC_SRC_OUTPUT_AB_RAW = 1, IDC_SRC_INPUT_AB = 2 };
+int idc_upsample_lab2rgb(idc_handle h, int img, int source, int interp, int out_h, int out_w, const double* L, uint8_t* rgb);
 
 /* ---- introspection for parity tests and roofline accounting -------------------------------- */
 int idc_num_layers(idc_handle h);

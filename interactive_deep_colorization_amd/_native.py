@@ -27,7 +27,12 @@ EXPORTED_SYMBOLS = [
     "idc_layer_times_ms", "idc_get_activation", "idc_op_conv2d", "idc_op_deconv4x4s2",
     "idc_set_image_l", "idc_set_hints", "idc_get_hint_planes", "idc_forward_resident",
     "idc_dist_bins", "idc_keep_dist", "idc_dist_at", "idc_get_dist", "idc_suggest_colors",
+    "idc_stream_wait", "idc_stream_signal", "idc_alloc_host", "idc_free_host", "idc_forward_async", "idc_wait",
+    "idc_comm_unique_id", "idc_broadcast_weights", "idc_upsample_lab2rgb",
 ]
+IDC_INTERP_CUBIC, IDC_INTERP_LINEAR, IDC_INTERP_NEAREST = 0, 1, 2
+IDC_SRC_OUTPUT_AB, IDC_SRC_OUTPUT_AB_RAW, IDC_SRC_INPUT_AB = 0, 1, 2
+IDC_UNIQUE_ID_BYTES = 128
 IDC_HINT_AB, IDC_HINT_RGB = 0, 1
 
 
@@ -121,6 +126,15 @@ def load():
     proto("idc_dist_at", ci, [vp, ci, ci, ci, c_float_p])
     proto("idc_get_dist", ci, [vp, ci, c_float_p])
     proto("idc_suggest_colors", ci, [vp, ci, ci, ci, ci, ci, ctypes.c_uint, c_float_p, vp, vp, vp])
+    proto("idc_stream_wait", ci, [vp, vp])
+    proto("idc_stream_signal", ci, [vp, vp])
+    proto("idc_alloc_host", vp, [csz])
+    proto("idc_free_host", ci, [vp])
+    proto("idc_forward_async", ci, [vp, ci, ci, c_float_p, c_float_p, c_float_p, cf, c_float_p])
+    proto("idc_wait", ci, [vp, ci])
+    proto("idc_comm_unique_id", ci, [vp])
+    proto("idc_broadcast_weights", ci, [vp, vp, ci, ci, ci])
+    proto("idc_upsample_lab2rgb", ci, [vp, ci, ci, ci, ci, ci, vp, vp])
     _lib = lib
     return lib
 

@@ -99,6 +99,7 @@ class ColorizeImageBase(object):
         self.net = net
         self._l_resident = False
         self._hints_on_device = False
+        self._dev_out_token = None
         if hasattr(self, '_dist_on_device'):
             self._dist_on_device = False
             self.dist_ab_set = False
@@ -207,6 +208,9 @@ class ColorizeImageBase(object):
         self.output_rgb = rgb
         self.output_lab = lab_q
         self.output_ab = lab_q[1:]
+        # the same two maps are resident on the device (refreshed output_ab in float64, the hint planes): the display /
+        # full-resolution getters read them there as long as the caller has not replaced these attributes
+        self._dev_out_token = self.output_ab
         return self.output_rgb
 
     def _set_out_ab_(self):
@@ -238,11 +242,34 @@ class ColorizeImageBase(object):
     def get_img_gray_fullres(self):
         return lab2rgb_transpose(self.img_l_fullres, self._zeros_ab(self.img_l_fullres))
 
+    def _out_on_device(self):
+        return self.net_set and getattr(self, '_dev_out_token', None) is not None and self._dev_out_token is self.__dict__.get('output_ab')
+
+    def _in_on_device(self):
+        # only when the hint planes exist on the device alone (net_forward_hints): arrays the caller handed in may have
+        # been edited in place since the last forward (put_point does), and the reference would show those edits
+        return self.net_set and self._hints_on_device and self.ab_mean == 0 and self.ab_norm == 1
+
     def get_img_fullres(self):
+        """Bilinear (``scipy.ndimage.zoom`` order 1) upsample of ``output_ab`` + Lab->RGB with the full-res L
+        (``:123-131``) -- on the device when the map is still the one the last forward left there."""
+        if self._out_on_device():
+            return self.net.upsample_lab2rgb(self.img_l_fullres[0], 'output_ab', 'linear')
         return lab2rgb_transpose(self.img_l_fullres, self._up(self.output_ab, 1))
 
     def get_input_img_fullres(self):
+        if self._in_on_device():
+            return self.net.upsample_lab2rgb(self.img_l_fullres[0], 'input_ab', 'linear')
         return lab2rgb_transpose(self.img_l_fullres, self._up(self.input_ab, 1))
+
+    def get_result_window(self, l_win):
+        """The display step of ``GUIDraw.compute_result`` (``ui/gui_draw.py:280-283``) on the device:
+        ``cv2.resize(output_ab, (win_w, win_h), INTER_CUBIC)`` + ``lab2rgb`` with the window-sized L plane ``l_win``
+        (win_h, win_w) -> (win_h, win_w, 3) uint8.  Not in the reference's model class (the GUI does it on the host
+        with cv2 + skimage after every click); SURVEY.md 8f rank 1."""
+        if not self._out_on_device():
+            raise RuntimeError('get_result_window needs the result of the last net_forward (output_ab was replaced)')
+        return self.net.upsample_lab2rgb(np.asarray(l_win), 'output_ab', 'cubic')
 
     def get_input_img(self):
         return lab2rgb_transpose(self.img_l, self.input_ab)
@@ -258,6 +285,8 @@ class ColorizeImageBase(object):
         return lab2rgb_transpose(50 * self.input_mask, self.input_ab)
 
     def get_sup_fullres(self):
+        if self._in_on_device():
+            return self.net.upsample_lab2rgb(50 * self._up(self.input_mask, 0)[0], 'input_ab', 'nearest')
         return lab2rgb_transpose(50 * self._up(self.input_mask, 0), self._up(self.input_ab, 0))
 
 

@@ -4,6 +4,7 @@
 // Replaces: SIGGRAPHGenerator.__init__/forward (models/pytorch/model.py:6-175) and the
 // load_state_dict/eval part of ColorizeImageTorch.prep_net (data/colorize_image.py:216-233).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -308,6 +309,7 @@ struct Layer {
     int halo = 0;
     ConvConfig cfg{2, 2};
     bool v2 = false;                     // bf16 large-tile kernel (layout-2 weights)
+    bool click = false;                  // batch-1 click-path kernel (conv_click: whole K slice by LDS-DMA)
     bool fused_head = false;             // conv10_2 only: model_out + tanh run in this layer's epilogue
     int fused_short = -1;                // deconv layers: index of the shortcut conv layer riding in this launch's K loop
     bool skip = false;                   // layer fused into another launch: not launched itself
@@ -337,6 +339,7 @@ struct idc_context {
     float *d_L = nullptr, *d_ab = nullptr, *d_mask = nullptr, *d_out = nullptr, *d_dist = nullptr;
     float* d_scratch = nullptr; size_t scratch_bytes = 0;
     float* d_partial = nullptr; size_t partial_bytes = 0;    // split-K slice sums (grown on demand)
+    void* d_zeros = nullptr;             // 256 zero bytes: LDS-DMA source of out-of-image halo rows (conv_click)
     float *d_glob_in = nullptr, *d_glob_vec = nullptr;   // global hints: [max_batch][316] inputs, [max_batch][512] branch output
     int t_conv4_3 = -1, t_pred313 = -1;
     float *d_pred_ab = nullptr, *d_dist313 = nullptr, *h_pred_ab = nullptr, *h_dist313 = nullptr;   // 313 head outputs
@@ -349,6 +352,22 @@ struct idc_context {
     int dist_n = 0;                      // images whose distribution is resident from the last forward (0 = none)
     HintRect *d_hints = nullptr, *h_hints = nullptr; int hints_cap = 0;   // click session: hint list staging
     float* d_centres = nullptr; double* d_sugg = nullptr; unsigned* d_sugg_counts = nullptr;   // colour suggestions
+    std::vector<char> l_set;             // per image slot: d_L holds an uploaded L plane (idc_forward_resident refuses otherwise)
+    hipEvent_t ev_sync = nullptr;        // idc_stream_wait / idc_stream_signal
+    // two-slot transfer pipeline (idc_forward_async / idc_wait): slot 0 = the buffers above, slot 1 its own set
+    struct PipeSlot {
+        float *d_L = nullptr, *d_ab = nullptr, *d_mask = nullptr, *d_out = nullptr;   // device I/O planes
+        float *h_in = nullptr, *h_out = nullptr;                                       // pinned staging (pageable callers)
+        hipEvent_t ev_in = nullptr, ev_comp = nullptr, ev_out = nullptr;
+        bool pending = false, staged_out = false;
+        float* user_out = nullptr; int n = 0;
+    } pipe[2];
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    bool pipe_ready = false;
+    unsigned char* d_up_rgb = nullptr; double* d_up_L = nullptr; size_t up_cap = 0;    // idc_upsample_lab2rgb staging
+    unsigned char* h_up_rgb = nullptr; double* h_up_L = nullptr;
+    bool out_resident = false;           // d_out / d_labq hold the last forward's ab map / refreshed Lab
+    bool labq_resident = false;
     int profiling = 0;                   // 0 off, 1 = an event pair around every launch, 2 = one pair around the whole forward
     std::vector<hipEvent_t> ev;          // kProfRing slots x 2 per timed step: [pack, layers..., head, softmax]
     int n_timed = 0;
@@ -379,6 +398,7 @@ static int g_fuse_conv1 = !(getenv("IDC_FUSE_CONV1") && atoi(getenv("IDC_FUSE_CO
 // Split-K policy of the small-tile kernels (speed only): 0 = automatic (launches that would leave most CUs idle,
 // i.e. the batch-1 click path), 1 = never, 2 = always split as far as the cin chunks allow (tests).
 static int g_splitk_policy = 0;
+static int g_click = -1;                 // conv_click for small launches: -1 = environment default (on), 0 off, 1 on (idc_set_option "click")
 // Shortcut fusion (conv_igemm_v2<.,.,1,true>) is correct (parity-tested under tile policy 2) but measured slower
 // than two launches on MI355X (4x re-reads of the skip tensor by the four phase workgroups, VGPR spills around
 // the staged K loop): 0.87 ms -> 1.25 ms at level 1.  Off unless the tile policy forces every variant on.
@@ -405,6 +425,10 @@ struct SmallTileTuning {
     int sk_below[2] = {env_int("IDC_SK_BELOW_FP32", 256), env_int("IDC_SK_BELOW_BF16", 128)};   // split K when fewer tiles than this
     int sk_goal[2] = {env_int("IDC_SK_GOAL_FP32", 512), env_int("IDC_SK_GOAL_BF16", 256)};      // ... until about this many workgroups
     int v2_min_blocks = env_int("IDC_V2_MIN_BLOCKS", 128);      // large-tile bf16 kernel from this many workgroups on
+    int click = env_int("IDC_CLICK", 1);                        // conv_click for small launches (the batch-1 click path)
+    int click_max_wgs = env_int("IDC_CLICK_MAX_WGS", 1024);     // ... when its grid has at most this many workgroups
+    int click_goal = env_int("IDC_CLICK_GOAL", 256);            // ... split K over the cin chunks until about this many exist
+    int click_wp = env_int("IDC_CLICK_WP", 4);                  // rows-of-4 per workgroup (4 = 16x16 sites, 256 threads)
 };
 static const SmallTileTuning& tuning() { static const SmallTileTuning t; return t; }
 
@@ -480,6 +504,30 @@ static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, i
             L.v2 = true; L.cfg = c2; a.tiles_x = tx; a.tiles_y = ty;
             a.ksplit = 1; a.kc_per = a.nkc;
             return;
+        }
+    }
+    // batch-1 click path: small launches are chains of exposed memory round trips in conv_igemm's K loop; conv_click
+    // requests a workgroup's whole K slice at entry (as many cin chunks as fit in LDS next to their halo tiles)
+    L.click = false;
+    if ((g_click < 0 ? tuning().click : g_click) && g_tile_policy != 1 && (L.spec->kind == kConv3x3 || L.spec->kind == kDeconv4x4)) {
+        int wp = tuning().click_wp;
+        while (wp > 1 && 4 * wp > Hs * 2) wp >>= 1;               // tiny images: do not launch mostly-empty tiles
+        const int maxc = conv_click_max_chunks(wp, L.halo, a.ntaps);
+        const int tx = (Ws + 15) / 16, ty = (Hs + 4 * wp - 1) / (4 * wp);
+        const long long tiles = (long long)tx * ty * n_policy * a.ncg * a.nphase;
+        if (maxc >= 1) {
+            int kc_per = maxc < a.nkc ? maxc : a.nkc;
+            while (kc_per > 1 && tiles * ((a.nkc + kc_per - 1) / kc_per) < tuning().click_goal) --kc_per;
+            if (g_splitk_policy == 1 && kc_per < a.nkc) kc_per = 0;           // "never split": only when all of K fits
+            if (g_splitk_policy == 2) kc_per = 1;
+            if (kc_per >= 1) {
+                const int ks = (a.nkc + kc_per - 1) / kc_per;
+                if (tiles * ks <= tuning().click_max_wgs) {
+                    L.click = true; L.cfg = ConvConfig{1, wp};
+                    a.tiles_x = tx; a.tiles_y = ty; a.kc_per = kc_per; a.ksplit = ks;
+                    return;
+                }
+            }
         }
     }
     L.cfg = choose_config(n_policy, Hs, Ws, L.blob.ncg * kCoutGroup, a.nphase);
@@ -562,6 +610,15 @@ static int alloc_graph(idc_context* c) {
     HIPCHK(c, hipMalloc((void**)&c->d_ab, nb * hw * 2 * 4));
     HIPCHK(c, hipMalloc((void**)&c->d_mask, nb * hw * 4));
     HIPCHK(c, hipMalloc((void**)&c->d_out, nb * hw * 2 * 4));
+    // resident planes start defined: no hints (ab = 0, mask = 0); an L plane has to be uploaded before a resident forward
+    HIPCHK(c, hipMemset(c->d_L, 0, nb * hw * 4));
+    HIPCHK(c, hipMemset(c->d_ab, 0, nb * hw * 2 * 4));
+    HIPCHK(c, hipMemset(c->d_mask, 0, nb * hw * 4));
+    HIPCHK(c, hipMemset(c->d_out, 0, nb * hw * 2 * 4));
+    c->l_set.assign(nb, 0);
+    HIPCHK(c, hipMalloc(&c->d_zeros, 256));
+    HIPCHK(c, hipMemset(c->d_zeros, 0, 256));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_sync, hipEventDisableTiming));
     HIPCHK(c, hipHostMalloc((void**)&c->h_in, nb * hw * 4 * 4, hipHostMallocDefault));
     HIPCHK(c, hipHostMalloc((void**)&c->h_out, nb * hw * 2 * 4, hipHostMallocDefault));
     if (c->flags & IDC_FLAG_DIST_HEAD) {
@@ -615,7 +672,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             Layer& P = c->layers[j];
             const LayerSpec& ps = *P.spec;
             if (P.src != L.dst || P.v2 || ps.kind != kConv3x3 || ps.cin != 64 || ps.cout != 64 || ps.dilation != 1 ||
-                ps.in_stride != 1 || ps.act != 1 || ps.resid || c->tensors[P.dst].is_f32 || P.args.ksplit > 1) continue;
+                ps.in_stride != 1 || ps.act != 1 || ps.resid || c->tensors[P.dst].is_f32 || P.args.ksplit > 1 || P.click) continue;
             bool only_consumer = true;
             for (const Layer& Q : c->layers) if (&Q != &P && (Q.src == L.dst || Q.resid == L.dst)) only_consumer = false;
             if (only_consumer) { L.fused_next = (int)j; P.skip = true; }
@@ -643,6 +700,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
         if (L.skip) { tic(); toc(); continue; }
         ConvArgs& a = L.args;
         a.in = ti.ptr; a.out = to.ptr;
+        a.zeros = c->d_zeros;
         a.out_f32 = to.is_f32;
         a.img_shift = ((c->flags & IDC_FLAG_GLOBAL_HINTS) && L.dst == c->t_conv4_3) ? c->d_glob_vec : nullptr;
         if (L.spec->kind == kConvIm2col) {          // model.py:139-148 input pack, fused into the operand staging
@@ -703,7 +761,8 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
                 le = launch_conv1_1_bf16(a, s);
             if (L.fused_short >= 0) le = launch_conv_ds(a, s);    // deconv + its shortcut conv in one K loop
             if (le == hipErrorInvalidConfiguration)
-                le = L.v2 ? launch_conv_v2(L.cfg, L.halo, a, s) : launch_conv(c->precision, L.cfg, L.halo, a, s);
+                le = L.click ? launch_conv_click(c->precision, L.cfg.wp, L.halo, a, s)
+                   : L.v2 ? launch_conv_v2(L.cfg, L.halo, a, s) : launch_conv(c->precision, L.cfg, L.halo, a, s);
             HIPCHK(c, le);
         }
         if (a.ksplit > 1) HIPCHK(c, launch_splitk_epilogue(c->precision, a, s));
@@ -740,6 +799,8 @@ static int check_forward_args(idc_context* c, int n) {
     return IDC_OK;
 }
 
+static int drain_pipeline(idc_context* c);
+
 static int forward_host(idc_context* c, int n, const float* L_mc, const float* ab, const float* mask, float maskcent,
                         float* out_ab, float* dist_q, bool keep_dist = false) {
     int rc = check_forward_args(c, n);
@@ -748,7 +809,11 @@ static int forward_host(idc_context* c, int n, const float* L_mc, const float* a
     if ((dist_q || keep_dist) && !(c->flags & IDC_FLAG_DIST_HEAD))
         return fail(&c->err, IDC_ERR_UNSUPPORTED, "handle was created without IDC_FLAG_DIST_HEAD");
     HIPCHK(c, hipSetDevice(c->device));
+    rc = drain_pipeline(c);
+    if (rc) return rc;
     const size_t hw = (size_t)c->H * c->W;
+    for (int i = 0; i < n; ++i) c->l_set[i] = 1;
+    c->out_resident = true; c->labq_resident = false;
     float* hL = c->h_in; float* hab = hL + (size_t)n * hw; float* hm = hab + (size_t)n * hw * 2;
     memcpy(hL, L_mc, (size_t)n * hw * 4);
     memcpy(hab, ab, (size_t)n * hw * 2 * 4);
@@ -774,6 +839,22 @@ static void destroy_ctx(idc_context* c) {
     for (auto& t : c->tensors) if (t.ptr) (void)hipFree(t.ptr);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->own_blob && c->d_blob) (void)hipFree(c->d_blob);
+    for (auto& sl : c->pipe) {
+        void* dv[] = {sl.d_L, sl.d_ab, sl.d_mask, sl.d_out};
+        if (&sl != &c->pipe[0]) for (void* p : dv) if (p) (void)hipFree(p);
+        if (sl.h_in) (void)hipHostFree(sl.h_in);
+        if (sl.h_out) (void)hipHostFree(sl.h_out);
+        hipEvent_t evs[] = {sl.ev_in, sl.ev_comp, sl.ev_out};
+        for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+    }
+    if (c->s_in) (void)hipStreamDestroy(c->s_in);
+    if (c->s_out) (void)hipStreamDestroy(c->s_out);
+    if (c->ev_sync) (void)hipEventDestroy(c->ev_sync);
+    if (c->d_zeros) (void)hipFree(c->d_zeros);
+    if (c->d_up_rgb) (void)hipFree(c->d_up_rgb);
+    if (c->d_up_L) (void)hipFree(c->d_up_L);
+    if (c->h_up_rgb) (void)hipHostFree(c->h_up_rgb);
+    if (c->h_up_L) (void)hipHostFree(c->h_up_L);
     void* dev[] = {c->d_L, c->d_ab, c->d_mask, c->d_out, c->d_dist, c->d_scratch, c->d_glob_in, c->d_glob_vec, c->d_pred_ab, c->d_dist313, c->d_partial, c->d_rgb, c->d_labq, c->d_hints, c->d_centres, c->d_sugg, c->d_sugg_counts, c->d_post_in};
     for (void* p : dev) if (p) (void)hipFree(p);
     void* host[] = {c->h_in, c->h_out, c->h_dist, c->h_pred_ab, c->h_rgb, c->h_labq, c->h_hints};
@@ -814,6 +895,7 @@ int idc_set_tile_policy(int policy) {
 int idc_set_option(const char* name, int value) {
     if (!name) return fail(nullptr, IDC_ERR_INVALID_ARG, "null option name");
     if (strcmp(name, "fuse_conv1") == 0) { g_fuse_conv1 = value != 0; return IDC_OK; }
+    if (strcmp(name, "click") == 0) { g_click = value; return IDC_OK; }              // -1 = the IDC_CLICK default
     return fail(nullptr, IDC_ERR_INVALID_ARG, "unknown option '%s'", name);
 }
 
@@ -906,13 +988,25 @@ int idc_set_weights_host(idc_handle h, const void* blob, size_t blob_bytes) {
     return IDC_OK;
 }
 
-int idc_set_weights_device(idc_handle h, const void* dev_blob, size_t blob_bytes, int copy) {
-    if (!h || !dev_blob) return fail(h ? &h->err : nullptr, IDC_ERR_INVALID_ARG, "null handle/blob");
-    HIPCHK(h, hipSetDevice(h->device));
+// header + payload checksum of a packed blob in device memory: one D2H copy at load time (136 MB, a few ms) -- a
+// truncated or stale broadcast must not become silent garbage weights
+static int verify_device_blob(idc_context* h, const void* dev_blob, size_t blob_bytes) {
     BlobHeader hd;
     if (blob_bytes < sizeof(hd)) return fail(&h->err, IDC_ERR_INVALID_ARG, "blob too small");
     HIPCHK(h, hipMemcpy(&hd, dev_blob, sizeof(hd), hipMemcpyDeviceToHost));
     int rc = validate_header(h, hd, blob_bytes);
+    if (rc) return rc;
+    std::vector<uint8_t> tmp(h->plan.total_bytes);
+    HIPCHK(h, hipMemcpy(tmp.data(), dev_blob, tmp.size(), hipMemcpyDeviceToHost));
+    if (fnv1a(tmp.data() + sizeof(hd), tmp.size() - sizeof(hd)) != hd.checksum)
+        return fail(&h->err, IDC_ERR_INVALID_ARG, "device blob checksum mismatch");
+    return IDC_OK;
+}
+
+int idc_set_weights_device(idc_handle h, const void* dev_blob, size_t blob_bytes, int copy) {
+    if (!h || !dev_blob) return fail(h ? &h->err : nullptr, IDC_ERR_INVALID_ARG, "null handle/blob");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = verify_device_blob(h, dev_blob, blob_bytes);
     if (rc) return rc;
     if (copy) {
         if (!h->own_blob || !h->d_blob) {
@@ -1052,7 +1146,10 @@ int idc_lab2rgb(idc_handle h, int n, const float* L, const float* ab, uint8_t* r
     memcpy(h->h_in, L, (size_t)n * hw * 4);
     memcpy(h->h_in + (size_t)n * hw, ab, (size_t)n * hw * 2 * 4);
     HIPCHK(h, hipMemcpyAsync(h->d_post_in, h->h_in, (size_t)n * hw * 3 * 4, hipMemcpyHostToDevice, h->stream));
-    return run_lab_post(h, n, h->d_post_in, 0.f, h->d_post_in + (size_t)n * hw, rgb, lab_q);
+    rc = run_lab_post(h, n, h->d_post_in, 0.f, h->d_post_in + (size_t)n * hw, rgb, lab_q);
+    h->labq_resident = rc == IDC_OK && lab_q != nullptr;        // d_labq = rgb2lab of exactly what was passed in
+    if (h->labq_resident && h->last_n < n) h->last_n = n;
+    return rc;
 }
 
 int idc_forward_rgb(idc_handle h, int n, const float* L_mc, const float* ab, const float* mask, float maskcent,
@@ -1065,7 +1162,9 @@ int idc_forward_rgb(idc_handle h, int n, const float* L_mc, const float* ab, con
     // forward (leaves L_mc in d_L and the ab map in d_out), then the colour step on the same stream
     rc = forward_host(h, n, L_mc, ab, mask, maskcent, out_ab ? out_ab : h->h_out, nullptr);
     if (rc) return rc;
-    return run_lab_post(h, n, h->d_L, l_cent, h->d_out, rgb, lab_q);
+    rc = run_lab_post(h, n, h->d_L, l_cent, h->d_out, rgb, lab_q);
+    h->labq_resident = rc == IDC_OK && lab_q != nullptr;
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------- click session
@@ -1083,6 +1182,7 @@ int idc_set_image_l(idc_handle h, int img, const float* L_mc) {
     const size_t hw = (size_t)h->H * h->W;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(h->d_L + (size_t)img * hw, L_mc, hw * 4, hipMemcpyHostToDevice));
+    h->l_set[img] = 1;
     return IDC_OK;
 }
 
@@ -1140,9 +1240,14 @@ int idc_forward_resident(idc_handle h, int n, float maskcent, float l_cent, floa
     int rc = check_forward_args(h, n);
     if (rc) return rc;
     HIPCHK(h, hipSetDevice(h->device));
+    for (int i = 0; i < n; ++i)
+        if (!h->l_set[i]) return fail(&h->err, IDC_ERR_INVALID_ARG, "I need to have an image! (slot %d has no L plane: idc_set_image_l)", i);
+    rc = drain_pipeline(h);
+    if (rc) return rc;
     const size_t hw = (size_t)h->H * h->W;
     rc = run_graph(h, n, h->d_L, h->d_ab, h->d_mask, maskcent, h->d_out, (h->flags & IDC_FLAG_DIST_HEAD) ? h->d_dist : nullptr);
     if (rc) return rc;
+    h->out_resident = true; h->labq_resident = rgb != nullptr && lab_q != nullptr;
     if (out_ab) HIPCHK(h, hipMemcpyAsync(h->h_out, h->d_out, (size_t)n * hw * 2 * 4, hipMemcpyDeviceToHost, h->stream));
     if (rgb) {
         rc = run_lab_post(h, n, h->d_L, l_cent, h->d_out, rgb, lab_q);      // synchronises the stream
@@ -1258,6 +1363,250 @@ int idc_global_histogram(idc_handle h, int n, const uint8_t* rgb, const float* c
     return IDC_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- stream ordering
+// The handle's work runs on its own non-blocking stream.  A caller that produces device inputs or consumes device
+// outputs on ANOTHER stream orders the two with these (or synchronises fully): wait = "the handle's stream waits for
+// everything enqueued so far on caller_stream"; signal = "caller_stream waits for everything the handle enqueued so far".
+int idc_stream_wait(idc_handle h, void* caller_stream) {
+    if (!h) return fail(nullptr, IDC_ERR_INVALID_ARG, "null handle");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipEventRecord(h->ev_sync, (hipStream_t)caller_stream));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_sync, 0));
+    return IDC_OK;
+}
+
+int idc_stream_signal(idc_handle h, void* caller_stream) {
+    if (!h) return fail(nullptr, IDC_ERR_INVALID_ARG, "null handle");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipEventRecord(h->ev_sync, h->stream));
+    HIPCHK(h, hipStreamWaitEvent((hipStream_t)caller_stream, h->ev_sync, 0));
+    return IDC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- transfer pipeline
+// End-to-end batches: two slots, three streams.  Slot k's H2D copies run on the copy-in
+// stream while the other slot computes; its D2H runs on the copy-out stream while the next batch computes.  Callers that
+// pass pinned host memory (idc_alloc_host, or their own hipHostMalloc / hipHostRegister) are copied from / to directly;
+// pageable pointers go through the slot's pinned staging with a host memcpy on the calling thread.
+void* idc_alloc_host(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+int idc_free_host(void* p) {
+    if (!p) return IDC_OK;
+    return hipHostFree(p) == hipSuccess ? IDC_OK : fail(nullptr, IDC_ERR_HIP, "hipHostFree failed");
+}
+
+static bool is_pinned(const void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+
+static int ensure_pipeline(idc_context* h) {
+    if (h->pipe_ready) return IDC_OK;
+    const size_t hw = (size_t)h->H * h->W, nb = (size_t)h->max_batch;
+    HIPCHK(h, hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) {
+        auto& sl = h->pipe[k];
+        if (k == 0) { sl.d_L = h->d_L; sl.d_ab = h->d_ab; sl.d_mask = h->d_mask; sl.d_out = h->d_out; }
+        else {
+            HIPCHK(h, hipMalloc((void**)&sl.d_L, nb * hw * 4));
+            HIPCHK(h, hipMalloc((void**)&sl.d_ab, nb * hw * 2 * 4));
+            HIPCHK(h, hipMalloc((void**)&sl.d_mask, nb * hw * 4));
+            HIPCHK(h, hipMalloc((void**)&sl.d_out, nb * hw * 2 * 4));
+        }
+        HIPCHK(h, hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&sl.ev_comp, hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&sl.ev_out, hipEventDisableTiming));
+    }
+    h->pipe_ready = true;
+    return IDC_OK;
+}
+
+static int wait_slot(idc_context* h, int slot) {
+    auto& sl = h->pipe[slot];
+    if (!sl.pending) return IDC_OK;
+    HIPCHK(h, hipEventSynchronize(sl.ev_out));
+    if (sl.staged_out) memcpy(sl.user_out, sl.h_out, (size_t)sl.n * h->H * h->W * 2 * 4);
+    sl.pending = false;
+    return IDC_OK;
+}
+
+static int drain_pipeline(idc_context* c) {
+    if (!c->pipe_ready) return IDC_OK;
+    for (int k = 0; k < 2; ++k) { int rc = wait_slot(c, k); if (rc) return rc; }
+    return IDC_OK;
+}
+
+int idc_forward_async(idc_handle h, int slot, int n, const float* L_mc, const float* ab, const float* mask, float maskcent,
+                      float* out_ab) {
+    int rc = check_forward_args(h, n);
+    if (rc) return rc;
+    if (slot < 0 || slot > 1) return fail(&h->err, IDC_ERR_INVALID_ARG, "slot %d not in 0..1", slot);
+    if (!L_mc || !ab || !mask || !out_ab) return fail(&h->err, IDC_ERR_INVALID_ARG, "null tensor pointer");
+    HIPCHK(h, hipSetDevice(h->device));
+    rc = ensure_pipeline(h);
+    if (rc) return rc;
+    auto& sl = h->pipe[slot];
+    if (sl.pending) return fail(&h->err, IDC_ERR_INVALID_ARG, "slot %d is still in flight: idc_wait it first", slot);
+    const size_t hw = (size_t)h->H * h->W, nb = (size_t)h->max_batch;
+    const float *sL = L_mc, *sab = ab, *sm = mask;
+    if (!(is_pinned(L_mc) && is_pinned(ab) && is_pinned(mask))) {
+        if (!sl.h_in) HIPCHK(h, hipHostMalloc((void**)&sl.h_in, nb * hw * 4 * 4, hipHostMallocDefault));
+        float* hL = sl.h_in; float* hab = hL + (size_t)n * hw; float* hm = hab + (size_t)n * hw * 2;
+        memcpy(hL, L_mc, (size_t)n * hw * 4); memcpy(hab, ab, (size_t)n * hw * 2 * 4); memcpy(hm, mask, (size_t)n * hw * 4);
+        sL = hL; sab = hab; sm = hm;
+    }
+    sl.staged_out = !is_pinned(out_ab);
+    if (sl.staged_out && !sl.h_out) HIPCHK(h, hipHostMalloc((void**)&sl.h_out, nb * hw * 2 * 4, hipHostMallocDefault));
+    // copy-in stream: the slot's previous inputs were consumed (its previous forward finished: idc_wait was called)
+    HIPCHK(h, hipMemcpyAsync(sl.d_L, sL, (size_t)n * hw * 4, hipMemcpyHostToDevice, h->s_in));
+    HIPCHK(h, hipMemcpyAsync(sl.d_ab, sab, (size_t)n * hw * 2 * 4, hipMemcpyHostToDevice, h->s_in));
+    HIPCHK(h, hipMemcpyAsync(sl.d_mask, sm, (size_t)n * hw * 4, hipMemcpyHostToDevice, h->s_in));
+    HIPCHK(h, hipEventRecord(sl.ev_in, h->s_in));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, sl.ev_in, 0));
+    rc = run_graph(h, n, sl.d_L, sl.d_ab, sl.d_mask, maskcent, sl.d_out, nullptr);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(sl.ev_comp, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->s_out, sl.ev_comp, 0));
+    HIPCHK(h, hipMemcpyAsync(sl.staged_out ? sl.h_out : out_ab, sl.d_out, (size_t)n * hw * 2 * 4, hipMemcpyDeviceToHost, h->s_out));
+    HIPCHK(h, hipEventRecord(sl.ev_out, h->s_out));
+    sl.pending = true; sl.user_out = out_ab; sl.n = n;
+    if (slot == 0) { for (int i = 0; i < n; ++i) h->l_set[i] = 1; h->out_resident = true; h->labq_resident = false; }
+    return IDC_OK;
+}
+
+int idc_wait(idc_handle h, int slot) {
+    if (!h) return fail(nullptr, IDC_ERR_INVALID_ARG, "null handle");
+    if (slot < 0 || slot > 1) return fail(&h->err, IDC_ERR_INVALID_ARG, "slot %d not in 0..1", slot);
+    if (!h->pipe_ready) return IDC_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    return wait_slot(h, slot);
+}
+
+// ---------------------------------------------------------------------------------------------- RCCL weight broadcast
+// SURVEY.md 8b's export list / 8e: one broadcast of the packed blob from `root` over xGMI, called by every rank's
+// process with its own handle.  librccl is opened at the first call (the copy torch already loaded, if any, else
+// /opt/rocm's) -- the library has no link-time dependency on it, single-GPU users never touch it.
+struct IdcNcclId { char internal[128]; };                  // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128), passed by value
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, IdcNcclId, int) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+static Rccl* rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* nm : names) { r.lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD); if (r.lib) break; }     // already in the process (torch)
+        for (const char* nm : names) { if (r.lib) break; r.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL); }
+        if (r.lib) {
+            r.GetUniqueId = (int (*)(void*))dlsym(r.lib, "ncclGetUniqueId");
+            r.CommInitRank = (int (*)(void**, int, IdcNcclId, int))dlsym(r.lib, "ncclCommInitRank");
+            r.Broadcast = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(r.lib, "ncclBroadcast");
+            r.CommDestroy = (int (*)(void*))dlsym(r.lib, "ncclCommDestroy");
+            r.GetErrorString = (const char* (*)(int))dlsym(r.lib, "ncclGetErrorString");
+            if (!r.GetUniqueId || !r.CommInitRank || !r.Broadcast || !r.CommDestroy) r.lib = nullptr;
+        }
+    }
+    return r.lib ? &r : nullptr;
+}
+
+int idc_comm_unique_id(void* id128) {
+    if (!id128) return fail(nullptr, IDC_ERR_INVALID_ARG, "null id buffer");
+    Rccl* r = rccl();
+    if (!r) return fail(nullptr, IDC_ERR_UNSUPPORTED, "librccl.so could not be opened");
+    const int e = r->GetUniqueId(id128);
+    if (e != 0) return fail(nullptr, IDC_ERR_HIP, "ncclGetUniqueId failed: %s", r->GetErrorString ? r->GetErrorString(e) : "?");
+    return IDC_OK;
+}
+
+int idc_broadcast_weights(idc_handle h, const void* unique_id, int rank, int world, int root) {
+    if (!h || !unique_id) return fail(h ? &h->err : nullptr, IDC_ERR_INVALID_ARG, "null handle / id");
+    if (world < 1 || rank < 0 || rank >= world || root < 0 || root >= world)
+        return fail(&h->err, IDC_ERR_INVALID_ARG, "rank %d / root %d outside world %d", rank, root, world);
+    if (rank == root && !h->weights_set) return fail(&h->err, IDC_ERR_NO_WEIGHTS, "the root rank has no weights to broadcast");
+    Rccl* r = rccl();
+    if (!r) return fail(&h->err, IDC_ERR_UNSUPPORTED, "librccl.so could not be opened");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (rank != root && (!h->own_blob || !h->d_blob)) {
+        h->d_blob = nullptr;
+        HIPCHK(h, hipMalloc((void**)&h->d_blob, h->plan.total_bytes));
+        h->own_blob = true;
+    }
+    IdcNcclId id;
+    memcpy(&id, unique_id, sizeof(id));
+    void* comm = nullptr;
+    int e = r->CommInitRank(&comm, world, id, rank);
+    if (e != 0) return fail(&h->err, IDC_ERR_HIP, "ncclCommInitRank failed: %s", r->GetErrorString ? r->GetErrorString(e) : "?");
+    e = r->Broadcast(h->d_blob, h->d_blob, h->plan.total_bytes, /*ncclUint8*/ 1, root, comm, h->stream);
+    hipError_t he = hipStreamSynchronize(h->stream);
+    (void)r->CommDestroy(comm);
+    if (e != 0) return fail(&h->err, IDC_ERR_HIP, "ncclBroadcast failed: %s", r->GetErrorString ? r->GetErrorString(e) : "?");
+    if (he != hipSuccess) return fail(&h->err, IDC_ERR_HIP, "stream sync after ncclBroadcast: %s", hipGetErrorString(he));
+    if (rank != root) {                     // the received bytes are validated like any other device blob
+        h->weights_set = false;
+        int rc = verify_device_blob(h, h->d_blob, h->plan.total_bytes);
+        if (rc) return rc;
+        h->weights_set = true;
+    }
+    return IDC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- display step
+int idc_upsample_lab2rgb(idc_handle h, int img, int source, int interp, int out_h, int out_w, const double* L, uint8_t* rgb) {
+    int rc = check_img(h, img);
+    if (rc) return rc;
+    if (!L || !rgb || out_h <= 0 || out_w <= 0) return fail(&h->err, IDC_ERR_INVALID_ARG, "bad output geometry / null pointer");
+    if (interp < 0 || interp > 2) return fail(&h->err, IDC_ERR_INVALID_ARG, "interp %d not in 0..2", interp);
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t hw = (size_t)h->H * h->W;
+    const void *pa = nullptr, *pb = nullptr; int f64 = 0;
+    if (source == IDC_SRC_OUTPUT_AB) {
+        if (!h->labq_resident || img >= h->last_n) return fail(&h->err, IDC_ERR_UNSUPPORTED, "no refreshed output_ab is resident (run idc_forward_rgb / idc_forward_resident with lab_q first)");
+        pa = h->d_labq + ((size_t)img * 3 + 1) * hw; pb = h->d_labq + ((size_t)img * 3 + 2) * hw; f64 = 1;
+    } else if (source == IDC_SRC_OUTPUT_AB_RAW) {
+        if (!h->out_resident || img >= h->last_n) return fail(&h->err, IDC_ERR_UNSUPPORTED, "no forward result is resident");
+        pa = h->d_out + (size_t)img * 2 * hw; pb = h->d_out + ((size_t)img * 2 + 1) * hw;
+    } else if (source == IDC_SRC_INPUT_AB) {
+        pa = h->d_ab + (size_t)img * 2 * hw; pb = h->d_ab + ((size_t)img * 2 + 1) * hw;
+    } else {
+        return fail(&h->err, IDC_ERR_INVALID_ARG, "source %d not in 0..2", source);
+    }
+    rc = drain_pipeline(h);
+    if (rc) return rc;
+    const size_t np = (size_t)out_h * out_w;
+    if (h->up_cap < np) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->d_up_rgb) (void)hipFree(h->d_up_rgb);
+        if (h->d_up_L) (void)hipFree(h->d_up_L);
+        if (h->h_up_rgb) (void)hipHostFree(h->h_up_rgb);
+        if (h->h_up_L) (void)hipHostFree(h->h_up_L);
+        h->d_up_rgb = nullptr; h->d_up_L = nullptr; h->h_up_rgb = nullptr; h->h_up_L = nullptr; h->up_cap = 0;
+        HIPCHK(h, hipMalloc((void**)&h->d_up_rgb, np * 3));
+        HIPCHK(h, hipMalloc((void**)&h->d_up_L, np * 8));
+        HIPCHK(h, hipHostMalloc((void**)&h->h_up_rgb, np * 3, hipHostMallocDefault));
+        HIPCHK(h, hipHostMalloc((void**)&h->h_up_L, np * 8, hipHostMallocDefault));
+        h->up_cap = np;
+    }
+    memcpy(h->h_up_L, L, np * 8);
+    HIPCHK(h, hipMemcpyAsync(h->d_up_L, h->h_up_L, np * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, launch_upsample_lab2rgb(pa, pb, f64, h->H, h->W, interp, (const double*)h->d_up_L, out_h, out_w, h->d_up_rgb, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_up_rgb, h->d_up_rgb, np * 3, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    memcpy(rgb, h->h_up_rgb, np * 3);
+    return IDC_OK;
+}
+
 int idc_sync(idc_handle h) {
     if (!h) return fail(nullptr, IDC_ERR_INVALID_ARG, "null handle");
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1287,7 +1636,8 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
                 if (C.fused_short == layer - 1 || C.fused_next == layer - 1) snprintf(out->kernel, sizeof(out->kernel), "fused into %s", C.spec->name);
             out->flops = 0; out->min_bytes = 0; out->launches = 0;
         } else {
-            snprintf(out->kernel, sizeof(out->kernel), L.v2 ? "conv_igemm_v2<%d,%d>" : (h->precision == IDC_BF16 ? "conv_igemm<bf16,%d,%d>" : "conv_igemm<f32,%d,%d>"),
+            snprintf(out->kernel, sizeof(out->kernel), L.click ? (h->precision == IDC_BF16 ? "conv_click<bf16,%d,%d>" : "conv_click<f32,%d,%d>")
+                     : L.v2 ? "conv_igemm_v2<%d,%d>" : (h->precision == IDC_BF16 ? "conv_igemm<bf16,%d,%d>" : "conv_igemm<f32,%d,%d>"),
                      L.cfg.wm, L.cfg.wp);
             if (L.fused_head) strncat(out->kernel, "+head", sizeof(out->kernel) - strlen(out->kernel) - 1);
             if (L.args.ksplit > 1) {
@@ -1447,12 +1797,16 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_mul = 0.f;
     a.in2 = nullptr; a.wgt2 = nullptr; a.nkc2 = 0;
     a.out_f32 = io_bf16 ? 0 : 1;
-    DevBuf d_part;
+    DevBuf d_part, d_zero;
     if (a.ksplit > 1) {
         HIPCHK(nullctx, d_part.alloc((size_t)a.ksplit * n * Ho * Wo * cpad * 4));
         a.partial = (float*)d_part.p;
     }
-    HIPCHK(nullctx, L.v2 ? launch_conv_v2(L.cfg, L.halo, a, nullptr) : launch_conv(precision, L.cfg, L.halo, a, nullptr));
+    HIPCHK(nullctx, d_zero.alloc(256));
+    HIPCHK(nullctx, hipMemset(d_zero.p, 0, 256));
+    a.zeros = d_zero.p;
+    HIPCHK(nullctx, L.click ? launch_conv_click(precision, L.cfg.wp, L.halo, a, nullptr)
+                    : L.v2 ? launch_conv_v2(L.cfg, L.halo, a, nullptr) : launch_conv(precision, L.cfg, L.halo, a, nullptr));
     if (a.ksplit > 1) HIPCHK(nullctx, launch_splitk_epilogue(precision, a, nullptr));
     HIPCHK(nullctx, launch_nhwc_to_nchw(io_bf16, d_yn.p, (float*)d_y.p, n, spec.cout, Ho, Wo, cpad, nullptr));
     HIPCHK(nullctx, hipMemcpy(y, d_y.p, yout * 4, hipMemcpyDeviceToHost));

@@ -60,6 +60,7 @@ struct ConvArgs {
     const float* head_b;    // [2]
     float* head_out;        // NCHW fp32 [N][2][Hs][Ws]
     float head_mul;
+    const void* zeros;      // >= 16 zero bytes in device memory: LDS-DMA source of out-of-image halo rows (conv_click)
     int dy[36], dx[36], tw[36];   // [phase*9 + t]: tap offset in sites, packed-weight tap index
     int ro[4], co[4];
 };
@@ -82,6 +83,11 @@ hipError_t launch_conv1_block(const ConvArgs& a, hipStream_t s);
 // conv1_1 (4 -> 64, input pack fused) as one 32x32 tile per workgroup, bf16; hipErrorInvalidConfiguration if the
 // launch does not qualify (the caller then uses launch_conv)
 hipError_t launch_conv1_1_bf16(const ConvArgs& a, hipStream_t s);
+// Batch-1 click-path kernel (conv_click): tile 16 x 4*wp sites x 64 couts, the workgroup's whole K slice (kc_per chunks x
+// all taps) requested by LDS-DMA at entry; a.kc_per <= conv_click_max_chunks(wp, halo, ntaps), a.ksplit = ceil(nkc / kc_per),
+// a.tiles_x / tiles_y count 16 x 4*wp tiles, a.zeros set.  Layout-1 weights.
+hipError_t launch_conv_click(int precision, int wp, int halo, const ConvArgs& a, hipStream_t s);
+int conv_click_max_chunks(int wp, int halo, int ntaps);
 // Second half of a split-K launch: out = act(sum_s partial[s] + bias [+ resid]) [* bn_scale + bn_shift] [+ img_shift]
 // over all N*Hout*Wout*CoutPad outputs (geometry and epilogue fields taken from the same ConvArgs).
 hipError_t launch_splitk_epilogue(int precision, const ConvArgs& a, hipStream_t s);
@@ -117,6 +123,12 @@ constexpr size_t glob_param_floats() { return (size_t)kGlobIn * kGlobC + 3 * kGl
 // L [N,1,H,W] fp32 (+ l_add), ab [N,2,H,W] fp32 -> rgb [N,H,W,3] u8, lab_q [N,3,H,W] f64 (or nullptr)
 hipError_t launch_lab_post(const float* L, float l_add, const float* ab, unsigned char* rgb, double* lab_q, int N,
                            int H, int W, hipStream_t s);
+
+// Display / full-resolution step (ui/gui_draw.py:280-283, colorize_image.py:123-158): (a, b) planes [H,W] (fp32 or fp64)
+// resized to [oh,ow] -- interp 0 cv2 INTER_CUBIC, 1 scipy zoom order 1, 2 scipy zoom order 0 -- then Lab -> sRGB uint8
+// with L_out [oh,ow] (float64) -> rgb [oh,ow,3]
+hipError_t launch_upsample_lab2rgb(const void* a_plane, const void* b_plane, int src_f64, int H, int W, int interp, const double* L_out,
+                                   int oh, int ow, unsigned char* rgb, hipStream_t s);
 
 // Global statistics (global_stats.prototxt): rgb u8 [N,H,W,3] -> counts [N][313] (uint32, zeroed by the caller) of
 // the 4x4-pooled ab values' nearest centre, and sat_sum [N] (float64, zeroed) = sum of HSV saturation over pixels.

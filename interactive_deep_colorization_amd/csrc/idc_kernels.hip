@@ -26,6 +26,19 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // 16-byte slot held in registers
 
+// in-kernel cycle stamps for the tuning harness (tools/ablate): compiled out of the library
+#ifdef IDC_TIMING
+__device__ long long* g_idc_dbg;
+#define IDC_STAMP(i) do { if (tid == 0) g_idc_dbg[(size_t)blockIdx.x * 16 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define IDC_STAMP(i) do {} while (0)
+#endif
+#ifdef IDC_TIMING_FINE
+#define IDC_STAMP_FINE(i) IDC_STAMP(i)
+#else
+#define IDC_STAMP_FINE(i) do {} while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // MFMA wrappers on 16-byte fragments.  A lane (row/col = lane&15, group g = lane>>4) holds the
 // 16-byte slot (ks*4+g) of its row; the K index it stands for is the same permutation for both
@@ -164,6 +177,7 @@ __global__ __launch_bounds__(WM* WP * 64) void conv_igemm(const ConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wp = wave / WM;
     const int px = lane & 15, g = lane >> 4;
+    IDC_STAMP(0);
 
     // ---- which tile -------------------------------------------------------------------------
     int b = xcd_remap(blockIdx.x, gridDim.x);
@@ -286,6 +300,7 @@ __global__ __launch_bounds__(WM* WP * 64) void conv_igemm(const ConvArgs a) {
         }
     };
     load_halo(kc0);
+    bool first_ = true;
 
     for (int kc = kc0; kc < nkc; ++kc) {
         __syncthreads();                       // every wave is done reading the previous halo
@@ -297,6 +312,7 @@ __global__ __launch_bounds__(WM* WP * 64) void conv_igemm(const ConvArgs a) {
             for (int j = 0; j < N_WITEMS; ++j)
                 *(u32x4*)(wcur + (tid + j * NT) * kSlotBytes) = wreg[j];
             __syncthreads();
+            if (first_) { IDC_STAMP(1); first_ = false; }
             // prefetch the next (tap, chunk) weight tile; it lands in registers under the MFMAs
             {
                 int t2 = t + 1, kc2 = kc;
@@ -350,6 +366,7 @@ __global__ __launch_bounds__(WM* WP * 64) void conv_igemm(const ConvArgs a) {
             for (int j = 0; j < 4; ++j) acc[i][j] = tot[i][j];
     }
 
+    IDC_STAMP(2);
     // ---- epilogue: lane owns couts co0..co0+15 of pixel px in each of its 4 rows ----------------
     const int CoutPad = a.ncg * kCoutGroup;
     const int co0 = (ct * WM + wm) * kCoutGroup + g * 16;
@@ -367,6 +384,11 @@ __global__ __launch_bounds__(WM* WP * 64) void conv_igemm(const ConvArgs a) {
                     *(float4*)(o + ci * 4) = float4{acc[ci][pj][0], acc[ci][pj][1], acc[ci][pj][2], acc[ci][pj][3]};
             }
         }
+        IDC_STAMP(3);
+#ifdef IDC_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        IDC_STAMP(4);
+#endif
         return;
     }
     const bool has_bn = a.bn_scale != nullptr;
@@ -389,6 +411,253 @@ __global__ __launch_bounds__(WM* WP * 64) void conv_igemm(const ConvArgs a) {
                                        a.img_shift ? a.img_shift + (size_t)n * CoutPad + co0 : nullptr);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_click<T, WP, HALO> -- the batch-1 click path (ui/gui_draw.py:272-286 fires it on every
+// drag pixel).  At N = 1 a layer is a chain of dependent memory round trips, not MFMA work: conv_igemm's K loop exposes
+// one L2 round trip (~1 us under load) per tap-step because each step's 16-32 MFMAs per wave are far too short to cover
+// the next weight tile's latency (rocprofv3, profiles/r02a_click_bf16_trace.txt: 20.8 us for a 512->512 layer whose MFMA
+// work is 2.3 us per workgroup).  Here a workgroup's WHOLE K slice is requested at kernel entry instead:
+//   * workgroup = (16 x 4*WP) sites x 64 couts x `kc_per` cin chunks x all taps (one deconv phase's taps);
+//   * every operand goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, nothing to wait for
+//     until the data is needed): the halo tile of each chunk (source-side XOR swizzle, zero rows read a zero page) and the
+//     ntaps weight tiles of each chunk (exact LDS images, idc_layout.h layout 1) -- up to 123 KiB per workgroup;
+//   * taps are then consumed in issue order behind COUNTED vmcnt waits (tap t needs the halo and tiles 0..t: the later
+//     tiles are still in flight while the first MFMAs run), one barrier per wait group;
+//   * split-K over the cin chunks fills the chip (ksplit = nkc / kc_per workgroups per tile); raw fp32 slice sums +
+//     splitk_epilogue as for conv_igemm, or the full fused epilogue when one workgroup owns all of K.
+// Same fragments, MFMA wrappers, fp32 blocked accumulation and epilogue arithmetic as conv_igemm: results are
+// bit-identical to conv_igemm with the same split (the parity tests compare both against the oracle).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int WP, int HALO>
+__global__ __launch_bounds__(WP * 64) void conv_click(const ConvArgs a) {
+    constexpr int NT = WP * 64;
+    constexpr int TW = 16, TH = 4 * WP;
+    constexpr int HWP = TW + 2 * HALO, HHP = TH + 2 * HALO, HROWS = HWP * HHP;
+    constexpr int W_BYTES = kWBlockBytes;                          // 64 couts x 128 B
+    constexpr int N_HITEMS = (HROWS * kSlots + NT - 1) / NT;
+    constexpr int HALO_BYTES = N_HITEMS * NT * kSlotBytes;
+    constexpr int N_WITEMS = (W_BYTES / kSlotBytes) / NT;          // 8 / WP
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wp = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 15, g = lane >> 4;
+    IDC_STAMP(0);
+
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int ksplit = a.ksplit > 1 ? a.ksplit : 1;
+    const int sid = b % ksplit; b /= ksplit;
+    const int txi = b % a.tiles_x; b /= a.tiles_x;
+    const int tyi = b % a.tiles_y; b /= a.tiles_y;
+    const int n = b % a.N; b /= a.N;
+    const int ct = b % a.ncg;
+    const int phase = b / a.ncg;
+    const int ty0 = tyi * TH, tx0 = txi * TW;
+    const int Hs = a.Hs, Ws = a.Ws, si = a.si;
+    const int Win = Ws * si;
+    const int pix_bytes = a.nkc * kRowBytes;
+    const char* const in_img = (const char*)a.in + (size_t)n * (size_t)(Hs * si) * Win * pix_bytes;
+    const int ntaps = a.ntaps;
+    const int kc0 = ksplit > 1 ? sid * a.kc_per : 0;
+    const int kc1 = ksplit > 1 ? (kc0 + a.kc_per < a.nkc ? kc0 + a.kc_per : a.nkc) : a.nkc;
+    const int nch = kc1 - kc0;                                     // chunks of this slice (<= a.kc_per)
+    const int* const tap_dy = a.dy + phase * 9;
+    const int* const tap_dx = a.dx + phase * 9;
+    const int* const tap_tw = a.tw + phase * 9;
+    char* const halo0 = smem;                                      // [chunk][HALO_BYTES]
+    char* const wbuf0 = smem + a.kc_per * HALO_BYTES;              // [chunk][tap][W_BYTES]
+
+    // ---- request everything: halo tiles first (every tap needs them), then the weight tiles in consumption order ----
+    {
+        const char* zero = (const char*)a.zeros;
+#pragma unroll
+        for (int j = 0; j < N_HITEMS; ++j) {
+            const int item = tid + j * NT;
+            const int hr = item >> 3, sig = item & 7;
+            const int hy = hr / HWP, hx = hr - hy * HWP;
+            const int sy = ty0 - HALO + hy, sx = tx0 - HALO + hx;
+            const bool inside = (unsigned)sy < (unsigned)Hs && (unsigned)sx < (unsigned)Ws && item < HROWS * kSlots;
+            const int off = ((sy * si) * Win + sx * si) * pix_bytes + ((sig ^ swz(hr)) * kSlotBytes);
+            for (int c = 0; c < nch; ++c) {
+                const char* src = inside ? in_img + off + (size_t)(kc0 + c) * kRowBytes : zero;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(halo0 + c * HALO_BYTES + (wp * 64 + j * NT) * kSlotBytes), 16, 0, 0);
+            }
+        }
+        const char* const wbase = (const char*)a.wgt + (size_t)ct * kWBlockBytes + (size_t)tid * kSlotBytes;
+        const size_t w_kc_stride = (size_t)a.ncg * kWBlockBytes;
+        const size_t w_tap_stride = w_kc_stride * a.nkc;
+        for (int c = 0; c < nch; ++c)
+            for (int t = 0; t < ntaps; ++t) {
+                const char* src = wbase + (size_t)tap_tw[t] * w_tap_stride + (size_t)(kc0 + c) * w_kc_stride;
+#pragma unroll
+                for (int j = 0; j < N_WITEMS; ++j)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)j * NT * kSlotBytes),
+                                                     (__attribute__((address_space(3))) void*)(wbuf0 + (size_t)(c * ntaps + t) * W_BYTES + (wp * 64 + j * NT) * kSlotBytes), 16, 0, 0);
+            }
+    }
+
+    IDC_STAMP_FINE(5);
+    constexpr bool kBlockedAcc = sizeof(T) == 4;
+    f32x4 acc[4][4], tot[kBlockedAcc ? 4 : 1][kBlockedAcc ? 4 : 1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kBlockedAcc) tot[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    const int wrow_byte = px * kRowBytes;                          // + ci*16 rows
+    const int wsw = px & 7;
+
+    // ---- consume: wait group = one tap (its N_WITEMS pieces per wave); pieces still outstanding after tap (c, t) landed:
+    //      N_WITEMS * (taps that follow).  vmcnt's field holds 0..63: more than that outstanding = wait for at most 63.
+    const int total_steps = nch * ntaps;
+    int step = 0;
+    for (int c = 0; c < nch; ++c) {
+        const char* const halo = halo0 + c * HALO_BYTES;
+        for (int t = 0; t < ntaps; ++t, ++step) {
+            const int left = (total_steps - 1 - step) * N_WITEMS;      // wave-uniform
+            // counted wait as a switch on the (uniform) remaining count; steps land in order
+            if (left >= 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+            else if (left >= 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else if (left >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else if (left >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (left >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (left >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (left >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (left >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (left >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                          // every wave's pieces of this step (and all earlier ones) landed
+            if (step == 0) IDC_STAMP(1);
+            const char* const wcur = wbuf0 + (size_t)(c * ntaps + t) * W_BYTES;
+            const int dy = tap_dy[t], dx = tap_dx[t];
+            int xrow[4];
+#pragma unroll
+            for (int pj = 0; pj < 4; ++pj) xrow[pj] = (wp * 4 + pj + HALO + dy) * HWP + (px + HALO + dx);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int slot = ks * 4 + g;
+                u32x4 wf[4], xf[4];
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci)
+                    wf[ci] = *(const u32x4*)(wcur + wrow_byte + ci * 16 * kRowBytes + ((slot ^ wsw) * kSlotBytes));
+#pragma unroll
+                for (int pj = 0; pj < 4; ++pj)
+                    xf[pj] = *(const u32x4*)(halo + xrow[pj] * kRowBytes + ((slot ^ swz(xrow[pj])) * kSlotBytes));
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+                    for (int pj = 0; pj < 4; ++pj) Mma<T>::run(acc[ci][pj], wf[ci], xf[pj]);
+            }
+        }
+        if (kBlockedAcc) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    tot[i][j] += acc[i][j];
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+        }
+    }
+    if (kBlockedAcc) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = tot[i][j];
+    }
+
+    IDC_STAMP(2);
+    // ---- epilogue (as conv_igemm): lane owns couts co0..co0+15 of pixel px in each of its 4 rows ----
+    const int CoutPad = a.ncg * kCoutGroup;
+    const int co0 = ct * kCoutGroup + g * 16;
+    const int so = a.so, Wout = Ws * so, Hout = Hs * so;
+    const int ro = a.ro[phase], cof = a.co[phase];
+    if (ksplit > 1) {
+        float* const slab = a.partial + (size_t)sid * a.N * Hout * Wout * CoutPad;
+#pragma unroll
+        for (int pj = 0; pj < 4; ++pj) {
+            const int sy = ty0 + wp * 4 + pj, sx = tx0 + px;
+            if (sy < Hs && sx < Ws) {
+                float* o = slab + (((size_t)n * Hout + (sy * so + ro)) * Wout + (sx * so + cof)) * CoutPad + co0;
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci)
+                    *(float4*)(o + ci * 4) = float4{acc[ci][pj][0], acc[ci][pj][1], acc[ci][pj][2], acc[ci][pj][3]};
+            }
+        }
+        IDC_STAMP(3);
+#ifdef IDC_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        IDC_STAMP(4);
+#endif
+        return;
+    }
+    const bool has_bn = a.bn_scale != nullptr;
+    float bias[16], bsc[16], bsh[16];
+    load16(bias, a.bias + co0);
+    if (has_bn) { load16(bsc, a.bn_scale + co0); load16(bsh, a.bn_shift + co0); }
+#pragma unroll
+    for (int pj = 0; pj < 4; ++pj) {
+        const int sy = ty0 + wp * 4 + pj, sx = tx0 + px;
+        if (sy < Hs && sx < Ws) {
+            const size_t opix = ((size_t)n * Hout + (sy * so + ro)) * Wout + (sx * so + cof);
+            float v[16];
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[ci * 4 + r] = acc[ci][pj][r];
+            epilogue16<sizeof(T) == 2>(a, v, opix * CoutPad + co0, bias, bsc, bsh, has_bn,
+                                       a.img_shift ? a.img_shift + (size_t)n * CoutPad + co0 : nullptr);
+        }
+    }
+}
+
+static constexpr int click_halo_bytes(int wp, int halo) {
+    const int nt = wp * 64;
+    const int hrows = (16 + 2 * halo) * (4 * wp + 2 * halo);
+    return ((hrows * kSlots + nt - 1) / nt) * nt * kSlotBytes;
+}
+// largest kc_per (cin chunks per workgroup) whose halo tiles + weight tiles fit the 160 KiB of LDS; 0 = does not fit
+int conv_click_max_chunks(int wp, int halo, int ntaps) {
+    const int per = click_halo_bytes(wp, halo) + ntaps * kWBlockBytes;
+    return (160 * 1024) / per;
+}
+
+template <typename T, int WP, int HALO>
+static hipError_t launch_click_t(const ConvArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)a.kc_per * (click_halo_bytes(WP, HALO) + a.ntaps * kWBlockBytes);
+    const long long blocks = (long long)a.tiles_x * a.tiles_y * a.N * a.ncg * a.nphase * (a.ksplit > 1 ? a.ksplit : 1);
+    if (blocks <= 0 || blocks > 0x7fffffffLL || lds > 160 * 1024 || a.zeros == nullptr) return hipErrorInvalidValue;
+    if (a.ksplit > 1 && a.partial == nullptr) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((conv_click<T, WP, HALO>), dim3((unsigned)blocks), dim3(WP * 64), lds, s, a);
+    return hipGetLastError();
+}
+
+#define IDC_FOR_EACH_CLICK(X) X(4, 1) X(4, 2) X(2, 1) X(2, 2) X(1, 1) X(1, 2)
+
+hipError_t launch_conv_click(int precision, int wp, int halo, const ConvArgs& a, hipStream_t s) {
+#define X(WP, HL) \
+    if (wp == WP && halo == HL) return precision == 1 ? launch_click_t<__bf16, WP, HL>(a, s) : launch_click_t<float, WP, HL>(a, s);
+    IDC_FOR_EACH_CLICK(X)
+#undef X
+    return hipErrorInvalidConfiguration;
+}
+
+static hipError_t init_kernels_click() {
+    hipError_t e;
+#define X(WP, HL)                                                                                                          \
+    e = hipFuncSetAttribute((const void*)conv_click<__bf16, WP, HL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    if (e != hipSuccess) return e;                                                                                         \
+    e = hipFuncSetAttribute((const void*)conv_click<float, WP, HL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+    if (e != hipSuccess) return e;
+    IDC_FOR_EACH_CLICK(X)
+#undef X
+    return hipSuccess;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -434,6 +703,8 @@ hipError_t init_kernels() {
     e = set_lds_attr<__bf16, WM, WP, HL>(); if (e != hipSuccess) return e;
     IDC_FOR_EACH_CONV(X)
 #undef X
+    e = init_kernels_click();
+    if (e != hipSuccess) return e;
     return init_kernels_v2();
 }
 
@@ -534,17 +805,6 @@ hipError_t launch_splitk_epilogue(int precision, const ConvArgs& a, hipStream_t 
 //   * swizzle (row>>1)&7: conflict-free for 32-row x 2-k-group fragments (tools/bank model).
 // ================================================================================================
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-#ifdef IDC_TIMING
-__device__ long long* g_idc_dbg;
-#define IDC_STAMP(i) do { if (tid == 0) g_idc_dbg[(size_t)blockIdx.x * 16 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
-#else
-#define IDC_STAMP(i) do {} while (0)
-#endif
-#ifdef IDC_TIMING_FINE
-#define IDC_STAMP_FINE(i) IDC_STAMP(i)
-#else
-#define IDC_STAMP_FINE(i) do {} while (0)
-#endif
 
 template <int WCO, int WPX, int HALO>
 __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs a) {
@@ -2051,6 +2311,119 @@ hipError_t launch_lab_post(const float* L, float l_add, const float* ab, unsigne
     const long long npix = (long long)N * H * W;
     const int blocks = (int)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096);
     hipLaunchKernelGGL(lab_post_kernel, dim3(blocks), dim3(256), 0, s, L, l_add, ab, rgb, lab_q, npix, H * W);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// upsample_lab2rgb: the display step that follows every net_forward in the GUI (ui/gui_draw.py:280-283):
+//     ab_win = cv2.resize(output_ab, (win_w, win_h), interpolation=cv2.INTER_CUBIC); lab2rgb(concat(l_win, ab_win)) -> uint8
+// and the full-resolution getters (data/colorize_image.py:123-158): scipy.ndimage.zoom(ab, order=1 | 0) + lab2rgb with
+// the full-resolution L.  One thread per OUTPUT pixel: interpolate (a, b) from the resident planes, then the float64
+// Lab -> sRGB -> uint8 of lab_post_kernel.
+//   interp 0: cv2 INTER_CUBIC as resize.cpp computes it for 64F data -- source coordinate fx = (float)((dx + .5) * scale
+//             - .5), taps sx-1 .. sx+2 clamped to the image, float32 Keys coefficients with A = -0.75
+//             (interpolateCubic), rows first (four horizontal sums in double, left to right), then the vertical sum;
+//   interp 1: scipy.ndimage.zoom(order=1): coordinate = dst * (in - 1) / (out - 1), linear, double;
+//   interp 2: scipy.ndimage.zoom(order=0): nearest of the same coordinate (floor(c + .5)).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lab_to_rgb_u8(double L, double a, double b, unsigned char* q) {
+    const double Mi[3][3] = {{3.240481343200526, -1.5371515162713185, -0.4985363261688878},
+                             {-0.9692549499965682, 1.8759900014898907, 0.04155592655829284},
+                             {0.05564663913517716, -0.20404133836651123, 1.0573110696453443}};
+    const double white[3] = {0.95047, 1.0, 1.08883};
+    double f[3];
+    f[1] = (L + 16.0) / 116.0;
+    f[0] = a / 500.0 + f[1];
+    f[2] = fmax(f[1] - b / 200.0, 0.0);
+    double xyz[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xyz[i] = (f[i] > 0.2068966 ? f[i] * f[i] * f[i] : (f[i] - 16.0 / 116.0) / 7.787) * white[i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double lin = xyz[0] * Mi[c][0] + xyz[1] * Mi[c][1] + xyz[2] * Mi[c][2];
+        double s = lin > 0.0031308 ? 1.055 * pow(fmax(lin, 0.0), 1.0 / 2.4) - 0.055 : 12.92 * lin;
+        s = fmin(fmax(s, 0.0), 1.0);
+        q[c] = (unsigned char)(s * 255.0);
+    }
+}
+
+__device__ __forceinline__ void cubic_coeffs(float x, float* c) {       // cv2 interpolateCubic
+    const float A = -0.75f;
+    c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+    c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+    c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+    c[3] = 1.f - c[0] - c[1] - c[2];
+}
+
+template <typename S>
+__global__ __launch_bounds__(256) void upsample_lab2rgb_kernel(const S* __restrict__ pa, const S* __restrict__ pb, int H, int W,
+                                                               int interp, const double* __restrict__ Lout, int oh, int ow,
+                                                               unsigned char* __restrict__ rgb) {
+    const long long npix = (long long)oh * ow;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
+        const int dy = (int)(p / ow), dx = (int)(p - (long long)dy * ow);
+        double ab[2];
+        if (interp == 0) {
+            const double sc_x = (double)W / ow, sc_y = (double)H / oh;
+            float fx = (float)((dx + 0.5) * sc_x - 0.5), fy = (float)((dy + 0.5) * sc_y - 0.5);
+            const int sx = (int)floorf(fx), sy = (int)floorf(fy);
+            fx -= sx; fy -= sy;
+            float cx[4], cy[4];
+            cubic_coeffs(fx, cx); cubic_coeffs(fy, cy);
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                const S* src = ch ? pb : pa;
+                double rows[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    int yy = sy - 1 + k; yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
+                    double v = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int xx = sx - 1 + j; xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
+                        v += (double)src[(size_t)yy * W + xx] * (double)cx[j];
+                    }
+                    rows[k] = v;
+                }
+                ab[ch] = rows[0] * (double)cy[0] + rows[1] * (double)cy[1] + rows[2] * (double)cy[2] + rows[3] * (double)cy[3];
+            }
+        } else {
+            const double zy = oh > 1 ? (double)(H - 1) / (double)(oh - 1) : 0.0, zx = ow > 1 ? (double)(W - 1) / (double)(ow - 1) : 0.0;
+            const double cyy = dy * zy, cxx = dx * zx;
+            if (interp == 2) {
+                int yy = (int)floor(cyy + 0.5), xx = (int)floor(cxx + 0.5);
+                yy = yy > H - 1 ? H - 1 : yy; xx = xx > W - 1 ? W - 1 : xx;
+                ab[0] = (double)pa[(size_t)yy * W + xx]; ab[1] = (double)pb[(size_t)yy * W + xx];
+            } else {
+                const int y0 = (int)floor(cyy), x0 = (int)floor(cxx);
+                const double ty = cyy - y0, tx = cxx - x0;
+                const int y1 = y0 + 1 > H - 1 ? H - 1 : y0 + 1, x1 = x0 + 1 > W - 1 ? W - 1 : x0 + 1;   // weight 0 there
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {
+                    const S* src = ch ? pb : pa;
+                    const double v00 = (double)src[(size_t)y0 * W + x0], v01 = (double)src[(size_t)y0 * W + x1];
+                    const double v10 = (double)src[(size_t)y1 * W + x0], v11 = (double)src[(size_t)y1 * W + x1];
+                    ab[ch] = v00 * ((1.0 - ty) * (1.0 - tx)) + v01 * ((1.0 - ty) * tx) + v10 * (ty * (1.0 - tx)) + v11 * (ty * tx);
+                }
+            }
+        }
+        unsigned char q[3];
+        lab_to_rgb_u8(Lout[p], ab[0], ab[1], q);
+        rgb[p * 3 + 0] = q[0]; rgb[p * 3 + 1] = q[1]; rgb[p * 3 + 2] = q[2];
+    }
+}
+
+hipError_t launch_upsample_lab2rgb(const void* a_plane, const void* b_plane, int src_f64, int H, int W, int interp, const double* L_out,
+                                   int oh, int ow, unsigned char* rgb, hipStream_t s) {
+    const long long npix = (long long)oh * ow;
+    if (npix <= 0 || interp < 0 || interp > 2) return hipErrorInvalidValue;
+    const int blocks = (int)((npix + 255) / 256 < 8192 ? (npix + 255) / 256 : 8192);
+    if (src_f64)
+        hipLaunchKernelGGL(upsample_lab2rgb_kernel<double>, dim3(blocks), dim3(256), 0, s, (const double*)a_plane, (const double*)b_plane, H, W,
+                           interp, L_out, oh, ow, rgb);
+    else
+        hipLaunchKernelGGL(upsample_lab2rgb_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)a_plane, (const float*)b_plane, H, W,
+                           interp, L_out, oh, ow, rgb);
     return hipGetLastError();
 }
 

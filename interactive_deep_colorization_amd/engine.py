@@ -116,12 +116,16 @@ class HipColorizer(object):
         N.check(self.lib.idc_create(self.device, self.H, self.W, self.max_batch, self._prec, self._flags,
                                     ctypes.byref(self._h)))
         self._blob_keepalive = None
+        self._pinned = []
 
     # ---- lifetime -------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             self.lib.idc_destroy(self._h)
             self._h = ctypes.c_void_p()
+            for ptr in getattr(self, "_pinned", []):
+                self.lib.idc_free_host(ctypes.c_void_p(ptr))
+            self._pinned = []
 
     def __del__(self):
         try:
@@ -325,6 +329,68 @@ class HipColorizer(object):
 
     def sync(self):
         self._chk(self.lib.idc_sync(self._h))
+
+    # ---- stream ordering against a caller stream (e.g. torch.cuda.current_stream().cuda_stream) --------------
+    def stream_wait(self, caller_stream):
+        """Work enqueued on this handle after the call waits for everything already enqueued on ``caller_stream``."""
+        self._chk(self.lib.idc_stream_wait(self._h, ctypes.c_void_p(int(caller_stream))))
+
+    def stream_signal(self, caller_stream):
+        """Work enqueued on ``caller_stream`` after the call waits for everything this handle has enqueued."""
+        self._chk(self.lib.idc_stream_signal(self._h, ctypes.c_void_p(int(caller_stream))))
+
+    # ---- overlapped host transfers: two slots (SURVEY.md 7.2 #6) ----------------------------------------------
+    def pinned_empty(self, shape, dtype=np.float32):
+        """numpy array over pinned host memory (``idc_alloc_host``): ``forward_async`` transfers it in place.  The
+        memory belongs to this object and is released by ``close()``: do not use the array afterwards."""
+        shape = tuple(int(x) for x in shape)
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        ptr = self.lib.idc_alloc_host(nbytes)
+        if not ptr:
+            raise MemoryError("idc_alloc_host(%d) failed" % nbytes)
+        self._pinned.append(ptr)
+        buf = (ctypes.c_char * nbytes).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def forward_async(self, slot, L_mc, ab, mask, out, maskcent=0.0):
+        """Enqueue one batch on pipeline slot 0/1 (float32 C-contiguous arrays, used in place -- keep them alive and
+        untouched until ``wait(slot)``); ``out`` (n,2,H,W) float32 receives the result."""
+        n = L_mc.shape[0]
+        for a, shp in ((L_mc, (n, 1, self.H, self.W)), (ab, (n, 2, self.H, self.W)), (mask, (n, 1, self.H, self.W)), (out, (n, 2, self.H, self.W))):
+            if a.dtype != np.float32 or not a.flags.c_contiguous or tuple(a.shape) != shp:
+                raise ValueError("forward_async needs float32 C-contiguous arrays of shape %s" % (shp,))
+        self._chk(self.lib.idc_forward_async(self._h, int(slot), int(n), _fptr(L_mc), _fptr(ab), _fptr(mask), float(maskcent), _fptr(out)))
+
+    def wait(self, slot):
+        self._chk(self.lib.idc_wait(self._h, int(slot)))
+
+    # ---- RCCL weight broadcast through the C ABI (one call per rank) -------------------------------------------
+    def comm_unique_id(self):
+        buf = (ctypes.c_char * N.IDC_UNIQUE_ID_BYTES)()
+        N.check(self.lib.idc_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)))
+        return bytes(buf)
+
+    def broadcast_weights(self, unique_id, rank, world, root=0):
+        if len(unique_id) != N.IDC_UNIQUE_ID_BYTES:
+            raise ValueError("unique id must be %d bytes" % N.IDC_UNIQUE_ID_BYTES)
+        buf = ctypes.create_string_buffer(bytes(unique_id), N.IDC_UNIQUE_ID_BYTES)
+        self._chk(self.lib.idc_broadcast_weights(self._h, ctypes.cast(buf, ctypes.c_void_p), int(rank), int(world), int(root)))
+
+    # ---- display / full-resolution step on the device (ui/gui_draw.py:280-283, colorize_image.py:123-158) ------
+    def upsample_lab2rgb(self, L_out, source="output_ab", interp="cubic", img=0):
+        """ab planes of slot ``img`` resized to ``L_out.shape`` and combined with that L plane -> (oh, ow, 3) uint8.
+        source: 'output_ab' (refreshed, float64), 'output_ab_raw', 'input_ab'; interp: 'cubic' (cv2 INTER_CUBIC),
+        'linear' / 'nearest' (scipy.ndimage.zoom order 1 / 0)."""
+        Ld = np.ascontiguousarray(np.asarray(L_out, dtype=np.float64))
+        if Ld.ndim == 3 and Ld.shape[0] == 1:
+            Ld = Ld[0]
+        oh, ow = Ld.shape
+        rgb = np.empty((oh, ow, 3), np.uint8)
+        src = {"output_ab": N.IDC_SRC_OUTPUT_AB, "output_ab_raw": N.IDC_SRC_OUTPUT_AB_RAW, "input_ab": N.IDC_SRC_INPUT_AB}[source]
+        itp = {"cubic": N.IDC_INTERP_CUBIC, "linear": N.IDC_INTERP_LINEAR, "nearest": N.IDC_INTERP_NEAREST}[interp]
+        self._chk(self.lib.idc_upsample_lab2rgb(self._h, int(img), src, itp, int(oh), int(ow), Ld.ctypes.data_as(ctypes.c_void_p),
+                                                rgb.ctypes.data_as(ctypes.c_void_p)))
+        return rgb
 
     @property
     def stream(self):

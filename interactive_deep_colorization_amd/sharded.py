@@ -35,11 +35,11 @@ def init_process_group(backend=None):
     rank, local_rank, world = dist_env()
     if world == 1 and not dist.is_initialized():
         return rank, local_rank, world
+    if backend is None:
+        backend = dist.get_backend() if dist.is_initialized() else ("nccl" if torch.cuda.is_available() else "gloo")
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)          # also when the caller created the group: torch's "current device" must be ours
     if not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -63,9 +63,15 @@ class ShardedColorizer(object):
         self.weights_broadcast_ms = None
 
     # ---- the one collective -------------------------------------------------------------------
-    def broadcast_weights(self, packed_blob=None, src=0):
+    def broadcast_weights(self, packed_blob=None, src=0, transport="torch"):
         """Rank ``src`` passes the packed blob (uint8 ndarray from ``engine.pack_weights``); the
-        others pass None.  After the call every rank's engine holds the weights."""
+        others pass None.  After the call every rank's engine holds the weights.
+
+        ``transport='torch'``: ``torch.distributed.broadcast`` on a uint8 tensor (RCCL when the group is ``nccl``; the
+        receivers' engines adopt the device memory the broadcast landed in; ``gloo`` groups move host bytes -- the CPU
+        tests and the single-GPU dry run of bench.py).  ``transport='c_abi'``: the library's own
+        ``idc_broadcast_weights`` (``ncclBroadcast`` from librccl, communicator created from a unique id that travels
+        through the existing process group) -- the path a non-Python host would use."""
         import time
 
         import torch
@@ -77,21 +83,34 @@ class ShardedColorizer(object):
             self.engine.set_weights_blob(packed_blob)
             self.weights_broadcast_ms = 0.0
             return
+        if transport == "c_abi":
+            if self.rank == src:
+                if packed_blob is None or int(packed_blob.size) != nbytes:
+                    raise ValueError("rank %d must provide a %d-byte packed blob" % (src, nbytes))
+                self.engine.set_weights_blob(packed_blob)
+            box = [self.engine.comm_unique_id() if self.rank == src else None]
+            dist.broadcast_object_list(box, src=src)
+            dist.barrier()
+            t0 = time.perf_counter()
+            self.engine.broadcast_weights(box[0], self.rank, self.world_size, src)
+            self.weights_broadcast_ms = (time.perf_counter() - t0) * 1e3
+            return
         on_gpu = dist.get_backend() == "nccl"
+        gpu_dev = torch.device("cuda", int(getattr(self.engine, "device", 0))) if on_gpu else None
         if self.rank == src:
             if packed_blob is None or int(packed_blob.size) != nbytes:
                 raise ValueError("rank %d must provide a %d-byte packed blob" % (src, nbytes))
             t = torch.from_numpy(np.ascontiguousarray(packed_blob, dtype=np.uint8))
             if on_gpu:
-                t = t.cuda(non_blocking=False)
+                t = t.to(gpu_dev, non_blocking=False)
         else:
-            t = torch.empty(nbytes, dtype=torch.uint8, device="cuda" if on_gpu else "cpu")
+            t = torch.empty(nbytes, dtype=torch.uint8, device=gpu_dev if on_gpu else "cpu")      # the ENGINE's device, explicitly
         if on_gpu:
-            torch.cuda.synchronize()
+            torch.cuda.synchronize(gpu_dev)
         t0 = time.perf_counter()
         dist.broadcast(t, src=src)
         if on_gpu:
-            torch.cuda.synchronize()
+            torch.cuda.synchronize(gpu_dev)
         self.weights_broadcast_ms = (time.perf_counter() - t0) * 1e3
         if on_gpu:
             # adopt the device memory the broadcast landed in; the tensor is kept alive by the engine

@@ -273,9 +273,13 @@ def test_device_colour_post_matches_host_formulas(golden, make_sd):
     np.testing.assert_allclose(labq[0], ocs.rgb2lab(rgb[0]).transpose(2, 0, 1), atol=1e-9)
     out, rgb2, labq2 = e.forward_rgb(g["L_mc"], g["ab"], g["mask"], 0.0, l_cent=50.0)
     assert np.abs(out - g["out_ab"]).max() <= FP32_TOL["he"]
+    # the fused form adds l_cent to the float32 L_mc plane in float64; the two-call form is handed float32(L_mc + 50):
+    # the last-bit difference in L may flip a value sitting exactly on a truncation edge (1 LSB, a handful of values)
     rgb3, labq3 = e.lab2rgb(L, out)
-    np.testing.assert_array_equal(rgb2, rgb3)
-    np.testing.assert_array_equal(labq2, labq3)
+    dd = np.abs(rgb2.astype(int) - rgb3.astype(int))
+    assert dd.max() <= 1 and (dd > 0).mean() <= 1e-4, (dd.max(), (dd > 0).mean())
+    same = (dd.max(axis=-1) == 0)[:, None]                                   # pixels whose uint8 triple agrees: identical refresh
+    np.testing.assert_array_equal(np.where(same, labq2, 0), np.where(same, labq3, 0))
 
 
 @pytest.mark.parametrize("precision,tiles", [("fp32", "auto"), ("bf16", "small"), ("bf16", "large")])

@@ -66,11 +66,23 @@ int main(int argc, char** argv) {
         for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) { int ph = r * 2 + c; a.ro[ph] = r; a.co[ph] = c;
             for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) { int t = ph * 9 + i * 2 + j; a.dy[t] = T_d[r][i]; a.dx[t] = T_d[c][j]; a.tw[t] = T_k[r][i] * 4 + T_k[c][j]; } }
     }
+    void* zeros = nullptr; float* partial = nullptr;
+    if (v2 == 4 || v2 == 5) {   // batch-1 small-tile comparison: 4 = conv_click (whole K slice by LDS-DMA), 5 = conv_igemm with split-K
+        const int ksplit = argc > 10 ? atoi(argv[10]) : a.nkc;
+        a.kc_per = (a.nkc + ksplit - 1) / ksplit; a.ksplit = (a.nkc + a.kc_per - 1) / a.kc_per;
+        if (a.ksplit < 2) { a.ksplit = 1; a.kc_per = a.nkc; }
+        CK(hipMalloc(&zeros, 256)); CK(hipMemset(zeros, 0, 256)); a.zeros = zeros;
+        CK(hipMalloc((void**)&partial, (size_t)a.ksplit * N * HW * HW * C * 4)); a.partial = partial;
+        if (v2 == 4) wm = 1;
+        a.tiles_x = (HW + 15) / 16; a.tiles_y = (HW + 4 * wp - 1) / (4 * wp);
+        printf("small-tile mode %s: ksplit %d, kc_per %d, %d workgroups\n", v2 == 4 ? "conv_click" : "conv_igemm", a.ksplit, a.kc_per,
+               a.tiles_x * a.tiles_y * N * (a.ncg / wm) * a.ksplit);
+    }
     idc::ConvConfig cfg{wm, wp};
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-#define LAUNCH() (v2 == 2 ? idc::launch_conv_ds(a, 0) : v2 ? idc::launch_conv_v2(cfg, halo, a, 0) : idc::launch_conv(prec, cfg, halo, a, 0))
+#define LAUNCH() (v2 == 4 ? idc::launch_conv_click(prec, wp, halo, a, 0) : v2 == 5 ? idc::launch_conv(prec, cfg, halo, a, 0) : v2 == 2 ? idc::launch_conv_ds(a, 0) : v2 ? idc::launch_conv_v2(cfg, halo, a, 0) : idc::launch_conv(prec, cfg, halo, a, 0))
 #ifdef IDC_TIMING
-    int nb = a.tiles_x * a.tiles_y * N * (a.ncg / wm) * a.nphase;
+    int nb = a.tiles_x * a.tiles_y * N * (a.ncg / wm) * a.nphase * (a.ksplit > 1 ? a.ksplit : 1);
     long long* dbg; CK(hipMalloc(&dbg, (size_t)nb * 128)); CK(hipMemset(dbg, 0, (size_t)nb * 128));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(idc::g_idc_dbg), &dbg, sizeof(dbg)));
 #endif

@@ -51,21 +51,14 @@ def child():
 
 
 def main():
-    combos = []
-    base = {}
-    combos.append(("default", base))
-    for goal in (384, 512, 768, 1024, 2048):
-        combos.append(("sk_goal=%d" % goal, {"IDC_SK_GOAL_BF16": str(goal), "IDC_SK_GOAL_FP32": str(goal), "IDC_SK_BELOW_BF16": "512", "IDC_SK_BELOW_FP32": "512"}))
-    for wp in (1, 2, 4):
-        for goal in (512, 1024):
-            combos.append(("wp=%d sk_goal=%d" % (wp, goal), {"IDC_ST_FORCE_WP": str(wp), "IDC_SK_GOAL_BF16": str(goal), "IDC_SK_GOAL_FP32": str(goal),
-                                                              "IDC_SK_BELOW_BF16": "1024", "IDC_SK_BELOW_FP32": "1024"}))
-    for wm in (1,):
-        for wp in (2, 4):
-            combos.append(("wm=1 wp=%d sk_goal=1024" % wp, {"IDC_ST_FORCE_WM": "1", "IDC_ST_FORCE_WP": str(wp), "IDC_SK_GOAL_BF16": "1024", "IDC_SK_GOAL_FP32": "1024",
-                                                             "IDC_SK_BELOW_BF16": "1024", "IDC_SK_BELOW_FP32": "1024"}))
-    combos.append(("v2 from 32 blocks", {"IDC_V2_MIN_BLOCKS": "32"}))
-    combos.append(("v2 from 64 blocks", {"IDC_V2_MIN_BLOCKS": "64"}))
+    combos = [("default (conv_click)", {})]
+    combos.append(("click off", {"IDC_CLICK": "0"}))
+    for wp in (4, 2):
+        for goal in (128, 256, 512):
+            for mx in (1024, 4096):
+                if wp == 4 and goal == 256 and mx == 1024:
+                    continue
+                combos.append(("click wp=%d goal=%d max=%d" % (wp, goal, mx), {"IDC_CLICK_WP": str(wp), "IDC_CLICK_GOAL": str(goal), "IDC_CLICK_MAX_WGS": str(mx)}))
     results = []
     for name, env in combos:
         e = dict(os.environ); e.update(env)

@@ -1,6 +1,6 @@
 // MFMA issue-rate microbenchmark for MI355X: what v_mfma_f32_32x32x16_bf16 sustains on this box, by operand data.
 //
-//   mfma_peak [seconds-per-arm]          (default 10)
+//   mfma_peak [seconds-per-arm] [zeros|ones|random]     (default 10 s, all three arms)
 //
 // Arms: operand fill = zeros | constant 1.0 | uniform random [-1,1) bf16 (per lane, per register; the accumulators
 // see a random walk), each held for `seconds` of back-to-back launches of 256 CUs x 8 waves x 8 independent
@@ -55,6 +55,7 @@ static unsigned short bf16_of(float f) {
 
 int main(int argc, char** argv) {
     const double seconds = argc > 1 ? atof(argv[1]) : 10.0;
+    const int only = argc > 2 ? (argv[2][0] == 'z' ? 0 : argv[2][0] == 'o' ? 1 : 2) : -1;
     const int blocks = 256, threads = 512, iters = 20000;
     const size_t nthr = (size_t)blocks * threads;
     u32x4* d_ops; float* d_out; long long* d_clk;
@@ -63,6 +64,7 @@ int main(int argc, char** argv) {
     const double flop_per_launch = 8.0 * 2 * 32 * 32 * 16 * (double)iters * (threads / 64) * blocks;
     const char* names[3] = {"zeros", "constant 1.0", "uniform random [-1,1)"};
     for (int fill = 0; fill < 3; ++fill) {
+        if (only >= 0 && fill != only) continue;
         std::vector<unsigned short> h(nthr * 6 * 8);
         unsigned long long st = 0x9e3779b97f4a7c15ull;
         for (auto& v : h) {
@@ -85,8 +87,8 @@ int main(int argc, char** argv) {
             double cyc = 0, wall = 0; for (int b = 0; b < blocks; ++b) { cyc += hc[2 * b]; wall += hc[2 * b + 1]; }
             const double ghz = cyc / wall * 0.1;                                        // wall_clock64 = 100 MHz
             const double tf = flop_per_launch * n / ms / 1e9;
-            const double cyc_per_mfma = (cyc / blocks) / ((double)iters * 8 * 2);        // per SIMD: 2 waves share it
-            printf("  t=%5.1fs  %7.1f TFLOP/s  shader clock %.3f GHz  %.2f cycles per MFMA per SIMD\n", elapsed + ms / 1e3, tf, ghz, cyc_per_mfma);
+            const double interval = ghz * 1e9 * 1024.0 * 32768.0 / (tf * 1e12);          // shader cycles between MFMAs on one SIMD (32 = issue-bound)
+            printf("  t=%5.1fs  %7.1f TFLOP/s  shader clock %.3f GHz  MFMA issue interval %.1f cycles per SIMD\n", elapsed + ms / 1e3, tf, ghz, interval);
             elapsed += ms / 1e3; sum_tf += tf; ++nwin; if (tf > best) best = tf;
         }
         printf("  mean %.1f TFLOP/s (best window %.1f) = %.3f of the nominal 2500\n", sum_tf / nwin, best, sum_tf / nwin / 2500.0);
