@@ -425,9 +425,10 @@ struct SmallTileTuning {
     int sk_below[2] = {env_int("IDC_SK_BELOW_FP32", 256), env_int("IDC_SK_BELOW_BF16", 128)};   // split K when fewer tiles than this
     int sk_goal[2] = {env_int("IDC_SK_GOAL_FP32", 512), env_int("IDC_SK_GOAL_BF16", 256)};      // ... until about this many workgroups
     int v2_min_blocks = env_int("IDC_V2_MIN_BLOCKS", 128);      // large-tile bf16 kernel from this many workgroups on
+    int v2_half_tiles = env_int("IDC_V2_HALF_TILES", 1);        // 4-wave large tiles for grids of 128..255 workgroups
     int click = env_int("IDC_CLICK", 1);                        // conv_click for small launches (the batch-1 click path)
     int click_max_wgs = env_int("IDC_CLICK_MAX_WGS", 1024);     // ... when its grid has at most this many workgroups
-    int click_goal = env_int("IDC_CLICK_GOAL", 256);            // ... split K over the cin chunks until about this many exist
+    int click_goal = env_int("IDC_CLICK_GOAL", 512);            // ... split K over the cin chunks until about this many exist (same-box A/B: 512 beats 256 by 1.5 % bf16 / 3 % fp32)
     int click_wp = env_int("IDC_CLICK_WP", 4);                  // rows-of-4 per workgroup (4 = 16x16 sites, 256 threads)
 };
 static const SmallTileTuning& tuning() { static const SmallTileTuning t; return t; }
@@ -497,9 +498,16 @@ static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, i
     // 128 couts x (32x16 sites); used when its grid covers at least half of the 256 CUs
     L.v2 = false;
     if (precision == IDC_BF16 && v2_eligible(*L.spec) && g_tile_policy != 1) {
-        const ConvConfig c2 = (a.ncg % 4 == 0) ? ConvConfig{4, 2} : ConvConfig{2, 4};
-        const int tx = (Ws + 31) / 32, ty = (Hs + 4 * c2.wp - 1) / (4 * c2.wp);
-        const long long blocks = (long long)tx * ty * n_policy * (a.ncg / c2.wm) * a.nphase;
+        ConvConfig c2 = (a.ncg % 4 == 0) ? ConvConfig{4, 2} : ConvConfig{2, 4};
+        int tx = (Ws + 31) / 32, ty = (Hs + 4 * c2.wp - 1) / (4 * c2.wp);
+        long long blocks = (long long)tx * ty * n_policy * (a.ncg / c2.wm) * a.nphase;
+        // between one half and one full wave of workgroups (batch-1 conv10_2: 128 tiles on 256 CUs): the 4-wave tile
+        // 128 couts x (32 x 8 sites) doubles the grid
+        if (blocks >= tuning().v2_min_blocks && blocks < 256 && a.nphase == 1 && tuning().v2_half_tiles) {
+            c2 = ConvConfig{2, 2};
+            ty = (Hs + 4 * c2.wp - 1) / (4 * c2.wp);
+            blocks = (long long)tx * ty * n_policy * (a.ncg / c2.wm) * a.nphase;
+        }
         if (g_tile_policy == 2 || blocks >= tuning().v2_min_blocks) {
             L.v2 = true; L.cfg = c2; a.tiles_x = tx; a.tiles_y = ty;
             a.ksplit = 1; a.kc_per = a.nkc;
@@ -509,16 +517,21 @@ static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, i
     // batch-1 click path: small launches are chains of exposed memory round trips in conv_igemm's K loop; conv_click
     // requests a workgroup's whole K slice at entry (as many cin chunks as fit in LDS next to their halo tiles)
     L.click = false;
-    if ((g_click < 0 ? tuning().click : g_click) && g_tile_policy != 1 && (L.spec->kind == kConv3x3 || L.spec->kind == kDeconv4x4)) {
+    // ... "small" = fewer than v2_min_blocks big tiles (the criterion that hands a layer to the throughput kernels, applied to
+    // every precision and cout width): conv_igemm's ring loop is the better kernel once the K loop is long and the chip full
+    const int wm_big = a.ncg % 4 == 0 ? 4 : (a.ncg % 2 == 0 ? 2 : 1), rows_big = wm_big == 4 ? 8 : 16;
+    const long long big_tiles = (long long)((Ws + 31) / 32) * ((Hs + rows_big - 1) / rows_big) * n_policy * (a.ncg / wm_big) * a.nphase;
+    if ((g_click < 0 ? tuning().click : g_click) && g_tile_policy != 1 && big_tiles < tuning().v2_min_blocks &&
+        (L.spec->kind == kConv3x3 || L.spec->kind == kDeconv4x4)) {
         int wp = tuning().click_wp;
         while (wp > 1 && 4 * wp > Hs * 2) wp >>= 1;               // tiny images: do not launch mostly-empty tiles
         const int maxc = conv_click_max_chunks(wp, L.halo, a.ntaps);
         const int tx = (Ws + 15) / 16, ty = (Hs + 4 * wp - 1) / (4 * wp);
         const long long tiles = (long long)tx * ty * n_policy * a.ncg * a.nphase;
         if (maxc >= 1) {
-            int kc_per = maxc < a.nkc ? maxc : a.nkc;
-            while (kc_per > 1 && tiles * ((a.nkc + kc_per - 1) / kc_per) < tuning().click_goal) --kc_per;
-            if (g_splitk_policy == 1 && kc_per < a.nkc) kc_per = 0;           // "never split": only when all of K fits
+            int kc_per = maxc < a.nkc ? maxc : a.nkc;                         // split-K policy "never": one workgroup walks all chunks
+            if (g_splitk_policy == 0)
+                while (kc_per > 1 && tiles * ((a.nkc + kc_per - 1) / kc_per) < tuning().click_goal) --kc_per;
             if (g_splitk_policy == 2) kc_per = 1;
             if (kc_per >= 1) {
                 const int ks = (a.nkc + kc_per - 1) / kc_per;

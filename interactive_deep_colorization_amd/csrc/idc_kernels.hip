@@ -415,30 +415,42 @@ __global__ __launch_bounds__(WM* WP * 64) void conv_igemm(const ConvArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // conv_click<T, WP, HALO> -- the batch-1 click path (ui/gui_draw.py:272-286 fires it on every
-// drag pixel).  At N = 1 a layer is a chain of dependent memory round trips, not MFMA work: conv_igemm's K loop exposes
-// one L2 round trip (~1 us under load) per tap-step because each step's 16-32 MFMAs per wave are far too short to cover
-// the next weight tile's latency (rocprofv3, profiles/r02a_click_bf16_trace.txt: 20.8 us for a 512->512 layer whose MFMA
-// work is 2.3 us per workgroup).  Here a workgroup's WHOLE K slice is requested at kernel entry instead:
-//   * workgroup = (16 x 4*WP) sites x 64 couts x `kc_per` cin chunks x all taps (one deconv phase's taps);
-//   * every operand goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, nothing to wait for
-//     until the data is needed): the halo tile of each chunk (source-side XOR swizzle, zero rows read a zero page) and the
-//     ntaps weight tiles of each chunk (exact LDS images, idc_layout.h layout 1) -- up to 123 KiB per workgroup;
-//   * taps are then consumed in issue order behind COUNTED vmcnt waits (tap t needs the halo and tiles 0..t: the later
-//     tiles are still in flight while the first MFMAs run), one barrier per wait group;
-//   * split-K over the cin chunks fills the chip (ksplit = nkc / kc_per workgroups per tile); raw fp32 slice sums +
-//     splitk_epilogue as for conv_igemm, or the full fused epilogue when one workgroup owns all of K.
-// Same fragments, MFMA wrappers, fp32 blocked accumulation and epilogue arithmetic as conv_igemm: results are
-// bit-identical to conv_igemm with the same split (the parity tests compare both against the oracle).
+// drag pixel).  At N = 1 a layer has one wave per SIMD and a short K loop, so nothing hides a latency unless the kernel
+// does it itself.  In-kernel stamps of conv_igemm on a 512->512 layer at 32x32 (tools/ablate, profiles/r02_click_anatomy.txt):
+// 7.5 k cycles of prologue, 13 k of main loop for 4.9 k of MFMA issue (every tap-step pays the LDS round trip of its
+// fragments and a barrier with nothing else in flight), 12 k of epilogue (fp32 slice sums stored as 16-byte pieces of 32
+// different lines per instruction).  This kernel is the same GEMM with the three phases rebuilt around one wave per SIMD:
+//   * workgroup = (16 x 4*WP) sites x 64 couts x the cin chunks [kc0, kc1) of one split-K slice x all taps; a "step" is one
+//     (chunk, tap) pair = 32 MFMAs per wave (bf16);
+//   * operands travel global -> LDS by LDS-DMA only (no VGPR round trip, nothing to wait for until the data is needed):
+//     the chunk's halo tile (source-side XOR swizzle; out-of-image rows read a zero page) and one 8 KiB weight tile per
+//     step through a 4-deep ring, requested THREE steps ahead, counted vmcnt waits (never 0 in the loop);
+//   * the fragments of step s+1 are read (16 ds_read_b128 into a second register set) while the MFMAs of step s issue, and
+//     the barrier that publishes step s+1's tile sits at the top of step s: a step's MFMAs never wait for LDS;
+//   * ring slot reuse: the tile of step s+3 lands in the slot of step s-1, whose fragment reads were consumed by MFMAs every
+//     wave issued before it reached the barrier at the top of step s (program order) -- no read can be in flight;
+//   * next chunk's halo tile: second halo buffer, requested at the chunk's tap 1;
+//   * split-K epilogue: the wave's 64 px x 64 couts fp32 tile goes through LDS once, so that every store instruction
+//     writes four whole 256-byte runs; non-split launches use the fused epilogue of conv_igemm.
+// Same fragments, MFMA wrappers, fp32 blocked accumulation and epilogue arithmetic as conv_igemm.
 // ------------------------------------------------------------------------------------------------
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 template <typename T, int WP, int HALO>
-__global__ __launch_bounds__(WP * 64) void conv_click(const ConvArgs a) {
+__global__ __launch_bounds__(WP * 64, 2) void conv_click(const ConvArgs a) {
     constexpr int NT = WP * 64;
+    // bf16: cross-step fragment prefetch (two register sets).  fp32 steps are 16x longer in MFMA time (exact-fp32 MFMA runs
+    // at 1/16 of the bf16 rate) and need the registers for the blocked accumulators: one fragment set, the step's own
+    // tile is published at its top, and two workgroups per CU (<= 256 registers, <= 80 KiB LDS) cover each other's waits.
+    constexpr bool PF = sizeof(T) == 2;
     constexpr int TW = 16, TH = 4 * WP;
     constexpr int HWP = TW + 2 * HALO, HHP = TH + 2 * HALO, HROWS = HWP * HHP;
     constexpr int W_BYTES = kWBlockBytes;                          // 64 couts x 128 B
-    constexpr int N_HITEMS = (HROWS * kSlots + NT - 1) / NT;
-    constexpr int HALO_BYTES = N_HITEMS * NT * kSlotBytes;
-    constexpr int N_WITEMS = (W_BYTES / kSlotBytes) / NT;          // 8 / WP
+    constexpr int NH = (HROWS * kSlots + NT - 1) / NT;             // halo DMA pieces per wave
+    constexpr int HALO_BYTES = NH * NT * kSlotBytes;
+    constexpr int NW = (W_BYTES / kSlotBytes) / NT;                // weight DMA pieces per wave and step (8 / WP)
+    constexpr int RING = 4;
+    static_assert(NW + NH <= 63 && 3 * NW + NH <= 63, "vmcnt field");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -463,44 +475,67 @@ __global__ __launch_bounds__(WP * 64) void conv_click(const ConvArgs a) {
     const int ntaps = a.ntaps;
     const int kc0 = ksplit > 1 ? sid * a.kc_per : 0;
     const int kc1 = ksplit > 1 ? (kc0 + a.kc_per < a.nkc ? kc0 + a.kc_per : a.nkc) : a.nkc;
-    const int nch = kc1 - kc0;                                     // chunks of this slice (<= a.kc_per)
-    const int* const tap_dy = a.dy + phase * 9;
-    const int* const tap_dx = a.dx + phase * 9;
-    const int* const tap_tw = a.tw + phase * 9;
-    char* const halo0 = smem;                                      // [chunk][HALO_BYTES]
-    char* const wbuf0 = smem + a.kc_per * HALO_BYTES;              // [chunk][tap][W_BYTES]
-
-    // ---- request everything: halo tiles first (every tap needs them), then the weight tiles in consumption order ----
-    {
-        const char* zero = (const char*)a.zeros;
+    const int nch = kc1 - kc0;
+    const int total = nch * ntaps;
+    // tap tables live in lanes 0..8 of two VGPRs and are read with v_readlane: a scalar load inside the step loop would
+    // share lgkmcnt with the fragment reads (SMEM returns out of order: every use costs an lgkmcnt(0))
+    int v_roff = 0, v_tw = 0;
 #pragma unroll
-        for (int j = 0; j < N_HITEMS; ++j) {
-            const int item = tid + j * NT;
-            const int hr = item >> 3, sig = item & 7;
-            const int hy = hr / HWP, hx = hr - hy * HWP;
-            const int sy = ty0 - HALO + hy, sx = tx0 - HALO + hx;
-            const bool inside = (unsigned)sy < (unsigned)Hs && (unsigned)sx < (unsigned)Ws && item < HROWS * kSlots;
-            const int off = ((sy * si) * Win + sx * si) * pix_bytes + ((sig ^ swz(hr)) * kSlotBytes);
-            for (int c = 0; c < nch; ++c) {
-                const char* src = inside ? in_img + off + (size_t)(kc0 + c) * kRowBytes : zero;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(halo0 + c * HALO_BYTES + (wp * 64 + j * NT) * kSlotBytes), 16, 0, 0);
-            }
-        }
-        const char* const wbase = (const char*)a.wgt + (size_t)ct * kWBlockBytes + (size_t)tid * kSlotBytes;
-        const size_t w_kc_stride = (size_t)a.ncg * kWBlockBytes;
-        const size_t w_tap_stride = w_kc_stride * a.nkc;
-        for (int c = 0; c < nch; ++c)
-            for (int t = 0; t < ntaps; ++t) {
-                const char* src = wbase + (size_t)tap_tw[t] * w_tap_stride + (size_t)(kc0 + c) * w_kc_stride;
-#pragma unroll
-                for (int j = 0; j < N_WITEMS; ++j)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)j * NT * kSlotBytes),
-                                                     (__attribute__((address_space(3))) void*)(wbuf0 + (size_t)(c * ntaps + t) * W_BYTES + (wp * 64 + j * NT) * kSlotBytes), 16, 0, 0);
-            }
+    for (int t = 0; t < kMaxTaps; ++t) {                           // all 27 scalar loads in one round trip (entries past ntaps are 0)
+        const int ro_ = a.dy[phase * 9 + t] * HWP + a.dx[phase * 9 + t], tw_ = a.tw[phase * 9 + t];
+        v_roff = lane == t ? ro_ : v_roff;
+        v_tw = lane == t ? tw_ : v_tw;
     }
+    const int nhalo = a.kc_per > 1 ? 2 : 1;
+    char* const halo0 = smem;                                      // [nhalo][HALO_BYTES]
+    char* const ring = smem + nhalo * HALO_BYTES;                  // [RING][W_BYTES]
 
+    const char* const wbase = (const char*)a.wgt + (size_t)ct * kWBlockBytes + (size_t)tid * kSlotBytes;
+    const size_t w_kc_stride = (size_t)a.ncg * kWBlockBytes;
+    const size_t w_tap_stride = w_kc_stride * a.nkc;
+    // weight tiles are requested in step order; (ic, it) = chunk / tap of the next step to request
+    int ic = 0, it = 0, is = 0;
+    auto dma_w_next = [&]() {
+        if (is < total) {
+            const char* src = wbase + (size_t)__builtin_amdgcn_readlane(v_tw, it) * w_tap_stride + (size_t)(kc0 + ic) * w_kc_stride;
+            char* const dst = ring + (is & (RING - 1)) * W_BYTES + wp * 64 * kSlotBytes;
+#pragma unroll
+            for (int j = 0; j < NW; ++j)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)j * NT * kSlotBytes),
+                                                 (__attribute__((address_space(3))) void*)(dst + j * NT * kSlotBytes), 16, 0, 0);
+        }
+        ++is;
+        if (++it == ntaps) { it = 0; ++ic; }
+    };
+    // the first three weight tiles are requested before the halo plan is even computed (their addresses need nothing but
+    // the tile indices): the 100+ VALU of the plan run under their flight
     IDC_STAMP_FINE(5);
+    dma_w_next(); dma_w_next(); dma_w_next();
+    // halo plan: this lane's source offset per piece (fixed for the kernel), -1 = zero row
+    int hoff[NH];
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+        const int item = tid + j * NT;
+        const int hr = item >> 3, sig = item & 7;
+        const int hy = hr / HWP, hx = hr - hy * HWP;
+        const int sy = ty0 - HALO + hy, sx = tx0 - HALO + hx;
+        const bool inside = (unsigned)sy < (unsigned)Hs && (unsigned)sx < (unsigned)Ws && item < HROWS * kSlots;
+        hoff[j] = inside ? ((sy * si) * Win + sx * si) * pix_bytes + ((sig ^ swz(hr)) * kSlotBytes) : -1;
+    }
+    auto dma_halo = [&](int c) {
+        const char* const base = in_img + (size_t)(kc0 + c) * kRowBytes;
+        char* const dst = halo0 + (c & (nhalo - 1)) * HALO_BYTES + wp * 64 * kSlotBytes;
+#pragma unroll
+        for (int j = 0; j < NH; ++j) {
+            const char* src = hoff[j] >= 0 ? base + hoff[j] : (const char*)a.zeros;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + j * NT * kSlotBytes), 16, 0, 0);
+        }
+    };
+    dma_halo(0);
+    IDC_STAMP_FINE(6);
+    IDC_STAMP_FINE(7);
+
     constexpr bool kBlockedAcc = sizeof(T) == 4;
     f32x4 acc[4][4], tot[kBlockedAcc ? 4 : 1][kBlockedAcc ? 4 : 1];
 #pragma unroll
@@ -510,51 +545,39 @@ __global__ __launch_bounds__(WP * 64) void conv_click(const ConvArgs a) {
             acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (kBlockedAcc) tot[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-    const int wrow_byte = px * kRowBytes;                          // + ci*16 rows
-    const int wsw = px & 7;
+    const int wfrag = px * kRowBytes + ((g ^ (px & 7)) * kSlotBytes);   // weight row px (+ ci*16 rows), logical slot g (ks flips bit 2)
 
-    // ---- consume: wait group = one tap (its N_WITEMS pieces per wave); pieces still outstanding after tap (c, t) landed:
-    //      N_WITEMS * (taps that follow).  vmcnt's field holds 0..63: more than that outstanding = wait for at most 63.
-    const int total_steps = nch * ntaps;
-    int step = 0;
-    for (int c = 0; c < nch; ++c) {
-        const char* const halo = halo0 + c * HALO_BYTES;
-        for (int t = 0; t < ntaps; ++t, ++step) {
-            const int left = (total_steps - 1 - step) * N_WITEMS;      // wave-uniform
-            // counted wait as a switch on the (uniform) remaining count; steps land in order
-            if (left >= 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
-            else if (left >= 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-            else if (left >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-            else if (left >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else if (left >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else if (left >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (left >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if (left >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (left >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                          // every wave's pieces of this step (and all earlier ones) landed
-            if (step == 0) IDC_STAMP(1);
-            const char* const wcur = wbuf0 + (size_t)(c * ntaps + t) * W_BYTES;
-            const int dy = tap_dy[t], dx = tap_dx[t];
-            int xrow[4];
+    struct Frags { u32x4 w[2][4], x[2][4]; };
+    // fragments of step (c, t) from LDS: ring slot `slot`, halo buffer of chunk c
+    auto read_frags = [&](Frags& f, int c, int t, int slot) {
+        const int roff = __builtin_amdgcn_readlane(v_roff, t);
+        const char* const wcur = ring + slot * W_BYTES;
+        const char* const halo = halo0 + (c & (nhalo - 1)) * HALO_BYTES;
+        int xa[4];
 #pragma unroll
-            for (int pj = 0; pj < 4; ++pj) xrow[pj] = (wp * 4 + pj + HALO + dy) * HWP + (px + HALO + dx);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int slot = ks * 4 + g;
-                u32x4 wf[4], xf[4];
-#pragma unroll
-                for (int ci = 0; ci < 4; ++ci)
-                    wf[ci] = *(const u32x4*)(wcur + wrow_byte + ci * 16 * kRowBytes + ((slot ^ wsw) * kSlotBytes));
-#pragma unroll
-                for (int pj = 0; pj < 4; ++pj)
-                    xf[pj] = *(const u32x4*)(halo + xrow[pj] * kRowBytes + ((slot ^ swz(xrow[pj])) * kSlotBytes));
-#pragma unroll
-                for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-                    for (int pj = 0; pj < 4; ++pj) Mma<T>::run(acc[ci][pj], wf[ci], xf[pj]);
-            }
+        for (int pj = 0; pj < 4; ++pj) {
+            const int xr = (wp * 4 + pj + HALO) * HWP + (px + HALO) + roff;
+            xa[pj] = xr * kRowBytes + ((g ^ swz(xr)) * kSlotBytes);
         }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci) f.w[ks][ci] = *(const u32x4*)(wcur + ((wfrag + ci * 16 * kRowBytes) ^ (ks * 4 * kSlotBytes)));
+#pragma unroll
+            for (int pj = 0; pj < 4; ++pj) f.x[ks][pj] = *(const u32x4*)(halo + (xa[pj] ^ (ks * 4 * kSlotBytes)));
+        }
+    };
+    auto mma_step = [&](const Frags& f) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+                for (int pj = 0; pj < 4; ++pj) Mma<T>::run(acc[ci][pj], f.w[ks][ci], f.x[ks][pj]);
+    };
+
+    int sc = 0, st = 0;                                            // chunk / tap of step s
+    auto fold_chunk = [&]() {
         if (kBlockedAcc) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -563,6 +586,65 @@ __global__ __launch_bounds__(WP * 64) void conv_click(const ConvArgs a) {
                     tot[i][j] += acc[i][j];
                     acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
+        }
+    };
+    if constexpr (PF) {
+        // step 0 published: its tile and the halo (requested last) have landed, so has everything else requested so far
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        IDC_STAMP(1);
+        Frags fa, fb;
+        read_frags(fa, 0, 0, 0);
+        // one step: publish step s+1 (counted wait + barrier), request step s+3 (+ the next chunk's halo at tap 1), issue
+        // the MFMAs of step s from `cur` while the fragments of step s+1 load into `nxt`
+        auto step = [&](int s, const Frags& cur, Frags& nxt) {
+            const bool more = s + 1 < total;
+            int nc = sc, nt = st + 1;
+            if (nt == ntaps) { nt = 0; ++nc; }
+            if (more) {
+                // pieces that may still be in flight once the tile of step s+1 (and, for a chunk's first step, its halo) is
+                // in: the tile of step s+2, plus the next chunk's halo when it was requested after the tile of step s+1
+                const bool w2 = s + 2 < total;
+                const bool halo_behind = nhalo == 2 && sc + 1 < nch && (st == 2 || st == 3) && nt != 0;
+                if (w2 && halo_behind) wait_vmcnt<NW + NH>();
+                else if (w2) wait_vmcnt<NW>();
+                else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+            }
+            dma_w_next();                                          // step s+3 -> the slot of step s-1 (reads consumed before the barrier)
+            if (st == 1 && sc + 1 < nch) dma_halo(sc + 1);         // -> the buffer of chunk c-1 (last read for step (c-1, last))
+            // (after the last step this reads a ring slot / halo buffer nobody needs: harmless, and branch-free -- behind a
+            //  branch hipcc joins the paths with an lgkmcnt(0) in front of the MFMAs)
+            read_frags(nxt, nc, nt, (s + 1) & (RING - 1));
+            mma_step(cur);
+            if (nt == 0) fold_chunk();
+            sc = nc; st = nt;
+        };
+        int s = 0;
+        for (; s + 1 < total; s += 2) {
+            step(s, fa, fb);
+            step(s + 1, fb, fa);
+        }
+        if (s < total) step(s, fa, fb);
+    } else {
+        bool first = true;
+        Frags f;
+        for (int s = 0; s < total; ++s) {
+            // publish step s: the tiles of steps s+1, s+2 (and a halo requested after the tile of step s) may stay in flight
+            const int ahead = total - 1 - s < 2 ? total - 1 - s : 2;
+            const bool halo_behind = nhalo == 2 && sc + 1 < nch && st >= 2 && st <= 4;
+            if (s == 0) wait_vmcnt<0>();                          // the first halo tile was requested last
+            else if (ahead == 2 && halo_behind) wait_vmcnt<2 * NW + NH>();
+            else if (ahead == 2) wait_vmcnt<2 * NW>();
+            else if (ahead == 1) wait_vmcnt<NW>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (first) { IDC_STAMP(1); first = false; }
+            dma_w_next();                                          // step s+3 -> the slot of step s-1
+            if (st == 1 && sc + 1 < nch) dma_halo(sc + 1);
+            read_frags(f, sc, st, s & (RING - 1));
+            mma_step(f);
+            if (++st == ntaps) { st = 0; ++sc; fold_chunk(); }
         }
     }
     if (kBlockedAcc) {
@@ -573,22 +655,35 @@ __global__ __launch_bounds__(WP * 64) void conv_click(const ConvArgs a) {
     }
 
     IDC_STAMP(2);
-    // ---- epilogue (as conv_igemm): lane owns couts co0..co0+15 of pixel px in each of its 4 rows ----
+    // ---- epilogue: lane owns couts co0..co0+15 of pixel px in each of its 4 rows ----
     const int CoutPad = a.ncg * kCoutGroup;
     const int co0 = ct * kCoutGroup + g * 16;
     const int so = a.so, Wout = Ws * so, Hout = Hs * so;
     const int ro = a.ro[phase], cof = a.co[phase];
     if (ksplit > 1) {
+        // raw fp32 slice sums: per pixel row, [16 px][64 couts] fp32 through a wave-private 4 KiB LDS tile so that a store
+        // instruction covers four whole 256-byte runs (lane l: pixel l/16, 16-byte piece l%16) instead of 64 scattered pieces
         float* const slab = a.partial + (size_t)sid * a.N * Hout * Wout * CoutPad;
+        __builtin_amdgcn_s_barrier();                              // every wave is done with the halo / ring
+        char* const tb = smem + wp * 4096;
 #pragma unroll
         for (int pj = 0; pj < 4; ++pj) {
-            const int sy = ty0 + wp * 4 + pj, sx = tx0 + px;
-            if (sy < Hs && sx < Ws) {
-                float* o = slab + (((size_t)n * Hout + (sy * so + ro)) * Wout + (sx * so + cof)) * CoutPad + co0;
 #pragma unroll
-                for (int ci = 0; ci < 4; ++ci)
-                    *(float4*)(o + ci * 4) = float4{acc[ci][pj][0], acc[ci][pj][1], acc[ci][pj][2], acc[ci][pj][3]};
+            for (int ci = 0; ci < 4; ++ci)                         // slot (g*4 + ci) of row px, XOR-swizzled by the row
+                *(f32x4*)(tb + px * 256 + (((g * 4 + ci) ^ px) * 16)) = acc[ci][pj];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int sy = ty0 + wp * 4 + pj;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = i * 4 + (lane >> 4), piece = lane & 15;
+                const f32x4 v = *(const f32x4*)(tb + row * 256 + ((piece ^ row) * 16));
+                const int sx = tx0 + row;
+                if (sy < Hs && sx < Ws) {
+                    float* o = slab + (((size_t)n * Hout + (sy * so + ro)) * Wout + (sx * so + cof)) * CoutPad + ct * kCoutGroup + piece * 4;
+                    *(f32x4*)o = v;
+                }
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         IDC_STAMP(3);
 #ifdef IDC_TIMING
@@ -615,6 +710,11 @@ __global__ __launch_bounds__(WP * 64) void conv_click(const ConvArgs a) {
                                        a.img_shift ? a.img_shift + (size_t)n * CoutPad + co0 : nullptr);
         }
     }
+    IDC_STAMP(3);
+#ifdef IDC_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    IDC_STAMP(4);
+#endif
 }
 
 static constexpr int click_halo_bytes(int wp, int halo) {
@@ -622,18 +722,25 @@ static constexpr int click_halo_bytes(int wp, int halo) {
     const int hrows = (16 + 2 * halo) * (4 * wp + 2 * halo);
     return ((hrows * kSlots + nt - 1) / nt) * nt * kSlotBytes;
 }
-// largest kc_per (cin chunks per workgroup) whose halo tiles + weight tiles fit the 160 KiB of LDS; 0 = does not fit
+static size_t click_lds_bytes(int wp, int halo, int kc_per) {
+    const size_t main_loop = (size_t)(kc_per > 1 ? 2 : 1) * click_halo_bytes(wp, halo) + 4 * (size_t)kWBlockBytes;
+    const size_t epilogue = (size_t)wp * 4096;
+    return main_loop > epilogue ? main_loop : epilogue;
+}
+// cin chunks one workgroup may walk: unbounded (the weight tiles stream through a ring, halo tiles alternate between two
+// buffers); kept as a function so that the engine's split policy has one place to ask
 int conv_click_max_chunks(int wp, int halo, int ntaps) {
-    const int per = click_halo_bytes(wp, halo) + ntaps * kWBlockBytes;
-    return (160 * 1024) / per;
+    (void)wp; (void)halo; (void)ntaps;
+    return 1 << 20;
 }
 
 template <typename T, int WP, int HALO>
 static hipError_t launch_click_t(const ConvArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)a.kc_per * (click_halo_bytes(WP, HALO) + a.ntaps * kWBlockBytes);
+    const size_t lds = click_lds_bytes(WP, HALO, a.kc_per);
     const long long blocks = (long long)a.tiles_x * a.tiles_y * a.N * a.ncg * a.nphase * (a.ksplit > 1 ? a.ksplit : 1);
     if (blocks <= 0 || blocks > 0x7fffffffLL || lds > 160 * 1024 || a.zeros == nullptr) return hipErrorInvalidValue;
     if (a.ksplit > 1 && a.partial == nullptr) return hipErrorInvalidValue;
+    if (a.ntaps < 4 || a.kc_per < 1) return hipErrorInvalidConfiguration;     // the halo-prefetch schedule assumes >= 4 taps per chunk
     hipLaunchKernelGGL((conv_click<T, WP, HALO>), dim3((unsigned)blocks), dim3(WP * 64), lds, s, a);
     return hipGetLastError();
 }
@@ -1098,7 +1205,9 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
         __syncthreads();                                       // every wave left the halo / weight tiles
         float* const tb = (float*)(smem + wave * 8192);
         float* const part = (float*)(smem + (NT / 64) * 8192);  // fused head: [wave][pj][32 px][2]
-        const int rr = lane >> 3, cc = lane & 7;
+        // (lane index recomputed from the hardware counter: held across the K loop it costs hipcc a spilled register)
+        const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        const int rr = lane_e >> 3, cc = lane_e & 7;
         const int co8 = cow + cc * 8;
         float cs[8], ct[8], hw0[8], hw1[8];
         if (has_bn) {
@@ -1337,7 +1446,7 @@ static hipError_t launch_conv_v2_t(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-#define IDC_FOR_EACH_CONV_V2(X) X(4, 2, 0) X(4, 2, 1) X(4, 2, 2) X(2, 4, 0) X(2, 4, 1) X(2, 4, 2)
+#define IDC_FOR_EACH_CONV_V2(X) X(4, 2, 0) X(4, 2, 1) X(4, 2, 2) X(2, 4, 0) X(2, 4, 1) X(2, 4, 2) X(2, 2, 0) X(2, 2, 1) X(2, 2, 2)
 
 __global__ void conv_ds_fused(const ConvArgs a);
 __global__ void conv1_block_fused(const ConvArgs a);
@@ -1431,9 +1540,13 @@ __global__ __launch_bounds__(512, 2) void conv_ds_fused(const ConvArgs a) {
 
     u32x4 hreg[S_ITEMS];
     auto load_halo_S = [&](int kc2) {
+        // (the item -> address arithmetic is recomputed per chunk on purpose: hoisted out of the chunk loop its 64-bit
+        //  addresses cost hipcc two spilled register pairs at the 256-VGPR cap)
+        int tid_ = tid;
+        asm volatile("" : "+v"(tid_));
 #pragma unroll
         for (int j = 0; j < S_ITEMS; ++j) {
-            const int item = tid + j * NT;
+            const int item = tid_ + j * NT;
             const int hr = item >> 3, sig = item & 7;          // LDS row (de-interleaved order) and physical slot
             const int hy = hr / SW, rem = hr - hy * SW;
             const int par = rem >= 33 ? 1 : 0, hx = 2 * (rem - par * 33) + par;
@@ -1445,9 +1558,11 @@ __global__ __launch_bounds__(512, 2) void conv_ds_fused(const ConvArgs a) {
         }
     };
     auto load_halo_D = [&](int kc) {
+        int tid_ = tid;
+        asm volatile("" : "+v"(tid_));
 #pragma unroll
         for (int j = 0; j < D_ITEMS; ++j) {
-            const int item = tid + j * NT;
+            const int item = tid_ + j * NT;
             const int hr = item >> 3, sig = item & 7;
             const int hy = hr / DW, hx = hr - hy * DW;
             const int Y = y0 - 1 + hy, X = x0 - 1 + hx;

@@ -45,9 +45,9 @@ def record(config, precision, style, images, out, ref):
 
 
 @pytest.mark.parametrize("precision,style,images,bound", [
-    ("bf16", "torch", (0, 7, 19, 31), (0.6, 0.06)),
+    ("bf16", "torch", (0, 7, 19, 31), (0.3, 0.05)),          # measured 0.14 / 0.022 (profiles/parity_r02.json); stated bound 0.6 / 0.06
     ("bf16", "he", (7, 20), (20.0, 2.0)),
-    ("fp32", "torch", (0, 31), (1e-3, None)),
+    ("fp32", "torch", (0, 31), (2e-4, None)),                # measured 3.1e-5; the BASELINE target is 1e-3
     ("fp32", "he", (5,), (3e-3, None)),
 ])
 def test_config3_batch32_against_the_oracle(make_sd, precision, style, images, bound):
@@ -68,9 +68,13 @@ def test_config3_batch32_against_the_oracle(make_sd, precision, style, images, b
         assert row["mean_abs"] <= bound[1], row
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_config5_512_global_hints_against_the_oracle(precision):
-    sd = weights.add_global_branch(weights.make_state_dict(5, "he", include_class=False), 5)
+@pytest.mark.parametrize("precision,style", [("fp32", "torch"), ("fp32", "he"), ("bf16", "he")])
+def test_config5_512_global_hints_against_the_oracle(precision, style):
+    """fp32: torch-init weights at the BASELINE bound 1e-3 against the fp32 oracle; he-style weights (full tanh range, the
+    stress case) against the FLOAT64 oracle at 3e-3 -- at 512x512 two fp32 implementations of this 30-layer net sit ~2e-3
+    from the float64 result each (summation order), so their mutual distance is recorded, not bounded at 3e-3."""
+    import torch
+    sd = weights.add_global_branch(weights.make_state_dict(5, style, include_class=False), 5)
     nb = 8 if precision == "bf16" else 2
     L, ab, m = workloads.random_batch(nb, 512, seed=9)
     ab = ab * 0; m = m * 0
@@ -82,9 +86,15 @@ def test_config5_512_global_hints_against_the_oracle(precision):
     e.close()
     idx = [1] if precision == "fp32" else [3]
     ref = siggraph_torch.forward(sd, L[idx], ab[idx], m[idx], 0.0, glob=glob[idx], sat=sat[idx])
-    row = record("configs[4] 512x512 global hints N=%d" % nb, precision, "he", idx, out[idx], ref)
-    if precision == "fp32":
-        assert row["max_abs"] <= 3e-3, row
+    row = record("configs[4] 512x512 global hints N=%d" % nb, precision, style, idx, out[idx], ref)
+    if precision == "fp32" and style == "torch":
+        assert row["max_abs"] <= 1e-3, row
+    elif precision == "fp32":
+        ref64 = siggraph_torch.forward(sd, L[idx], ab[idx], m[idx], 0.0, glob=glob[idx], sat=sat[idx], dtype=torch.float64)
+        row64 = record("configs[4] 512x512 global hints N=%d vs float64 oracle" % nb, precision, style, idx, out[idx], ref64)
+        oracle_noise = float(np.abs(ref.astype(np.float64) - ref64).max())
+        assert row64["max_abs"] <= 3e-3, (row64, oracle_noise)
+        assert row["max_abs"] <= 6e-3, row
     else:
         # bf16 through 30 layers, he-style weights, 4x the pixels of the 256x256 cases: bulk + tail stated separately
         assert row["mean_abs"] <= 2.0 and row["q999"] <= 20.0 and row["rel_rms"] <= 0.06 and row["max_abs"] <= 45.0, row

@@ -51,14 +51,13 @@ def child():
 
 
 def main():
-    combos = [("default (conv_click)", {})]
-    combos.append(("click off", {"IDC_CLICK": "0"}))
-    for wp in (4, 2):
-        for goal in (128, 256, 512):
-            for mx in (1024, 4096):
-                if wp == 4 and goal == 256 and mx == 1024:
-                    continue
-                combos.append(("click wp=%d goal=%d max=%d" % (wp, goal, mx), {"IDC_CLICK_WP": str(wp), "IDC_CLICK_GOAL": str(goal), "IDC_CLICK_MAX_WGS": str(mx)}))
+    combos = []
+    for rep in range(2):                                            # interleaved repeats: boxes and clock states drift
+        combos.append(("default #%d" % rep, {}))
+        combos.append(("v2 half tiles off #%d" % rep, {"IDC_V2_HALF_TILES": "0"}))
+        combos.append(("click off #%d" % rep, {"IDC_CLICK": "0"}))
+        combos.append(("click off, half tiles off #%d" % rep, {"IDC_CLICK": "0", "IDC_V2_HALF_TILES": "0"}))
+        combos.append(("click goal 512 #%d" % rep, {"IDC_CLICK_GOAL": "512"}))
     results = []
     for name, env in combos:
         e = dict(os.environ); e.update(env)
