@@ -426,6 +426,8 @@ struct SmallTileTuning {
     int sk_goal[2] = {env_int("IDC_SK_GOAL_FP32", 512), env_int("IDC_SK_GOAL_BF16", 256)};      // ... until about this many workgroups
     int v2_min_blocks = env_int("IDC_V2_MIN_BLOCKS", 128);      // large-tile bf16 kernel from this many workgroups on
     int v2_half_tiles = env_int("IDC_V2_HALF_TILES", 1);        // 4-wave large tiles for grids of 128..255 workgroups
+    int v2_force22 = env_int("IDC_V2_FORCE22", 0);
+    int v2_22_nkc = env_int("IDC_V2_22_NKC", 2);
     int click = env_int("IDC_CLICK", 1);                        // conv_click for small launches (the batch-1 click path)
     int click_max_wgs = env_int("IDC_CLICK_MAX_WGS", 1024);     // ... when its grid has at most this many workgroups
     int click_goal = env_int("IDC_CLICK_GOAL", 512);            // ... split K over the cin chunks until about this many exist (same-box A/B: 512 beats 256 by 1.5 % bf16 / 3 % fp32)
@@ -503,7 +505,14 @@ static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, i
         long long blocks = (long long)tx * ty * n_policy * (a.ncg / c2.wm) * a.nphase;
         // between one half and one full wave of workgroups (batch-1 conv10_2: 128 tiles on 256 CUs): the 4-wave tile
         // 128 couts x (32 x 8 sites) doubles the grid
-        if (blocks >= tuning().v2_min_blocks && blocks < 256 && a.nphase == 1 && tuning().v2_half_tiles) {
+        // ... and the same 4-wave tile wherever a CU walks several tiles with a short K loop each (128-cout layers, and
+        // layers with <= v2_22_nkc cin chunks): two 4-wave workgroups share a CU (75.5 KiB of LDS each) and run out of
+        // step, so one's prologue / epilogue hides under the other's MFMAs.  Same-box A/B at N = 32 (profiles/
+        // r02_tile22_ab.txt): conv10_2 -9.5 %, conv2_1 -8..14 %, conv2_2 -6 %, conv9_2 -6..12 %, conv3_1 -22 %; the
+        // 512->512 trunk (one tile per CU, long K) is 1-2 % (dilated: 15 %) slower with it and keeps the 8-wave tile.
+        const int force22 = tuning().v2_force22;     // experiment switch: 0 = rule above, 1 = never, 2 = everywhere
+        const bool rule22 = force22 == 2 || (force22 == 0 && (c2.wm == 2 || a.nkc <= tuning().v2_22_nkc) && blocks >= 256);
+        if (a.nphase == 1 && ((blocks >= tuning().v2_min_blocks && blocks < 256 && tuning().v2_half_tiles) || rule22)) {
             c2 = ConvConfig{2, 2};
             ty = (Hs + 4 * c2.wp - 1) / (4 * c2.wp);
             blocks = (long long)tx * ty * n_policy * (a.ncg / c2.wm) * a.nphase;
