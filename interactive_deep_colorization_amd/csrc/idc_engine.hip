@@ -378,6 +378,7 @@ struct idc_context {
 #define HIPCHK(ctx, expr)                                                                                  \
     do {                                                                                                   \
         hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) (void)hipGetLastError();   /* reported through our own status: do not leave it sticky for the caller's runtime */ \
         if (e_ != hipSuccess)                                                                              \
             return fail((ctx) ? &(ctx)->err : nullptr, IDC_ERR_HIP, "%s failed: %s (%s:%d)", #expr,        \
                         hipGetErrorString(e_), __FILE__, __LINE__);                                        \
@@ -658,10 +659,8 @@ static int alloc_graph(idc_context* c) {
         HIPCHK(c, hipMalloc((void**)&c->d_glob_vec, nb * kGlobC * 4));
         HIPCHK(c, hipMemset(c->d_glob_in, 0, nb * kGlobIn * 4));
     }
-    c->n_timed = (int)c->layers.size() + 3;
-    c->ev.resize((size_t)c->n_timed * 2 * kProfRing);
-    for (auto& e : c->ev) HIPCHK(c, hipEventCreate(&e));
-    return IDC_OK;
+    c->n_timed = (int)c->layers.size() + 3;           // profiling events (2240 per handle) are created by idc_set_profiling, not here:
+    return IDC_OK;                                    // a process holding many handles must not exhaust the runtime's signal pool
 }
 
 static int run_graph(idc_context* c, int n, const float* dL, const float* dab, const float* dmask, float maskcent,
@@ -1423,8 +1422,9 @@ int idc_free_host(void* p) {
 
 static bool is_pinned(const void* p) {
     hipPointerAttribute_t at;
-    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return at.type == hipMemoryTypeHost;
+    const hipError_t e = hipPointerGetAttributes(&at, p);
+    (void)hipGetLastError();                      // pageable memory is "invalid value" to this query: not an error of ours, never sticky
+    return e == hipSuccess && at.type == hipMemoryTypeHost;
 }
 
 static int ensure_pipeline(idc_context* h) {
@@ -1695,6 +1695,11 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
 
 int idc_set_profiling(idc_handle h, int on) {
     if (!h) return fail(nullptr, IDC_ERR_INVALID_ARG, "null handle");
+    if (on != 0 && h->ev.empty()) {
+        HIPCHK(h, hipSetDevice(h->device));
+        h->ev.assign((size_t)h->n_timed * 2 * kProfRing, nullptr);
+        for (auto& e : h->ev) HIPCHK(h, hipEventCreate(&e));
+    }
     h->profiling = on == 2 ? 2 : (on != 0 ? 1 : 0);
     h->prof_count = 0;
     return IDC_OK;
@@ -1702,6 +1707,7 @@ int idc_set_profiling(idc_handle h, int on) {
 
 int idc_layer_times_ms(idc_handle h, float* ms, int capacity) {
     if (!h || !ms) return fail(h ? &h->err : nullptr, IDC_ERR_INVALID_ARG, "null argument");
+    if (h->ev.empty()) return fail(&h->err, IDC_ERR_INVALID_ARG, "no forward was recorded with profiling on");
     if (capacity < h->n_timed) return fail(&h->err, IDC_ERR_INVALID_ARG, "capacity %d < %d", capacity, h->n_timed);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const int slots = (int)(h->prof_count < kProfRing ? h->prof_count : kProfRing);
@@ -1712,7 +1718,7 @@ int idc_layer_times_ms(idc_handle h, float* ms, int capacity) {
         for (int sl = 0; sl < slots; ++sl) {
             float t = 0.f;
             const size_t base = (size_t)sl * h->n_timed * 2;
-            if (hipEventElapsedTime(&t, h->ev[base + i * 2], h->ev[base + i * 2 + 1]) != hipSuccess) t = 0.f;
+            if (hipEventElapsedTime(&t, h->ev[base + i * 2], h->ev[base + i * 2 + 1]) != hipSuccess) { t = 0.f; (void)hipGetLastError(); }
             sum += t;
         }
         ms[i] = (float)(sum / slots);

@@ -39,3 +39,49 @@ def state_dict_for(seed, style):
 @pytest.fixture(scope="session")
 def make_sd():
     return state_dict_for
+
+
+# ---- two HIP runtimes share the GPU-test process: the library links /opt/rocm's libamdhip64, torch carries its own copy.
+# Each runtime owns its queues / signals per process; a runtime that initialises AFTER the other one has created dozens of
+# streams can find the device's per-process queue budget spent ("No HIP GPUs are available" from torch's lazy init after
+# ~100 tests).  So (1) torch's runtime is initialised first, as in bench.py / sharded.py, and (2) every engine a test
+# module leaves behind (module-level caches) is destroyed when the module finishes.
+_LIVE_ENGINES = []
+
+
+def pytest_sessionstart(session):
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+            torch.zeros(1, device="cuda").cpu()
+    except Exception:
+        pass
+    try:
+        from interactive_deep_colorization_amd import engine as _engine
+        if not getattr(_engine.HipColorizer, "_tracked", False):
+            _orig_init = _engine.HipColorizer.__init__
+
+            def _init(self, *a, **kw):
+                _orig_init(self, *a, **kw)
+                _LIVE_ENGINES.append(self)
+            _engine.HipColorizer.__init__ = _init
+            _engine.HipColorizer._tracked = True
+    except Exception:
+        pass
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _close_engines_left_by_the_module():
+    yield
+    while _LIVE_ENGINES:
+        e = _LIVE_ENGINES.pop()
+        try:
+            e.close()
+        except Exception:
+            pass
+    for modname in ("test_net_gpu",):
+        import sys
+        m = sys.modules.get(modname) or sys.modules.get("tests." + modname)
+        if m is not None and hasattr(m, "_ENGINES"):
+            m._ENGINES.clear()

@@ -30,6 +30,7 @@ def per_kernel(db, counter):
 def main():
     fetch_db, write_db, forwards = sys.argv[1], sys.argv[2], int(sys.argv[3])
     out = sys.argv[4] if len(sys.argv) > 4 else "profiles/pmc_traffic.json"
+    tag = sys.argv[5] if len(sys.argv) > 5 else "?"
     f, fc = per_kernel(fetch_db, "FETCH_SIZE")
     w, wc = per_kernel(write_db, "WRITE_SIZE")
     kernels = {}
@@ -45,7 +46,7 @@ def main():
     conv = [k for k in kernels if "conv" in k]
     conv_launches = sum(fc[k] for k in conv)
     conv_bytes = sum(2.0 * f[k] * 1024.0 + w.get(k, 0.0) * 1024.0 for k in conv)
-    res = {"forwards_in_run": forwards,
+    res = {"tag": tag, "forwards_in_run": forwards,
            "hbm_bytes_per_forward": (rd_total + wr_total) / forwards,
            "read_bytes_per_forward": rd_total / forwards,
            "write_bytes_per_forward": wr_total / forwards,

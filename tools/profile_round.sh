@@ -1,26 +1,41 @@
 #!/bin/bash
-# One gpurun call: default bench line, then rocprofv3 kernel-trace stats and the two HBM PMC passes of the
-# same command (bench.py --steps 5 --warmup 2, no latency/CPU legs).  Summaries -> gpurun_out/prof_<tag>/.
-#   gpurun --timeout 900 -- 'bash tools/profile_round.sh r01b'
-TAG=${1:-r01}
+# One gpurun call: default bench line, then rocprofv3 kernel-trace stats and the PMC passes of the same command
+# (bench.py --steps 5 --warmup 2, no latency / CPU / end-to-end / probe legs), the N=1 click-path traces, and the
+# single-GPU dry run of the N>1 control flow.  Summaries -> gpurun_out/prof_<tag>/.
+#   gpurun --timeout 1500 -- 'bash tools/profile_round.sh r02'
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd $R
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
-tail -1 $OUT/bench.json
+tail -1 $OUT/bench.json | cut -c1-300
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 5 --warmup 2 --no-latency --no-cpu-baseline"
+CMD="python $R/bench.py --steps 5 --warmup 2 --no-latency --no-cpu-baseline --no-end-to-end --no-peak-probe"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o x -- $CMD > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o x -- $CMD > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o x -- $CMD > $OUT/pmc_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc_sq -o x -- $CMD > $OUT/pmc_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -d $OUT/pmc_grbm -o x -- $CMD > $OUT/pmc_grbm.log 2>&1
 cd $R
-for p in stats pmc_fetch pmc_write pmc_sq; do
+for p in stats pmc_fetch pmc_write pmc_sq pmc_grbm; do
   f=$(find $OUT/$p -name "*.db" | head -1)
   [ -n "$f" ] && python tools/rocpd_summary.py $f --family conv > $OUT/${p}_summary.txt
   grep -h '"metric"' $OUT/$p.log | tail -1 > $OUT/${p}_benchline.json
 done
-python tools/pmc_traffic.py $(find $OUT/pmc_fetch -name "*.db" | head -1) $(find $OUT/pmc_write -name "*.db" | head -1) 12 $OUT/pmc_traffic.json
+python tools/pmc_traffic.py $(find $OUT/pmc_fetch -name "*.db" | head -1) $(find $OUT/pmc_write -name "*.db" | head -1) 12 $OUT/pmc_traffic.json $TAG
+# click path (N=1) kernel traces
+cd /tmp
+for p in bf16 fp32; do
+  rocprofv3 --kernel-trace --stats -d $OUT/click_$p -o x -- python $R/tools/click_trace.py $p > $OUT/click_$p.log 2>&1
+  f=$(find $OUT/click_$p -name "*.db" | head -1)
+  [ -n "$f" ] && python $R/tools/click_trace.py --gaps $f > $OUT/click_${p}_trace.txt && python $R/tools/rocpd_summary.py $f --family conv > $OUT/click_${p}_stats.txt
+done
+cd $R
+# N>1 control flow on one GPU: 2 ranks over gloo, both on device 0 (NOT a scaling measurement)
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29571 \
+    bench.py --gpus 2 --steps 10 --warmup 2 --dryrun-single-gpu > $OUT/dryrun_2ranks.json 2> $OUT/dryrun_2ranks.err
+tail -1 $OUT/dryrun_2ranks.json | cut -c1-400
+python tools/extra_configs.py > $OUT/extra_configs.txt 2>&1
 find $OUT -name "*.db" -delete        # keep the summaries, drop the raw databases (size)
-ls -la $OUT
+ls $OUT
