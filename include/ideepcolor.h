@@ -46,8 +46,8 @@ typedef enum idc_precision { IDC_FP32 = 0, IDC_BF16 = 1 } idc_precision;
 
 /* idc_create flags */
 #define IDC_FLAG_DIST_HEAD   0x1u  /* also build model_class (529-bin) head: SIGGRAPHGenerator(dist=True), model.py:105,159-160 */
-/* (0x2 reserved: hipGraph replay was left out of the batch-1 path on measurement -- its 40 launches leave 6 us of gaps
- *  in a 690 us forward, profiles/r02a_click_bf16_trace.txt) */
+/* (0x2 reserved: hipGraph replay was left out of the batch-1 path on measurement -- its 51 launches leave < 1 us of gaps
+ *  in a 615 us forward, profiles/r02a_click_bf16_trace.txt) */
 #define IDC_FLAG_DIST313     0x8u  /* also build the 313-bin distribution / soft-decode head of
                                       models/reference_model/deploy_nopred.prototxt:650-850 (needs the pred.* tensors, see idc_forward_dist313) */
 #define IDC_FLAG_GLOBAL_HINTS 0x4u /* also build the Global-Hints branch of models/global_model/deploy_nodist.prototxt:37-172,
