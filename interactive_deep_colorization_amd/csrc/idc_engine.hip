@@ -916,7 +916,7 @@ int idc_set_tile_policy(int policy) {
 int idc_set_option(const char* name, int value) {
     if (!name) return fail(nullptr, IDC_ERR_INVALID_ARG, "null option name");
     if (strcmp(name, "fuse_conv1") == 0) { g_fuse_conv1 = value != 0; return IDC_OK; }
-    if (strcmp(name, "click") == 0) { g_click = value; return IDC_OK; }              // -1 = the IDC_CLICK default
+    if (strcmp(name, "click") == 0) { g_click = value; return IDC_OK; }
     return fail(nullptr, IDC_ERR_INVALID_ARG, "unknown option '%s'", name);
 }
 
