@@ -1521,6 +1521,7 @@ __global__ __launch_bounds__(512, 2) void conv_ds_fused(const ConvArgs a) {
     const char* const imgD = (const char*)a.in + (size_t)n * Hs * Ws * pixD;
     const char* const imgS = (const char*)a.in2 + (size_t)n * (4 * (size_t)Hs * Ws) * pixS;
     const int cg0 = ct * 2;
+    IDC_STAMP(0);
 
     f32x16 acc[2][4];
     {
@@ -1581,7 +1582,9 @@ __global__ __launch_bounds__(512, 2) void conv_ds_fused(const ConvArgs a) {
                                              (__attribute__((address_space(3))) void*)(dst + j * NT * kSlotBytes), 16, 0, 0);
     };
     auto dma_D = [&](int tw, int kc, int buf) {                // this wave's 64 couts x 64 cin of its phase's tap
-        const char* src = (const char*)a.wgt + (((size_t)tw * nkc + kc) * ncg + cg0 + wco) * kWBlockBytes + (size_t)lane * kSlotBytes;
+        int lane_ = lane;
+        asm volatile("" : "+v"(lane_));                        // (keeps the per-tap 64-bit addresses out of the loop-invariant set)
+        const char* src = (const char*)a.wgt + (((size_t)tw * nkc + kc) * ncg + cg0 + wco) * kWBlockBytes + (size_t)lane_ * kSlotBytes;
         char* dst = ringD + buf * D_WB;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
@@ -1589,52 +1592,55 @@ __global__ __launch_bounds__(512, 2) void conv_ds_fused(const ConvArgs a) {
                                              (__attribute__((address_space(3))) void*)(dst + j * 64 * kSlotBytes), 16, 0, 0);
     };
     // one K step of 64 channels: 4 k16 steps x 8 MFMAs, fragments of step kk+1 in flight under step kk (as conv_igemm_v2)
-    auto stage = [&](const char* const wcur, const int wrow_byte, const int (&xaddr)[4]) {
-        const int wslot0 = (h ^ swz2(px)) * kSlotBytes;
-        u32x4 wfA[2], xfA[4], wfB[2], xfB[4];
-        auto read_frags = [&](int kk, u32x4 (&wf)[2], u32x4 (&xf)[4]) {
+    const int wslot0 = (h ^ swz2(px)) * kSlotBytes;
+    u32x4 wfA[2], xfA[4], wfB[2], xfB[4];
+    auto read_frags = [&](const char* const wcur, const int wrow_byte, const int (&xaddr)[4], int kk, u32x4 (&wf)[2], u32x4 (&xf)[4]) {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-                wf[mi] = *(const u32x4*)(wcur + ((wrow_byte + mi * 32 * kRowBytes + wslot0) ^ (kk * 2 * kSlotBytes)));
+        for (int mi = 0; mi < 2; ++mi)
+            wf[mi] = *(const u32x4*)(wcur + ((wrow_byte + mi * 32 * kRowBytes + wslot0) ^ (kk * 2 * kSlotBytes)));
+#pragma unroll
+        for (int pj = 0; pj < 4; ++pj)
+            xf[pj] = *(const u32x4*)(halo + (xaddr[pj] ^ (kk * 2 * kSlotBytes)));
+    };
+    auto mma8 = [&](const u32x4 (&wf)[2], const u32x4 (&xf)[4]) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int pj = 0; pj < 4; ++pj)
-                xf[pj] = *(const u32x4*)(halo + (xaddr[pj] ^ (kk * 2 * kSlotBytes)));
-        };
-        auto mma8 = [&](const u32x4 (&wf)[2], const u32x4 (&xf)[4]) {
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int pj = 0; pj < 4; ++pj)
-                    acc[mi][pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[mi]),
-                                                                          __builtin_bit_cast(bf16x8, xf[pj]),
-                                                                          acc[mi][pj], 0, 0, 0);
-        };
+                acc[mi][pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[mi]),
+                                                                      __builtin_bit_cast(bf16x8, xf[pj]),
+                                                                      acc[mi][pj], 0, 0, 0);
+    };
 #define IDC_STAGE_INTERLEAVE()                                                        \
     _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) {                               \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
     }                                                                                 \
     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        read_frags(0, wfA, xfA);
+    auto stage = [&](const char* const wcur, const int wrow_byte, const int (&xaddr)[4]) {
+        read_frags(wcur, wrow_byte, xaddr, 0, wfA, xfA);
         __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-        read_frags(1, wfB, xfB);
+        read_frags(wcur, wrow_byte, xaddr, 1, wfB, xfB);
         mma8(wfA, xfA);
         IDC_STAGE_INTERLEAVE()
-        read_frags(2, wfA, xfA);
+        read_frags(wcur, wrow_byte, xaddr, 2, wfA, xfA);
         mma8(wfB, xfB);
         IDC_STAGE_INTERLEAVE()
-        read_frags(3, wfB, xfB);
+        read_frags(wcur, wrow_byte, xaddr, 3, wfB, xfB);
         mma8(wfA, xfA);
         IDC_STAGE_INTERLEAVE()
         mma8(wfB, xfB);
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-#undef IDC_STAGE_INTERLEAVE
     };
 
     // ---------------------------------------------------------------- S part: 3x3 conv of the skip tensor
     load_halo_S(0);
     dma_S(0, 0, 0);
+    IDC_STAMP_FINE(5);
     int buf = 0;
+#ifdef IDC_TIMING
+    bool first_ = true;
+#endif
     for (int kc2 = 0; kc2 < nkc2; ++kc2) {
         __syncthreads();
 #pragma unroll
@@ -1643,6 +1649,9 @@ __global__ __launch_bounds__(512, 2) void conv_ds_fused(const ConvArgs a) {
         for (int t = 0; t < 9; ++t) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+#ifdef IDC_TIMING
+            if (first_) { IDC_STAMP(1); first_ = false; }
+#endif
             if (t + 1 < 9) {
                 dma_S(t + 1, kc2, buf ^ 1);
             } else if (!last_kc) {
@@ -1665,44 +1674,98 @@ __global__ __launch_bounds__(512, 2) void conv_ds_fused(const ConvArgs a) {
         }
     }
     // ---------------------------------------------------------------- hand-over: the D part reuses the whole LDS
+    IDC_STAMP(8);
     const int* const tdy = a.dy + ph * 9;
     const int* const tdx = a.dx + ph * 9;
     const int* const ttw = a.tw + ph * 9;
+    // the phase's 2x2 taps as a table in lanes 0..3 (halo row offset, weight tap), read back with v_readlane: no scalar
+    // loads inside the loop (hipcc drains lgkmcnt to 0 for them, which would also wait for the prefetched fragments)
+    int v_xoff = 0, v_tw = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        if (lane == t) { v_xoff = (1 + tdy[t]) * DW + 1 + tdx[t]; v_tw = ttw[t]; }
     __syncthreads();                                           // every wave left the S halo and ring
 #pragma unroll
     for (int j = 0; j < D_ITEMS; ++j) *(u32x4*)(halo + (tid + j * NT) * kSlotBytes) = hreg[j];
-    dma_D(ttw[0], 0, 0);
-    buf = 0;
-    // ---------------------------------------------------------------- D part: the wave's deconv phase, 2x2 taps
-    for (int kc = 0; kc < nkc; ++kc) {
-        if (kc > 0) {
-            __syncthreads();
+    dma_D(__builtin_amdgcn_readlane(v_tw, 0), 0, 0);
+    dma_D(__builtin_amdgcn_readlane(v_tw, 1), 0, 1);
+    // ---------------------------------------------------------------- D part: the wave's deconv phase, 2x2 taps.
+    // Weight tiles are wave-private (own ring, own vmcnt), so a step needs no workgroup barrier: the two waves of a SIMD
+    // drift apart and fill each other's bubbles; only the halo chunk change synchronises.  Step s = (kc, t) = (s >> 2,
+    // s & 3) uses ring slot s & 1; tile s+2 is requested when the last fragments of tile s have been consumed, and the
+    // first fragments of step s+1 are read under the last 8 MFMAs of step s.  The tail is branch-free (a join would make
+    // hipcc wait for the prefetched fragments): past the last tile the request re-reads 1 KiB of the zero page, and the
+    // halo half of a prefetch that crosses a chunk change is simply read again after the change.
+    const int wrowD = px * kRowBytes;
+    const int nsteps = 4 * nkc;
+    int xa[4];
+    {
+        const int xo = __builtin_amdgcn_readlane(v_xoff, 0);
 #pragma unroll
-            for (int j = 0; j < D_ITEMS; ++j) *(u32x4*)(halo + (tid + j * NT) * kSlotBytes) = hreg[j];
-        }
-        const bool last_kc = kc + 1 == nkc;
-        for (int t = 0; t < 4; ++t) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (t + 1 < 4) {
-                dma_D(ttw[t + 1], kc, buf ^ 1);
-            } else if (!last_kc) {
-                dma_D(ttw[0], kc + 1, buf ^ 1);
-                load_halo_D(kc + 1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const int dy = tdy[t], dx = tdx[t];
-            int xaddr[4];
-#pragma unroll
-            for (int pj = 0; pj < 4; ++pj) {
-                const int xr = (pj + 1 + dy) * DW + (px + 1 + dx);
-                xaddr[pj] = xr * kRowBytes + ((h ^ swz2(xr)) * kSlotBytes);
-            }
-            stage(ringD + buf * D_WB, px * kRowBytes, xaddr);
-            buf ^= 1;
+        for (int pj = 0; pj < 4; ++pj) {
+            const int xr = pj * DW + px + xo;
+            xa[pj] = xr * kRowBytes + ((h ^ swz2(xr)) * kSlotBytes);
         }
     }
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");           // tile 0 landed (tile 1 may still be in flight)
+    __syncthreads();                                           // halo chunk 0 visible
+    IDC_STAMP(9);
+    read_frags(ringD, wrowD, xa, 0, wfA, xfA);
+    for (int st = 0; st < nsteps; ++st) {
+        const int t = st & 3, kc = st >> 2;
+        const char* const wcur = ringD + (st & 1) * D_WB;
+        const char* const wnext = ringD + ((st + 1) & 1) * D_WB;
+        const bool swap = t == 3 && st + 1 < nsteps;
+        if (swap) load_halo_D(kc + 1);                         // next chunk's rows wait in registers
+        read_frags(wcur, wrowD, xa, 1, wfB, xfB);
+        mma8(wfA, xfA);
+        IDC_STAGE_INTERLEAVE()
+        read_frags(wcur, wrowD, xa, 2, wfA, xfA);
+        mma8(wfB, xfB);
+        IDC_STAGE_INTERLEAVE()
+        read_frags(wcur, wrowD, xa, 3, wfB, xfB);
+        mma8(wfA, xfA);
+        IDC_STAGE_INTERLEAVE()
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // tile st+1 landed; tile st's fragment reads are all back
+        {
+            const int s2 = st + 2;
+            const bool real = s2 < nsteps;
+            const int tw2 = __builtin_amdgcn_readlane(v_tw, s2 & 3);
+            int lane_ = lane;
+            asm volatile("" : "+v"(lane_));
+            const char* src = real ? (const char*)a.wgt + (((size_t)tw2 * nkc + (s2 >> 2)) * ncg + cg0 + wco) * kWBlockBytes + (size_t)lane_ * kSlotBytes
+                                   : (const char*)a.zeros + (lane_ & 15) * kSlotBytes;
+            const int jstep = real ? 64 * kSlotBytes : 0;
+            char* dst = ringD + (st & 1) * D_WB;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)j * jstep),
+                                                 (__attribute__((address_space(3))) void*)(dst + j * 64 * kSlotBytes), 16, 0, 0);
+        }
+        {
+            const int xo = __builtin_amdgcn_readlane(v_xoff, (st + 1) & 3);
+#pragma unroll
+            for (int pj = 0; pj < 4; ++pj) {
+                const int xr = pj * DW + px + xo;
+                xa[pj] = xr * kRowBytes + ((h ^ swz2(xr)) * kSlotBytes);
+            }
+        }
+        read_frags(wnext, wrowD, xa, 0, wfA, xfA);
+        mma8(wfB, xfB);
+        IDC_STAGE_INTERLEAVE()
+        if (swap) {
+            __syncthreads();                                   // every wave is done with halo chunk kc
+#pragma unroll
+            for (int j = 0; j < D_ITEMS; ++j) *(u32x4*)(halo + (tid + j * NT) * kSlotBytes) = hreg[j];
+            __syncthreads();
+#pragma unroll
+            for (int pj = 0; pj < 4; ++pj) xfA[pj] = *(const u32x4*)(halo + xa[pj]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the zero-page requests of the last two steps target this ring)
+#undef IDC_STAGE_INTERLEAVE
     // ---------------------------------------------------------------- epilogue: (ReLU,) round, transpose, whole-line stores
+    IDC_STAMP(2);
     __syncthreads();
     char* const tb16 = smem + wave * 4096;
     typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -1737,11 +1800,16 @@ __global__ __launch_bounds__(512, 2) void conv_ds_fused(const ConvArgs a) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    IDC_STAMP(3);
+#ifdef IDC_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    IDC_STAMP(4);
+#endif
 }
 
 // deconv 4x4 s2 + its 3x3 shortcut conv in one launch: bf16, Cout a multiple of 128, (ReLU | none), no BN
 hipError_t launch_conv_ds(const ConvArgs& a, hipStream_t s) {
-    if (a.in2 == nullptr || a.wgt2 == nullptr || a.nphase != 4 || a.so != 2 || a.si != 1 || (a.ncg & 1) || a.out_f32 ||
+    if (a.in2 == nullptr || a.wgt2 == nullptr || a.zeros == nullptr || a.nphase != 4 || a.so != 2 || a.si != 1 || (a.ncg & 1) || a.out_f32 ||
         a.bn_scale != nullptr || a.act == 2 || a.img_shift != nullptr || a.resid != nullptr || a.head_w != nullptr)
         return hipErrorInvalidConfiguration;
     const long long blocks = (long long)((a.Ws + 31) / 32) * ((a.Hs + 3) / 4) * a.N * (a.ncg / 2);

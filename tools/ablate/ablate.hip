@@ -67,11 +67,11 @@ int main(int argc, char** argv) {
             for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) { int t = ph * 9 + i * 2 + j; a.dy[t] = T_d[r][i]; a.dx[t] = T_d[c][j]; a.tw[t] = T_k[r][i] * 4 + T_k[c][j]; } }
     }
     void* zeros = nullptr; float* partial = nullptr;
+    CK(hipMalloc(&zeros, 256)); CK(hipMemset(zeros, 0, 256)); a.zeros = zeros;
     if (v2 == 4 || v2 == 5) {   // batch-1 small-tile comparison: 4 = conv_click (whole K slice by LDS-DMA), 5 = conv_igemm with split-K
         const int ksplit = argc > 10 ? atoi(argv[10]) : a.nkc;
         a.kc_per = (a.nkc + ksplit - 1) / ksplit; a.ksplit = (a.nkc + a.kc_per - 1) / a.kc_per;
         if (a.ksplit < 2) { a.ksplit = 1; a.kc_per = a.nkc; }
-        CK(hipMalloc(&zeros, 256)); CK(hipMemset(zeros, 0, 256)); a.zeros = zeros;
         CK(hipMalloc((void**)&partial, (size_t)a.ksplit * N * HW * HW * C * 4)); a.partial = partial;
         if (v2 == 4) wm = 1;
         a.tiles_x = (HW + 15) / 16; a.tiles_y = (HW + 4 * wp - 1) / (4 * wp);
@@ -82,7 +82,7 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 #define LAUNCH() (v2 == 4 ? idc::launch_conv_click(prec, wp, halo, a, 0) : v2 == 5 ? idc::launch_conv(prec, cfg, halo, a, 0) : v2 == 2 ? idc::launch_conv_ds(a, 0) : v2 ? idc::launch_conv_v2(cfg, halo, a, 0) : idc::launch_conv(prec, cfg, halo, a, 0))
 #ifdef IDC_TIMING
-    int nb = a.tiles_x * a.tiles_y * N * (a.ncg / wm) * a.nphase * (a.ksplit > 1 ? a.ksplit : 1);
+    int nb = v2 == 2 ? ((HW + 31) / 32) * ((HW + 3) / 4) * N * (a.ncg / 2) : a.tiles_x * a.tiles_y * N * (a.ncg / wm) * a.nphase * (a.ksplit > 1 ? a.ksplit : 1);
     long long* dbg; CK(hipMalloc(&dbg, (size_t)nb * 128)); CK(hipMemset(dbg, 0, (size_t)nb * 128));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(idc::g_idc_dbg), &dbg, sizeof(dbg)));
 #endif
@@ -101,8 +101,8 @@ int main(int argc, char** argv) {
         long long t0 = h[0]; for (int b = 0; b < nb; ++b) if (h[b * 16] < t0) t0 = h[b * 16];
         double s[5] = {0, 0, 0, 0, 0}; long long tend = 0;
         for (int b = 0; b < nb; ++b) { for (int i = 0; i < 5; ++i) s[i] += (double)(h[b * 16 + i] - (i ? h[b * 16 + i - 1] : t0)); if (h[b * 16 + 4] > tend) tend = h[b * 16 + 4]; }
-        if (v2 == 2) { double st[5] = {0,0,0,0,0}; for (int b = 0; b < nb; ++b) for (int q = 0; q < 5; ++q) st[q] += (double)(h[b * 16 + 8 + q] - (q ? h[b * 16 + 8 + q - 1] : h[b * 16 + 1]));
-            printf("  stage spans (mean ticks): deconv %.0f | p00 %.0f | p01 %.0f | p10 %.0f | p11 %.0f\n", st[0] / nb, st[1] / nb, st[2] / nb, st[3] / nb, st[4] / nb); }
+        if (v2 == 2) { double st[3] = {0, 0, 0}; for (int b = 0; b < nb; ++b) { st[0] += (double)(h[b * 16 + 8] - h[b * 16 + 1]); st[1] += (double)(h[b * 16 + 9] - h[b * 16 + 8]); st[2] += (double)(h[b * 16 + 2] - h[b * 16 + 9]); }
+            printf("  conv_ds_fused main loop split (mean ticks): S part after its first barrier %.0f | hand-over to first D barrier %.0f | D part %.0f\n", st[0] / nb, st[1] / nb, st[2] / nb); }
         printf("  timing (ticks, mean over %d blocks): start-offset %.0f | prologue %.0f | mainloop %.0f | epilogue-issue %.0f | store-drain %.0f | kernel span %lld\n",
                nb, s[0] / nb, s[1] / nb, s[2] / nb, s[3] / nb, s[4] / nb, tend - t0);
 #ifdef IDC_TIMING_FINE
