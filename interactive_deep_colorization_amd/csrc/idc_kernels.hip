@@ -1082,7 +1082,10 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
     // weight-tile index the NEXT tap will request right after its barrier (tap t+1 requests tap t+2's tile, the chunk's
     // last tap the first tile of the next chunk): read from the tap table one tap early, so that no scalar load sits
     // between the barrier and the first fragment reads
-    constexpr bool RING3 = NT == 512;      // 8-wave tiles (one workgroup per CU): LDS has room for a third weight slot
+#ifndef IDC_V2_RING3
+#define IDC_V2_RING3 1                     // (0: the 2-slot loop for every tile shape -- A/B builds of tools/ablate only)
+#endif
+    constexpr bool RING3 = NT == 512 && IDC_V2_RING3;   // 8-wave tiles (one workgroup per CU): LDS has room for a third weight slot
     if constexpr (RING3) {
         // ---- K loop, three weight slots: the barrier at the top of step s publishes tile s+1 (requested a whole step
         // earlier, so neither the vmcnt wait nor the barrier waits for data), tile s+2 is requested right behind it into
@@ -1591,11 +1594,11 @@ hipError_t launch_conv_v2(ConvConfig cfg, int halo, const ConvArgs& a, hipStream
 //     skip tensor's (10 x 66)-pixel halo is fetched once instead of once per phase launch;
 //   * S part (shortcut): K = 9 taps x Cs.  The halo tile is stored de-interleaved by x parity (LDS row = y*66 +
 //     (x&1)*33 + x/2): a phase wave reads pixels of one parity, i.e. 32 consecutive rows -> the same conflict-free
-//     ds_read_b128 pattern as conv_igemm_v2.  Weight tiles (128 couts) are shared, 2-deep LDS-DMA ring;
+//     ds_read_b128 pattern as conv_igemm_v2.  Weight tiles (128 couts) are shared, 3-slot LDS-DMA ring (barrier one step early);
 //   * D part (deconv): K = 4 taps x Cd, taps and weight tiles depend on the phase, so every wave streams its own
-//     8 KiB tile (64 couts x 64 cin) through a wave-private 2-deep ring;
+//     8 KiB tile (64 couts x 64 cin) through a wave-private 2-deep ring, no workgroup barrier inside a halo chunk;
 //   * epilogue = the bf16-transpose one (bias in the accumulators, ReLU on packed pairs), per-wave output phase.
-// LDS: S part 90 KiB halo + 32 KiB ring; D part 32 KiB halo + 128 KiB rings = 160 KiB (the two parts reuse the space,
+// LDS: S part 90 KiB halo + 48 KiB ring (3 slots); D part 32 KiB halo + 128 KiB rings = 160 KiB (the two parts reuse the space,
 // one drained hand-over in between).
 // ================================================================================================
 __global__ __launch_bounds__(512, 2) void conv_ds_fused(const ConvArgs a) {
@@ -1603,7 +1606,7 @@ __global__ __launch_bounds__(512, 2) void conv_ds_fused(const ConvArgs a) {
     constexpr int SW = 66, SROWS = 10 * SW, S_ITEMS = (SROWS * kSlots + NT - 1) / NT, S_HALO_BYTES = S_ITEMS * NT * kSlotBytes;
     constexpr int DW = 34, DROWS = 6 * DW, D_ITEMS = (DROWS * kSlots + NT - 1) / NT, D_HALO_BYTES = D_ITEMS * NT * kSlotBytes;
     constexpr int S_WB = 2 * kWBlockBytes, D_WB = kWBlockBytes;
-    static_assert(S_HALO_BYTES + 2 * S_WB <= 160 * 1024 && D_HALO_BYTES + 16 * D_WB <= 160 * 1024, "LDS budget");
+    static_assert(S_HALO_BYTES + 3 * S_WB <= 160 * 1024 && D_HALO_BYTES + 16 * D_WB <= 160 * 1024, "LDS budget");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const halo = smem;
@@ -1722,62 +1725,89 @@ __global__ __launch_bounds__(512, 2) void conv_ds_fused(const ConvArgs a) {
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
     }                                                                                 \
     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-    auto stage = [&](const char* const wcur, const int wrow_byte, const int (&xaddr)[4]) {
-        read_frags(wcur, wrow_byte, xaddr, 0, wfA, xfA);
-        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-        read_frags(wcur, wrow_byte, xaddr, 1, wfB, xfB);
-        mma8(wfA, xfA);
-        IDC_STAGE_INTERLEAVE()
-        read_frags(wcur, wrow_byte, xaddr, 2, wfA, xfA);
-        mma8(wfB, xfB);
-        IDC_STAGE_INTERLEAVE()
-        read_frags(wcur, wrow_byte, xaddr, 3, wfB, xfB);
-        mma8(wfA, xfA);
-        IDC_STAGE_INTERLEAVE()
-        mma8(wfB, xfB);
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-    };
 
     // ---------------------------------------------------------------- S part: 3x3 conv of the skip tensor
+    // Three weight slots, as conv_igemm_v2's 8-wave K loop: the barrier at the top of step s publishes tile s+1 (requested
+    // a step earlier), tile s+2 is requested behind it, and the first fragments of step s+1 are read under the last 8
+    // MFMAs of step s.  Requests past the last tile re-read the zero page (branch-free tail).
     load_halo_S(0);
     dma_S(0, 0, 0);
     IDC_STAMP_FINE(5);
-    int buf = 0;
-#ifdef IDC_TIMING
-    bool first_ = true;
-#endif
-    for (int kc2 = 0; kc2 < nkc2; ++kc2) {
-        __syncthreads();
+    dma_S(1, 0, 1);
+    int rt = 2, rkc = 0;                                       // request cursor: (tap, chunk) of tile s+2
+    auto dma_S_req = [&](int slot_off) {
+        const bool real = rkc < nkc2;
+        const char* src = real ? (const char*)a.wgt2 + (((size_t)rt * nkc2 + rkc) * ncg + cg0) * kWBlockBytes + (size_t)tid * kSlotBytes
+                               : (const char*)a.zeros + (tid & 15) * kSlotBytes;
+        const size_t jstep = real ? (size_t)NT * kSlotBytes : 0;
+        char* dst = ringS + slot_off + wave * 64 * kSlotBytes;
 #pragma unroll
-        for (int j = 0; j < S_ITEMS; ++j) *(u32x4*)(halo + (tid + j * NT) * kSlotBytes) = hreg[j];
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)j * jstep),
+                                             (__attribute__((address_space(3))) void*)(dst + j * NT * kSlotBytes), 16, 0, 0);
+    };
+    int xs[4];
+    auto set_xs = [&](int t) {
+        const int ky = t / 3, kx = t - ky * 3;                 // 0..2 (= tap offset + 1)
+        const int c = cof + kx, par = c & 1, sh = c >> 1;      // output x = 2*xs + cof reads skip x + kx - 1: halo col 2*xs + c
+#pragma unroll
+        for (int pj = 0; pj < 4; ++pj) {
+            const int xr = (2 * pj + ro + ky) * SW + par * 33 + px + sh;
+            xs[pj] = xr * kRowBytes + ((h ^ swz2(xr)) * kSlotBytes);
+        }
+    };
+    const int wrowS = (wco * 64 + px) * kRowBytes;
+    int off_cur = 0, off_next = S_WB, off_free = 2 * S_WB;
+#pragma unroll
+    for (int j = 0; j < S_ITEMS; ++j) *(u32x4*)(halo + (tid + j * NT) * kSlotBytes) = hreg[j];
+    set_xs(0);
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");           // my pieces of tile 0 (tile 1 may still be in flight)
+    __syncthreads();                                           // halo chunk 0 and tile 0 are visible
+    IDC_STAMP(1);
+    read_frags(ringS, wrowS, xs, 0, wfA, xfA);
+    for (int kc2 = 0; kc2 < nkc2; ++kc2) {
         const bool last_kc = kc2 + 1 == nkc2;
-        for (int t = 0; t < 9; ++t) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-#ifdef IDC_TIMING
-            if (first_) { IDC_STAMP(1); first_ = false; }
-#endif
-            if (t + 1 < 9) {
-                dma_S(t + 1, kc2, buf ^ 1);
-            } else if (!last_kc) {
-                dma_S(0, kc2 + 1, buf ^ 1);
-                load_halo_S(kc2 + 1);
-            } else {
-                load_halo_D(0);                                // the deconv input's first chunk: rows wait in registers
+        auto tap_body = [&](int t, auto last_tag) {
+            constexpr bool LAST = decltype(last_tag)::value;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // my pieces of the next step's tile
+            __syncthreads();                                    // ... everybody's: published; everybody left slot off_free
+            dma_S_req(off_free);
+            if constexpr (LAST) {
+                if (!last_kc) load_halo_S(kc2 + 1);
+                else load_halo_D(0);                            // the deconv input's first chunk: rows wait in registers
             }
             __builtin_amdgcn_sched_barrier(0);
-            const int ky = t / 3, kx = t - ky * 3;             // 0..2 (= tap offset + 1)
-            const int c = cof + kx, par = c & 1, sh = c >> 1;  // output x = 2*xs + cof reads skip x + kx - 1: halo col 2*xs + c
-            int xaddr[4];
+            const char* const wcur = ringS + off_cur;
+            read_frags(wcur, wrowS, xs, 1, wfB, xfB);
+            mma8(wfA, xfA);
+            IDC_STAGE_INTERLEAVE()
+            read_frags(wcur, wrowS, xs, 2, wfA, xfA);
+            mma8(wfB, xfB);
+            IDC_STAGE_INTERLEAVE()
+            read_frags(wcur, wrowS, xs, 3, wfB, xfB);
+            mma8(wfA, xfA);
+            IDC_STAGE_INTERLEAVE()
+            set_xs(LAST ? 0 : t + 1);
+            if (++rt == 9) { rt = 0; ++rkc; }
+            read_frags(ringS + off_next, wrowS, xs, 0, wfA, xfA);
+            mma8(wfB, xfB);
+            IDC_STAGE_INTERLEAVE()
+            if constexpr (LAST) {
+                if (!last_kc) {
+                    __syncthreads();                            // everybody is done with halo chunk kc2
 #pragma unroll
-            for (int pj = 0; pj < 4; ++pj) {
-                const int xr = (2 * pj + ro + ky) * SW + par * 33 + px + sh;
-                xaddr[pj] = xr * kRowBytes + ((h ^ swz2(xr)) * kSlotBytes);
+                    for (int j = 0; j < S_ITEMS; ++j) *(u32x4*)(halo + (tid + j * NT) * kSlotBytes) = hreg[j];
+                    __syncthreads();
+#pragma unroll
+                    for (int pj = 0; pj < 4; ++pj) xfA[pj] = *(const u32x4*)(halo + xs[pj]);
+                }
             }
-            stage(ringS + buf * S_WB, (wco * 64 + px) * kRowBytes, xaddr);
-            buf ^= 1;
-        }
+            const int o_ = off_cur; off_cur = off_next; off_next = off_free; off_free = o_;
+        };
+        for (int t = 0; t < 8; ++t) tap_body(t, std::false_type{});
+        tap_body(8, std::true_type{});
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the trailing zero-page requests target LDS the D part reuses
     // ---------------------------------------------------------------- hand-over: the D part reuses the whole LDS
     IDC_STAMP(8);
     const int* const tdy = a.dy + ph * 9;
