@@ -998,9 +998,12 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
     u32x4 hreg[N_HITEMS];
     auto load_halo = [&](const Stage& st, int kc) {
         const int Win = Ws * st.si, pix_bytes = st.nkc * kRowBytes;
+        int tid_ = tid;
+        if constexpr (NT == 256) asm volatile("" : "+v"(tid_));   // 4-wave tiles have 11-14 items: recompute their addresses per
+                                                                  // chunk (hoisted, the 64-bit selects cost hipcc spills)
 #pragma unroll
         for (int j = 0; j < N_HITEMS; ++j) {
-            const int item = tid + j * NT;
+            const int item = tid_ + j * NT;
             const int hr = item >> 3, sig = item & 7;
             const int hy = hr / HWP, hx = hr - hy * HWP;
             const int sy = ty0 - HALO + hy, sx = tx0 - HALO + hx;
@@ -1082,114 +1085,6 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
     // weight-tile index the NEXT tap will request right after its barrier (tap t+1 requests tap t+2's tile, the chunk's
     // last tap the first tile of the next chunk): read from the tap table one tap early, so that no scalar load sits
     // between the barrier and the first fragment reads
-#ifndef IDC_V2_RING3
-#define IDC_V2_RING3 1                     // (0: the 2-slot loop for every tile shape -- A/B builds of tools/ablate only)
-#endif
-    constexpr bool RING3 = NT == 512 && IDC_V2_RING3;   // 8-wave tiles (one workgroup per CU): LDS has room for a third weight slot
-    if constexpr (RING3) {
-        // ---- K loop, three weight slots: the barrier at the top of step s publishes tile s+1 (requested a whole step
-        // earlier, so neither the vmcnt wait nor the barrier waits for data), tile s+2 is requested right behind it into
-        // the slot tile s-1 left, and the first fragments of step s+1 are read under the last 8 MFMAs of step s: a step's
-        // MFMAs start on registers that are already there instead of behind a barrier + an LDS round trip.  A halo chunk
-        // change (single halo buffer) re-reads the pixel half of that prefetch after the swap.  Requests past the last tile
-        // re-read the zero page, which keeps the loop branch-free (a join makes hipcc wait for the prefetched fragments).
-        const int ntaps = cur.ntaps, nkc = cur.nkc;
-        u32x4 wfA[2], xfA[4], wfB[2], xfB[4];
-        auto read_frags = [&](const char* const wcur, int kk, u32x4 (&wf)[2], u32x4 (&xf)[4]) {
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-                wf[mi] = *(const u32x4*)(wcur + ((wrow_byte + mi * 32 * kRowBytes + wslot0) ^ (kk * 2 * kSlotBytes)));
-#pragma unroll
-            for (int pj = 0; pj < 4; ++pj)
-                xf[pj] = *(const u32x4*)(halo + (xa[pj] ^ (kk * 2 * kSlotBytes)));
-        };
-        auto mma8 = [&](const u32x4 (&wf)[2], const u32x4 (&xf)[4]) {
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int pj = 0; pj < 4; ++pj)
-                    acc[mi][pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[mi]),
-                                                                          __builtin_bit_cast(bf16x8, xf[pj]),
-                                                                          acc[mi][pj], 0, 0, 0);
-        };
-#define IDC_STAGE_INTERLEAVE()                                                        \
-    _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) {                               \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
-    }                                                                                 \
-    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        auto dma_req = [&](int tw, int kc, int slot_off) {
-            const bool real = kc < nkc;
-            const char* src = real ? cur.wb + ((size_t)tw * nkc + kc) * w_kc_stride : (const char*)a.zeros + (tid & 15) * kSlotBytes;
-            const size_t jstep = real ? (size_t)NT * kSlotBytes : 0;
-            char* dst = wbuf + slot_off + wave * 64 * kSlotBytes;
-#pragma unroll
-            for (int j = 0; j < N_WITEMS; ++j)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)j * jstep),
-                                                 (__attribute__((address_space(3))) void*)(dst + j * NT * kSlotBytes), 16, 0, 0);
-        };
-        // request cursor: the (tap, chunk) of the tile the next request asks for; tile 0 is in flight already
-        int rt = 0, rkc = 0;
-        auto advance = [&]() { if (++rt == ntaps) { rt = 0; ++rkc; } };
-        advance();
-        dma_req(tap_tw[rt], rkc, W_BYTES);                      // tile 1 -> slot 1
-        advance();
-        int tw_req = tap_tw[rt], kc_req = rkc;                  // tile 2, requested at the top of step 0
-        int off_cur = 0, off_next = W_BYTES, off_free = 2 * W_BYTES;
-#pragma unroll
-        for (int j = 0; j < N_HITEMS; ++j) *(u32x4*)(halo + (tid + j * NT) * kSlotBytes) = hreg[j];
-        IDC_STAMP_FINE(7);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_WITEMS) : "memory");   // my pieces of tile 0 (tile 1 may still be in flight)
-        __syncthreads();                                        // halo chunk 0 and tile 0 are visible
-        read_frags(wbuf, 0, wfA, xfA);
-        for (int kc = 0; kc < nkc; ++kc) {
-            const bool last_kc = kc + 1 == nkc;
-            auto tap_body = [&](int t, auto last_tag) {
-                constexpr bool LAST = decltype(last_tag)::value;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // my pieces of the NEXT step's tile landed (requested a step ago)
-                __syncthreads();                                    // ... everybody's: published; everybody left slot off_free
-                if (first) { IDC_STAMP(1); first = false; }
-                dma_req(tw_req, kc_req, off_free);
-                if constexpr (LAST) { if (!last_kc) load_halo(cur, kc + 1); }
-                __builtin_amdgcn_sched_barrier(0);
-                const char* const wcur = wbuf + off_cur;
-                read_frags(wcur, 1, wfB, xfB);
-                mma8(wfA, xfA);
-                IDC_STAGE_INTERLEAVE()
-                read_frags(wcur, 2, wfA, xfA);
-                mma8(wfB, xfB);
-                IDC_STAGE_INTERLEAVE()
-                read_frags(wcur, 3, wfB, xfB);
-                mma8(wfA, xfA);
-                IDC_STAGE_INTERLEAVE()
-                {
-                    const int tn = LAST ? 0 : t + 1;            // the tap that runs next
-                    set_xa(tap_dy[tn], tap_dx[tn]);
-                    advance();
-                    tw_req = tap_tw[rt]; kc_req = rkc;
-                }
-                read_frags(wbuf + off_next, 0, wfA, xfA);
-                mma8(wfB, xfB);
-                IDC_STAGE_INTERLEAVE()
-                if constexpr (LAST) {
-                    if (!last_kc) {
-                        __syncthreads();                        // everybody is done with halo chunk kc
-#pragma unroll
-                        for (int j = 0; j < N_HITEMS; ++j) *(u32x4*)(halo + (tid + j * NT) * kSlotBytes) = hreg[j];
-                        __syncthreads();
-#pragma unroll
-                        for (int pj = 0; pj < 4; ++pj) xfA[pj] = *(const u32x4*)(halo + xa[pj]);
-                    }
-                }
-                const int o_ = off_cur; off_cur = off_next; off_next = off_free; off_free = o_;
-            };
-            for (int t = 0; t + 1 < ntaps; ++t) tap_body(t, std::false_type{});
-            tap_body(ntaps - 1, std::true_type{});
-        }
-#undef IDC_STAGE_INTERLEAVE
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the trailing zero-page requests target the ring)
-        IDC_STAMP(8);
-    } else {
     int tw_dma = a.ntaps > 1 ? tap_tw[1] : tap_tw[0];
     for (int q = 0; q < nstage; ++q) {
         for (int kc = 0; kc < cur.nkc; ++kc) {
@@ -1274,7 +1169,6 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
         if (q + 1 < nstage) cur = make_stage(q + 1);
     }
 
-    }
     IDC_STAMP(2);
     // ---- epilogue: lane (pixel px, half h) owns couts h*32 + mi*16 + reg of its wave's 64 ----------
     const int CoutPad = a.ncg * kCoutGroup;
@@ -1541,7 +1435,7 @@ static constexpr size_t conv_v2_lds_bytes_c(int wco, int wpx, int halo) {
     const int nt = wco * wpx * 64;
     const int hrows = (32 + 2 * halo) * (4 * wpx + 2 * halo);
     const int items = (hrows * kSlots + nt - 1) / nt;
-    return (size_t)items * nt * kSlotBytes + (nt == 512 ? 3 : 2) * (size_t)(64 * wco) * kRowBytes;
+    return (size_t)items * nt * kSlotBytes + 2 * (size_t)(64 * wco) * kRowBytes;
 }
 
 template <int WCO, int WPX, int HALO>

@@ -6,5 +6,4 @@
 cd "$(dirname "$0")"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -DABL_NAME=\"BASE\" ablate.hip -o ablate_BASE
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -DABL_NAME=\"TIMING\" -DIDC_TIMING ablate.hip -o ablate_TIMING
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -DABL_NAME=\"RING2\" -DIDC_V2_RING3=0 ablate.hip -o ablate_RING2
-ls -la ablate_BASE ablate_TIMING ablate_RING2
+ls -la ablate_BASE ablate_TIMING
