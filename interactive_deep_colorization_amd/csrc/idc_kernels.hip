@@ -999,8 +999,8 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
     auto load_halo = [&](const Stage& st, int kc) {
         const int Win = Ws * st.si, pix_bytes = st.nkc * kRowBytes;
         int tid_ = tid;
-        if constexpr (NT == 256) asm volatile("" : "+v"(tid_));   // 4-wave tiles have 11-14 items: recompute their addresses per
-                                                                  // chunk (hoisted, the 64-bit selects cost hipcc spills)
+        if constexpr (NT == 256 && HALO == 2) asm volatile("" : "+v"(tid_));   // 14 items: recompute their addresses per chunk
+                                                                  // (hoisted, the 64-bit selects cost hipcc 9 spilled registers)
 #pragma unroll
         for (int j = 0; j < N_HITEMS; ++j) {
             const int item = tid_ + j * NT;
