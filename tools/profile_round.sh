@@ -37,6 +37,7 @@ timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --mast
     bench.py --gpus 2 --steps 10 --warmup 2 --dryrun-single-gpu > $OUT/dryrun_2ranks.json 2> $OUT/dryrun_2ranks.err
 tail -1 $OUT/dryrun_2ranks.json | cut -c1-400
 python tools/extra_configs.py > $OUT/extra_configs.txt 2>&1
+python tools/gpu_diag.py 2>/dev/null | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" > $OUT/layer_table.txt
 # identical launches on bench / damped / all-zero operands: how much of the forward time is the DVFS response to switching activity
 python tools/power_probe.py 30 2>/dev/null | grep "^{" > $OUT/power_probe.txt
 find $OUT -name "*.db" -delete        # keep the summaries, drop the raw databases (size)
