@@ -1086,6 +1086,17 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
     // last tap the first tile of the next chunk): read from the tap table one tap early, so that no scalar load sits
     // between the barrier and the first fragment reads
     int tw_dma = a.ntaps > 1 ? tap_tw[1] : tap_tw[0];
+#ifdef IDC_STEP_PROBE
+    // intra-step probe of the tuning harness: cycle counter at seven points of ONE steady-state step (chunk 2, tap 4), kept in
+    // scalar registers (selected, not branched) and stored after the K loop
+    long long pr_[7] = {0, 0, 0, 0, 0, 0, 0};
+#define IDC_PROBE(i) const long long pn##i = (long long)__builtin_readcyclecounter();
+#define IDC_PROBE_KEEP() { const bool on_ = kc == 2 && t == 4; pr_[0] = on_ ? pn0 : pr_[0]; pr_[1] = on_ ? pn1 : pr_[1]; pr_[2] = on_ ? pn2 : pr_[2]; \
+    pr_[3] = on_ ? pn3 : pr_[3]; pr_[4] = on_ ? pn4 : pr_[4]; pr_[5] = on_ ? pn5 : pr_[5]; pr_[6] = on_ ? pn6 : pr_[6]; }
+#else
+#define IDC_PROBE(i)
+#define IDC_PROBE_KEEP()
+#endif
     for (int q = 0; q < nstage; ++q) {
         for (int kc = 0; kc < cur.nkc; ++kc) {
             __syncthreads();                   // previous chunk's halo reads are done
@@ -1099,8 +1110,10 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
             auto tap_body = [&](int t, auto last_tag) {
                 constexpr bool LAST = decltype(last_tag)::value;
                 const char* const wcur = wbuf + buf * W_BYTES;
+                IDC_PROBE(0)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // my pieces of this tap's weight tile landed
                 __syncthreads();               // everybody's landed; everybody left the other buffer
+                IDC_PROBE(1)
                 if (first) { IDC_STAMP(1); first = false; }
                 const int xaddr[4] = {xa[0], xa[1], xa[2], xa[3]};
                 // explicit 2-stage software pipeline over the four k16 steps of the chunk: fragments of
@@ -1143,15 +1156,28 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
                     load_halo(cur, kc + 1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                IDC_PROBE(2)
                 read_frags(1, wfB, xfB);
                 mma8(wfA, xfA);
                 IDC_STAGE_INTERLEAVE()
+#ifdef IDC_STEP_PROBE
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                IDC_PROBE(3)
                 read_frags(2, wfA, xfA);
                 mma8(wfB, xfB);
                 IDC_STAGE_INTERLEAVE()
+#ifdef IDC_STEP_PROBE
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                IDC_PROBE(4)
                 read_frags(3, wfB, xfB);
                 mma8(wfA, xfA);
                 IDC_STAGE_INTERLEAVE()
+#ifdef IDC_STEP_PROBE
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                IDC_PROBE(5)
                 {
                     const int tn = LAST ? 0 : t + 1;            // the tap that runs next
                     set_xa(tap_dy[tn], tap_dx[tn]);
@@ -1160,6 +1186,11 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
                 mma8(wfB, xfB);
                 __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
 #undef IDC_STAGE_INTERLEAVE
+#ifdef IDC_STEP_PROBE
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                IDC_PROBE(6)
+                IDC_PROBE_KEEP()
                 buf ^= 1;
             };
             for (int t = 0; t + 1 < cur.ntaps; ++t) tap_body(t, std::false_type{});
@@ -1170,6 +1201,9 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2(const ConvArgs
     }
 
     IDC_STAMP(2);
+#ifdef IDC_STEP_PROBE
+    if (tid == 0) for (int i = 0; i < 7; ++i) g_idc_dbg[(size_t)blockIdx.x * 16 + 9 + i] = pr_[i];
+#endif
     // ---- epilogue: lane (pixel px, half h) owns couts h*32 + mi*16 + reg of its wave's 64 ----------
     const int CoutPad = a.ncg * kCoutGroup;
     const bool has_bn = a.bn_scale != nullptr;

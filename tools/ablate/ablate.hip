@@ -103,6 +103,11 @@ int main(int argc, char** argv) {
         for (int b = 0; b < nb; ++b) { for (int i = 0; i < 5; ++i) s[i] += (double)(h[b * 16 + i] - (i ? h[b * 16 + i - 1] : t0)); if (h[b * 16 + 4] > tend) tend = h[b * 16 + 4]; }
         if (v2 == 2) { double st[3] = {0, 0, 0}; for (int b = 0; b < nb; ++b) { st[0] += (double)(h[b * 16 + 8] - h[b * 16 + 1]); st[1] += (double)(h[b * 16 + 9] - h[b * 16 + 8]); st[2] += (double)(h[b * 16 + 2] - h[b * 16 + 9]); }
             printf("  conv_ds_fused main loop split (mean ticks): S part after its first barrier %.0f | hand-over to first D barrier %.0f | D part %.0f\n", st[0] / nb, st[1] / nb, st[2] / nb); }
+#ifdef IDC_STEP_PROBE
+        { double d[6] = {0, 0, 0, 0, 0, 0}; int cnt = 0; for (int b = 0; b < nb; ++b) { if (h[b * 16 + 15] == 0) continue; ++cnt; for (int i = 0; i < 6; ++i) d[i] += (double)(h[b * 16 + 10 + i] - h[b * 16 + 9 + i]); }
+          if (cnt) printf("  one steady-state step of wave 0 (mean cycles over %d blocks): vmcnt+barrier %.0f | first reads + request issue %.0f | MFMA group 1 %.0f | group 2 %.0f | group 3 %.0f | tap-table update + group 4 %.0f | sum %.0f\n",
+                          cnt, d[0] / cnt, d[1] / cnt, d[2] / cnt, d[3] / cnt, d[4] / cnt, d[5] / cnt, (d[0] + d[1] + d[2] + d[3] + d[4] + d[5]) / cnt); }
+#endif
         printf("  timing (ticks, mean over %d blocks): start-offset %.0f | prologue %.0f | mainloop %.0f | epilogue-issue %.0f | store-drain %.0f | kernel span %lld\n",
                nb, s[0] / nb, s[1] / nb, s[2] / nb, s[3] / nb, s[4] / nb, tend - t0);
 #ifdef IDC_TIMING_FINE

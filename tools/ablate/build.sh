@@ -6,4 +6,5 @@
 cd "$(dirname "$0")"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -DABL_NAME=\"BASE\" ablate.hip -o ablate_BASE
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -DABL_NAME=\"TIMING\" -DIDC_TIMING ablate.hip -o ablate_TIMING
-ls -la ablate_BASE ablate_TIMING
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -DABL_NAME=\"PROBE\" -DIDC_TIMING -DIDC_STEP_PROBE ablate.hip -o ablate_PROBE
+ls -la ablate_BASE ablate_TIMING ablate_PROBE
