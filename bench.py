@@ -280,6 +280,30 @@ def main():
     }
     if world == 1 and not args.no_end_to_end:
         result["end_to_end"] = measure_end_to_end(e, nb, args.steps, args.warmup, value)
+    if world == 1 and not args.no_peak_probe and args.precision == "bf16":
+        # the SAME launches on all-zero operands (weights and inputs): no kernel branches on data, so the instruction
+        # streams are identical and the time difference is the clock the power management grants -- separates the code's
+        # cycle efficiency from the DVFS response to switching activity (tools/power_probe.py)
+        try:
+            e.load_state_dict({k: np.zeros_like(v) for k, v in sd.items()})
+            for t_ in (dL, dab, dm):
+                t_.zero_()
+            torch.cuda.synchronize(dev)
+            for _ in range(args.warmup):
+                e.forward_device(nb, dL, dab, dm, dout, 0.0, sync=False)
+            e.sync()
+            tz = time.perf_counter()
+            for _ in range(args.steps):
+                e.forward_device(nb, dL, dab, dm, dout, 0.0, sync=False)
+            e.sync()
+            zms = (time.perf_counter() - tz) / args.steps * 1e3
+            result["roofline"]["zero_operand_probe"] = {
+                "ms_per_step": round(zms, 4), "whole_forward_frac_of_nominal": round(conv_flops / (zms * 1e-3) / 1e12 / peak, 4),
+                "bench_operands_ms_per_step": round(ms_per_step, 4), "dvfs_factor": round(zms / ms_per_step, 4),
+                "how": "same engine, same %d launches, all-zero weights and inputs, %d steps after the timed region: what the "
+                       "instruction streams deliver at the clock an idle data path is granted" % (len(conv_rows), args.steps)}
+        except Exception as ex:                                   # never let a diagnostic leg take the bench line down
+            result["roofline"]["zero_operand_probe"] = {"error": str(ex)[:200]}
     e.close()
     if args.dryrun_single_gpu:
         result["dryrun_single_gpu"] = ("%d ranks shared ONE GPU over a gloo group: control-flow check only, `value` is not a "
