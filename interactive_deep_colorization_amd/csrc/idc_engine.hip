@@ -641,6 +641,9 @@ static int alloc_graph(idc_context* c) {
     c->l_set.assign(nb, 0);
     HIPCHK(c, hipMalloc(&c->d_zeros, 256));
     HIPCHK(c, hipMemset(c->d_zeros, 0, 256));
+    // the memsets above run on the NULL stream, the kernels on the handle's non-blocking stream: every conv launch reads the
+    // zero page (out-of-image halo rows), so make the fills complete before the handle can launch anything
+    HIPCHK(c, hipStreamSynchronize(nullptr));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_sync, hipEventDisableTiming));
     HIPCHK(c, hipHostMalloc((void**)&c->h_in, nb * hw * 4 * 4, hipHostMallocDefault));
     HIPCHK(c, hipHostMalloc((void**)&c->h_out, nb * hw * 2 * 4, hipHostMallocDefault));
