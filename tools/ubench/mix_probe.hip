@@ -17,14 +17,26 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 constexpr int kLds = 144 * 1024;
 __constant__ int tapy[16] = {-1, -1, -1, 0, 0, 0, 1, 1, 1, -1, -1, -1, 0, 0, 0, 1};
 __constant__ int tapx[16] = {-1, 0, 1, -1, 0, 1, -1, 0, 1, -1, 0, 1, -1, 0, 1, -1};
-__constant__ int tapd[16] = {144, 144, 4608, 144, 144, 4608, 144, 144, -10080, 144, 144, 4608, 144, 144, 4608, -10080};
+__constant__ int tapd[16] = {144, 144, 4608, 144, 144, 4608, 144, 144, -10080, 144, 144, 4608, 144, 144, 4608, -9792};   // (sums to 0: the addresses cycle)
 
 template <int READS, bool BARRIER, int DMA, int STREAM = 0, bool SWAP = false, int XA = 0, bool PAD = false>
-__global__ __launch_bounds__(512, 2) void mix(const char* __restrict__ gsrc, float* out, long long* clk, int steps) {
+__global__ __launch_bounds__(512, 2) void mix(const char* __restrict__ gsrc, float* out, long long* clk, int steps, unsigned seed) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = lane & 31, h = lane >> 5, wco = wave & 3, wpx = wave >> 2;
-    for (int i = tid; i < kLds / 16; i += 512) ((u32x4*)smem)[i] = u32x4{0u, 0u, 0u, 0u};
+    for (int i = tid; i < kLds / 16; i += 512) {
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (seed) {                                            // uniform random bf16 pairs in [-1, 1): sign + exponent 0x3f00..0x3f7f + mantissa
+            unsigned x = (unsigned)i * 2654435761u + seed + blockIdx.x * 40503u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+                const unsigned lo = (x & 0x80ffu) | 0x3f00u, hi = ((x >> 16) & 0x80ffu) | 0x3f00u;
+                v[e] = lo | (hi << 16);
+            }
+        }
+        ((u32x4*)smem)[i] = v;
+    }
     __syncthreads();
     char* const halo = smem;                       // 34 x 10 rows of 128 B
     char* const wbuf = smem + 48 * 1024;           // two 32 KiB tiles
@@ -62,6 +74,11 @@ __global__ __launch_bounds__(512, 2) void mix(const char* __restrict__ gsrc, flo
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
     }                                                                                 \
     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) { wfA[mi] = *(const u32x4*)(wbuf + wrow + mi * 4096 + wslot0); wfB[mi] = *(const u32x4*)(wbuf + 32768 + wrow + mi * 4096 + wslot0); }
+#pragma unroll
+    for (int pj = 0; pj < 4; ++pj) { xfA[pj] = *(const u32x4*)(halo + xa[pj]); xfB[pj] = *(const u32x4*)(halo + (xa[pj] ^ 32)); }
+    __syncthreads();
     const long long c0 = clock64(), w0 = wall_clock64();
     int buf = 0;
     for (int s = 0; s < steps; ++s) {
@@ -77,9 +94,12 @@ __global__ __launch_bounds__(512, 2) void mix(const char* __restrict__ gsrc, flo
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)j * 8192 + (unsigned)tid * 16),
                                              (__attribute__((address_space(3))) void*)(ring + j * 8192 + wave * 1024), 16, 0, 0);
         if (SWAP && s % 9 == 8) {                              // the halo chunk change: barrier, 6 x 16 B per thread into the halo tile, (next step's barrier)
+            u32x4 keep[6];                                     // (rewrites the tile with its own content: the operand statistics stay what they were)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) keep[j] = *(const u32x4*)(halo + (tid + j * 512) * 16);
             __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 6; ++j) *(u32x4*)(halo + (tid + j * 512) * 16) = u32x4{0u, 0u, 0u, 0u};
+            for (int j = 0; j < 6; ++j) *(u32x4*)(halo + (tid + j * 512) * 16) = keep[j];
         }
         __builtin_amdgcn_sched_barrier(0);
         read_frags(wcur, 1, wfB, xfB); mma8(wfA, xfA); IL()
@@ -115,13 +135,14 @@ __global__ __launch_bounds__(512, 2) void mix(const char* __restrict__ gsrc, flo
     if (tid == 0) { clk[blockIdx.x * 2] = c1 - c0; clk[blockIdx.x * 2 + 1] = w1 - w0; }
 }
 
+static unsigned g_seed = 0;
 template <int READS, bool BARRIER, int DMA, int STREAM = 0, bool SWAP = false, int XA = 0, bool PAD = false>
 static void run(const char* gsrc, float* out, long long* clk, int steps, const char* what) {
     CK(hipFuncSetAttribute((const void*)mix<READS, BARRIER, DMA, STREAM, SWAP, XA, PAD>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    hipLaunchKernelGGL((mix<READS, BARRIER, DMA, STREAM, SWAP, XA, PAD>), dim3(256), dim3(512), kLds, 0, gsrc, out, clk, steps);
+    hipLaunchKernelGGL((mix<READS, BARRIER, DMA, STREAM, SWAP, XA, PAD>), dim3(256), dim3(512), kLds, 0, gsrc, out, clk, steps, g_seed);
     CK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL((mix<READS, BARRIER, DMA, STREAM, SWAP, XA, PAD>), dim3(256), dim3(512), kLds, 0, gsrc, out, clk, steps);
+    hipLaunchKernelGGL((mix<READS, BARRIER, DMA, STREAM, SWAP, XA, PAD>), dim3(256), dim3(512), kLds, 0, gsrc, out, clk, steps, g_seed);
     CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -137,10 +158,11 @@ static void run(const char* gsrc, float* out, long long* clk, int steps, const c
 
 int main(int argc, char** argv) {
     const int steps = argc > 1 ? atoi(argv[1]) : 4000;
+    g_seed = argc > 2 ? (unsigned)atoi(argv[2]) : 0;      // 0: zero operands (cycles); else: uniform random bf16 operands (the power cap)
     char* gsrc; float* out; long long* clk;
-    CK(hipMalloc(&gsrc, 8 << 20)); CK(hipMemset(gsrc, 0, 8 << 20));
+    CK(hipMalloc(&gsrc, 8 << 20)); CK(hipMemset(gsrc, g_seed ? 0x3e : 0, 8 << 20));
     CK(hipMalloc(&out, 256 * 512 * 4)); CK(hipMalloc(&clk, 512 * 8));
-    printf("# one step = 32 MFMA per wave, 2 waves per SIMD: 2048 MFMA cycles per step at 100 %%\n");
+    printf("# one step = 32 MFMA per wave, 2 waves per SIMD: 2048 MFMA cycles per step at 100 %%; operands: %s\n", g_seed ? "uniform random bf16" : "zero");
     run<0, false, 0>(gsrc, out, clk, steps, "MFMA only");
     run<6, false, 0>(gsrc, out, clk, steps, "+ 6 ds_read_b128 per 8 MFMA (the kernel's 0.75)");
     run<4, false, 0>(gsrc, out, clk, steps, "+ 4 ds_read_b128 per 8 MFMA (0.50)");
