@@ -249,13 +249,25 @@ int idc_free_host(void* p);
 int idc_forward_async(idc_handle h, int slot, int n, const float* L_mc, const float* ab, const float* mask, float maskcent,
                       float* out_ab);
 int idc_wait(idc_handle h, int slot);
+/* Where the stages of the slot's last completed batch sat on the device clock: ms6 = milliseconds since the pipeline's
+ * first use of {H2D start, H2D end, compute start, compute end, D2H start, D2H end} (HIP events on the three streams).
+ * Call after idc_wait(slot).  bench.py's end_to_end leg prints the spans and the overlap achieved, so that a box whose
+ * copies do not run under the other slot's kernels shows it (SURVEY.md 8d config 3 "end-to-end").
+ * ZERO-COPY alternative (no copy engine involved at all): idc_forward_device accepts PINNED HOST pointers
+ * (idc_alloc_host / hipHostMalloc memory is mapped into the device's address space at the same address): conv1's
+ * operand staging then reads L / ab / mask over PCIe and the tanh head writes out_ab straight into host memory; the
+ * result is valid after idc_sync (or an idc_stream_signal'ed consumer).  Bit-identical to idc_forward. */
+int idc_pipeline_times(idc_handle h, int slot, float* ms6);
 
 /* ---- multi-GPU weight distribution (SURVEY.md 8b export list, 8e): one RCCL broadcast of the packed blob over xGMI.
  *      Every rank (one process per GPU) creates its handle; the root also loads the weights.  idc_comm_unique_id
  *      (root only) fills 128 bytes that the caller ships to the other ranks by any side channel (a file, a socket,
  *      torch.distributed's store); then EVERY rank calls idc_broadcast_weights(h, id, rank, world, root).  Non-root
- *      handles receive into their own device allocation, verify header + checksum and become ready.  librccl.so is
- *      opened on first use; IDC_ERR_UNSUPPORTED if it cannot be found.  No data-path collective exists: images are
+ *      handles receive into their own device allocation, verify header + checksum and become ready.  librccl is
+ *      opened on first use -- the copy that ships beside the libamdhip64 this library is bound to (RCCL launches on the
+ *      handle's stream, so both must belong to ONE HIP runtime; a process can hold torch's bundled runtime as well);
+ *      IDC_ERR_UNSUPPORTED if it cannot be found.  EXPERIMENTAL at world > 1: exercised on hardware with one rank
+ *      only (no multi-GPU box was available to the builder); sharded.py's default transport is torch.distributed.  No data-path collective exists: images are
  *      independent (colorize_image.py:232 eval-mode BN), each rank runs its own shard. */
 #define IDC_UNIQUE_ID_BYTES 128
 int idc_comm_unique_id(void* id128);

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "idc_layer_times_ms", "idc_get_activation", "idc_op_conv2d", "idc_op_deconv4x4s2",
     "idc_set_image_l", "idc_set_hints", "idc_get_hint_planes", "idc_forward_resident",
     "idc_dist_bins", "idc_keep_dist", "idc_dist_at", "idc_get_dist", "idc_suggest_colors",
-    "idc_stream_wait", "idc_stream_signal", "idc_alloc_host", "idc_free_host", "idc_forward_async", "idc_wait",
+    "idc_stream_wait", "idc_stream_signal", "idc_alloc_host", "idc_free_host", "idc_forward_async", "idc_wait", "idc_pipeline_times",
     "idc_comm_unique_id", "idc_broadcast_weights", "idc_upsample_lab2rgb",
 ]
 IDC_INTERP_CUBIC, IDC_INTERP_LINEAR, IDC_INTERP_NEAREST = 0, 1, 2
@@ -132,6 +132,7 @@ def load():
     proto("idc_free_host", ci, [vp])
     proto("idc_forward_async", ci, [vp, ci, ci, c_float_p, c_float_p, c_float_p, cf, c_float_p])
     proto("idc_wait", ci, [vp, ci])
+    proto("idc_pipeline_times", ci, [vp, ci, c_float_p])
     proto("idc_comm_unique_id", ci, [vp])
     proto("idc_broadcast_weights", ci, [vp, vp, ci, ci, ci])
     proto("idc_upsample_lab2rgb", ci, [vp, ci, ci, ci, ci, ci, vp, vp])

@@ -27,6 +27,7 @@ from scipy.ndimage import zoom
 
 from . import color_bins, colorspace
 from .colorspace import lab2rgb_transpose, rgb2lab_transpose  # same helper names as the reference
+from ._native import IdcError
 from .engine import HipColorizer
 from .workloads import put_point  # noqa: F401  notebook helper (DemoInteractiveColorization.ipynb:131-139)
 
@@ -253,13 +254,21 @@ class ColorizeImageBase(object):
     def get_img_fullres(self):
         """Bilinear (``scipy.ndimage.zoom`` order 1) upsample of ``output_ab`` + Lab->RGB with the full-res L
         (``:123-131``) -- on the device when the map is still the one the last forward left there."""
+        # (the Python-side token can outlive the engine's resident map -- a direct net.forward / forward_async on the
+        #  engine, a want_rgb=False forward: the engine then answers IDC_ERR_UNSUPPORTED and the host path takes over)
         if self._out_on_device():
-            return self.net.upsample_lab2rgb(self.img_l_fullres[0], 'output_ab', 'linear')
+            try:
+                return self.net.upsample_lab2rgb(self.img_l_fullres[0], 'output_ab', 'linear')
+            except IdcError:
+                self._dev_out_token = None
         return lab2rgb_transpose(self.img_l_fullres, self._up(self.output_ab, 1))
 
     def get_input_img_fullres(self):
         if self._in_on_device():
-            return self.net.upsample_lab2rgb(self.img_l_fullres[0], 'input_ab', 'linear')
+            try:
+                return self.net.upsample_lab2rgb(self.img_l_fullres[0], 'input_ab', 'linear')
+            except IdcError:
+                pass
         return lab2rgb_transpose(self.img_l_fullres, self._up(self.input_ab, 1))
 
     def get_result_window(self, l_win):
@@ -269,7 +278,11 @@ class ColorizeImageBase(object):
         with cv2 + skimage after every click); SURVEY.md 8f rank 1."""
         if not self._out_on_device():
             raise RuntimeError('get_result_window needs the result of the last net_forward (output_ab was replaced)')
-        return self.net.upsample_lab2rgb(np.asarray(l_win), 'output_ab', 'cubic')
+        try:
+            return self.net.upsample_lab2rgb(np.asarray(l_win), 'output_ab', 'cubic')
+        except IdcError as ex:
+            self._dev_out_token = None
+            raise RuntimeError('get_result_window: the engine no longer holds the last net_forward result (%s)' % ex)
 
     def get_input_img(self):
         return lab2rgb_transpose(self.img_l, self.input_ab)
@@ -286,7 +299,10 @@ class ColorizeImageBase(object):
 
     def get_sup_fullres(self):
         if self._in_on_device():
-            return self.net.upsample_lab2rgb(50 * self._up(self.input_mask, 0)[0], 'input_ab', 'nearest')
+            try:
+                return self.net.upsample_lab2rgb(50 * self._up(self.input_mask, 0)[0], 'input_ab', 'nearest')
+            except IdcError:
+                pass
         return lab2rgb_transpose(50 * self._up(self.input_mask, 0), self._up(self.input_ab, 0))
 
 
@@ -522,6 +538,13 @@ class ColorizeImageCaffeGlobDist(ColorizeImageCaffe):
         self._set_out_ab_()
         return ret
 
+    def _set_out_ab_(self):
+        # the reference refreshes output_ab from output_rgb once more after this class's net_forward (:461-463);
+        # _finish_forward has just done exactly that on the device (the float64 map still resident there), so the
+        # attributes and the device token stay as they are -- get_result_window / get_img_fullres keep working
+        if self._dev_out_token is None or self._dev_out_token is not self.__dict__.get('output_ab'):
+            ColorizeImageCaffe._set_out_ab_(self)
+
     def net_forward(self, input_ab, input_mask, glob_dist=-1):
         if not self.net_set:
             print('I need to have a net!')
@@ -609,5 +632,16 @@ class ColorizeImageCaffeDist(ColorizeImageCaffe):
     def compute_entropy(self):
         self.dist_entropy = np.sum(self.dist_ab * np.log(self.dist_ab), axis=0)
 
-    plot_dist_grid = ColorizeImageTorchDist.plot_dist_grid            # same bodies as the reference's (:547-561)
-    plot_dist_entropy = ColorizeImageTorchDist.plot_dist_entropy
+    def plot_dist_grid(self, h, w):
+        """Plots the (23 x 23 grid) distribution at pixel (h, w) (``:549-555``)."""
+        import matplotlib.pyplot as plt
+        plt.figure()
+        plt.imshow(self.dist_ab_grid[:, :, h, w], extent=[-110, 110, 110, -110], interpolation='nearest')
+        plt.colorbar(); plt.ylabel('a'); plt.xlabel('b')
+
+    def plot_dist_entropy(self):
+        """Plots the per-pixel entropy map of the predicted distribution (``:557-561``)."""
+        import matplotlib.pyplot as plt
+        plt.figure()
+        plt.imshow(-self.dist_entropy, interpolation='nearest')
+        plt.colorbar()

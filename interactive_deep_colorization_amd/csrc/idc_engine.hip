@@ -359,10 +359,12 @@ struct idc_context {
         float *d_L = nullptr, *d_ab = nullptr, *d_mask = nullptr, *d_out = nullptr;   // device I/O planes
         float *h_in = nullptr, *h_out = nullptr;                                       // pinned staging (pageable callers)
         hipEvent_t ev_in = nullptr, ev_comp = nullptr, ev_out = nullptr;
-        bool pending = false, staged_out = false;
+        hipEvent_t ev_in0 = nullptr, ev_comp0 = nullptr, ev_out0 = nullptr;             // stage starts (idc_pipeline_times)
+        bool pending = false, staged_out = false, timed = false;
         float* user_out = nullptr; int n = 0;
     } pipe[2];
     hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_pipe_base = nullptr, ev_slot0_free = nullptr;
     bool pipe_ready = false;
     unsigned char* d_up_rgb = nullptr; double* d_up_L = nullptr; size_t up_cap = 0;    // idc_upsample_lab2rgb staging
     unsigned char* h_up_rgb = nullptr; double* h_up_L = nullptr;
@@ -810,7 +812,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
     }
     toc();
     c->dist_n = (ddist || ((c->flags & IDC_FLAG_DIST313) && (c->want_dist313 || c->keep_dist313))) ? n : 0;
-    c->last_n = n;
+    if (dout == c->d_out) c->last_n = n;       // images whose ab map sits in the handle's own d_out (display step source)
     if (c->profiling == 2) (void)hipEventRecord(c->ev[ring + 1], s);
     if (c->profiling) ++c->prof_count;
     return IDC_OK;
@@ -868,9 +870,11 @@ static void destroy_ctx(idc_context* c) {
         if (&sl != &c->pipe[0]) for (void* p : dv) if (p) (void)hipFree(p);
         if (sl.h_in) (void)hipHostFree(sl.h_in);
         if (sl.h_out) (void)hipHostFree(sl.h_out);
-        hipEvent_t evs[] = {sl.ev_in, sl.ev_comp, sl.ev_out};
+        hipEvent_t evs[] = {sl.ev_in, sl.ev_comp, sl.ev_out, sl.ev_in0, sl.ev_comp0, sl.ev_out0};
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     }
+    if (c->ev_pipe_base) (void)hipEventDestroy(c->ev_pipe_base);
+    if (c->ev_slot0_free) (void)hipEventDestroy(c->ev_slot0_free);
     if (c->s_in) (void)hipStreamDestroy(c->s_in);
     if (c->s_out) (void)hipStreamDestroy(c->s_out);
     if (c->ev_sync) (void)hipEventDestroy(c->ev_sync);
@@ -1074,6 +1078,10 @@ int idc_forward_device(idc_handle h, int n, const float* d_L_mc, const float* d_
     if (rc) return rc;
     if (!d_L_mc || !d_ab || !d_mask || !d_out_ab) return fail(&h->err, IDC_ERR_INVALID_ARG, "null tensor pointer");
     HIPCHK(h, hipSetDevice(h->device));
+    // the result lands in the CALLER's buffer: whatever an earlier forward left in d_out / d_labq is no longer "the last
+    // forward's map" (idc_upsample_lab2rgb must not serve it), unless the caller handed the handle's own planes back
+    h->out_resident = d_out_ab == h->d_out;
+    h->labq_resident = false;
     rc = run_graph(h, n, d_L_mc, d_ab, d_mask, maskcent, d_out_ab, (h->flags & IDC_FLAG_DIST_HEAD) ? h->d_dist : nullptr);
     if (rc) return rc;
     if (sync) HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1444,10 +1452,13 @@ static int ensure_pipeline(idc_context* h) {
             HIPCHK(h, hipMalloc((void**)&sl.d_mask, nb * hw * 4));
             HIPCHK(h, hipMalloc((void**)&sl.d_out, nb * hw * 2 * 4));
         }
-        HIPCHK(h, hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
-        HIPCHK(h, hipEventCreateWithFlags(&sl.ev_comp, hipEventDisableTiming));
-        HIPCHK(h, hipEventCreateWithFlags(&sl.ev_out, hipEventDisableTiming));
+        // timing-capable events: idc_pipeline_times reports where each stage of a batch sat on the device's clock
+        hipEvent_t* evs[] = {&sl.ev_in, &sl.ev_comp, &sl.ev_out, &sl.ev_in0, &sl.ev_comp0, &sl.ev_out0};
+        for (hipEvent_t* e : evs) HIPCHK(h, hipEventCreate(e));
     }
+    HIPCHK(h, hipEventCreate(&h->ev_pipe_base));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_slot0_free, hipEventDisableTiming));
+    HIPCHK(h, hipEventRecord(h->ev_pipe_base, h->stream));
     h->pipe_ready = true;
     return IDC_OK;
 }
@@ -1488,19 +1499,28 @@ int idc_forward_async(idc_handle h, int slot, int n, const float* L_mc, const fl
     }
     sl.staged_out = !is_pinned(out_ab);
     if (sl.staged_out && !sl.h_out) HIPCHK(h, hipHostMalloc((void**)&sl.h_out, nb * hw * 2 * 4, hipHostMallocDefault));
-    // copy-in stream: the slot's previous inputs were consumed (its previous forward finished: idc_wait was called)
+    // copy-in stream: the slot's previous inputs were consumed (its previous forward finished: idc_wait was called).
+    // Slot 0 shares its planes with the handle's resident L / hint planes: work already enqueued on the compute stream
+    // that reads or writes them (idc_set_hints, an unsynchronised idc_forward_device on them) goes first.
+    if (slot == 0) {
+        HIPCHK(h, hipEventRecord(h->ev_slot0_free, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->s_in, h->ev_slot0_free, 0));
+    }
+    HIPCHK(h, hipEventRecord(sl.ev_in0, h->s_in));
     HIPCHK(h, hipMemcpyAsync(sl.d_L, sL, (size_t)n * hw * 4, hipMemcpyHostToDevice, h->s_in));
     HIPCHK(h, hipMemcpyAsync(sl.d_ab, sab, (size_t)n * hw * 2 * 4, hipMemcpyHostToDevice, h->s_in));
     HIPCHK(h, hipMemcpyAsync(sl.d_mask, sm, (size_t)n * hw * 4, hipMemcpyHostToDevice, h->s_in));
     HIPCHK(h, hipEventRecord(sl.ev_in, h->s_in));
     HIPCHK(h, hipStreamWaitEvent(h->stream, sl.ev_in, 0));
+    HIPCHK(h, hipEventRecord(sl.ev_comp0, h->stream));
     rc = run_graph(h, n, sl.d_L, sl.d_ab, sl.d_mask, maskcent, sl.d_out, nullptr);
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(sl.ev_comp, h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->s_out, sl.ev_comp, 0));
+    HIPCHK(h, hipEventRecord(sl.ev_out0, h->s_out));
     HIPCHK(h, hipMemcpyAsync(sl.staged_out ? sl.h_out : out_ab, sl.d_out, (size_t)n * hw * 2 * 4, hipMemcpyDeviceToHost, h->s_out));
     HIPCHK(h, hipEventRecord(sl.ev_out, h->s_out));
-    sl.pending = true; sl.user_out = out_ab; sl.n = n;
+    sl.pending = true; sl.timed = true; sl.user_out = out_ab; sl.n = n;
     if (slot == 0) { for (int i = 0; i < n; ++i) h->l_set[i] = 1; h->out_resident = true; h->labq_resident = false; }
     return IDC_OK;
 }
@@ -1513,6 +1533,18 @@ int idc_wait(idc_handle h, int slot) {
     return wait_slot(h, slot);
 }
 
+int idc_pipeline_times(idc_handle h, int slot, float* ms6) {
+    if (!h || !ms6) return fail(h ? &h->err : nullptr, IDC_ERR_INVALID_ARG, "null argument");
+    if (slot < 0 || slot > 1) return fail(&h->err, IDC_ERR_INVALID_ARG, "slot %d not in 0..1", slot);
+    if (!h->pipe_ready || !h->pipe[slot].timed) return fail(&h->err, IDC_ERR_UNSUPPORTED, "slot %d has not run a batch yet", slot);
+    auto& sl = h->pipe[slot];
+    if (sl.pending) return fail(&h->err, IDC_ERR_INVALID_ARG, "slot %d is still in flight: idc_wait it first", slot);
+    HIPCHK(h, hipSetDevice(h->device));
+    hipEvent_t evs[6] = {sl.ev_in0, sl.ev_in, sl.ev_comp0, sl.ev_comp, sl.ev_out0, sl.ev_out};
+    for (int i = 0; i < 6; ++i) HIPCHK(h, hipEventElapsedTime(&ms6[i], h->ev_pipe_base, evs[i]));
+    return IDC_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- RCCL weight broadcast
 // SURVEY.md 8b's export list / 8e: one broadcast of the packed blob from `root` over xGMI, called by every rank's
 // process with its own handle.  librccl is opened at the first call (the copy torch already loaded, if any, else
@@ -1520,6 +1552,7 @@ int idc_wait(idc_handle h, int slot) {
 struct IdcNcclId { char internal[128]; };                  // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128), passed by value
 struct Rccl {
     void* lib = nullptr;
+    std::string path;
     int (*GetUniqueId)(void*) = nullptr;
     int (*CommInitRank)(void**, int, IdcNcclId, int) = nullptr;
     int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
@@ -1531,9 +1564,25 @@ static Rccl* rccl() {
     static bool tried = false;
     if (!tried) {
         tried = true;
-        const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
-        for (const char* nm : names) { r.lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD); if (r.lib) break; }     // already in the process (torch)
-        for (const char* nm : names) { if (r.lib) break; r.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL); }
+        // RCCL launches its kernels on OUR stream handle, so it has to be the copy bound to the SAME libamdhip64 this
+        // library resolved (a process that imported torch after this library holds two HIP runtimes: torch's bundled
+        // librccl belongs to the other one, and a stream handle of one runtime means nothing to the other).  The HIP
+        // runtime we call is found with dladdr; the librccl that ships beside it is the one to open.
+        Dl_info di;
+        std::string dir;
+        if (dladdr((const void*)&hipStreamSynchronize, &di) && di.dli_fname) {
+            dir = di.dli_fname;
+            const size_t sl = dir.rfind('/');
+            dir = sl == std::string::npos ? std::string() : dir.substr(0, sl + 1);
+        }
+        if (!dir.empty()) {
+            const std::string cands[] = {dir + "librccl.so.1", dir + "librccl.so"};
+            for (const std::string& nm : cands) { r.lib = dlopen(nm.c_str(), RTLD_NOW | RTLD_LOCAL); if (r.lib) { r.path = nm; break; } }
+        }
+        if (!r.lib && dir.empty()) {              // dladdr unavailable: the historical search (documented as unverified)
+            const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+            for (const char* nm : names) { r.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL); if (r.lib) { r.path = nm; break; } }
+        }
         if (r.lib) {
             r.GetUniqueId = (int (*)(void*))dlsym(r.lib, "ncclGetUniqueId");
             r.CommInitRank = (int (*)(void**, int, IdcNcclId, int))dlsym(r.lib, "ncclCommInitRank");

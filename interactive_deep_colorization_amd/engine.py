@@ -100,6 +100,30 @@ def pack_weights(sd, precision="bf16", dist=False, global_hints=False, dist313=F
     return blob
 
 
+class _PinnedBuffer(object):
+    """Owner of one idc_alloc_host allocation.  numpy arrays made from it (``np.asarray`` through the array interface)
+    hold it as their base, so the pinned memory is returned to the driver only when the last view is collected."""
+
+    def __init__(self, lib, nbytes):
+        self._lib = lib
+        self.nbytes = max(int(nbytes), 1)
+        self.ptr = lib.idc_alloc_host(self.nbytes)
+        if not self.ptr:
+            raise MemoryError("idc_alloc_host(%d) failed" % self.nbytes)
+
+    @property
+    def __array_interface__(self):
+        return {"shape": (self.nbytes,), "typestr": "|u1", "data": (int(self.ptr), False), "version": 3}
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self._lib.idc_free_host(ctypes.c_void_p(self.ptr))
+                self.ptr = None
+        except Exception:
+            pass
+
+
 class HipColorizer(object):
     def __init__(self, H=256, W=None, max_batch=1, precision="bf16", device=0, dist=False, global_hints=False, dist313=False):
         self.lib = N.load()
@@ -116,16 +140,20 @@ class HipColorizer(object):
         N.check(self.lib.idc_create(self.device, self.H, self.W, self.max_batch, self._prec, self._flags,
                                     ctypes.byref(self._h)))
         self._blob_keepalive = None
-        self._pinned = []
 
     # ---- lifetime -------------------------------------------------------------------------
     def close(self):
+        """Destroy the handle (idc_destroy drains its streams first).  Pinned buffers handed out by ``pinned_empty``
+        are NOT freed here: each is released when the last numpy view of it is garbage-collected, so an array that
+        outlives the engine stays valid memory."""
         if getattr(self, "_h", None) is not None and self._h:
+            for slot in (0, 1):                       # batches still in flight own caller buffers: finish them first
+                try:
+                    self.lib.idc_wait(self._h, slot)
+                except Exception:
+                    pass
             self.lib.idc_destroy(self._h)
             self._h = ctypes.c_void_p()
-            for ptr in getattr(self, "_pinned", []):
-                self.lib.idc_free_host(ctypes.c_void_p(ptr))
-            self._pinned = []
 
     def __del__(self):
         try:
@@ -321,9 +349,14 @@ class HipColorizer(object):
         self._chk(self.lib.idc_set_dist_temperature(self._h, float(S)))
 
     def forward_device(self, n, d_L, d_ab, d_mask, d_out, maskcent=0.0, sync=False):
-        """Device-pointer form (ints / objects with ``data_ptr()``); enqueued on the handle stream."""
+        """Device-pointer form (ints / objects with ``data_ptr()`` / numpy arrays over PINNED host memory from
+        ``pinned_empty``, which the device reads and writes in place); enqueued on the handle stream."""
         def p(x):
-            return ctypes.c_void_p(int(x.data_ptr()) if hasattr(x, "data_ptr") else int(x))
+            if hasattr(x, "data_ptr"):
+                return ctypes.c_void_p(int(x.data_ptr()))
+            if isinstance(x, np.ndarray):               # pinned host memory (pinned_empty): zero-copy, see idc_pipeline_times' note
+                return ctypes.c_void_p(int(x.ctypes.data))
+            return ctypes.c_void_p(int(x))
         self._chk(self.lib.idc_forward_device(self._h, int(n), p(d_L), p(d_ab), p(d_mask), float(maskcent),
                                               p(d_out), 1 if sync else 0))
 
@@ -341,16 +374,14 @@ class HipColorizer(object):
 
     # ---- overlapped host transfers: two slots ----------------------------------------------
     def pinned_empty(self, shape, dtype=np.float32):
-        """numpy array over pinned host memory (``idc_alloc_host``): ``forward_async`` transfers it in place.  The
-        memory belongs to this object and is released by ``close()``: do not use the array afterwards."""
+        """numpy array over pinned host memory (``idc_alloc_host``): ``forward_async`` transfers it in place and
+        ``forward_device`` may be given it directly (zero-copy: the memory is mapped into the device's address space).
+        The memory lives as long as any array that views it (the base buffer frees it when collected), not as long as
+        this engine."""
         shape = tuple(int(x) for x in shape)
         nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
-        ptr = self.lib.idc_alloc_host(nbytes)
-        if not ptr:
-            raise MemoryError("idc_alloc_host(%d) failed" % nbytes)
-        self._pinned.append(ptr)
-        buf = (ctypes.c_char * nbytes).from_address(ptr)
-        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+        raw = np.asarray(_PinnedBuffer(self.lib, nbytes))           # uint8 view; .base keeps the owner alive
+        return raw[:nbytes].view(dtype).reshape(shape)
 
     def forward_async(self, slot, L_mc, ab, mask, out, maskcent=0.0):
         """Enqueue one batch on pipeline slot 0/1 (float32 C-contiguous arrays, used in place -- keep them alive and
@@ -363,6 +394,13 @@ class HipColorizer(object):
 
     def wait(self, slot):
         self._chk(self.lib.idc_wait(self._h, int(slot)))
+
+    def pipeline_times(self, slot):
+        """ms since the pipeline's first use of (H2D start, H2D end, compute start, compute end, D2H start, D2H end) of the
+        slot's last completed batch (after ``wait(slot)``)."""
+        ms = np.zeros(6, np.float32)
+        self._chk(self.lib.idc_pipeline_times(self._h, int(slot), _fptr(ms)))
+        return ms
 
     # ---- RCCL weight broadcast through the C ABI (one call per rank) -------------------------------------------
     def comm_unique_id(self):

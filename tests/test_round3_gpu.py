@@ -1,0 +1,106 @@
+"""Round-3 GPU tests: zero-copy (mapped pinned host memory) I/O of idc_forward_device, per-stage pipeline timing,
+residency flags after a device-pointer forward, pinned-array lifetime across close(), wrapper fallbacks.
+Everything goes through the C ABI (ctypes); the oracle is not needed here (bit-for-bit self-consistency)."""
+import gc
+import os
+
+import numpy as np
+import pytest
+
+from interactive_deep_colorization_amd import _native as N
+from interactive_deep_colorization_amd import api, engine, workloads
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("precision,size,nb", [("bf16", 64, 4), ("fp32", 64, 2), ("bf16", 256, 32)])
+def test_mapped_io_equals_idc_forward_bit_for_bit(make_sd, precision, size, nb):
+    """idc_forward_device on PINNED HOST pointers (mapped into the device's address space): conv1's operand staging
+    reads L / ab / mask over PCIe, the head writes out_ab into host memory.  Same bits as the copying idc_forward --
+    at the bench geometry (N=32, 256x256: conv1_block_fused + the fused tanh head) and on the small-tile kernels."""
+    e = engine.HipColorizer(size, size, max_batch=nb, precision=precision)
+    e.load_state_dict(make_sd(0, "he"))
+    L, ab, m = workloads.random_batch(nb, size, seed=11)
+    ref = e.forward(L, ab, m, 0.5)
+    pin = [e.pinned_empty(x.shape) for x in (L, ab, m)] + [e.pinned_empty((nb, 2, size, size))]
+    for dst, src in zip(pin[:3], (L, ab, m)):
+        dst[...] = src
+    pin[3][...] = -7.0
+    for _ in range(2):                                        # back to back on the stream, then one sync
+        e.forward_device(nb, pin[0], pin[1], pin[2], pin[3], 0.5, sync=False)
+    e.sync()
+    np.testing.assert_array_equal(pin[3], ref)
+    e.close()
+    gc.collect()
+    assert float(np.abs(pin[3] - ref).max()) == 0.0           # the pinned arrays outlive the engine
+
+
+def test_pipeline_times_are_ordered_and_plausible(make_sd):
+    e = engine.HipColorizer(256, 256, max_batch=8, precision="bf16")
+    e.load_state_dict(make_sd(0, "he"))
+    with pytest.raises(N.IdcError):
+        e.pipeline_times(0)                                   # nothing ran yet
+    bufs = []
+    for k in range(2):
+        L, ab, m = workloads.random_batch(8, 256, seed=3 + k)
+        arrs = [e.pinned_empty(x.shape) for x in (L, ab, m)] + [e.pinned_empty((8, 2, 256, 256))]
+        for dst, src in zip(arrs[:3], (L, ab, m)):
+            dst[...] = src
+        bufs.append(arrs)
+    for i in range(6):
+        k = i & 1
+        if i >= 2:
+            e.wait(k)
+        e.forward_async(k, *bufs[k], 0.0)
+    with pytest.raises(N.IdcError):
+        e.pipeline_times(1)                                   # still in flight
+    e.wait(0); e.wait(1)
+    t0, t1 = e.pipeline_times(0), e.pipeline_times(1)
+    for t in (t0, t1):
+        assert np.all(np.diff(t) >= -1e-3), t                # h2d start <= h2d end <= compute start <= ... <= d2h end
+        assert 0.0 < t[3] - t[2] < 50.0 and t[1] - t[0] < 50.0 and t[5] - t[4] < 50.0, t
+    assert t1[3] > t0[3]                                      # batch 5 (slot 1) computed after batch 4 (slot 0)
+    e.close()
+
+
+def test_forward_device_invalidates_the_resident_result(make_sd):
+    """after idc_forward_device the result is in the CALLER's buffer; the display step must not serve the map an
+    older forward left in d_out / d_labq."""
+    import torch
+    e = engine.HipColorizer(64, 64, max_batch=2, precision="bf16")
+    e.load_state_dict(make_sd(0, "he"))
+    L, ab, m = workloads.random_batch(2, 64, seed=5)
+    e.forward_rgb(L, ab, m, 0.0)
+    Lw = np.full((64, 64), 50.0)
+    e.upsample_lab2rgb(Lw, "output_ab", "linear")            # resident: fine
+    e.upsample_lab2rgb(Lw, "output_ab_raw", "nearest")
+    dev = torch.device("cuda", 0)
+    dL, dab, dm = (torch.from_numpy(x).to(dev) for x in (L, ab, m))
+    dout = torch.empty((2, 2, 64, 64), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize(dev)
+    e.forward_device(2, dL, dab, dm, dout, 0.0, sync=True)
+    for src in ("output_ab", "output_ab_raw"):
+        with pytest.raises(N.IdcError):
+            e.upsample_lab2rgb(Lw, src, "linear")
+    e.close()
+
+
+def test_wrapper_getters_fall_back_when_the_engine_lost_the_map(make_sd):
+    """the Python-side token can outlive the engine's resident map (a direct engine call in between); the
+    full-resolution getters then take the host route instead of raising; GlobDist keeps its device route."""
+    rgb = np.load(os.path.join(HERE, "golden", "mortar_pestle_256_rgb.npy"))
+    model = api.ColorizeImageTorch(Xd=256, precision="bf16")
+    model.prep_net(path="", state_dict=make_sd(0, "he"))
+    model.set_image(rgb)
+    hab, hm = workloads.hints_config2(256, 5, 3, 0)
+    model.net_forward(hab, hm)
+    dev_img = model.get_img_fullres()
+    L, ab, m = workloads.random_batch(1, 256, seed=2)
+    model.net.forward(L, ab, m, 0.0)                           # behind the wrapper's back: labq no longer resident
+    host_img = model.get_img_fullres()                         # must not raise
+    d = np.abs(dev_img.astype(np.int32) - host_img.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() <= 2e-4
+    with pytest.raises(RuntimeError):
+        model.get_result_window(np.full((300, 300), 50.0))
+    model.net.close()
