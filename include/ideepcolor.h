@@ -243,7 +243,9 @@ int idc_stream_signal(idc_handle h, void* caller_stream);
  *      Host buffers stay caller-owned and must stay untouched until the slot's idc_wait.  Pinned memory (idc_alloc_host,
  *      or the caller's own hipHostMalloc / hipHostRegister) is transferred in place; pageable memory is staged through
  *      pinned buffers with a host memcpy on the calling thread (correct, but the memcpy then bounds the rate).
- *      The blocking entry points drain both slots first. */
+ *      The blocking entry points drain both slots first.  Each slot owns its device planes: a pipelined batch neither
+ *      reads nor replaces the handle's resident L / hint planes or its resident result (idc_forward_resident,
+ *      idc_upsample_lab2rgb keep referring to the last BLOCKING forward). */
 void* idc_alloc_host(size_t bytes);
 int idc_free_host(void* p);
 int idc_forward_async(idc_handle h, int slot, int n, const float* L_mc, const float* ab, const float* mask, float maskcent,

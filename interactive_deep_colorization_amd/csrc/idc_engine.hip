@@ -45,6 +45,11 @@ BlobPlan make_blob_plan(int precision, unsigned flags) {
         off = align_up(off, 256); lb.w_off = off; off += lb.w_bytes;
         lb.w2_off = (size_t)-1;
         if (precision == IDC_BF16 && v2_eligible(s)) { off = align_up(off, 256); lb.w2_off = off; off += lb.w_bytes; }
+        lb.w3_off = (size_t)-1; lb.w3_bytes = 0;
+        if (precision == IDC_FP32 && wino_eligible(s)) {
+            lb.w3_bytes = (size_t)s.cin * cout_pad(s.cout) * 16 * 4;          // 16 transformed values per (cin, cout)
+            off = align_up(off, 256); lb.w3_off = off; off += lb.w3_bytes;
+        }
         off = align_up(off, 256); lb.bias_off = off; off += (size_t)cout_pad(s.cout) * 4;
         if (s.bnkey) {
             off = align_up(off, 256); lb.bn_scale_off = off; off += (size_t)cout_pad(s.cout) * 4;
@@ -139,6 +144,32 @@ static void pack_layer_weights(uint8_t* wimg, int precision, int layout, const L
     }
 }
 
+// Winograd F(2x2,3x3) weight image of one 3x3 layer (fp32 path, idc_wino.hip): U = G g G^T per (cout, cin) in float64,
+// G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], stored in MFMA A-operand order
+//   [chunk = ci/32][pos = i*4+j][cout block = co/16][ks][lane = g*16 + co%16][e],   ci%32 = (ks*4 + g)*4 + e
+// so that one wave-wide 16-byte load is the fragment of (pos, 16 couts, 16 cin).
+static void pack_wino_weights(uint8_t* img, const LayerSpec& s, const LayerBlob& lb, const float* w) {
+    memset(img, 0, lb.w3_bytes);
+    static const double G[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
+    const int ncb = cout_pad(s.cout) / 16;
+    float* const out = (float*)img;
+    for (int co = 0; co < s.cout; ++co)
+        for (int ci = 0; ci < s.cin; ++ci) {
+            const float* g = w + ((size_t)co * s.cin + ci) * 9;
+            double t[4][3];
+            for (int i = 0; i < 4; ++i)
+                for (int kx = 0; kx < 3; ++kx) t[i][kx] = G[i][0] * g[0 * 3 + kx] + G[i][1] * g[1 * 3 + kx] + G[i][2] * g[2 * 3 + kx];
+            const int c = ci / 32, within = ci % 32, slot = within / 4, e = within % 4, ks = slot / 4, gq = slot % 4;
+            const int cbg = co / 16, m = co % 16, lane = gq * 16 + m;
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) {
+                    const double u = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
+                    const size_t idx = (((((size_t)c * 16 + (i * 4 + j)) * ncb + cbg) * 2 + ks) * 64 + lane) * 4 + e;
+                    out[idx] = (float)u;
+                }
+        }
+}
+
 static int fail(std::string* err, int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -190,6 +221,7 @@ static int pack_weights_impl(int precision, unsigned flags, const idc_tensor_des
         if (!dims_are(*b, {s.cout})) return fail(err, IDC_ERR_MISSING_KEY, "key '%s' has the wrong shape", bk.c_str());
         pack_layer_weights(base + lb.w_off, precision, 1, s, lb, w->data);
         if (lb.w2_off != (size_t)-1) pack_layer_weights(base + lb.w2_off, precision, 2, s, lb, w->data);
+        if (lb.w3_off != (size_t)-1) pack_wino_weights(base + lb.w3_off, s, lb, w->data);
         float* bias = (float*)(base + lb.bias_off);
         for (int c = 0; c < s.cout; ++c) bias[c] = b->data[c];
         if (s.bnkey) {
@@ -310,6 +342,7 @@ struct Layer {
     ConvConfig cfg{2, 2};
     bool v2 = false;                     // bf16 large-tile kernel (layout-2 weights)
     bool click = false;                  // batch-1 click-path kernel (conv_click: whole K slice by LDS-DMA)
+    bool wino = false;                   // fp32 Winograd F(2x2,3x3) kernel (conv_wino_f32, idc_wino.hip)
     bool fused_head = false;             // conv10_2 only: model_out + tanh run in this layer's epilogue
     int fused_short = -1;                // deconv layers: index of the shortcut conv layer riding in this launch's K loop
     bool skip = false;                   // layer fused into another launch: not launched itself
@@ -354,7 +387,7 @@ struct idc_context {
     float* d_centres = nullptr; double* d_sugg = nullptr; unsigned* d_sugg_counts = nullptr;   // colour suggestions
     std::vector<char> l_set;             // per image slot: d_L holds an uploaded L plane (idc_forward_resident refuses otherwise)
     hipEvent_t ev_sync = nullptr;        // idc_stream_wait / idc_stream_signal
-    // two-slot transfer pipeline (idc_forward_async / idc_wait): slot 0 = the buffers above, slot 1 its own set
+    // two-slot transfer pipeline (idc_forward_async / idc_wait): each slot owns its device planes
     struct PipeSlot {
         float *d_L = nullptr, *d_ab = nullptr, *d_mask = nullptr, *d_out = nullptr;   // device I/O planes
         float *h_in = nullptr, *h_out = nullptr;                                       // pinned staging (pageable callers)
@@ -364,7 +397,7 @@ struct idc_context {
         float* user_out = nullptr; int n = 0;
     } pipe[2];
     hipStream_t s_in = nullptr, s_out = nullptr;
-    hipEvent_t ev_pipe_base = nullptr, ev_slot0_free = nullptr;
+    hipEvent_t ev_pipe_base = nullptr;
     bool pipe_ready = false;
     unsigned char* d_up_rgb = nullptr; double* d_up_L = nullptr; size_t up_cap = 0;    // idc_upsample_lab2rgb staging
     unsigned char* h_up_rgb = nullptr; double* h_up_L = nullptr;
@@ -401,6 +434,7 @@ static int g_fuse_conv1 = !(getenv("IDC_FUSE_CONV1") && atoi(getenv("IDC_FUSE_CO
 // Split-K policy of the small-tile kernels (speed only): 0 = automatic (launches that would leave most CUs idle,
 // i.e. the batch-1 click path), 1 = never, 2 = always split as far as the cin chunks allow (tests).
 static int g_splitk_policy = 0;
+static int g_wino = !(getenv("IDC_WINO") && atoi(getenv("IDC_WINO")) == 0);   // fp32 3x3 stride-1 layers in Winograd form (idc_set_option "winograd" / env IDC_WINO=0 for A/B)
 static int g_click = -1;                 // conv_click for small launches: -1 = environment default (on), 0 off, 1 on (idc_set_option "click")
 // Shortcut fusion (conv_igemm_v2<.,.,1,true>) is correct (parity-tested under tile policy 2) but measured slower
 // than two launches on MI355X (4x re-reads of the skip tensor by the four phase workgroups, VGPR spills around
@@ -499,6 +533,10 @@ static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, i
     a.nkc = L.blob.nkc; a.ncg = L.blob.ncg;
     a.act = L.spec->act;
     a.out_f32 = L.spec->out_f32;
+    // fp32 path: every 3x3 stride-1 layer whose U image is in the blob runs as Winograd F(2x2,3x3): 2.25x fewer multiplies
+    // on the exact-fp32 matrix pipe, no split-K at batch 1 (one workgroup per 16 tiles x 32 couts)
+    L.wino = precision == IDC_FP32 && g_wino && g_tile_policy != 1 && L.blob.w3_off != (size_t)-1 && L.spec->resid == nullptr;
+    if (L.wino) { L.v2 = false; L.click = false; a.ksplit = 1; a.kc_per = a.nkc; a.tiles_x = a.tiles_y = 0; return; }
     // large-tile bf16 kernel: 256 couts x (32x8 sites) when the cout groups divide by 4, else
     // 128 couts x (32x16 sites); used when its grid covers at least half of the 256 CUs
     L.v2 = false;
@@ -735,7 +773,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
         } else {
             a.pk_L = nullptr;
         }
-        a.wgt = c->d_blob + (L.v2 ? L.blob.w2_off : L.blob.w_off);
+        a.wgt = c->d_blob + (L.wino ? L.blob.w3_off : L.v2 ? L.blob.w2_off : L.blob.w_off);
         a.bias = (const float*)(c->d_blob + L.blob.bias_off);
         a.bn_scale = L.blob.bn_scale_off != (size_t)-1 ? (const float*)(c->d_blob + L.blob.bn_scale_off) : nullptr;
         a.bn_shift = L.blob.bn_shift_off != (size_t)-1 ? (const float*)(c->d_blob + L.blob.bn_shift_off) : nullptr;
@@ -786,6 +824,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
                 (long long)((a.Ws + 31) / 32) * ((a.Hs + 31) / 32) * c->max_batch >= 128)
                 le = launch_conv1_1_bf16(a, s);
             if (L.fused_short >= 0) le = launch_conv_ds(a, s);    // deconv + its shortcut conv in one K loop
+            if (L.wino) le = launch_conv_wino(a, s);
             if (le == hipErrorInvalidConfiguration)
                 le = L.click ? launch_conv_click(c->precision, L.cfg.wp, L.halo, a, s)
                    : L.v2 ? launch_conv_v2(L.cfg, L.halo, a, s) : launch_conv(c->precision, L.cfg, L.halo, a, s);
@@ -867,14 +906,13 @@ static void destroy_ctx(idc_context* c) {
     if (c->own_blob && c->d_blob) (void)hipFree(c->d_blob);
     for (auto& sl : c->pipe) {
         void* dv[] = {sl.d_L, sl.d_ab, sl.d_mask, sl.d_out};
-        if (&sl != &c->pipe[0]) for (void* p : dv) if (p) (void)hipFree(p);
+        for (void* p : dv) if (p) (void)hipFree(p);
         if (sl.h_in) (void)hipHostFree(sl.h_in);
         if (sl.h_out) (void)hipHostFree(sl.h_out);
         hipEvent_t evs[] = {sl.ev_in, sl.ev_comp, sl.ev_out, sl.ev_in0, sl.ev_comp0, sl.ev_out0};
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     }
     if (c->ev_pipe_base) (void)hipEventDestroy(c->ev_pipe_base);
-    if (c->ev_slot0_free) (void)hipEventDestroy(c->ev_slot0_free);
     if (c->s_in) (void)hipStreamDestroy(c->s_in);
     if (c->s_out) (void)hipStreamDestroy(c->s_out);
     if (c->ev_sync) (void)hipEventDestroy(c->ev_sync);
@@ -924,6 +962,8 @@ int idc_set_option(const char* name, int value) {
     if (!name) return fail(nullptr, IDC_ERR_INVALID_ARG, "null option name");
     if (strcmp(name, "fuse_conv1") == 0) { g_fuse_conv1 = value != 0; return IDC_OK; }
     if (strcmp(name, "click") == 0) { g_click = value; return IDC_OK; }
+    if (strcmp(name, "winograd") == 0) { g_wino = value != 0; return IDC_OK; }
+    if (strcmp(name, "winograd_form") == 0) { set_wino_form(value); return IDC_OK; }     // 0 automatic, 12 / 21 / 22 = <TB,CB> (tests, tuning)
     return fail(nullptr, IDC_ERR_INVALID_ARG, "unknown option '%s'", name);
 }
 
@@ -1445,19 +1485,19 @@ static int ensure_pipeline(idc_context* h) {
     HIPCHK(h, hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
     for (int k = 0; k < 2; ++k) {
         auto& sl = h->pipe[k];
-        if (k == 0) { sl.d_L = h->d_L; sl.d_ab = h->d_ab; sl.d_mask = h->d_mask; sl.d_out = h->d_out; }
-        else {
-            HIPCHK(h, hipMalloc((void**)&sl.d_L, nb * hw * 4));
-            HIPCHK(h, hipMalloc((void**)&sl.d_ab, nb * hw * 2 * 4));
-            HIPCHK(h, hipMalloc((void**)&sl.d_mask, nb * hw * 4));
-            HIPCHK(h, hipMalloc((void**)&sl.d_out, nb * hw * 2 * 4));
-        }
+        // both slots own their planes (50 MB each at N = 32): nothing here aliases the handle's resident L / hint / output
+        // planes, so the copy-in stream never has to be ordered against the compute stream (ordering slot 0's copies behind
+        // "everything enqueued so far" serialises them behind the OTHER slot's kernels: measured 0.89 instead of 0.97 of
+        // the device-resident rate, profiles/r03a_bench.json)
+        HIPCHK(h, hipMalloc((void**)&sl.d_L, nb * hw * 4));
+        HIPCHK(h, hipMalloc((void**)&sl.d_ab, nb * hw * 2 * 4));
+        HIPCHK(h, hipMalloc((void**)&sl.d_mask, nb * hw * 4));
+        HIPCHK(h, hipMalloc((void**)&sl.d_out, nb * hw * 2 * 4));
         // timing-capable events: idc_pipeline_times reports where each stage of a batch sat on the device's clock
         hipEvent_t* evs[] = {&sl.ev_in, &sl.ev_comp, &sl.ev_out, &sl.ev_in0, &sl.ev_comp0, &sl.ev_out0};
         for (hipEvent_t* e : evs) HIPCHK(h, hipEventCreate(e));
     }
     HIPCHK(h, hipEventCreate(&h->ev_pipe_base));
-    HIPCHK(h, hipEventCreateWithFlags(&h->ev_slot0_free, hipEventDisableTiming));
     HIPCHK(h, hipEventRecord(h->ev_pipe_base, h->stream));
     h->pipe_ready = true;
     return IDC_OK;
@@ -1499,13 +1539,7 @@ int idc_forward_async(idc_handle h, int slot, int n, const float* L_mc, const fl
     }
     sl.staged_out = !is_pinned(out_ab);
     if (sl.staged_out && !sl.h_out) HIPCHK(h, hipHostMalloc((void**)&sl.h_out, nb * hw * 2 * 4, hipHostMallocDefault));
-    // copy-in stream: the slot's previous inputs were consumed (its previous forward finished: idc_wait was called).
-    // Slot 0 shares its planes with the handle's resident L / hint planes: work already enqueued on the compute stream
-    // that reads or writes them (idc_set_hints, an unsynchronised idc_forward_device on them) goes first.
-    if (slot == 0) {
-        HIPCHK(h, hipEventRecord(h->ev_slot0_free, h->stream));
-        HIPCHK(h, hipStreamWaitEvent(h->s_in, h->ev_slot0_free, 0));
-    }
+    // copy-in stream: the slot's previous inputs were consumed (its previous forward finished: idc_wait was called)
     HIPCHK(h, hipEventRecord(sl.ev_in0, h->s_in));
     HIPCHK(h, hipMemcpyAsync(sl.d_L, sL, (size_t)n * hw * 4, hipMemcpyHostToDevice, h->s_in));
     HIPCHK(h, hipMemcpyAsync(sl.d_ab, sab, (size_t)n * hw * 2 * 4, hipMemcpyHostToDevice, h->s_in));
@@ -1521,7 +1555,6 @@ int idc_forward_async(idc_handle h, int slot, int n, const float* L_mc, const fl
     HIPCHK(h, hipMemcpyAsync(sl.staged_out ? sl.h_out : out_ab, sl.d_out, (size_t)n * hw * 2 * 4, hipMemcpyDeviceToHost, h->s_out));
     HIPCHK(h, hipEventRecord(sl.ev_out, h->s_out));
     sl.pending = true; sl.timed = true; sl.user_out = out_ab; sl.n = n;
-    if (slot == 0) { for (int i = 0; i < n; ++i) h->l_set[i] = 1; h->out_resident = true; h->labq_resident = false; }
     return IDC_OK;
 }
 
@@ -1710,7 +1743,7 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
                 if (C.fused_short == layer - 1 || C.fused_next == layer - 1) snprintf(out->kernel, sizeof(out->kernel), "fused into %s", C.spec->name);
             out->flops = 0; out->min_bytes = 0; out->launches = 0;
         } else {
-            snprintf(out->kernel, sizeof(out->kernel), L.click ? (h->precision == IDC_BF16 ? "conv_click<bf16,%d,%d>" : "conv_click<f32,%d,%d>")
+            snprintf(out->kernel, sizeof(out->kernel), L.wino ? "conv_wino_f32" : L.click ? (h->precision == IDC_BF16 ? "conv_click<bf16,%d,%d>" : "conv_click<f32,%d,%d>")
                      : L.v2 ? "conv_igemm_v2<%d,%d>" : (h->precision == IDC_BF16 ? "conv_igemm<bf16,%d,%d>" : "conv_igemm<f32,%d,%d>"),
                      L.cfg.wm, L.cfg.wp);
             if (L.fused_head) strncat(out->kernel, "+head", sizeof(out->kernel) - strlen(out->kernel) - 1);
@@ -1833,14 +1866,24 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     L.spec = &spec;
     L.blob.nkc = spec.cin / kc; L.blob.ncg = cout_pad(spec.cout) / kCoutGroup;
     L.blob.w_bytes = (size_t)weight_taps(spec.kind) * L.blob.nkc * L.blob.ncg * kWBlockBytes;
+    L.blob.w_off = 0; L.blob.w2_off = (size_t)-1; L.blob.bias_off = L.blob.bn_scale_off = L.blob.bn_shift_off = L.blob.fbias_off = (size_t)-1;
     const int cpad = cout_pad(spec.cout);
+    // fp32 3x3 stride-1 ops without a shortcut sum take the Winograd kernel exactly as inside the network
+    const bool wino_ok = precision == IDC_FP32 && wino_eligible(spec) && resid == nullptr;
+    L.blob.w3_off = wino_ok ? 0 : (size_t)-1;
+    L.blob.w3_bytes = wino_ok ? (size_t)spec.cin * cpad * 16 * 4 : 0;
+    if (wino_ok && L.blob.w3_bytes > L.blob.w_bytes) L.blob.w_bytes = L.blob.w3_bytes;      // one staging buffer serves either image
     std::vector<uint8_t> wimg(L.blob.w_bytes);
     const int Hs = h / spec.in_stride, Ws = w / spec.in_stride;
     const int so = spec.kind == kDeconv4x4 ? 2 : 1;
     const int Ho = Hs * so, Wo = Ws * so;
     fill_taps(L);
     set_geometry(L, precision, n, n, Hs, Ws);
-    pack_layer_weights(wimg.data(), precision, L.v2 ? 2 : 1, spec, L.blob, weight);
+    if (L.wino) pack_wino_weights(wimg.data(), spec, L.blob, weight);
+    else {
+        if (wino_ok) L.blob.w_bytes = (size_t)weight_taps(spec.kind) * L.blob.nkc * L.blob.ncg * kWBlockBytes;
+        pack_layer_weights(wimg.data(), precision, L.v2 ? 2 : 1, spec, L.blob, weight);
+    }
     std::vector<float> hb(cpad, 0.f), hs(cpad, 1.f), ht(cpad, 0.f);
     for (int c = 0; c < spec.cout; ++c) {
         hb[c] = bias[c];
@@ -1885,7 +1928,7 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     HIPCHK(nullctx, d_zero.alloc(256));
     HIPCHK(nullctx, hipMemset(d_zero.p, 0, 256));
     a.zeros = d_zero.p;
-    HIPCHK(nullctx, L.click ? launch_conv_click(precision, L.cfg.wp, L.halo, a, nullptr)
+    HIPCHK(nullctx, L.wino ? launch_conv_wino(a, nullptr) : L.click ? launch_conv_click(precision, L.cfg.wp, L.halo, a, nullptr)
                     : L.v2 ? launch_conv_v2(L.cfg, L.halo, a, nullptr) : launch_conv(precision, L.cfg, L.halo, a, nullptr));
     if (a.ksplit > 1) HIPCHK(nullctx, launch_splitk_epilogue(precision, a, nullptr));
     HIPCHK(nullctx, launch_nhwc_to_nchw(io_bf16, d_yn.p, (float*)d_y.p, n, spec.cout, Ho, Wo, cpad, nullptr));

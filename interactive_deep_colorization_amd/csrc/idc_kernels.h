@@ -91,6 +91,11 @@ int conv_click_max_chunks(int wp, int halo, int ntaps);
 // Second half of a split-K launch: out = act(sum_s partial[s] + bias [+ resid]) [* bn_scale + bn_shift] [+ img_shift]
 // over all N*Hout*Wout*CoutPad outputs (geometry and epilogue fields taken from the same ConvArgs).
 hipError_t launch_splitk_epilogue(int precision, const ConvArgs& a, hipStream_t s);
+// fp32 Winograd F(2x2,3x3) form of a 3x3 stride-1 conv (idc_wino.hip): a.wgt = the layer's U image, a.out fp32,
+// a.dy[8] = dilation (1 | 2); hipErrorInvalidConfiguration if the launch does not qualify
+hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t s);
+hipError_t init_kernels_wino();
+void set_wino_form(int form);      // 0 = by grid size, 12 / 21 / 22 = force conv_wino_f32<TB,CB> (speed only)
 // One-time: raise the dynamic-LDS limit of every conv instantiation.
 hipError_t init_kernels();
 size_t conv_lds_bytes(ConvConfig cfg, int halo);

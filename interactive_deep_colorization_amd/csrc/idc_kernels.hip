@@ -811,6 +811,8 @@ hipError_t init_kernels() {
 #undef X
     e = init_kernels_click();
     if (e != hipSuccess) return e;
+    e = init_kernels_wino();
+    if (e != hipSuccess) return e;
     return init_kernels_v2();
 }
 

@@ -80,6 +80,8 @@ inline int cout_pad(int cout) { return cout <= 64 ? 64 : ((cout + 127) / 128) * 
 inline int weight_taps(LayerKind k) { return k == kConv3x3 ? 9 : (k == kDeconv4x4 ? 16 : 1); }
 // channels of the GEMM K dimension per tap, before padding to the 128-byte chunk
 inline int k_channels(const LayerSpec& s) { return s.kind == kConvIm2col ? 36 : s.cin; }
+// layers the fp32 Winograd kernel (conv_wino_f32) can run: 3x3, stride 1, no shortcut sum, 32 | Cin
+inline bool wino_eligible(const LayerSpec& s) { return s.kind == kConv3x3 && s.in_stride == 1 && s.resid == nullptr && s.cin % 32 == 0; }
 // layers the bf16 large-tile kernel (conv_igemm_v2, >= 128 couts per workgroup) can run
 inline bool v2_eligible(const LayerSpec& s) { return s.kind != kConvIm2col && cout_pad(s.cout) >= 128; }
 
@@ -87,6 +89,8 @@ inline bool v2_eligible(const LayerSpec& s) { return s.kind != kConvIm2col && co
 struct LayerBlob {
     size_t w_off, w_bytes;        // [tap][kc][cg][64][128B]
     size_t w2_off;                // same size, layout 2 (bf16 large-tile kernel) or (size_t)-1
+    size_t w3_off, w3_bytes;      // fp32 only: Winograd F(2x2,3x3) image U = G g G^T, [chunk][pos 16][cout/16][ks 2][64 lanes][16 B]
+                                  // (idc_wino.hip), or (size_t)-1 / 0
     size_t bias_off;              // fp32 [cout_pad]
     size_t bn_scale_off, bn_shift_off;   // fp32 [cout_pad] or (size_t)-1
     size_t fbias_off;             // layers with a shortcut sum: fp32 [cout_pad] = bias + the shortcut conv's bias, or (size_t)-1

@@ -1,0 +1,333 @@
+// idc_wino.hip -- Winograd F(2x2,3x3) form of the 3x3 stride-1 convolutions on the fp32 path (gfx950).
+//
+// Why only fp32 ("Winograd study"): a fused Winograd kernel keeps 16 position-accumulators per output tile, so a
+// workgroup's per-position GEMM tile shrinks 4x and its operand traffic per MFMA grows 4x.  With bf16 MFMAs (32 cycles for
+// 32768 flops) that is ~1 KB of operands per MFMA -- L2-bound; with the exact-fp32 v_mfma_f32_16x16x4_f32 (32 cycles for 2048
+// flops) the same bytes are spread over 16x the matrix-pipe time and the 2.25x fewer multiplies are nearly pure gain.  The
+// transforms are exact in fp32 up to rounding (CPU emulation, oracle/emulate.py: error vs float64 unchanged on torch-init
+// weights, +20 % mean on full-range weights -- inside the reference's own fp32 noise).
+//
+//   Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A            models/pytorch/model.py:13-102 (every 3x3, stride 1, pad = dilation)
+//
+// conv_wino_f32: one workgroup = 16 tiles of 2x2 outputs (an 8x8 block of one dilation sub-grid) x 32 output channels x
+// all 16 transform positions, K = Cin in 128-byte (32-channel) chunks; 8 waves, wave w owns positions 2w, 2w+1:
+//   * dilation d = 2 is four independent d = 1 problems on the parity sub-grids: a workgroup's pixels are Y0 + d*k;
+//   * per chunk the (4+4+2)^2 = 100-pixel input patch goes global -> registers -> LDS (one chunk ahead), every thread
+//     transforms one (tile, 16-byte channel slot, row i of B^T d B) from it: 8 ds_read_b128, 8 float4 add/sub, 4
+//     ds_write_b128 into the position planes V[pos][tile][32 ch] (slot ^ (tile & 7): conflict-free both ways);
+//   * the transformed weights U = G g G^T are packed on the host (float64 transform, idc_engine.hip) in the exact order the
+//     MFMA A operand wants them: [chunk][pos][16 couts][ks][lane][4 floats] -- each wave streams ITS positions' fragments
+//     global -> registers with fully coalesced 1 KiB loads, one chunk ahead; no weights in LDS at all;
+//   * MFMA: v_mfma_f32_16x16x4_f32 on 16-byte fragments (4 MFMAs per fragment pair, the same K permutation on both operands),
+//     per chunk 2 positions x 2 cout blocks x 8 = 32 MFMAs per wave, blocked accumulation per chunk like conv_igemm<float>;
+//   * output transform: the 16 position sums of a (tile, cout) meet in LDS (32 KiB), one thread per (tile, cout) forms the
+//     2x2 outputs, adds the bias, applies activation / eval-BN / per-image shift and stores 128-byte runs of couts.
+// No split-K at batch 1: 256 tiles x 16 cout groups = 256 workgroups for a 512->512 layer at 32x32.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "idc_kernels.h"
+
+#include "idc_layout.h"
+
+#ifndef IDC_STAMP            // in-kernel cycle stamps exist only in the tuning harness (tools/ablate includes idc_kernels.hip first)
+#define IDC_STAMP(i) do {} while (0)
+#endif
+
+namespace idc {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+__device__ __forceinline__ int xcd_remap_w(int b, int nb) {
+    const int xcd = b & 7, q = nb >> 3, r = nb & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (b >> 3);
+}
+
+__device__ __forceinline__ f32x4 as_f(const u32x4& v) { return __builtin_bit_cast(f32x4, v); }
+
+constexpr int kWinoNT = 512;
+constexpr int wino_v_bytes(int tb) { return 16 * 16 * tb * kRowBytes; }                  // one V buffer: [pos 16][tile 16*TB][128 B]
+constexpr int wino_p_items(int tb) { return (10 * (8 * tb + 2) * 8 + kWinoNT - 1) / kWinoNT; }   // 16-byte patch pieces per thread
+constexpr int wino_lds(int tb) { return 2 * wino_v_bytes(tb) + wino_p_items(tb) * kWinoNT * kSlotBytes; }
+
+// TB = tile blocks of 16 per workgroup (tiles: 4 rows x 4*TB columns = an 8 x 8*TB pixel block of one sub-grid),
+// CB = 16-cout blocks per workgroup.  A weight fragment (1 KiB per wave) feeds 4*TB MFMAs, a V fragment 4*CB: <1,2> is the
+// small-grid form, <2,1> halves the weight stream for the same number of workgroups (batch 1: the kernel is bound by the
+// L2 -> CU stream of U, 64 KiB per chunk and workgroup in the <1,2> form), <2,2> is the throughput form.
+template <int TB, int CB>
+__global__ __launch_bounds__(kWinoNT, 2) void conv_wino_f32(const ConvArgs a) {
+    constexpr int NT = kWinoNT, TXL = 4 * TB, PW = 8 * TB + 2, NTILE = 16 * TB, VB = wino_v_bytes(TB), PI = wino_p_items(TB);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Vb = smem;
+    char* const Pb = smem + 2 * VB;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    IDC_STAMP(0);
+
+    int b = xcd_remap_w(blockIdx.x, gridDim.x);
+    // block order: tile blocks fastest, the cout group slowest -- each XCD (a contiguous range of the logical order) then
+    // works on few cout groups whose U slices stay in that XCD's 4 MiB L2 for all tile blocks
+    const int d = a.dy[8];                                     // dilation (tap (2,2) sits at +d)
+    const int bx = b % a.tiles_x; b /= a.tiles_x;
+    const int by = b % a.tiles_y; b /= a.tiles_y;
+    const int par = b % (d * d); b /= d * d;
+    const int n = b % a.N;
+    const int cg = b / a.N;                                    // group of 16*CB couts
+    const int Y0 = par / d + d * 8 * by, X0 = par % d + d * 8 * TB * bx;   // first output pixel; the block's pixels are Y0 + d*k
+    const int H = a.Hs, W = a.Ws;
+    const int nkc = a.nkc;
+    const int pix_bytes = nkc * kRowBytes;
+    const char* const img = (const char*)a.in + (size_t)n * H * W * pix_bytes;
+
+    // ---- patch staging plan (fixed over the K loop): item k = (patch pixel k>>3, slot k&7) ---------------------------
+    int poff[PI];
+#pragma unroll
+    for (int j = 0; j < PI; ++j) {
+        const int k = tid + j * NT;
+        const int p = k >> 3, s = k & 7;
+        const int py = p / PW, px = p - py * PW;
+        const int Y = Y0 + d * (py - 1), X = X0 + d * (px - 1);
+        const bool inside = k < 10 * PW * 8 && (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W;
+        poff[j] = inside ? (Y * W + X) * pix_bytes + s * kSlotBytes : -1;
+    }
+    u32x4 xr[PI];
+    auto load_patch = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < PI; ++j)
+            xr[j] = *(const u32x4*)((poff[j] >= 0 && c < nkc) ? img + poff[j] + c * kRowBytes : (const char*)a.zeros);
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int j = 0; j < PI; ++j) *(u32x4*)(Pb + (tid + j * NT) * kSlotBytes) = xr[j];
+    };
+
+    // ---- input transform: item = (tile tt, row i of B^T d B, slot ts); TB items per thread --------------------------------
+    const int ts = tid & 7, ti = (tid >> 3) & 3;
+    const int rA = ti == 0 ? 0 : (ti == 2 ? 2 : 1), rB = ti == 3 ? 3 : (ti == 2 ? 1 : 2);
+    const float sgn = ti == 1 ? 1.f : -1.f;                    // rows: d0-d2 | d1+d2 | d2-d1 | d1-d3
+    auto transform = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < TB; ++q) {
+            const int tt = (tid >> 5) + q * 16;
+            const int pbase = ((2 * (tt / TXL)) * PW + 2 * (tt % TXL)) * kRowBytes + ts * kSlotBytes;
+            f32x4 t[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 u = *(const f32x4*)(Pb + pbase + (rA * PW + c) * kRowBytes);
+                const f32x4 v = *(const f32x4*)(Pb + pbase + (rB * PW + c) * kRowBytes);
+                t[c] = u + sgn * v;
+            }
+            char* const dst = Vb + buf * VB + ((ti * 4) * NTILE + tt) * kRowBytes + ((ts ^ (tt & 7)) * kSlotBytes);
+            *(f32x4*)(dst) = t[0] - t[2];
+            *(f32x4*)(dst + NTILE * kRowBytes) = t[1] + t[2];
+            *(f32x4*)(dst + 2 * NTILE * kRowBytes) = t[2] - t[1];
+            *(f32x4*)(dst + 3 * NTILE * kRowBytes) = t[1] - t[3];
+        }
+    };
+
+    // ---- weight fragments: this wave's positions p0, p0+1; [chunk][pos][cout block of 16][ks][lane][16 B] -------------
+    const int p0 = wave * 2;
+    const int ncb = a.ncg * 4;                                 // 16-cout blocks in the layer
+    const char* const ubase = (const char*)a.wgt + ((size_t)(cg * CB) * 2 * 64 + lane) * kSlotBytes;
+    const size_t u_pos_stride = (size_t)ncb * 2 * 64 * kSlotBytes;
+    u32x4 areg[2][2][CB][2];                                   // [buffer][pos][cout block][ks]
+    auto load_A = [&](int c, auto bufc) {
+        constexpr int B = decltype(bufc)::value;
+        const bool real = c < nkc;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const char* src = real ? ubase + ((size_t)c * 16 + p0 + pp) * u_pos_stride : (const char*)a.zeros;
+            const int step = real ? 64 * kSlotBytes : 0;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    areg[B][pp][cb][ks] = *(const u32x4*)(src + (cb * 2 + ks) * step);
+        }
+    };
+
+    const int fn = lane & 15, fg = lane >> 4;
+    f32x4 tot[2][CB][TB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+#pragma unroll
+            for (int k = 0; k < TB; ++k) tot[i][j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue -------------------------------------------------------------------------------------------------
+    load_patch(0);
+    load_A(0, std::integral_constant<int, 0>{});
+    store_patch();
+    __syncthreads();
+    load_patch(1);
+    transform(0);
+    __syncthreads();
+    IDC_STAMP(1);
+
+    auto chunk = [&](int c, auto curc) {
+        constexpr int CUR = decltype(curc)::value;
+        load_A(c + 1, std::integral_constant<int, CUR ^ 1>{});  // next chunk's fragments (zero page past the end)
+        store_patch();                                         // patch of chunk c+1 (its transform runs after the barrier)
+        load_patch(c + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[2][CB][TB];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < CB; ++j)
+#pragma unroll
+                for (int k = 0; k < TB; ++k) acc[i][j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const char* const vcur = Vb + CUR * VB;
+        f32x4 bf[2][TB][2];
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    bf[pp][tb][ks] = *(const f32x4*)(vcur + ((p0 + pp) * NTILE + tb * 16 + fn) * kRowBytes + (((ks * 4 + fg) ^ (fn & 7)) * kSlotBytes));
+#ifndef IDC_WINO_ABL_NO_MFMA
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                        for (int tb = 0; tb < TB; ++tb)
+                            acc[pp][cb][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(areg[CUR][pp][cb][ks])[e], bf[pp][tb][ks][e], acc[pp][cb][tb], 0, 0, 0);
+#else       // timing ablation (tools/ablate): keep the operands live, drop the matrix work
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int tb = 0; tb < TB; ++tb)
+                    acc[pp][cb][tb] += as_f(areg[CUR][pp][cb][0]) * bf[pp][tb][0] + as_f(areg[CUR][pp][cb][1]) * bf[pp][tb][1];
+#endif
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < CB; ++j)
+#pragma unroll
+                for (int k = 0; k < TB; ++k) tot[i][j][k] += acc[i][j][k];
+        __syncthreads();                                       // the patch of chunk c+1 is complete
+#ifndef IDC_WINO_ABL_NO_TRANSFORM
+        if (c + 1 < nkc) transform(CUR ^ 1);
+#endif
+        __syncthreads();                                       // V[CUR ^ 1] is complete
+    };
+    int c = 0;
+    for (; c + 1 < nkc; c += 2) {
+        chunk(c, std::integral_constant<int, 0>{});
+        chunk(c + 1, std::integral_constant<int, 1>{});
+    }
+    if (c < nkc) chunk(c, std::integral_constant<int, 0>{});
+
+    IDC_STAMP(2);
+    // ---- output transform: the 16 position sums of every (tile, cout) meet in LDS -----------------------------------
+    // (the last barrier of the K loop is behind us: nobody reads V any more)
+    char* const Mx = smem;                                     // [pos 16][tile 16*TB][128-B row of couts], 16-B slot ^ (tile & 7)
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb)
+                *(f32x4*)(Mx + ((p0 + pp) * NTILE + tb * 16 + fn) * kRowBytes + (((cb * 4 + fg) ^ (fn & 7)) * kSlotBytes)) = tot[pp][cb][tb];
+    __syncthreads();
+    const int CoutPad = a.ncg * kCoutGroup;
+    const bool has_bn = a.bn_scale != nullptr;
+    constexpr int NC = 16 * CB;
+#pragma unroll
+    for (int q = 0; q < (NTILE * NC) / NT; ++q) {
+        const int idx = tid + q * NT;
+        const int oc = idx % NC, ot = idx / NC;
+        float m[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+            m[p] = *(const float*)(Mx + (p * NTILE + ot) * kRowBytes + (((oc >> 2) ^ (ot & 7)) * kSlotBytes) + (oc & 3) * 4);
+        float s0[4], s1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s0[j] = m[0 * 4 + j] + m[1 * 4 + j] + m[2 * 4 + j];
+            s1[j] = m[1 * 4 + j] - m[2 * 4 + j] - m[3 * 4 + j];
+        }
+        const float y[2][2] = {{s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3]}, {s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]}};
+        const int co = cg * NC + oc;
+        const float bias = a.bias[co];
+        const float bsc = has_bn ? a.bn_scale[co] : 1.f, bsh = has_bn ? a.bn_shift[co] : 0.f;
+        const float ish = a.img_shift ? a.img_shift[(size_t)n * CoutPad + co] : 0.f;
+        float* const out = (float*)a.out + (size_t)n * H * W * CoutPad + co;
+        const int oy = Y0 + d * 2 * (ot / TXL), ox = X0 + d * 2 * (ot % TXL);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int yy = oy + d * i, xx = ox + d * j;
+                float v = y[i][j] + bias;
+                if (a.act == 1) v = fmaxf(v, 0.f);
+                else if (a.act == 2) v = v > 0.f ? v : 0.2f * v;
+                if (has_bn) v = fmaf(v, bsc, bsh);
+                v += ish;
+                if (yy < H && xx < W) out[((size_t)yy * W + xx) * CoutPad] = v;
+            }
+    }
+    IDC_STAMP(3);
+#ifdef IDC_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    IDC_STAMP(4);
+#endif
+}
+
+int g_wino_form = getenv("IDC_WINO_FORM") ? atoi(getenv("IDC_WINO_FORM")) : 0;      // tuning: 0 automatic, 12 / 21 / 22 = force <TB,CB>
+
+void set_wino_form(int form) { g_wino_form = form; }
+
+template <int TB, int CB>
+static hipError_t launch_wino_t(ConvArgs& a, int d, hipStream_t s) {
+    a.tiles_x = ((a.Ws + d - 1) / d + 8 * TB - 1) / (8 * TB);
+    a.tiles_y = ((a.Hs + d - 1) / d + 7) / 8;
+    const long long blocks = (long long)a.tiles_x * a.tiles_y * d * d * a.N * (a.ncg * 4 / CB);
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((conv_wino_f32<TB, CB>), dim3((unsigned)blocks), dim3(kWinoNT), wino_lds(TB), s, a);
+    return hipGetLastError();
+}
+
+// 3x3 stride-1 conv (dilation 1 or 2), fp32, Winograd F(2x2,3x3).  a.wgt = the layer's U image (idc_engine.hip packs it),
+// a.nkc = Cin / 32, a.ncg = CoutPad / 64, a.Hs / a.Ws = image size, a.dy[8] = dilation; tiles_x / tiles_y are set here.
+// Form by grid size (speed only: every form computes the same sums in the same order): the throughput form <2,2> when it
+// still gives every CU a workgroup, else <1,2>.
+hipError_t launch_conv_wino(const ConvArgs& a0, hipStream_t s) {
+    ConvArgs a = a0;
+    const int d = a.dy[8];
+    if ((d != 1 && d != 2) || a.si != 1 || a.so != 1 || a.nphase != 1 || a.ntaps != 9 || a.resid != nullptr || !a.out_f32 ||
+        a.zeros == nullptr || a.nkc < 1)
+        return hipErrorInvalidConfiguration;
+    const long long t2 = (long long)(((a.Ws + d - 1) / d + 15) / 16) * (((a.Hs + d - 1) / d + 7) / 8) * d * d * a.N;   // 8x16-pixel blocks
+    int form = g_wino_form;
+    // (measured, profiles/r03_wino_harness.txt: <2,1> loses to <1,2> on every shape -- its transform work per workgroup doubles --
+    //  and is kept for the tests and the tuning switch only)
+    if (form != 12 && form != 21 && form != 22) form = t2 * (a.ncg * 2) >= 256 ? 22 : 12;
+    if (form == 22) return launch_wino_t<2, 2>(a, d, s);
+    if (form == 21) return launch_wino_t<2, 1>(a, d, s);
+    return launch_wino_t<1, 2>(a, d, s);
+}
+
+hipError_t init_kernels_wino() {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wino_f32<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_lds(1));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)conv_wino_f32<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_lds(2));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)conv_wino_f32<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_lds(2));
+}
+
+}  // namespace idc

@@ -77,7 +77,8 @@ SPLITK_POLICIES = {"auto": 0, "never": 1, "always": 2}
 
 
 def set_option(name, value):
-    """Process-wide test switch (``idc_set_option``): 'fuse_conv1' 0/1."""
+    """Process-wide switches (``idc_set_option``; speed / kernel choice only): 'fuse_conv1' 0/1, 'click' -1/0/1,
+    'winograd' 0/1 (fp32 3x3 stride-1 layers as Winograd F(2x2,3x3), default on), 'winograd_form' 0/12/21/22."""
     N.check(N.load().idc_set_option(name.encode(), int(value)))
 
 

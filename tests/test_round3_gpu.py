@@ -7,11 +7,81 @@ import os
 import numpy as np
 import pytest
 
+import torch
+
 from interactive_deep_colorization_amd import _native as N
 from interactive_deep_colorization_amd import api, engine, workloads
+from oracle import siggraph_torch
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
+WINO_LAYERS = ["conv1_2", "conv2_2", "conv3_2", "conv3_3", "conv4_2", "conv4_3", "conv5_1", "conv5_2", "conv5_3", "conv6_1", "conv6_2",
+               "conv6_3", "conv7_1", "conv7_2", "conv7_3", "conv3_3_short", "conv8_2", "conv8_3", "conv2_2_short", "conv9_2",
+               "conv1_2_short", "conv10_2"]
+
+
+@pytest.fixture(autouse=True)
+def _reset_options():
+    yield
+    engine.set_option("winograd", 1)
+    engine.set_option("winograd_form", 0)
+    engine.set_splitk_policy("auto")
+
+
+# ------------------------------------------------------------------------------------------------ fp32 Winograd F(2x2,3x3)
+@pytest.mark.parametrize("form", [0, 12, 21, 22])
+@pytest.mark.parametrize("name", ["net64_he_s0_mc05", "net32x48_he_s2", "net64_torch_s1_mc0"])
+def test_winograd_fp32_layer_by_layer(golden, make_sd, name, form):
+    """Every 3x3 stride-1 layer of the fp32 path runs as conv_wino_f32 (dilation 1 and 2, ragged 32x48 geometry with 3x... pixel
+    trunks, batch 2, every <TB,CB> form forced): each against the float64 oracle at the tolerance of the direct fp32 kernels,
+    the ab map against the reference golden."""
+    g = golden(name)
+    style, seed = str(g["weight_style"]), int(g["weight_seed"])
+    n, _, H, W = g["L_mc"].shape
+    _, _, acts = siggraph_torch.forward(make_sd(seed, style), g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]),
+                                        return_acts=True, dtype=torch.float64)
+    engine.set_option("winograd_form", form)
+    e = engine.HipColorizer(H, W, max_batch=n, precision="fp32")
+    e.load_state_dict(make_sd(seed, style))
+    out = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
+    table = {r["name"]: r["kernel"] for r in e.layer_table()}
+    assert [k for k in WINO_LAYERS if table[k] != "conv_wino_f32"] == [], table
+    assert not any("splitK" in v for k, v in table.items() if k in WINO_LAYERS)
+    for k in WINO_LAYERS:
+        ref = acts[k]
+        err = np.abs(e.activation(k, n) - ref).max()
+        assert err <= 2e-4 * (1 + np.abs(ref).max()), "layer %s (form %d): max-abs err %.3e" % (k, form, err)
+    d = np.abs(out - g["out_ab"])
+    assert d.max() <= (3e-3 if style == "he" else 1e-3), d.max()
+    np.testing.assert_array_equal(e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"])), out)       # deterministic
+    # the direct kernels compute the same network (different summation order only)
+    engine.set_option("winograd", 0)
+    base = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
+    assert not any(v == "conv_wino_f32" for v in (r["kernel"] for r in e.layer_table()))
+    assert np.abs(out - base).max() <= (3e-3 if style == "he" else 5e-4)
+    e.close()
+
+
+def test_winograd_fp32_click_config(golden, make_sd):
+    """BASELINE configs[1] (one 256x256 image, 5 hints), fp32 default = Winograd: the reference golden at 1e-3, batch == images alone."""
+    g = golden("config2_mortar_5hints_torchinit")
+    e = engine.HipColorizer(256, 256, max_batch=1, precision="fp32")
+    e.load_state_dict(make_sd(int(g["weight_seed"]), str(g["weight_style"])))
+    out = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
+    kernels = [r["kernel"] for r in e.layer_table() if r["launches"] > 0]
+    assert sum(k == "conv_wino_f32" for k in kernels) >= 20 and sum("splitK" in k for k in kernels) <= 4, kernels
+    assert np.abs(out - g["out_ab"]).max() <= 1e-3
+    e.close()
+    L, ab, m = workloads.random_batch(3, 64, seed=9)
+    e = engine.HipColorizer(64, 64, max_batch=3, precision="fp32")
+    e.load_state_dict(make_sd(0, "he"))
+    whole = e.forward(L, ab, m, 0.0)
+    for i in range(3):
+        np.testing.assert_array_equal(e.forward(L[i:i + 1], ab[i:i + 1], m[i:i + 1], 0.0)[0], whole[i])
+    for form in (12, 21, 22):                 # the forms differ in tiling only: same sums in the same order, bit for bit
+        engine.set_option("winograd_form", form)
+        np.testing.assert_array_equal(e.forward(L, ab, m, 0.0), whole)
+    e.close()
 
 
 @pytest.mark.parametrize("precision,size,nb", [("bf16", 64, 4), ("fp32", 64, 2), ("bf16", 256, 32)])
