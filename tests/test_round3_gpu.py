@@ -69,7 +69,7 @@ def test_winograd_fp32_click_config(golden, make_sd):
     e.load_state_dict(make_sd(int(g["weight_seed"]), str(g["weight_style"])))
     out = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
     kernels = [r["kernel"] for r in e.layer_table() if r["launches"] > 0]
-    assert sum(k == "conv_wino_f32" for k in kernels) >= 20 and sum("splitK" in k for k in kernels) <= 4, kernels
+    assert sum(k == "conv_wino_f32" for k in kernels) >= 20 and sum("splitK" in k for k in kernels) <= 6, kernels      # only the stride-2 convs and the deconvs still split K
     assert np.abs(out - g["out_ab"]).max() <= 1e-3
     e.close()
     L, ab, m = workloads.random_batch(3, 64, seed=9)
