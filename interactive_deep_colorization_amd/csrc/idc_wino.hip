@@ -51,7 +51,10 @@ __device__ __forceinline__ f32x4 as_f(const u32x4& v) { return __builtin_bit_cas
 constexpr int kWinoNT = 512;
 constexpr int wino_v_bytes(int tb) { return 16 * 16 * tb * kRowBytes; }                  // one V buffer: [pos 16][tile 16*TB][128 B]
 constexpr int wino_p_items(int tb) { return (10 * (8 * tb + 2) * 8 + kWinoNT - 1) / kWinoNT; }   // 16-byte patch pieces per thread
-constexpr int wino_lds(int tb) { return 2 * wino_v_bytes(tb) + wino_p_items(tb) * kWinoNT * kSlotBytes; }
+constexpr int wino_p_bytes(int tb) { return wino_p_items(tb) * kWinoNT * kSlotBytes; }
+// two patch buffers; TB = 1: two V buffers (one barrier per chunk), TB = 2: ONE V buffer of 64 KiB (a chunk's B fragments are
+// read into registers up front, then the next chunk's transform overwrites it under the chunk's MFMAs -- see the K loops)
+constexpr int wino_lds(int tb) { return (tb == 1 ? 2 : 1) * wino_v_bytes(tb) + 2 * wino_p_bytes(tb); }
 
 // TB = tile blocks of 16 per workgroup (tiles: 4 rows x 4*TB columns = an 8 x 8*TB pixel block of one sub-grid),
 // CB = 16-cout blocks per workgroup.  A weight fragment (1 KiB per wave) feeds 4*TB MFMAs, a V fragment 4*CB: <1,2> is the
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(kWinoNT, 2) void conv_wino_f32(const ConvArgs a) {
     constexpr int NT = kWinoNT, TXL = 4 * TB, PW = 8 * TB + 2, NTILE = 16 * TB, VB = wino_v_bytes(TB), PI = wino_p_items(TB);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const Vb = smem;
-    char* const Pb = smem + 2 * VB;
+    char* const Pb = smem + (TB == 1 ? 2 : 1) * VB;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -101,20 +104,21 @@ __global__ __launch_bounds__(kWinoNT, 2) void conv_wino_f32(const ConvArgs a) {
         for (int j = 0; j < PI; ++j)
             xr[j] = *(const u32x4*)((poff[j] >= 0 && c < nkc) ? img + poff[j] + c * kRowBytes : (const char*)a.zeros);
     };
-    auto store_patch = [&]() {
+    constexpr int PB = wino_p_bytes(TB);
+    auto store_patch = [&](int pbuf) {
 #pragma unroll
-        for (int j = 0; j < PI; ++j) *(u32x4*)(Pb + (tid + j * NT) * kSlotBytes) = xr[j];
+        for (int j = 0; j < PI; ++j) *(u32x4*)(Pb + pbuf * PB + (tid + j * NT) * kSlotBytes) = xr[j];
     };
 
     // ---- input transform: item = (tile tt, row i of B^T d B, slot ts); TB items per thread --------------------------------
     const int ts = tid & 7, ti = (tid >> 3) & 3;
     const int rA = ti == 0 ? 0 : (ti == 2 ? 2 : 1), rB = ti == 3 ? 3 : (ti == 2 ? 1 : 2);
     const float sgn = ti == 1 ? 1.f : -1.f;                    // rows: d0-d2 | d1+d2 | d2-d1 | d1-d3
-    auto transform = [&](int buf) {
+    auto transform = [&](int buf, int pbuf) {
 #pragma unroll
         for (int q = 0; q < TB; ++q) {
             const int tt = (tid >> 5) + q * 16;
-            const int pbase = ((2 * (tt / TXL)) * PW + 2 * (tt % TXL)) * kRowBytes + ts * kSlotBytes;
+            const int pbase = pbuf * PB + ((2 * (tt / TXL)) * PW + 2 * (tt % TXL)) * kRowBytes + ts * kSlotBytes;
             f32x4 t[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(kWinoNT, 2) void conv_wino_f32(const ConvArgs a) {
     const int ncb = a.ncg * 4;                                 // 16-cout blocks in the layer
     const char* const ubase = (const char*)a.wgt + ((size_t)(cg * CB) * 2 * 64 + lane) * kSlotBytes;
     const size_t u_pos_stride = (size_t)ncb * 2 * 64 * kSlotBytes;
-    u32x4 areg[2][2][CB][2];                                   // [buffer][pos][cout block][ks]
+    u32x4 areg[TB == 1 ? 3 : 2][2][CB][2];                     // [buffer][pos][cout block][ks]; TB = 1: fragments are requested TWO chunks ahead
     auto load_A = [&](int c, auto bufc) {
         constexpr int B = decltype(bufc)::value;
         const bool real = c < nkc;
@@ -160,22 +164,9 @@ __global__ __launch_bounds__(kWinoNT, 2) void conv_wino_f32(const ConvArgs a) {
 #pragma unroll
             for (int k = 0; k < TB; ++k) tot[i][j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue -------------------------------------------------------------------------------------------------
-    load_patch(0);
-    load_A(0, std::integral_constant<int, 0>{});
-    store_patch();
-    __syncthreads();
-    load_patch(1);
-    transform(0);
-    __syncthreads();
-    IDC_STAMP(1);
-
-    auto chunk = [&](int c, auto curc) {
+    // one chunk's matrix work: B fragments from V[CUR], 2 x CB x TB x 8 MFMAs, blocked accumulation into tot
+    auto mma_chunk = [&](auto curc) {
         constexpr int CUR = decltype(curc)::value;
-        load_A(c + 1, std::integral_constant<int, CUR ^ 1>{});  // next chunk's fragments (zero page past the end)
-        store_patch();                                         // patch of chunk c+1 (its transform runs after the barrier)
-        load_patch(c + 2);
-        __builtin_amdgcn_sched_barrier(0);
         f32x4 acc[2][CB][TB];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -219,18 +210,239 @@ __global__ __launch_bounds__(kWinoNT, 2) void conv_wino_f32(const ConvArgs a) {
             for (int j = 0; j < CB; ++j)
 #pragma unroll
                 for (int k = 0; k < TB; ++k) tot[i][j][k] += acc[i][j][k];
-        __syncthreads();                                       // the patch of chunk c+1 is complete
-#ifndef IDC_WINO_ABL_NO_TRANSFORM
-        if (c + 1 < nkc) transform(CUR ^ 1);
-#endif
-        __syncthreads();                                       // V[CUR ^ 1] is complete
     };
-    int c = 0;
-    for (; c + 1 < nkc; c += 2) {
-        chunk(c, std::integral_constant<int, 0>{});
-        chunk(c + 1, std::integral_constant<int, 1>{});
+
+    if constexpr (TB == 1) {
+        // ---- one barrier per chunk: V and the patch are both double-buffered.  In chunk c (after the barrier that publishes
+        // V[c&1] and patch c+1 in P[(c+1)&1]) a wave stores the patch of chunk c+2 (registers, fetched a chunk ago) into
+        // P[c&1], requests patch c+3 and the fragments of chunk c+1, transforms patch c+1 into V[(c+1)&1] and runs chunk c's
+        // MFMAs -- nothing in the chunk waits for another wave, so the compiler interleaves the transform's LDS traffic and
+        // the loads with the matrix work.
+        load_patch(0);
+        load_A(0, std::integral_constant<int, 0>{});
+        load_A(nkc > 1 ? 1 : 0, std::integral_constant<int, 1>{});
+        store_patch(0);
+        load_patch(1);
+        __syncthreads();
+        transform(0, 0);
+        store_patch(1);
+        load_patch(2);
+        __syncthreads();
+        IDC_STAMP(1);
+        // Instruction order inside a chunk is pinned (sched_barrier between groups): a wave that issues its ten 1 KiB loads
+        // back to back sits in the memory-instruction queue for ~1 k cycles before it reaches its first MFMA (measured: the
+        // matrix work then ADDS to the load time instead of hiding it), so one load follows every group of four MFMAs.
+        // The weight fragments are requested TWO chunks ahead (three register sets): with one chunk (64 KiB per CU) in flight the
+        // L2 -> CU stream is latency-bound at ~29 B/clk, i.e. a chunk's fragments arrive a chunk and a bit after their request.
+        auto chunk1 = [&](int c, auto aidx) {
+            constexpr int AI = decltype(aidx)::value, AN = (AI + 2) % 3;
+            const int CUR = c & 1;
+            static_assert(CB == 2, "group plan below assumes 8 A fragments per chunk");
+            const int cn = c + 2 < nkc ? c + 2 : nkc - 1;       // past the end: a harmless re-read of the last chunk (no branch, no select)
+            const char* const asrc = ubase + ((size_t)cn * 16 + p0) * u_pos_stride;
+            const char* const vcur = Vb + CUR * VB;
+            f32x4 bf[2][2];
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    bf[pp][ks] = *(const f32x4*)(vcur + ((p0 + pp) * NTILE + fn) * kRowBytes + (((ks * 4 + fg) ^ (fn & 7)) * kSlotBytes));
+            store_patch(CUR);                                  // patch c+2 -> P[c&1] (its reader, the transform of chunk c-1, is behind the barrier)
+            f32x4 acc[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            auto mma4 = [&](int ks, int e) {
+#ifndef IDC_WINO_ABL_NO_MFMA
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+                        acc[pp][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(areg[AI][pp][cb][ks])[e], bf[pp][ks][e], acc[pp][cb], 0, 0, 0);
+#else
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) acc[pp][cb][e] += as_f(areg[AI][pp][cb][ks])[e] * bf[pp][ks][e];
+#endif
+            };
+            auto loadA1 = [&](int pp, int cb, int ks) {
+                areg[AN][pp][cb][ks] = *(const u32x4*)(asrc + (size_t)pp * u_pos_stride + (cb * 2 + ks) * 64 * kSlotBytes);
+            };
+            // transform of patch c+1 (P[(c+1)&1]) -> V[(c+1)&1], cut in three pieces
+            const int tt = tid >> 5;
+            const int pbase = (CUR ^ 1) * PB + ((2 * (tt / TXL)) * PW + 2 * (tt % TXL)) * kRowBytes + ts * kSlotBytes;
+            f32x4 tu[4], tv[4];
+            const bool do_tr = c + 1 < nkc;
+            mma4(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            loadA1(0, 0, 0); loadA1(0, 0, 1);
+            mma4(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            loadA1(0, 1, 0); loadA1(0, 1, 1);
+            mma4(0, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            loadA1(1, 0, 0); loadA1(1, 0, 1);
+            mma4(0, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            loadA1(1, 1, 0); loadA1(1, 1, 1);
+            mma4(1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_patch(c + 3);
+#ifndef IDC_WINO_ABL_NO_TRANSFORM
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tu[q] = *(const f32x4*)(Pb + pbase + (rA * PW + q) * kRowBytes);
+#endif
+            mma4(1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+#ifndef IDC_WINO_ABL_NO_TRANSFORM
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tv[q] = *(const f32x4*)(Pb + pbase + (rB * PW + q) * kRowBytes);
+#endif
+            mma4(1, 2);
+            __builtin_amdgcn_sched_barrier(0);
+#ifndef IDC_WINO_ABL_NO_TRANSFORM
+            if (do_tr) {
+                f32x4 t[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) t[q] = tu[q] + sgn * tv[q];
+                char* const dst = Vb + (CUR ^ 1) * VB + ((ti * 4) * NTILE + tt) * kRowBytes + ((ts ^ (tt & 7)) * kSlotBytes);
+                *(f32x4*)(dst) = t[0] - t[2];
+                *(f32x4*)(dst + NTILE * kRowBytes) = t[1] + t[2];
+                *(f32x4*)(dst + 2 * NTILE * kRowBytes) = t[2] - t[1];
+                *(f32x4*)(dst + 3 * NTILE * kRowBytes) = t[1] - t[3];
+            }
+#endif
+            mma4(1, 3);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) tot[i][j][0] += acc[i][j];
+            __syncthreads();
+        };
+        int c = 0;
+        for (; c + 2 < nkc; c += 3) {
+            chunk1(c, std::integral_constant<int, 0>{});
+            chunk1(c + 1, std::integral_constant<int, 1>{});
+            chunk1(c + 2, std::integral_constant<int, 2>{});
+        }
+        if (c < nkc) chunk1(c, std::integral_constant<int, 0>{});
+        if (c + 1 < nkc) chunk1(c + 1, std::integral_constant<int, 1>{});
+    } else {
+        // ---- TB = 2: ONE V buffer.  Chunk c: barrier A (V(c) and patch c+1 complete) -> every wave reads its 8 B fragments into
+        // registers -> barrier B (V is free) -> patch c+2 to P[c&1], fragment loads of chunk c+1, patch c+3, and the transform of
+        // patch c+1 INTO THE SAME V, all interleaved with the chunk's 32*CB MFMAs.  The transform writes 64 KiB of LDS per chunk
+        // (ds_write_b128 runs at ~80 B/clk per CU: ~800 cycles): between two barriers it was 35 % of the kernel, here it hides
+        // under the matrix work.
+        load_patch(0);
+        load_A(0, std::integral_constant<int, 0>{});
+        store_patch(0);
+        load_patch(1);
+        __syncthreads();
+        transform(0, 0);
+        store_patch(1);
+        load_patch(2);
+        IDC_STAMP(1);
+        auto chunk2 = [&](int c, auto curc) {
+            constexpr int CUR = decltype(curc)::value;
+            const int cn = c + 1 < nkc ? c + 1 : nkc - 1;
+            const char* const asrc = ubase + ((size_t)cn * 16 + p0) * u_pos_stride;
+            __syncthreads();                                       // A: V(c) and the patch of chunk c+1 are complete
+            f32x4 bf[2][TB][2];
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+                        bf[pp][tb][ks] = *(const f32x4*)(Vb + ((p0 + pp) * NTILE + tb * 16 + fn) * kRowBytes + (((ks * 4 + fg) ^ (fn & 7)) * kSlotBytes));
+            __syncthreads();                                       // B: every wave holds its fragments, V may be overwritten
+            store_patch(c & 1);                                    // patch c+2 -> P[c&1] (read by the transform of chunk c-1, long done)
+            f32x4 acc[2][CB][TB];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < CB; ++j)
+#pragma unroll
+                    for (int k = 0; k < TB; ++k) acc[i][j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            auto mmag = [&](int ks, int e) {
+#ifndef IDC_WINO_ABL_NO_MFMA
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                        for (int tb = 0; tb < TB; ++tb)
+                            acc[pp][cb][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(areg[CUR][pp][cb][ks])[e], bf[pp][tb][ks][e], acc[pp][cb][tb], 0, 0, 0);
+#else
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                        for (int tb = 0; tb < TB; ++tb) acc[pp][cb][tb][e] += as_f(areg[CUR][pp][cb][ks])[e] * bf[pp][tb][ks][e];
+#endif
+            };
+            auto loadA1 = [&](int pp, int cb, int ks) {
+                areg[CUR ^ 1][pp][cb][ks] = *(const u32x4*)(asrc + (size_t)pp * u_pos_stride + (cb * 2 + ks) * 64 * kSlotBytes);
+            };
+            const int pbuf = (c + 1) & 1;
+            const bool do_tr = c + 1 < nkc;
+            f32x4 tu[4], tv[4];
+            auto tr_read = [&](int q) {
+                const int tt = (tid >> 5) + q * 16;
+                const int pbase = pbuf * PB + ((2 * (tt / TXL)) * PW + 2 * (tt % TXL)) * kRowBytes + ts * kSlotBytes;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    tu[k] = *(const f32x4*)(Pb + pbase + (rA * PW + k) * kRowBytes);
+                    tv[k] = *(const f32x4*)(Pb + pbase + (rB * PW + k) * kRowBytes);
+                }
+            };
+            auto tr_write = [&](int q) {
+                const int tt = (tid >> 5) + q * 16;
+                f32x4 t[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t[k] = tu[k] + sgn * tv[k];
+                char* const dst = Vb + ((ti * 4) * NTILE + tt) * kRowBytes + ((ts ^ (tt & 7)) * kSlotBytes);
+                if (do_tr) {
+                    *(f32x4*)(dst) = t[0] - t[2];
+                    *(f32x4*)(dst + NTILE * kRowBytes) = t[1] + t[2];
+                    *(f32x4*)(dst + 2 * NTILE * kRowBytes) = t[2] - t[1];
+                    *(f32x4*)(dst + 3 * NTILE * kRowBytes) = t[1] - t[3];
+                }
+            };
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                mmag(g >> 2, g & 3);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g < 4) {                                       // the fragments (pos g>>1, ks g&1) of every cout block
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb) loadA1(g >> 1, cb, g & 1);
+                }
+#ifndef IDC_WINO_ABL_NO_TRANSFORM
+                if (g == 1) tr_read(0);
+                if (g == 3) tr_write(0);
+                if (g == 4) tr_read(1);
+                if (g == 6) tr_write(1);
+#endif
+                if (g == 5) load_patch(c + 3);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < CB; ++j)
+#pragma unroll
+                    for (int k = 0; k < TB; ++k) tot[i][j][k] += acc[i][j][k];
+        };
+        int c = 0;
+        for (; c + 1 < nkc; c += 2) {
+            chunk2(c, std::integral_constant<int, 0>{});
+            chunk2(c + 1, std::integral_constant<int, 1>{});
+        }
+        if (c < nkc) chunk2(c, std::integral_constant<int, 0>{});
+        __syncthreads();                                           // the epilogue reuses V: every wave's last fragment reads are done
     }
-    if (c < nkc) chunk(c, std::integral_constant<int, 0>{});
 
     IDC_STAMP(2);
     // ---- output transform: the 16 position sums of every (tile, cout) meet in LDS -----------------------------------
