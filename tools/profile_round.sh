@@ -40,5 +40,19 @@ python tools/extra_configs.py > $OUT/extra_configs.txt 2>&1
 python tools/gpu_diag.py 2>/dev/null | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" > $OUT/layer_table.txt
 # identical launches on bench / damped / all-zero operands: how much of the forward time is the DVFS response to switching activity
 python tools/power_probe.py 30 2>/dev/null | grep "^{" > $OUT/power_probe.txt
+# fp32 path (round 3: Winograd F(2x2,3x3) for the 3x3 stride-1 layers): bench line, kernel stats and SQ counters of the same command
+python bench.py --precision fp32 --no-cpu-baseline --no-end-to-end --no-peak-probe --no-latency > $OUT/bench_fp32.json 2>/dev/null
+IDC_WINO=0 python bench.py --precision fp32 --no-cpu-baseline --no-end-to-end --no-peak-probe --no-latency > $OUT/bench_fp32_direct.json 2>/dev/null
+cd /tmp
+CMD32="python $R/bench.py --precision fp32 --steps 3 --warmup 1 --no-latency --no-cpu-baseline --no-end-to-end --no-peak-probe"
+rocprofv3 --kernel-trace --stats -d $OUT/stats_fp32 -o x -- $CMD32 > $OUT/stats_fp32.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc_sq_fp32 -o x -- $CMD32 > $OUT/pmc_sq_fp32.log 2>&1
+cd $R
+for p in stats_fp32 pmc_sq_fp32; do
+  f=$(find $OUT/$p -name "*.db" | head -1)
+  [ -n "$f" ] && python tools/rocpd_summary.py $f --family conv > $OUT/${p}_summary.txt
+done
+# what a pure MFMA loop sustains on this box by operand data (8 s each)
+[ -x tools/ubench/mfma_peak ] && tools/ubench/mfma_peak 8 > $OUT/mfma_peak.txt 2>&1
 find $OUT -name "*.db" -delete        # keep the summaries, drop the raw databases (size)
 ls $OUT
