@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kWinoNT, 2) void conv_wino_f32(const ConvArgs a) {
             for (int k = 0; k < TB; ++k) tot[i][j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // one chunk's matrix work: B fragments from V[CUR], 2 x CB x TB x 8 MFMAs, blocked accumulation into tot
-    auto mma_chunk = [&](auto curc) {
+    [[maybe_unused]] auto mma_chunk = [&](auto curc) {
         constexpr int CUR = decltype(curc)::value;
         f32x4 acc[2][CB][TB];
 #pragma unroll

@@ -33,6 +33,9 @@ def main():
     tag = sys.argv[5] if len(sys.argv) > 5 else "?"
     f, fc = per_kernel(fetch_db, "FETCH_SIZE")
     w, wc = per_kernel(write_db, "WRITE_SIZE")
+    if forwards <= 0:        # automatic: model1 (conv1_block_fused, else conv1_1) is launched exactly once per forward
+        once = [k for k in fc if "conv1_block_fused" in k] or [k for k in fc if "conv1_1" in k]
+        forwards = fc[once[0]] if once else 1
     kernels = {}
     rd_total = wr_total = 0.0
     for name in f:

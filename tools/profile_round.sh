@@ -23,7 +23,7 @@ for p in stats pmc_fetch pmc_write pmc_sq pmc_grbm; do
   [ -n "$f" ] && python tools/rocpd_summary.py $f --family conv > $OUT/${p}_summary.txt
   grep -h '"metric"' $OUT/$p.log | tail -1 > $OUT/${p}_benchline.json
 done
-python tools/pmc_traffic.py $(find $OUT/pmc_fetch -name "*.db" | head -1) $(find $OUT/pmc_write -name "*.db" | head -1) 12 $OUT/pmc_traffic.json $TAG
+python tools/pmc_traffic.py $(find $OUT/pmc_fetch -name "*.db" | head -1) $(find $OUT/pmc_write -name "*.db" | head -1) 0 $OUT/pmc_traffic.json $TAG
 # click path (N=1) kernel traces
 cd /tmp
 for p in bf16 fp32; do
