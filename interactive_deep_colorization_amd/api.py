@@ -141,6 +141,8 @@ class ColorizeImageBase(object):
         shift = np.array((self.l_mean, self.ab_mean, self.ab_mean))[:, None, None] / scale
         self.img_lab_mc = self.img_lab / scale - shift
         self.img_l_mc = self.img_lab_mc[[0]]          # = L - 50 for every shipped backend
+        # the plane every net_forward hands to the engine, converted once per image instead of once per click
+        self._img_l_mc_f32 = np.ascontiguousarray(self.img_l_mc, dtype=np.float32)
         self.img_l_set = True
         self._l_resident = False
 
@@ -165,8 +167,9 @@ class ColorizeImageBase(object):
         self._hints_on_device = False
         self.input_ab = input_ab
         self.input_mask = input_mask
-        self.input_ab_mc = (input_ab - self.ab_mean) / self.ab_norm
-        self.input_mask_mult = input_mask * self.mask_mult
+        # (ab_mean 0 / ab_norm 1 / mask_mult 1 in the torch classes: the arithmetic is the identity, the arrays are passed on)
+        self.input_ab_mc = input_ab if (self.ab_mean == 0 and self.ab_norm == 1) else (input_ab - self.ab_mean) / self.ab_norm
+        self.input_mask_mult = input_mask if self.mask_mult == 1 else input_mask * self.mask_mult
         return 0
 
     def _stage_hints(self, hints, mode):
@@ -343,7 +346,7 @@ class ColorizeImageTorch(ColorizeImageBase):
         if ColorizeImageBase.net_forward(self, input_ab, input_mask) == -1:
             return -1
         # the device boundary -- stands for self.net.forward(...)[0].cpu().data.numpy() at :263
-        raw, rgb, lab_q = self.net.forward_rgb(self.img_l_mc, self.input_ab_mc, self.input_mask_mult, self.mask_cent,
+        raw, rgb, lab_q = self.net.forward_rgb(self._img_l_mc_f32, self.input_ab_mc, self.input_mask_mult, self.mask_cent,
                                                l_cent=self.l_mean)
         return self._finish_forward(raw[0], rgb[0], lab_q[0])
 
@@ -390,7 +393,7 @@ class ColorizeImageTorchDist(ColorizeImageTorch):
     def net_forward(self, input_ab, input_mask):
         if ColorizeImageBase.net_forward(self, input_ab, input_mask) == -1:
             return -1
-        out_ab, _ = self.net.forward_dist(self.img_l_mc, self.input_ab_mc, self.input_mask_mult, self.mask_cent,
+        out_ab, _ = self.net.forward_dist(self._img_l_mc_f32, self.input_ab_mc, self.input_mask_mult, self.mask_cent,
                                           want_dist=False)
         self._dist_on_device = True
         self.dist_ab_set = True
@@ -481,7 +484,7 @@ class ColorizeImageCaffe(ColorizeImageBase):
     def net_forward(self, input_ab, input_mask):
         if ColorizeImageBase.net_forward(self, input_ab, input_mask) == -1:
             return -1
-        raw, rgb, lab_q = self.net.forward_rgb(self.img_l_mc, self.input_ab_mc, self.input_mask_mult, 0.0, l_cent=self.l_mean)
+        raw, rgb, lab_q = self.net.forward_rgb(self._img_l_mc_f32, self.input_ab_mc, self.input_mask_mult, 0.0, l_cent=self.l_mean)
         return self._finish_forward(raw[0], rgb[0], lab_q[0])
 
 
@@ -607,7 +610,7 @@ class ColorizeImageCaffeDist(ColorizeImageCaffe):
     def net_forward(self, input_ab, input_mask):
         if ColorizeImageBase.net_forward(self, input_ab, input_mask) == -1:
             return -1
-        _, pred, _ = self.net.forward_dist313(self.img_l_mc, self.input_ab_mc, self.input_mask_mult, 0.0, want_dist=False)
+        _, pred, _ = self.net.forward_dist313(self._img_l_mc_f32, self.input_ab_mc, self.input_mask_mult, 0.0, want_dist=False)
         ret = self._finish_forward(pred[0])
         self._dist_on_device = True
         self.dist_ab_set = True

@@ -81,3 +81,43 @@ def test_bench_spread_helper():
     import bench
     s = bench._spread([100.0, 90.0, 110.0], 20)
     assert s["min"] == 90.0 and s["median"] == 100.0 and s["max"] == 110.0 and s["values"][0] == 100.0 and s["n"] == 3
+
+
+def test_emulation_fp32_mode_is_the_oracle_and_winograd_forms_are_exact_in_fp32():
+    """oracle/emulate.py (the CPU restatement of the engine's reduced-precision arithmetic behind profiles/parity_r03.json):
+    with every rounding switched off it is the oracle; its Winograd F(2x2,3x3) / F(2,3) forms equal the direct conv up to
+    fp32 rounding (dilation 1 and 2); the all-bf16 mode sits at the distance the GPU's bf16 path is measured at."""
+    import torch
+    from interactive_deep_colorization_amd import workloads
+    from oracle import emulate, siggraph_torch, weights
+    torch.manual_seed(0)
+    x, w, b = torch.randn(2, 8, 12, 16), torch.randn(5, 8, 3, 3), torch.randn(5)
+    for d in (1, 2):
+        ref = torch.nn.functional.conv2d(x, w, b, padding=d, dilation=d)
+        for mode in ("wino2d_fp32", "wino1d_fp32"):
+            assert float((emulate._conv3(x, w, b, d, mode) - ref).abs().max()) < 5e-5, (d, mode)
+        q = emulate._conv3(emulate.q(x), w, b, d, "wino2d")                  # bf16 operands: close to the bf16 direct conv, not equal
+        assert 1e-4 < float((q - ref).abs().max()) < 0.5
+    sd = weights.make_state_dict(1, "torch")
+    L, ab, m = workloads.random_batch(2, 32, seed=3)
+    ref = siggraph_torch.forward(sd, L, ab, m, 0.5)
+    assert np.abs(emulate.forward(sd, L, ab, m, 0.5, default="fp32") - ref).max() < 1e-3
+    wino = emulate.forward(sd, L, ab, m, 0.5, default="fp32", modes={n: "wino2d_fp32" for n in emulate.WINO_ELIGIBLE})
+    assert np.abs(wino - ref).max() < 1e-3
+    bf = emulate.error_stats(emulate.forward(sd, L, ab, m, 0.5, default="bf16"), ref)
+    assert 1e-3 < bf["max_abs"] < 0.6 and bf["mean_abs"] < 0.06          # the bf16 bound of the GPU tests
+    assert set(emulate.GROUPS["encoder"] + emulate.GROUPS["trunk"] + emulate.GROUPS["decoder"]) == set(emulate.LAYER_NAMES)
+
+
+def test_parity_r03_record_is_consistent():
+    """profiles/parity_r03.json: the all-bf16 row reproduces what the GPU measured (profiles/parity_r02.json) and no single
+    stored-tensor group carries the error on both weight styles."""
+    import json
+    with open(os.path.join(REPO, "profiles", "parity_r03.json")) as f:
+        d = json.load(f)["weights"]
+    assert 10.0 < d["he"]["all_bf16"]["max_abs"] < 16.0 and 0.10 < d["torch"]["all_bf16"]["max_abs"] < 0.18
+    for style in ("he", "torch"):
+        base = d[style]["all_bf16"]["mean_abs"]
+        assert all(d[style][g]["mean_abs"] > 0.4 * base for g in ("encoder_fp32", "trunk_fp32"))
+    assert d["he"]["decoder_fp32"]["mean_abs"] > 0.9 * d["he"]["all_bf16"]["mean_abs"]          # he: not the decoder
+    assert d["torch"]["decoder_fp32"]["mean_abs"] < 0.5 * d["torch"]["all_bf16"]["mean_abs"]    # torch-init: the decoder
