@@ -46,8 +46,8 @@ BlobPlan make_blob_plan(int precision, unsigned flags) {
         lb.w2_off = (size_t)-1;
         if (precision == IDC_BF16 && v2_eligible(s)) { off = align_up(off, 256); lb.w2_off = off; off += lb.w_bytes; }
         lb.w3_off = (size_t)-1; lb.w3_bytes = 0;
-        if (precision == IDC_FP32 && wino_eligible(s)) {
-            lb.w3_bytes = (size_t)s.cin * cout_pad(s.cout) * 16 * 4;          // 16 transformed values per (cin, cout)
+        if (wino_eligible(s) && s.cin % kc == 0) {                            // fp32: every batch size; bf16: the batch-1 click path
+            lb.w3_bytes = (size_t)s.cin * cout_pad(s.cout) * 16 * elem_bytes(precision);   // 16 transformed values per (cin, cout)
             off = align_up(off, 256); lb.w3_off = off; off += lb.w3_bytes;
         }
         off = align_up(off, 256); lb.bias_off = off; off += (size_t)cout_pad(s.cout) * 4;
@@ -148,24 +148,28 @@ static void pack_layer_weights(uint8_t* wimg, int precision, int layout, const L
 // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], stored in MFMA A-operand order
 //   [chunk = ci/32][pos = i*4+j][cout block = co/16][ks][lane = g*16 + co%16][e],   ci%32 = (ks*4 + g)*4 + e
 // so that one wave-wide 16-byte load is the fragment of (pos, 16 couts, 16 cin).
-static void pack_wino_weights(uint8_t* img, const LayerSpec& s, const LayerBlob& lb, const float* w) {
+// bf16: chunk = ci/64, ci%64 = (ks*4 + g)*8 + e, 8 bf16 per lane; U rounded to bf16 once, from the float64 transform.
+static void pack_wino_weights(uint8_t* img, int precision, const LayerSpec& s, const LayerBlob& lb, const float* w) {
     memset(img, 0, lb.w3_bytes);
     static const double G[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
     const int ncb = cout_pad(s.cout) / 16;
+    const int kc = kc_elems(precision), eps = kSlotBytes / elem_bytes(precision);     // channels per chunk, elements per 16-byte slot
     float* const out = (float*)img;
+    uint16_t* const out16 = (uint16_t*)img;
     for (int co = 0; co < s.cout; ++co)
         for (int ci = 0; ci < s.cin; ++ci) {
             const float* g = w + ((size_t)co * s.cin + ci) * 9;
             double t[4][3];
             for (int i = 0; i < 4; ++i)
                 for (int kx = 0; kx < 3; ++kx) t[i][kx] = G[i][0] * g[0 * 3 + kx] + G[i][1] * g[1 * 3 + kx] + G[i][2] * g[2 * 3 + kx];
-            const int c = ci / 32, within = ci % 32, slot = within / 4, e = within % 4, ks = slot / 4, gq = slot % 4;
+            const int c = ci / kc, within = ci % kc, slot = within / eps, e = within % eps, ks = slot / 4, gq = slot % 4;
             const int cbg = co / 16, m = co % 16, lane = gq * 16 + m;
             for (int i = 0; i < 4; ++i)
                 for (int j = 0; j < 4; ++j) {
                     const double u = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
-                    const size_t idx = (((((size_t)c * 16 + (i * 4 + j)) * ncb + cbg) * 2 + ks) * 64 + lane) * 4 + e;
-                    out[idx] = (float)u;
+                    const size_t idx = (((((size_t)c * 16 + (i * 4 + j)) * ncb + cbg) * 2 + ks) * 64 + lane) * eps + e;
+                    if (precision == IDC_BF16) out16[idx] = f32_to_bf16_rne((float)u);
+                    else out[idx] = (float)u;
                 }
         }
 }
@@ -221,7 +225,7 @@ static int pack_weights_impl(int precision, unsigned flags, const idc_tensor_des
         if (!dims_are(*b, {s.cout})) return fail(err, IDC_ERR_MISSING_KEY, "key '%s' has the wrong shape", bk.c_str());
         pack_layer_weights(base + lb.w_off, precision, 1, s, lb, w->data);
         if (lb.w2_off != (size_t)-1) pack_layer_weights(base + lb.w2_off, precision, 2, s, lb, w->data);
-        if (lb.w3_off != (size_t)-1) pack_wino_weights(base + lb.w3_off, s, lb, w->data);
+        if (lb.w3_off != (size_t)-1) pack_wino_weights(base + lb.w3_off, precision, s, lb, w->data);
         float* bias = (float*)(base + lb.bias_off);
         for (int c = 0; c < s.cout; ++c) bias[c] = b->data[c];
         if (s.bnkey) {
@@ -435,6 +439,7 @@ static int g_fuse_conv1 = !(getenv("IDC_FUSE_CONV1") && atoi(getenv("IDC_FUSE_CO
 // i.e. the batch-1 click path), 1 = never, 2 = always split as far as the cin chunks allow (tests).
 static int g_splitk_policy = 0;
 static int g_wino = !(getenv("IDC_WINO") && atoi(getenv("IDC_WINO")) == 0);   // fp32 3x3 stride-1 layers in Winograd form (idc_set_option "winograd" / env IDC_WINO=0 for A/B)
+static int g_wino_bf16 = !(getenv("IDC_WINO_BF16") && atoi(getenv("IDC_WINO_BF16")) == 0);   // bf16 batch-1 click path: Winograd instead of conv_click + split-K reduction (idc_set_option "winograd_bf16")
 static int g_click = -1;                 // conv_click for small launches: -1 = environment default (on), 0 off, 1 on (idc_set_option "click")
 // Shortcut fusion (conv_igemm_v2<.,.,1,true>) is correct (parity-tested under tile policy 2) but measured slower
 // than two launches on MI355X (4x re-reads of the skip tensor by the four phase workgroups, VGPR spills around
@@ -571,6 +576,13 @@ static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, i
     // every precision and cout width): conv_igemm's ring loop is the better kernel once the K loop is long and the chip full
     const int wm_big = a.ncg % 4 == 0 ? 4 : (a.ncg % 2 == 0 ? 2 : 1), rows_big = wm_big == 4 ? 8 : 16;
     const long long big_tiles = (long long)((Ws + 31) / 32) * ((Hs + rows_big - 1) / rows_big) * n_policy * (a.ncg / wm_big) * a.nphase;
+    // bf16 click path: a 3x3 stride-1 layer that would run conv_click + a split-K reduction launch runs as Winograd instead
+    // (16 position-GEMMs fill the chip without split-K: no slabs, no second launch; idc_wino.hip)
+    if (precision == IDC_BF16 && g_wino && g_wino_bf16 && g_tile_policy != 1 && big_tiles < tuning().v2_min_blocks &&
+        L.blob.w3_off != (size_t)-1 && L.spec->resid == nullptr && L.spec->kind == kConv3x3 && L.spec->in_stride == 1) {
+        L.wino = true; a.ksplit = 1; a.kc_per = a.nkc; a.tiles_x = a.tiles_y = 0;
+        return;
+    }
     if ((g_click < 0 ? tuning().click : g_click) && g_tile_policy != 1 && big_tiles < tuning().v2_min_blocks &&
         (L.spec->kind == kConv3x3 || L.spec->kind == kDeconv4x4)) {
         int wp = tuning().click_wp;
@@ -824,7 +836,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
                 (long long)((a.Ws + 31) / 32) * ((a.Hs + 31) / 32) * c->max_batch >= 128)
                 le = launch_conv1_1_bf16(a, s);
             if (L.fused_short >= 0) le = launch_conv_ds(a, s);    // deconv + its shortcut conv in one K loop
-            if (L.wino) le = launch_conv_wino(a, s);
+            if (L.wino) le = launch_conv_wino(c->precision, a, s);
             if (le == hipErrorInvalidConfiguration)
                 le = L.click ? launch_conv_click(c->precision, L.cfg.wp, L.halo, a, s)
                    : L.v2 ? launch_conv_v2(L.cfg, L.halo, a, s) : launch_conv(c->precision, L.cfg, L.halo, a, s);
@@ -963,6 +975,7 @@ int idc_set_option(const char* name, int value) {
     if (strcmp(name, "fuse_conv1") == 0) { g_fuse_conv1 = value != 0; return IDC_OK; }
     if (strcmp(name, "click") == 0) { g_click = value; return IDC_OK; }
     if (strcmp(name, "winograd") == 0) { g_wino = value != 0; return IDC_OK; }
+    if (strcmp(name, "winograd_bf16") == 0) { g_wino_bf16 = value != 0; return IDC_OK; }
     if (strcmp(name, "winograd_form") == 0) { set_wino_form(value); return IDC_OK; }     // 0 automatic, 12 / 21 / 22 = <TB,CB> (tests, tuning)
     return fail(nullptr, IDC_ERR_INVALID_ARG, "unknown option '%s'", name);
 }
@@ -1743,7 +1756,7 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
                 if (C.fused_short == layer - 1 || C.fused_next == layer - 1) snprintf(out->kernel, sizeof(out->kernel), "fused into %s", C.spec->name);
             out->flops = 0; out->min_bytes = 0; out->launches = 0;
         } else {
-            snprintf(out->kernel, sizeof(out->kernel), L.wino ? "conv_wino_f32" : L.click ? (h->precision == IDC_BF16 ? "conv_click<bf16,%d,%d>" : "conv_click<f32,%d,%d>")
+            snprintf(out->kernel, sizeof(out->kernel), L.wino ? (h->precision == IDC_BF16 ? "conv_wino_bf16" : "conv_wino_f32") : L.click ? (h->precision == IDC_BF16 ? "conv_click<bf16,%d,%d>" : "conv_click<f32,%d,%d>")
                      : L.v2 ? "conv_igemm_v2<%d,%d>" : (h->precision == IDC_BF16 ? "conv_igemm<bf16,%d,%d>" : "conv_igemm<f32,%d,%d>"),
                      L.cfg.wm, L.cfg.wp);
             if (L.fused_head) strncat(out->kernel, "+head", sizeof(out->kernel) - strlen(out->kernel) - 1);
@@ -1869,9 +1882,9 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     L.blob.w_off = 0; L.blob.w2_off = (size_t)-1; L.blob.bias_off = L.blob.bn_scale_off = L.blob.bn_shift_off = L.blob.fbias_off = (size_t)-1;
     const int cpad = cout_pad(spec.cout);
     // fp32 3x3 stride-1 ops without a shortcut sum take the Winograd kernel exactly as inside the network
-    const bool wino_ok = precision == IDC_FP32 && wino_eligible(spec) && resid == nullptr;
+    const bool wino_ok = wino_eligible(spec) && spec.cin % kc == 0 && resid == nullptr;
     L.blob.w3_off = wino_ok ? 0 : (size_t)-1;
-    L.blob.w3_bytes = wino_ok ? (size_t)spec.cin * cpad * 16 * 4 : 0;
+    L.blob.w3_bytes = wino_ok ? (size_t)spec.cin * cpad * 16 * eb : 0;
     if (wino_ok && L.blob.w3_bytes > L.blob.w_bytes) L.blob.w_bytes = L.blob.w3_bytes;      // one staging buffer serves either image
     std::vector<uint8_t> wimg(L.blob.w_bytes);
     const int Hs = h / spec.in_stride, Ws = w / spec.in_stride;
@@ -1879,7 +1892,7 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     const int Ho = Hs * so, Wo = Ws * so;
     fill_taps(L);
     set_geometry(L, precision, n, n, Hs, Ws);
-    if (L.wino) pack_wino_weights(wimg.data(), spec, L.blob, weight);
+    if (L.wino) pack_wino_weights(wimg.data(), precision, spec, L.blob, weight);
     else {
         if (wino_ok) L.blob.w_bytes = (size_t)weight_taps(spec.kind) * L.blob.nkc * L.blob.ncg * kWBlockBytes;
         pack_layer_weights(wimg.data(), precision, L.v2 ? 2 : 1, spec, L.blob, weight);
@@ -1928,7 +1941,7 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     HIPCHK(nullctx, d_zero.alloc(256));
     HIPCHK(nullctx, hipMemset(d_zero.p, 0, 256));
     a.zeros = d_zero.p;
-    HIPCHK(nullctx, L.wino ? launch_conv_wino(a, nullptr) : L.click ? launch_conv_click(precision, L.cfg.wp, L.halo, a, nullptr)
+    HIPCHK(nullctx, L.wino ? launch_conv_wino(precision, a, nullptr) : L.click ? launch_conv_click(precision, L.cfg.wp, L.halo, a, nullptr)
                     : L.v2 ? launch_conv_v2(L.cfg, L.halo, a, nullptr) : launch_conv(precision, L.cfg, L.halo, a, nullptr));
     if (a.ksplit > 1) HIPCHK(nullctx, launch_splitk_epilogue(precision, a, nullptr));
     HIPCHK(nullctx, launch_nhwc_to_nchw(io_bf16, d_yn.p, (float*)d_y.p, n, spec.cout, Ho, Wo, cpad, nullptr));

@@ -500,17 +500,234 @@ __global__ __launch_bounds__(kWinoNT, 2) void conv_wino_f32(const ConvArgs a) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// conv_wino_bf16<TB,CB>: the same F(2x2,3x3) decomposition with bf16 operands, for the BATCH-1 CLICK PATH only (the engine
+// selects it where a 3x3 stride-1 layer would otherwise run conv_click + a split-K reduction launch).  At batch 1 a bf16 layer
+// is bound by launch count and by the weight stream, not by the matrix pipes: 16 position-GEMMs fill 256 CUs without
+// split-K (no slabs, no reduction launch), for 16/9 of the weight bytes.  At N = 32 this form loses (Winograd
+// study: LDS / L2 operand traffic) and is never selected.  Arithmetic: input transform in fp32 from the bf16 activations,
+// rounded to bf16 (RNE); U = G g G^T in float64 from the fp32 master weights, rounded to bf16 once (packer); 16x16x32 bf16
+// MFMAs, fp32 accumulation; output transform and epilogue in fp32; bf16 (or fp32) store.  Error against float64 (CPU
+// emulation, profiles/parity_r03.json): 1.2-1.35x the direct bf16 kernels', inside the stated bf16 bounds.
+// Chunk = 64 channels (128-byte rows as in fp32); loop = the single-V scheme of the fp32 <2,*> forms for both TB.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_w;
+
+__device__ __forceinline__ unsigned pack_bf16x2_w(float lo, float hi) {
+    const __bf16 x = (__bf16)lo, y = (__bf16)hi;                 // v_cvt_pk_bf16_f32, RNE
+    return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+
+template <int TB, int CB>
+__global__ __launch_bounds__(kWinoNT, 2) void conv_wino_bf16(const ConvArgs a) {
+    constexpr int NT = kWinoNT, TXL = 4 * TB, PW = 8 * TB + 2, NTILE = 16 * TB, VB = wino_v_bytes(TB), PI = wino_p_items(TB);
+    constexpr int PB = wino_p_bytes(TB);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Vb = smem;                                     // one V buffer
+    char* const Pb = smem + VB;                                // two patch buffers
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int b = xcd_remap_w(blockIdx.x, gridDim.x);
+    const int d = a.dy[8];
+    const int bx = b % a.tiles_x; b /= a.tiles_x;
+    const int by = b % a.tiles_y; b /= a.tiles_y;
+    const int par = b % (d * d); b /= d * d;
+    const int n = b % a.N;
+    const int cg = b / a.N;
+    const int Y0 = par / d + d * 8 * by, X0 = par % d + d * 8 * TB * bx;
+    const int H = a.Hs, W = a.Ws;
+    const int nkc = a.nkc;                                     // 64-channel chunks
+    const int pix_bytes = nkc * kRowBytes;
+    const char* const img = (const char*)a.in + (size_t)n * H * W * pix_bytes;
+
+    int poff[PI];
+#pragma unroll
+    for (int j = 0; j < PI; ++j) {
+        const int k = tid + j * NT;
+        const int p = k >> 3, s = k & 7;
+        const int py = p / PW, px = p - py * PW;
+        const int Y = Y0 + d * (py - 1), X = X0 + d * (px - 1);
+        const bool inside = k < 10 * PW * 8 && (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W;
+        poff[j] = inside ? (Y * W + X) * pix_bytes + s * kSlotBytes : -1;
+    }
+    u32x4 xr[PI];
+    auto load_patch = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < PI; ++j)
+            xr[j] = *(const u32x4*)((poff[j] >= 0 && c < nkc) ? img + poff[j] + c * kRowBytes : (const char*)a.zeros);
+    };
+    auto store_patch = [&](int pbuf) {
+#pragma unroll
+        for (int j = 0; j < PI; ++j) *(u32x4*)(Pb + pbuf * PB + (tid + j * NT) * kSlotBytes) = xr[j];
+    };
+
+    // input transform on a 16-byte slot = 8 bf16 channels: even / odd elements as two fp32 vectors (dword << 16, dword & 0xffff0000)
+    const int ts = tid & 7, ti = (tid >> 3) & 3;
+    const int rA = ti == 0 ? 0 : (ti == 2 ? 2 : 1), rB = ti == 3 ? 3 : (ti == 2 ? 1 : 2);
+    const float sgn = ti == 1 ? 1.f : -1.f;
+    auto ev = [](const u32x4& v) { return f32x4{__uint_as_float(v.x << 16), __uint_as_float(v.y << 16), __uint_as_float(v.z << 16), __uint_as_float(v.w << 16)}; };
+    auto od = [](const u32x4& v) { return f32x4{__uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y & 0xffff0000u), __uint_as_float(v.z & 0xffff0000u), __uint_as_float(v.w & 0xffff0000u)}; };
+    auto pk = [](const f32x4& e, const f32x4& o) { return u32x4{pack_bf16x2_w(e[0], o[0]), pack_bf16x2_w(e[1], o[1]), pack_bf16x2_w(e[2], o[2]), pack_bf16x2_w(e[3], o[3])}; };
+    auto transform = [&](int pbuf, bool on) {
+#pragma unroll
+        for (int q = 0; q < TB; ++q) {
+            const int tt = (tid >> 5) + q * 16;
+            const int pbase = pbuf * PB + ((2 * (tt / TXL)) * PW + 2 * (tt % TXL)) * kRowBytes + ts * kSlotBytes;
+            f32x4 te[4], to[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const u32x4 u = *(const u32x4*)(Pb + pbase + (rA * PW + c) * kRowBytes);
+                const u32x4 v = *(const u32x4*)(Pb + pbase + (rB * PW + c) * kRowBytes);
+                te[c] = ev(u) + sgn * ev(v);
+                to[c] = od(u) + sgn * od(v);
+            }
+            char* const dst = Vb + ((ti * 4) * NTILE + tt) * kRowBytes + ((ts ^ (tt & 7)) * kSlotBytes);
+            if (on) {
+                *(u32x4*)(dst) = pk(te[0] - te[2], to[0] - to[2]);
+                *(u32x4*)(dst + NTILE * kRowBytes) = pk(te[1] + te[2], to[1] + to[2]);
+                *(u32x4*)(dst + 2 * NTILE * kRowBytes) = pk(te[2] - te[1], to[2] - to[1]);
+                *(u32x4*)(dst + 3 * NTILE * kRowBytes) = pk(te[1] - te[3], to[1] - to[3]);
+            }
+        }
+    };
+
+    const int p0 = wave * 2;
+    const int ncb = a.ncg * 4;
+    const char* const ubase = (const char*)a.wgt + ((size_t)(cg * CB) * 2 * 64 + lane) * kSlotBytes;
+    const size_t u_pos_stride = (size_t)ncb * 2 * 64 * kSlotBytes;
+    u32x4 areg[2][2][CB][2];
+    auto load_A = [&](int c, auto bufc) {
+        constexpr int B = decltype(bufc)::value;
+        const int cn = c < nkc ? c : nkc - 1;                  // past the end: a harmless re-read
+        const char* const src0 = ubase + ((size_t)cn * 16 + p0) * u_pos_stride;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    areg[B][pp][cb][ks] = *(const u32x4*)(src0 + (size_t)pp * u_pos_stride + (cb * 2 + ks) * 64 * kSlotBytes);
+    };
+    const int fn = lane & 15, fg = lane >> 4;
+    f32x4 tot[2][CB][TB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+#pragma unroll
+            for (int k = 0; k < TB; ++k) tot[i][j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    load_patch(0);
+    load_A(0, std::integral_constant<int, 0>{});
+    store_patch(0);
+    load_patch(1);
+    __syncthreads();
+    transform(0, true);
+    store_patch(1);
+    load_patch(2);
+    auto chunk = [&](int c, auto curc) {
+        constexpr int CUR = decltype(curc)::value;
+        __syncthreads();                                       // A: V(c) and the patch of chunk c+1 are complete
+        u32x4 bf[2][TB][2];
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    bf[pp][tb][ks] = *(const u32x4*)(Vb + ((p0 + pp) * NTILE + tb * 16 + fn) * kRowBytes + (((ks * 4 + fg) ^ (fn & 7)) * kSlotBytes));
+        __syncthreads();                                       // B: every wave holds its fragments, V may be overwritten
+        load_A(c + 1, std::integral_constant<int, CUR ^ 1>{});
+        store_patch(c & 1);                                    // patch c+2
+        load_patch(c + 3);
+        transform((c + 1) & 1, c + 1 < nkc);                   // patch c+1 -> V
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                    for (int tb = 0; tb < TB; ++tb)
+                        tot[pp][cb][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_w, areg[CUR][pp][cb][ks]),
+                                                                                  __builtin_bit_cast(bf16x8_w, bf[pp][tb][ks]), tot[pp][cb][tb], 0, 0, 0);
+    };
+    int c = 0;
+    for (; c + 1 < nkc; c += 2) {
+        chunk(c, std::integral_constant<int, 0>{});
+        chunk(c + 1, std::integral_constant<int, 1>{});
+    }
+    if (c < nkc) chunk(c, std::integral_constant<int, 0>{});
+    __syncthreads();
+
+    // ---- output transform (fp32) + epilogue: as the fp32 kernel; the store is bf16 unless the tensor is kept fp32 ---------
+    char* const Mx = smem;
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb)
+                *(f32x4*)(Mx + ((p0 + pp) * NTILE + tb * 16 + fn) * kRowBytes + (((cb * 4 + fg) ^ (fn & 7)) * kSlotBytes)) = tot[pp][cb][tb];
+    __syncthreads();
+    const int CoutPad = a.ncg * kCoutGroup;
+    const bool has_bn = a.bn_scale != nullptr;
+    constexpr int NC = 16 * CB;
+#pragma unroll
+    for (int q = 0; q < (NTILE * NC) / NT; ++q) {
+        const int idx = tid + q * NT;
+        const int oc = idx % NC, ot = idx / NC;
+        float m[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+            m[p] = *(const float*)(Mx + (p * NTILE + ot) * kRowBytes + (((oc >> 2) ^ (ot & 7)) * kSlotBytes) + (oc & 3) * 4);
+        float s0[4], s1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s0[j] = m[0 * 4 + j] + m[1 * 4 + j] + m[2 * 4 + j];
+            s1[j] = m[1 * 4 + j] - m[2 * 4 + j] - m[3 * 4 + j];
+        }
+        const float y[2][2] = {{s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3]}, {s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]}};
+        const int co = cg * NC + oc;
+        const float bias = a.bias[co];
+        const float bsc = has_bn ? a.bn_scale[co] : 1.f, bsh = has_bn ? a.bn_shift[co] : 0.f;
+        const float ish = a.img_shift ? a.img_shift[(size_t)n * CoutPad + co] : 0.f;
+        const size_t obase = (size_t)n * H * W * CoutPad + co;
+        const int oy = Y0 + d * 2 * (ot / TXL), ox = X0 + d * 2 * (ot % TXL);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int yy = oy + d * i, xx = ox + d * j;
+                float v = y[i][j] + bias;
+                if (a.act == 1) v = fmaxf(v, 0.f);
+                else if (a.act == 2) v = v > 0.f ? v : 0.2f * v;
+                if (has_bn) v = fmaf(v, bsc, bsh);
+                v += ish;
+                if (yy < H && xx < W) {
+                    const size_t o = obase + ((size_t)yy * W + xx) * CoutPad;
+                    if (a.out_f32) ((float*)a.out)[o] = v;
+                    else ((__bf16*)a.out)[o] = (__bf16)v;
+                }
+            }
+    }
+}
+
 int g_wino_form = getenv("IDC_WINO_FORM") ? atoi(getenv("IDC_WINO_FORM")) : 0;      // tuning: 0 automatic, 12 / 21 / 22 = force <TB,CB>
 
 void set_wino_form(int form) { g_wino_form = form; }
 
+constexpr int wino_lds_bf16(int tb) { return wino_v_bytes(tb) + 2 * wino_p_bytes(tb); }
+
 template <int TB, int CB>
-static hipError_t launch_wino_t(ConvArgs& a, int d, hipStream_t s) {
+static hipError_t launch_wino_t(ConvArgs& a, int d, int precision, hipStream_t s) {
     a.tiles_x = ((a.Ws + d - 1) / d + 8 * TB - 1) / (8 * TB);
     a.tiles_y = ((a.Hs + d - 1) / d + 7) / 8;
     const long long blocks = (long long)a.tiles_x * a.tiles_y * d * d * a.N * (a.ncg * 4 / CB);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((conv_wino_f32<TB, CB>), dim3((unsigned)blocks), dim3(kWinoNT), wino_lds(TB), s, a);
+    if (precision == 1) hipLaunchKernelGGL((conv_wino_bf16<TB, CB>), dim3((unsigned)blocks), dim3(kWinoNT), wino_lds_bf16(TB), s, a);
+    else hipLaunchKernelGGL((conv_wino_f32<TB, CB>), dim3((unsigned)blocks), dim3(kWinoNT), wino_lds(TB), s, a);
     return hipGetLastError();
 }
 
@@ -518,10 +735,10 @@ static hipError_t launch_wino_t(ConvArgs& a, int d, hipStream_t s) {
 // a.nkc = Cin / 32, a.ncg = CoutPad / 64, a.Hs / a.Ws = image size, a.dy[8] = dilation; tiles_x / tiles_y are set here.
 // Form by grid size (speed only: every form computes the same sums in the same order): the throughput form <2,2> when it
 // still gives every CU a workgroup, else <1,2>.
-hipError_t launch_conv_wino(const ConvArgs& a0, hipStream_t s) {
+hipError_t launch_conv_wino(int precision, const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     const int d = a.dy[8];
-    if ((d != 1 && d != 2) || a.si != 1 || a.so != 1 || a.nphase != 1 || a.ntaps != 9 || a.resid != nullptr || !a.out_f32 ||
+    if ((d != 1 && d != 2) || a.si != 1 || a.so != 1 || a.nphase != 1 || a.ntaps != 9 || a.resid != nullptr || (precision == 0 && !a.out_f32) ||
         a.zeros == nullptr || a.nkc < 1)
         return hipErrorInvalidConfiguration;
     const long long t2 = (long long)(((a.Ws + d - 1) / d + 15) / 16) * (((a.Hs + d - 1) / d + 7) / 8) * d * d * a.N;   // 8x16-pixel blocks
@@ -529,9 +746,9 @@ hipError_t launch_conv_wino(const ConvArgs& a0, hipStream_t s) {
     // (measured, profiles/r03_wino_harness.txt: <2,1> loses to <1,2> on every shape -- its transform work per workgroup doubles --
     //  and is kept for the tests and the tuning switch only)
     if (form != 12 && form != 21 && form != 22) form = t2 * (a.ncg * 2) >= 256 ? 22 : 12;
-    if (form == 22) return launch_wino_t<2, 2>(a, d, s);
-    if (form == 21) return launch_wino_t<2, 1>(a, d, s);
-    return launch_wino_t<1, 2>(a, d, s);
+    if (form == 22) return launch_wino_t<2, 2>(a, d, precision, s);
+    if (form == 21) return launch_wino_t<2, 1>(a, d, precision, s);
+    return launch_wino_t<1, 2>(a, d, precision, s);
 }
 
 hipError_t init_kernels_wino() {
@@ -539,7 +756,13 @@ hipError_t init_kernels_wino() {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)conv_wino_f32<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_lds(2));
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)conv_wino_f32<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_lds(2));
+    e = hipFuncSetAttribute((const void*)conv_wino_f32<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_lds(2));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)conv_wino_bf16<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_lds_bf16(1));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)conv_wino_bf16<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_lds_bf16(2));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)conv_wino_bf16<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_lds_bf16(2));
 }
 
 }  // namespace idc

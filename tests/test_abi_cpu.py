@@ -95,9 +95,10 @@ def _plan(precision, dist):
         off = _al(off); e["w_off"] = off; off += ntap * nkc * e["ncg"] * 8192
         if precision == "bf16" and kind != "im2col" and cpad >= 128:   # second image: layout 2 (conv_igemm_v2)
             off = _al(off); e["w2_off"] = off; off += ntap * nkc * e["ncg"] * 8192
-        if precision == "fp32" and kind == "c3" and wkey not in ("model2.0", "model3.0", "model4.0"):
-            # third image (fp32 only): Winograd F(2x2,3x3) weights U = G g G^T of the 3x3 stride-1 layers (idc_wino.hip)
-            off = _al(off); e["w3_off"] = off; off += cin * cpad * 16 * 4
+        if kind == "c3" and wkey not in ("model2.0", "model3.0", "model4.0"):
+            # third image: Winograd F(2x2,3x3) weights U = G g G^T of the 3x3 stride-1 layers (idc_wino.hip; fp32: every
+            # batch size, bf16: the batch-1 click path)
+            off = _al(off); e["w3_off"] = off; off += cin * cpad * 16 * (2 if precision == "bf16" else 4)
         off = _al(off); e["b_off"] = off; off += cpad * 4
         if bnkey:
             off = _al(off); e["s_off"] = off; off += cpad * 4
@@ -171,12 +172,17 @@ def test_pack_weights_layout(make_sd, precision, dist):
                 G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
                 U = G @ w[co, ci].astype(np.float64) @ G.T
                 i, j = rs.randint(4), rs.randint(4)
-                c, within = divmod(ci, 32)
-                slot, el = divmod(within, 4)
+                kc3, eps3 = (64, 8) if precision == "bf16" else (32, 4)        # channels per 128-byte chunk, elements per 16-byte slot
+                c, within = divmod(ci, kc3)
+                slot, el = divmod(within, eps3)
                 ks, gq = divmod(slot, 4)
-                idx = ((((c * 16 + i * 4 + j) * (e["cpad"] // 16) + co // 16) * 2 + ks) * 64 + gq * 16 + co % 16) * 4 + el
-                o3 = e["w3_off"] + idx * 4
-                assert float(blob[o3:o3 + 4].view(np.float32)[0]) == np.float32(U[i, j]), (e["wkey"], co, ci, i, j)
+                idx = ((((c * 16 + i * 4 + j) * (e["cpad"] // 16) + co // 16) * 2 + ks) * 64 + gq * 16 + co % 16) * eps3 + el
+                if precision == "bf16":
+                    o3 = e["w3_off"] + idx * 2
+                    assert int(blob[o3:o3 + 2].view(np.uint16)[0]) == int(_bf16_bits(np.float32(U[i, j])).ravel()[0]), (e["wkey"], co, ci, i, j)
+                else:
+                    o3 = e["w3_off"] + idx * 4
+                    assert float(blob[o3:o3 + 4].view(np.float32)[0]) == np.float32(U[i, j]), (e["wkey"], co, ci, i, j)
         np.testing.assert_array_equal(blob[e["b_off"]:e["b_off"] + e["cout"] * 4].view(np.float32), sd[e["wkey"] + ".bias"])
         if e["bnkey"]:
             g_, b_ = sd[e["bnkey"] + ".weight"].astype(np.float64), sd[e["bnkey"] + ".bias"].astype(np.float64)

@@ -24,6 +24,7 @@ WINO_LAYERS = ["conv1_2", "conv2_2", "conv3_2", "conv3_3", "conv4_2", "conv4_3",
 def _reset_options():
     yield
     engine.set_option("winograd", 1)
+    engine.set_option("winograd_bf16", 1)
     engine.set_option("winograd_form", 0)
     engine.set_splitk_policy("auto")
 
@@ -59,6 +60,62 @@ def test_winograd_fp32_layer_by_layer(golden, make_sd, name, form):
     base = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
     assert not any(v == "conv_wino_f32" for v in (r["kernel"] for r in e.layer_table()))
     assert np.abs(out - base).max() <= (3e-3 if style == "he" else 5e-4)
+    e.close()
+
+
+@pytest.mark.parametrize("form", [0, 12, 22])
+@pytest.mark.parametrize("name", ["net64_he_s0_mc05", "net32x48_he_s2", "net64_torch_s1_mc0"])
+def test_winograd_bf16_click_path_layer_by_layer(golden, make_sd, name, form):
+    """bf16, small launches (the batch-1 click path's kernel choice): every 3x3 stride-1 layer runs as conv_wino_bf16 instead of
+    conv_click + a split-K reduction launch.  Each layer against the float64 oracle at the bf16 per-layer tolerance (4 % of the
+    layer's range), the ab map inside the stated bf16 bounds, no split-K left on those layers; `winograd_bf16` = 0 restores
+    conv_click and lands within the same bounds."""
+    g = golden(name)
+    style, seed = str(g["weight_style"]), int(g["weight_seed"])
+    n, _, H, W = g["L_mc"].shape
+    _, _, acts = siggraph_torch.forward(make_sd(seed, style), g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]),
+                                        return_acts=True, dtype=torch.float64)
+    engine.set_option("winograd_form", form)
+    e = engine.HipColorizer(H, W, max_batch=n, precision="bf16")
+    e.load_state_dict(make_sd(seed, style))
+    out = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
+    table = {r["name"]: r["kernel"] for r in e.layer_table()}
+    wino = [k for k in WINO_LAYERS if table[k] == "conv_wino_bf16"]
+    assert len(wino) >= 19, table                               # (conv1_2 / conv1_2_short / conv10_2 may ride in fused launches)
+    assert not any("splitK" in table[k] for k in wino)
+    for k in wino:
+        ref = acts[k]
+        err = np.abs(e.activation(k, n) - ref).max()
+        assert err <= 0.04 * (1 + np.abs(ref).max()), "layer %s (form %d): max-abs err %.3e" % (k, form, err)
+    d = np.abs(out - g["out_ab"])
+    assert d.max() <= (20.0 if style == "he" else 0.6) and d.mean() <= (2.0 if style == "he" else 0.06), (d.max(), d.mean())
+    np.testing.assert_array_equal(e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"])), out)       # deterministic
+    engine.set_option("winograd_bf16", 0)
+    base = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
+    assert not any(r["kernel"] == "conv_wino_bf16" for r in e.layer_table())
+    db = np.abs(base - g["out_ab"])
+    assert db.max() <= (20.0 if style == "he" else 0.6)
+    e.close()
+
+
+def test_winograd_bf16_click_config(golden, make_sd):
+    """BASELINE configs[1] in bf16: <= 34 launches per click forward (52 with conv_click + split-K), the reference golden inside
+    the torch-init bf16 bound; the N = 32 throughput path never selects the bf16 Winograd form."""
+    g = golden("config2_mortar_5hints_torchinit")
+    e = engine.HipColorizer(256, 256, max_batch=1, precision="bf16")
+    e.load_state_dict(make_sd(int(g["weight_seed"]), str(g["weight_style"])))
+    out = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
+    rows = [r for r in e.layer_table() if r["launches"] > 0]
+    launches = sum(r["launches"] + (1 if "splitK" in r["kernel"] else 0) for r in rows)
+    assert sum(r["kernel"] == "conv_wino_bf16" for r in rows) >= 17 and launches <= 34, (launches, [r["kernel"] for r in rows])
+    d = np.abs(out - g["out_ab"])
+    assert d.max() <= 0.6 and d.mean() <= 0.06, (d.max(), d.mean())
+    e.close()
+    e = engine.HipColorizer(256, 256, max_batch=32, precision="bf16")
+    e.load_state_dict(make_sd(0, "he"))
+    L, ab, m = workloads.random_batch(1, 256, seed=3)
+    e.forward(L, ab, m, 0.0)
+    assert not any(r["kernel"].startswith("conv_wino") for r in e.layer_table())
     e.close()
 
 

@@ -82,11 +82,11 @@ int main(int argc, char** argv) {
     if (v2 == 6) {      // fp32 Winograd F(2x2,3x3): U image = 16 floats per (cin, cout); timing only (random U)
         CK(hipFree(w)); CK(hipMalloc(&w, (size_t)C * C * 64));
         hipLaunchKernelGGL(fill_bf16, dim3(2048), dim3(256), 0, 0, (unsigned short*)w, (size_t)C * C * 64 / 2, 7u);
-        a.wgt = w; a.out_f32 = 1;
+        a.wgt = w; a.out_f32 = prec ? 0 : 1;
     }
     idc::ConvConfig cfg{wm, wp};
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-#define LAUNCH() (v2 == 6 ? idc::launch_conv_wino(a, 0) : v2 == 4 ? idc::launch_conv_click(prec, wp, halo, a, 0) : v2 == 5 ? idc::launch_conv(prec, cfg, halo, a, 0) : v2 == 2 ? idc::launch_conv_ds(a, 0) : v2 ? idc::launch_conv_v2(cfg, halo, a, 0) : idc::launch_conv(prec, cfg, halo, a, 0))
+#define LAUNCH() (v2 == 6 ? idc::launch_conv_wino(prec, a, 0) : v2 == 4 ? idc::launch_conv_click(prec, wp, halo, a, 0) : v2 == 5 ? idc::launch_conv(prec, cfg, halo, a, 0) : v2 == 2 ? idc::launch_conv_ds(a, 0) : v2 ? idc::launch_conv_v2(cfg, halo, a, 0) : idc::launch_conv(prec, cfg, halo, a, 0))
 #ifdef IDC_TIMING
     int nb = v2 == 6 ? (int)(((HW + halo - 1) / halo + 7) / 8) * (((HW + halo - 1) / halo + 7) / 8) * halo * halo * N * (C / 32) : v2 == 2 ? ((HW + 31) / 32) * ((HW + 3) / 4) * N * (a.ncg / 2) : a.tiles_x * a.tiles_y * N * (a.ncg / wm) * a.nphase * (a.ksplit > 1 ? a.ksplit : 1);
     long long* dbg; CK(hipMalloc(&dbg, (size_t)nb * 128)); CK(hipMemset(dbg, 0, (size_t)nb * 128));
