@@ -522,8 +522,9 @@ __global__ __launch_bounds__(kWinoNT, 2) void conv_wino_bf16(const ConvArgs a) {
     constexpr int NT = kWinoNT, TXL = 4 * TB, PW = 8 * TB + 2, NTILE = 16 * TB, VB = wino_v_bytes(TB), PI = wino_p_items(TB);
     constexpr int PB = wino_p_bytes(TB);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const Vb = smem;                                     // one V buffer
-    char* const Pb = smem + VB;                                // two patch buffers
+    constexpr int NV = TB == 1 ? 2 : 1;                        // TB = 1: two V buffers, ONE barrier per chunk; TB = 2: one (LDS), two barriers
+    char* const Vb = smem;
+    char* const Pb = smem + NV * VB;                           // two patch buffers
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -569,7 +570,7 @@ __global__ __launch_bounds__(kWinoNT, 2) void conv_wino_bf16(const ConvArgs a) {
     auto ev = [](const u32x4& v) { return f32x4{__uint_as_float(v.x << 16), __uint_as_float(v.y << 16), __uint_as_float(v.z << 16), __uint_as_float(v.w << 16)}; };
     auto od = [](const u32x4& v) { return f32x4{__uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y & 0xffff0000u), __uint_as_float(v.z & 0xffff0000u), __uint_as_float(v.w & 0xffff0000u)}; };
     auto pk = [](const f32x4& e, const f32x4& o) { return u32x4{pack_bf16x2_w(e[0], o[0]), pack_bf16x2_w(e[1], o[1]), pack_bf16x2_w(e[2], o[2]), pack_bf16x2_w(e[3], o[3])}; };
-    auto transform = [&](int pbuf, bool on) {
+    auto transform = [&](int vbuf, int pbuf, bool on) {
 #pragma unroll
         for (int q = 0; q < TB; ++q) {
             const int tt = (tid >> 5) + q * 16;
@@ -582,7 +583,7 @@ __global__ __launch_bounds__(kWinoNT, 2) void conv_wino_bf16(const ConvArgs a) {
                 te[c] = ev(u) + sgn * ev(v);
                 to[c] = od(u) + sgn * od(v);
             }
-            char* const dst = Vb + ((ti * 4) * NTILE + tt) * kRowBytes + ((ts ^ (tt & 7)) * kSlotBytes);
+            char* const dst = Vb + vbuf * VB + ((ti * 4) * NTILE + tt) * kRowBytes + ((ts ^ (tt & 7)) * kSlotBytes);
             if (on) {
                 *(u32x4*)(dst) = pk(te[0] - te[2], to[0] - to[2]);
                 *(u32x4*)(dst + NTILE * kRowBytes) = pk(te[1] + te[2], to[1] + to[2]);
@@ -623,11 +624,12 @@ __global__ __launch_bounds__(kWinoNT, 2) void conv_wino_bf16(const ConvArgs a) {
     store_patch(0);
     load_patch(1);
     __syncthreads();
-    transform(0, true);
+    transform(0, 0, true);
     store_patch(1);
     load_patch(2);
     auto chunk = [&](int c, auto curc) {
         constexpr int CUR = decltype(curc)::value;
+        const int vcur = NV == 2 ? (c & 1) : 0;
         __syncthreads();                                       // A: V(c) and the patch of chunk c+1 are complete
         u32x4 bf[2][TB][2];
 #pragma unroll
@@ -636,12 +638,12 @@ __global__ __launch_bounds__(kWinoNT, 2) void conv_wino_bf16(const ConvArgs a) {
             for (int tb = 0; tb < TB; ++tb)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
-                    bf[pp][tb][ks] = *(const u32x4*)(Vb + ((p0 + pp) * NTILE + tb * 16 + fn) * kRowBytes + (((ks * 4 + fg) ^ (fn & 7)) * kSlotBytes));
-        __syncthreads();                                       // B: every wave holds its fragments, V may be overwritten
+                    bf[pp][tb][ks] = *(const u32x4*)(Vb + vcur * VB + ((p0 + pp) * NTILE + tb * 16 + fn) * kRowBytes + (((ks * 4 + fg) ^ (fn & 7)) * kSlotBytes));
+        if constexpr (NV == 1) __syncthreads();                // B: every wave holds its fragments, the one V buffer may be overwritten
         load_A(c + 1, std::integral_constant<int, CUR ^ 1>{});
         store_patch(c & 1);                                    // patch c+2
         load_patch(c + 3);
-        transform((c + 1) & 1, c + 1 < nkc);                   // patch c+1 -> V
+        transform(NV == 2 ? ((c + 1) & 1) : 0, (c + 1) & 1, c + 1 < nkc);      // patch c+1 -> V(c+1)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -718,7 +720,7 @@ int g_wino_form = getenv("IDC_WINO_FORM") ? atoi(getenv("IDC_WINO_FORM")) : 0;  
 
 void set_wino_form(int form) { g_wino_form = form; }
 
-constexpr int wino_lds_bf16(int tb) { return wino_v_bytes(tb) + 2 * wino_p_bytes(tb); }
+constexpr int wino_lds_bf16(int tb) { return (tb == 1 ? 2 : 1) * wino_v_bytes(tb) + 2 * wino_p_bytes(tb); }
 
 template <int TB, int CB>
 static hipError_t launch_wino_t(ConvArgs& a, int d, int precision, hipStream_t s) {

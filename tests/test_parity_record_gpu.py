@@ -1,7 +1,7 @@
 """Parity on the configurations the bench times, with the MEASURED errors written down.
 
 Every case appends {config, precision, weights, images, max_abs, mean_abs, rms, rel_rms, q999} to
-gpurun_out/parity_r02.json (copied to profiles/parity_r02.json after a GPU run), so headroom against the stated
+gpurun_out/parity_r03_gpu.json (copied to profiles/parity_r03_gpu.json after a GPU run; round 2: profiles/parity_r02.json), so headroom against the stated
 bounds is visible, not just pass/fail:
   * BASELINE configs[2] itself -- N=32, 256x256, bf16, the large-tile kernels at their real 4096-workgroup geometry --
     with torch-init weights, FOUR images of the batch against the oracle at the tight bf16 bound 0.6 / 0.06;
@@ -21,7 +21,7 @@ from oracle import siggraph_torch, weights
 
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(REPO, "gpurun_out", "parity_r02.json")
+OUT = os.path.join(REPO, "gpurun_out", "parity_r03_gpu.json")
 
 
 def record(config, precision, style, images, out, ref):
@@ -100,3 +100,25 @@ def test_config5_512_global_hints_against_the_oracle(precision, style):
     else:
         # bf16 through 30 layers, he-style weights, 4x the pixels of the 256x256 cases: bulk + tail stated separately
         assert row["mean_abs"] <= 2.0 and row["q999"] <= 20.0 and row["rel_rms"] <= 0.06 and row["max_abs"] <= 45.0, row
+
+
+@pytest.mark.parametrize("precision,style,bound", [
+    ("bf16", "torch", (0.6, 0.06)), ("bf16", "he", (20.0, 2.0)), ("fp32", "torch", (1e-3, None)), ("fp32", "he", (3e-3, None)),
+])
+def test_config2_click_path_against_the_oracle(make_sd, precision, style, bound):
+    """BASELINE configs[1] -- ONE 256x256 image, 5 hints: the click path's kernels (round 3: Winograd F(2x2,3x3) for the 3x3
+    stride-1 layers in both precisions, conv_click + split-K for the stride-2 convs and the deconvs), measured error recorded."""
+    sd = make_sd(0, style)
+    L = workloads.random_batch(1, 256, seed=7)[0].astype(np.float32)
+    hab, hm = workloads.hints_config2(256, 5, 3, 0)
+    ab, m = hab[None].astype(np.float32), hm[None].astype(np.float32)
+    e = engine.HipColorizer(256, 256, max_batch=1, precision=precision)
+    e.load_state_dict(sd)
+    out = e.forward(L, ab, m, 0.0)
+    assert sum(r["kernel"].startswith("conv_wino") for r in e.layer_table()) >= 17
+    e.close()
+    ref = siggraph_torch.forward(sd, L, ab, m, 0.0)
+    row = record("configs[1] N=1 256x256 (click path, Winograd)", precision, style, (0,), out, ref)
+    assert row["max_abs"] <= bound[0], row
+    if bound[1] is not None:
+        assert row["mean_abs"] <= bound[1], row
