@@ -14,6 +14,7 @@
 //     fp32 = an fmaf chain) on the same 16-byte fragments;
 //   * fused epilogue: +bias, +fp32 shortcut sum, ReLU/LeakyReLU, eval-BN affine AFTER the
 //     activation (model.py:13-17 order), 32/64-byte stores of 16 consecutive channels per lane.
+#include <stdlib.h>
 #include <type_traits>
 
 #include "idc_kernels.h"
@@ -1489,7 +1490,7 @@ static hipError_t launch_conv_v2_t(const ConvArgs& a, hipStream_t s) {
 #define IDC_FOR_EACH_CONV_V2(X) X(4, 2, 0) X(4, 2, 1) X(4, 2, 2) X(2, 4, 0) X(2, 4, 1) X(2, 4, 2) X(2, 2, 0) X(2, 2, 1) X(2, 2, 2)
 
 __global__ void conv_ds_fused(const ConvArgs a);
-__global__ void conv1_block_fused(const ConvArgs a);
+template <int NW, int RPW> __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 3) void conv1_block_fused_t(const ConvArgs a);
 
 hipError_t init_kernels_v2() {
     hipError_t e;
@@ -1502,7 +1503,9 @@ hipError_t init_kernels_v2() {
     // the two fused kernels use more than the default 64 KiB of dynamic LDS (set per device: this runs for every handle)
     e = hipFuncSetAttribute((const void*)conv_ds_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)conv1_block_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 34 * 34 * 128 + 36 * 36 * 8);
+    e = hipFuncSetAttribute((const void*)conv1_block_fused_t<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 34 * 10 * 128 + 36 * 12 * 8);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)conv1_block_fused_t<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 34 * 34 * 128 + 36 * 36 * 8);
 }
 
 // v2 tile = 32 sites wide, 4*wpx rows; cfg.wm = WCO (x64 couts), cfg.wp = WPX.
@@ -2024,30 +2027,35 @@ hipError_t launch_conv1_1_bf16(const ConvArgs& a, hipStream_t s) {
 //   phase 3: ReLU + eval-BN in the MFMA layout, bf16 LDS transpose, whole-line stores.
 // LDS: 34*34*128 B halo + 36*36*8 B patch = 154.6 KiB, one workgroup (8 waves) per CU.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 2) void conv1_block_fused(const ConvArgs a) {
-    constexpr int HW_ = 34, PW = 36, NSITE = HW_ * HW_;
+// NW waves x RPW pixel rows each: <8,4> = the 32x32 tile (one workgroup per CU), <4,2> = a 32x8 tile whose 46 KiB of LDS and
+// <= 168 registers let THREE workgroups share a CU, so that one's patch / conv1_1 / store phases run under another's conv1_2 MFMAs
+// (conv1_1 is recomputed on 34x10 sites per 32x8 outputs: 33 % extra instead of 13 %, of a conv that is 2 % of the block's MACs).
+template <int NW, int RPW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 3) void conv1_block_fused_t(const ConvArgs a) {
+    constexpr int NT = NW * 64, TH = NW * RPW;
+    constexpr int HW_ = 34, HH_ = TH + 2, PW = 36, PH = TH + 4, NSITE = HW_ * HH_;
     constexpr int HALO_BYTES = NSITE * kRowBytes;              // 147,968
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const halo = smem;
-    uint2* const patch = (uint2*)(smem + HALO_BYTES);          // [36][36] x 4 bf16
+    uint2* const patch = (uint2*)(smem + HALO_BYTES);          // [TH + 4][36] x 4 bf16
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = lane & 31, h = lane >> 5;
     const int Hs = a.Hs, Ws = a.Ws;
-    const int ntx = (Ws + 31) >> 5, nty = (Hs + 31) >> 5;
+    const int ntx = (Ws + 31) >> 5, nty = (Hs + TH - 1) / TH;
     int b = xcd_remap(blockIdx.x, gridDim.x);
     const int txi = b % ntx; b /= ntx;
     const int tyi = b % nty;
     const int n = b / nty;
-    const int ty0 = tyi * 32, tx0 = txi * 32;
+    const int ty0 = tyi * TH, tx0 = txi * 32;
     // ---- phase 0 -------------------------------------------------------------------------------
     {
         const size_t hw = (size_t)Hs * Ws;
         const float* const pL = a.pk_L + (size_t)n * hw;
         const float* const pA = a.pk_ab + (size_t)n * 2 * hw;
         const float* const pM = a.pk_mask + (size_t)n * hw;
-        for (int idx = tid; idx < PW * PW; idx += 512) {
+        for (int idx = tid; idx < PW * PH; idx += NT) {
             const int py = idx / PW, pxx = idx - py * PW;
             const int yy = ty0 - 2 + py, xx = tx0 - 2 + pxx;
             uint2 c = uint2{0u, 0u};
@@ -2083,7 +2091,7 @@ __global__ __launch_bounds__(512, 2) void conv1_block_fused(const ConvArgs a) {
         }
         __syncthreads();                                       // patch complete
         typedef short s16x2 __attribute__((ext_vector_type(2)));
-        for (int g = wave; g * 32 < NSITE; g += 8) {
+        for (int g = wave; g * 32 < NSITE; g += NW) {
             const int sidx = g * 32 + px;                      // halo site = halo row of the tile
             const int hy = sidx / HW_, hx = sidx - hy * HW_;
             const bool live = sidx < NSITE;
@@ -2124,7 +2132,7 @@ __global__ __launch_bounds__(512, 2) void conv1_block_fused(const ConvArgs a) {
         }
     }
     // ---- phase 2 -------------------------------------------------------------------------------
-    f32x16 acc[2][4];
+    f32x16 acc[2][RPW];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         f32x16 b16;
@@ -2134,7 +2142,7 @@ __global__ __launch_bounds__(512, 2) void conv1_block_fused(const ConvArgs a) {
             b16[q * 4 + 0] = bq.x; b16[q * 4 + 1] = bq.y; b16[q * 4 + 2] = bq.z; b16[q * 4 + 3] = bq.w;
         }
 #pragma unroll
-        for (int pj = 0; pj < 4; ++pj) acc[mi][pj] = b16;
+        for (int pj = 0; pj < RPW; ++pj) acc[mi][pj] = b16;
     }
     u32x4 wcur[4][2], wnxt[4][2];
     auto load_w = [&](int t, u32x4 (&w)[4][2]) {
@@ -2151,35 +2159,35 @@ __global__ __launch_bounds__(512, 2) void conv1_block_fused(const ConvArgs a) {
     for (int t = 0; t < 9; ++t) {
         if (t + 1 < 9) load_w(t + 1, wnxt);
         const int dy = t / 3 - 1, dx = t - (t / 3) * 3 - 1;
-        int xaddr[4];
+        int xaddr[RPW];
 #pragma unroll
-        for (int pj = 0; pj < 4; ++pj) {
-            const int xr = (wave * 4 + pj + 1 + dy) * HW_ + (px + 1 + dx);
+        for (int pj = 0; pj < RPW; ++pj) {
+            const int xr = (wave * RPW + pj + 1 + dy) * HW_ + (px + 1 + dx);
             xaddr[pj] = xr * kRowBytes + ((h ^ swz2(xr)) * kSlotBytes);
         }
         // 2-stage software pipeline over the four k16 steps, issue order pinned as in conv_igemm_v2 (only B comes from LDS)
-        u32x4 xfA[4], xfB[4];
-        auto read_x = [&](int kk, u32x4 (&xf)[4]) {
+        u32x4 xfA[RPW], xfB[RPW];
+        auto read_x = [&](int kk, u32x4 (&xf)[RPW]) {
 #pragma unroll
-            for (int pj = 0; pj < 4; ++pj) xf[pj] = *(const u32x4*)(halo + (xaddr[pj] ^ (kk * 2 * kSlotBytes)));
+            for (int pj = 0; pj < RPW; ++pj) xf[pj] = *(const u32x4*)(halo + (xaddr[pj] ^ (kk * 2 * kSlotBytes)));
         };
-        auto mma8 = [&](int kk, const u32x4 (&xf)[4]) {
+        auto mma8 = [&](int kk, const u32x4 (&xf)[RPW]) {
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int pj = 0; pj < 4; ++pj)
+                for (int pj = 0; pj < RPW; ++pj)
                     acc[mi][pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wcur[kk][mi]),
                                                                           __builtin_bit_cast(bf16x8, xf[pj]), acc[mi][pj], 0, 0, 0);
         };
 #define IDC_C1_INTERLEAVE()                                                           \
-    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                               \
+    _Pragma("unroll") for (int q_ = 0; q_ < RPW; ++q_) {                             \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
     }                                                                                 \
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, RPW, 0);
         __builtin_amdgcn_sched_barrier(0);
         read_x(0, xfA);
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, RPW, 0);
         read_x(1, xfB);
         mma8(0, xfA);
         IDC_C1_INTERLEAVE()
@@ -2190,7 +2198,7 @@ __global__ __launch_bounds__(512, 2) void conv1_block_fused(const ConvArgs a) {
         mma8(2, xfA);
         IDC_C1_INTERLEAVE()
         mma8(3, xfB);
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * RPW, 0);
 #undef IDC_C1_INTERLEAVE
         if (t + 1 < 9) {
 #pragma unroll
@@ -2218,7 +2226,7 @@ __global__ __launch_bounds__(512, 2) void conv1_block_fused(const ConvArgs a) {
             }
     }
 #pragma unroll
-    for (int pj = 0; pj < 4; ++pj) {
+    for (int pj = 0; pj < RPW; ++pj) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
             unsigned pk[8];
@@ -2233,7 +2241,7 @@ __global__ __launch_bounds__(512, 2) void conv1_block_fused(const ConvArgs a) {
             *(uint4*)(tb16 + px * 128 + (((s0 + 1) ^ (px & 7)) * 16)) = uint4{pk[4], pk[5], pk[6], pk[7]};
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int sy = ty0 + wave * 4 + pj;
+        const int sy = ty0 + wave * RPW + pj;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = i * 8 + rr;
@@ -2252,10 +2260,15 @@ __global__ __launch_bounds__(512, 2) void conv1_block_fused(const ConvArgs a) {
 hipError_t launch_conv1_block(const ConvArgs& a, hipStream_t s) {
     if (a.pk_L == nullptr || a.wgt2 == nullptr || a.head_b == nullptr || a.ncg != 1 || a.out_f32 || a.resid != nullptr)
         return hipErrorInvalidConfiguration;
-    const long long blocks = (long long)((a.Ws + 31) / 32) * ((a.Hs + 31) / 32) * a.N;
+    // 32x8 tile / three workgroups per CU: measured -2 % on this kernel (0.229 vs 0.234 ms), nothing on the
+    // forward (profiles/r03_conv1_tile8.txt) -- the A fragments of conv1_2 come from global memory per wave and tap, so the smaller
+    // tile doubles an L2 -> CU stream that is already 5 TB/s.  Off by default; IDC_C1_TILE8=1 selects it (parity-tested).
+    static const int tile8 = getenv("IDC_C1_TILE8") && atoi(getenv("IDC_C1_TILE8")) != 0;
+    const int th = tile8 ? 8 : 32;
+    const long long blocks = (long long)((a.Ws + 31) / 32) * ((a.Hs + th - 1) / th) * a.N;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    constexpr int lds = 34 * 34 * 128 + 36 * 36 * 8;
-    hipLaunchKernelGGL(conv1_block_fused, dim3((unsigned)blocks), dim3(512), lds, s, a);
+    if (tile8) hipLaunchKernelGGL((conv1_block_fused_t<4, 2>), dim3((unsigned)blocks), dim3(256), 34 * 10 * 128 + 36 * 12 * 8, s, a);
+    else hipLaunchKernelGGL((conv1_block_fused_t<8, 4>), dim3((unsigned)blocks), dim3(512), 34 * 34 * 128 + 36 * 36 * 8, s, a);
     return hipGetLastError();
 }
 
