@@ -579,7 +579,7 @@ static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, i
     // bf16 click path: a 3x3 stride-1 layer that would run conv_click + a split-K reduction launch runs as Winograd instead
     // (16 position-GEMMs fill the chip without split-K: no slabs, no second launch; idc_wino.hip)
     if (precision == IDC_BF16 && g_wino && g_wino_bf16 && g_tile_policy != 1 && big_tiles < tuning().v2_min_blocks &&
-        L.blob.w3_off != (size_t)-1 && L.spec->resid == nullptr && L.spec->kind == kConv3x3 && L.spec->in_stride == 1) {
+        L.blob.w3_off != (size_t)-1 && L.spec->resid == nullptr && L.spec->kind == kConv3x3) {
         L.wino = true; a.ksplit = 1; a.kc_per = a.nkc; a.tiles_x = a.tiles_y = 0;
         return;
     }

@@ -80,8 +80,9 @@ inline int cout_pad(int cout) { return cout <= 64 ? 64 : ((cout + 127) / 128) * 
 inline int weight_taps(LayerKind k) { return k == kConv3x3 ? 9 : (k == kDeconv4x4 ? 16 : 1); }
 // channels of the GEMM K dimension per tap, before padding to the 128-byte chunk
 inline int k_channels(const LayerSpec& s) { return s.kind == kConvIm2col ? 36 : s.cin; }
-// layers the fp32 Winograd kernel (conv_wino_f32) can run: 3x3, stride 1, no shortcut sum, 32 | Cin
-inline bool wino_eligible(const LayerSpec& s) { return s.kind == kConv3x3 && s.in_stride == 1 && s.resid == nullptr && s.cin % 32 == 0; }
+// layers the Winograd kernels (idc_wino.hip) can run: 3x3 (the conv itself always has stride 1; in_stride 2 = it reads a strided
+// view of its source), no shortcut sum, 32 | Cin
+inline bool wino_eligible(const LayerSpec& s) { return s.kind == kConv3x3 && s.resid == nullptr && s.cin % 32 == 0; }
 // layers the bf16 large-tile kernel (conv_igemm_v2, >= 128 couts per workgroup) can run
 inline bool v2_eligible(const LayerSpec& s) { return s.kind != kConvIm2col && cout_pad(s.cout) >= 128; }
 

@@ -85,7 +85,8 @@ __global__ __launch_bounds__(kWinoNT, 2) void conv_wino_f32(const ConvArgs a) {
     const int H = a.Hs, W = a.Ws;
     const int nkc = a.nkc;
     const int pix_bytes = nkc * kRowBytes;
-    const char* const img = (const char*)a.in + (size_t)n * H * W * pix_bytes;
+    const int si = a.si;                                       // 2: the layer reads x[::2, ::2] (model.py:149-151) -- a stride-1 conv on a strided view
+    const char* const img = (const char*)a.in + (size_t)n * (H * si) * (W * si) * pix_bytes;
 
     // ---- patch staging plan (fixed over the K loop): item k = (patch pixel k>>3, slot k&7) ---------------------------
     int poff[PI];
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(kWinoNT, 2) void conv_wino_f32(const ConvArgs a) {
         const int py = p / PW, px = p - py * PW;
         const int Y = Y0 + d * (py - 1), X = X0 + d * (px - 1);
         const bool inside = k < 10 * PW * 8 && (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W;
-        poff[j] = inside ? (Y * W + X) * pix_bytes + s * kSlotBytes : -1;
+        poff[j] = inside ? ((Y * si) * (W * si) + X * si) * pix_bytes + s * kSlotBytes : -1;
     }
     u32x4 xr[PI];
     auto load_patch = [&](int c) {
@@ -540,7 +541,8 @@ __global__ __launch_bounds__(kWinoNT, 2) void conv_wino_bf16(const ConvArgs a) {
     const int H = a.Hs, W = a.Ws;
     const int nkc = a.nkc;                                     // 64-channel chunks
     const int pix_bytes = nkc * kRowBytes;
-    const char* const img = (const char*)a.in + (size_t)n * H * W * pix_bytes;
+    const int si = a.si;                                       // 2: the layer reads x[::2, ::2] (model.py:149-151) -- a stride-1 conv on a strided view
+    const char* const img = (const char*)a.in + (size_t)n * (H * si) * (W * si) * pix_bytes;
 
     int poff[PI];
 #pragma unroll
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(kWinoNT, 2) void conv_wino_bf16(const ConvArgs a) {
         const int py = p / PW, px = p - py * PW;
         const int Y = Y0 + d * (py - 1), X = X0 + d * (px - 1);
         const bool inside = k < 10 * PW * 8 && (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W;
-        poff[j] = inside ? (Y * W + X) * pix_bytes + s * kSlotBytes : -1;
+        poff[j] = inside ? ((Y * si) * (W * si) + X * si) * pix_bytes + s * kSlotBytes : -1;
     }
     u32x4 xr[PI];
     auto load_patch = [&](int c) {
@@ -740,7 +742,7 @@ static hipError_t launch_wino_t(ConvArgs& a, int d, int precision, hipStream_t s
 hipError_t launch_conv_wino(int precision, const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     const int d = a.dy[8];
-    if ((d != 1 && d != 2) || a.si != 1 || a.so != 1 || a.nphase != 1 || a.ntaps != 9 || a.resid != nullptr || (precision == 0 && !a.out_f32) ||
+    if ((d != 1 && d != 2) || (a.si != 1 && a.si != 2) || a.so != 1 || a.nphase != 1 || a.ntaps != 9 || a.resid != nullptr || (precision == 0 && !a.out_f32) ||
         a.zeros == nullptr || a.nkc < 1)
         return hipErrorInvalidConfiguration;
     const long long t2 = (long long)(((a.Ws + d - 1) / d + 15) / 16) * (((a.Hs + d - 1) / d + 7) / 8) * d * d * a.N;   // 8x16-pixel blocks

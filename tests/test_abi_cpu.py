@@ -95,7 +95,7 @@ def _plan(precision, dist):
         off = _al(off); e["w_off"] = off; off += ntap * nkc * e["ncg"] * 8192
         if precision == "bf16" and kind != "im2col" and cpad >= 128:   # second image: layout 2 (conv_igemm_v2)
             off = _al(off); e["w2_off"] = off; off += ntap * nkc * e["ncg"] * 8192
-        if kind == "c3" and wkey not in ("model2.0", "model3.0", "model4.0"):
+        if kind == "c3":
             # third image: Winograd F(2x2,3x3) weights U = G g G^T of the 3x3 stride-1 layers (idc_wino.hip; fp32: every
             # batch size, bf16: the batch-1 click path)
             off = _al(off); e["w3_off"] = off; off += cin * cpad * 16 * (2 if precision == "bf16" else 4)
