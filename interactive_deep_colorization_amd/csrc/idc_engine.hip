@@ -50,6 +50,10 @@ BlobPlan make_blob_plan(int precision, unsigned flags) {
             lb.w3_bytes = (size_t)s.cin * cout_pad(s.cout) * 16 * elem_bytes(precision);   // 16 transformed values per (cin, cout)
             off = align_up(off, 256); lb.w3_off = off; off += lb.w3_bytes;
         }
+        if (precision == IDC_FP32 && wino_deconv_eligible(s)) {               // fp32 deconvs: F(2x2,2x2) over the four phases
+            lb.w3_bytes = (size_t)s.cin * cout_pad(s.cout) * 36 * 4;
+            off = align_up(off, 256); lb.w3_off = off; off += lb.w3_bytes;
+        }
         off = align_up(off, 256); lb.bias_off = off; off += (size_t)cout_pad(s.cout) * 4;
         if (s.bnkey) {
             off = align_up(off, 256); lb.bn_scale_off = off; off += (size_t)cout_pad(s.cout) * 4;
@@ -174,6 +178,37 @@ static void pack_wino_weights(uint8_t* img, int precision, const LayerSpec& s, c
         }
 }
 
+// Winograd F(2x2,2x2) image of a ConvTranspose 4x4 s2 p1 layer (fp32, conv_wino_deconv_f32): per output phase (r,s) the 2x2 sub-kernel
+// g[a][b] = W[ci][co][KY[r][a]][KY[s][b]], KY = {{3,1},{2,0}} (taps in ascending input offset: SURVEY.md Appendix C), U = G g G^T
+// with G = [[1,0],[1,1],[0,1]]; position p = ((r*2+s)*3 + i)*3 + j; same fragment order as pack_wino_weights with 36 positions.
+static void pack_wino_deconv_weights(uint8_t* img, const LayerSpec& s, const LayerBlob& lb, const float* w) {
+    memset(img, 0, lb.w3_bytes);
+    static const int KY[2][2] = {{3, 1}, {2, 0}};
+    const int ncb = cout_pad(s.cout) / 16;
+    float* const out = (float*)img;
+    for (int ci = 0; ci < s.cin; ++ci)
+        for (int co = 0; co < s.cout; ++co) {
+            const float* g16 = w + ((size_t)ci * s.cout + co) * 16;             // (Cin, Cout, 4, 4)
+            const int c = ci / 32, within = ci % 32, slot = within / 4, e = within % 4, ks = slot / 4, gq = slot % 4;
+            const int cbg = co / 16, m = co % 16, lane = gq * 16 + m;
+            for (int r = 0; r < 2; ++r)
+                for (int sx = 0; sx < 2; ++sx) {
+                    double g[2][2];
+                    for (int a = 0; a < 2; ++a)
+                        for (int b = 0; b < 2; ++b) g[a][b] = g16[KY[r][a] * 4 + KY[sx][b]];
+                    const double t[3][2] = {{g[0][0], g[0][1]}, {g[0][0] + g[1][0], g[0][1] + g[1][1]}, {g[1][0], g[1][1]}};   // G g
+                    for (int i = 0; i < 3; ++i) {
+                        const double u3[3] = {t[i][0], t[i][0] + t[i][1], t[i][1]};                                       // (G g) G^T
+                        for (int j = 0; j < 3; ++j) {
+                            const int p = ((r * 2 + sx) * 3 + i) * 3 + j;
+                            const size_t idx = (((((size_t)c * 36 + p) * ncb + cbg) * 2 + ks) * 64 + lane) * 4 + e;
+                            out[idx] = (float)u3[j];
+                        }
+                    }
+                }
+        }
+}
+
 static int fail(std::string* err, int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -225,7 +260,10 @@ static int pack_weights_impl(int precision, unsigned flags, const idc_tensor_des
         if (!dims_are(*b, {s.cout})) return fail(err, IDC_ERR_MISSING_KEY, "key '%s' has the wrong shape", bk.c_str());
         pack_layer_weights(base + lb.w_off, precision, 1, s, lb, w->data);
         if (lb.w2_off != (size_t)-1) pack_layer_weights(base + lb.w2_off, precision, 2, s, lb, w->data);
-        if (lb.w3_off != (size_t)-1) pack_wino_weights(base + lb.w3_off, precision, s, lb, w->data);
+        if (lb.w3_off != (size_t)-1) {
+            if (s.kind == kDeconv4x4) pack_wino_deconv_weights(base + lb.w3_off, s, lb, w->data);
+            else pack_wino_weights(base + lb.w3_off, precision, s, lb, w->data);
+        }
         float* bias = (float*)(base + lb.bias_off);
         for (int c = 0; c < s.cout; ++c) bias[c] = b->data[c];
         if (s.bnkey) {
@@ -439,6 +477,7 @@ static int g_fuse_conv1 = !(getenv("IDC_FUSE_CONV1") && atoi(getenv("IDC_FUSE_CO
 // i.e. the batch-1 click path), 1 = never, 2 = always split as far as the cin chunks allow (tests).
 static int g_splitk_policy = 0;
 static int g_wino = !(getenv("IDC_WINO") && atoi(getenv("IDC_WINO")) == 0);   // fp32 3x3 stride-1 layers in Winograd form (idc_set_option "winograd" / env IDC_WINO=0 for A/B)
+static int g_wino_deconv = !(getenv("IDC_WINO_DECONV") && atoi(getenv("IDC_WINO_DECONV")) == 0);   // fp32 deconvs as Winograd F(2x2,2x2) (idc_set_option "winograd_deconv")
 static int g_wino_bf16 = !(getenv("IDC_WINO_BF16") && atoi(getenv("IDC_WINO_BF16")) == 0);   // bf16 batch-1 click path: Winograd instead of conv_click + split-K reduction (idc_set_option "winograd_bf16")
 static int g_click = -1;                 // conv_click for small launches: -1 = environment default (on), 0 off, 1 on (idc_set_option "click")
 // Shortcut fusion (conv_igemm_v2<.,.,1,true>) is correct (parity-tested under tile policy 2) but measured slower
@@ -540,7 +579,14 @@ static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, i
     a.out_f32 = L.spec->out_f32;
     // fp32 path: every 3x3 stride-1 layer whose U image is in the blob runs as Winograd F(2x2,3x3): 2.25x fewer multiplies
     // on the exact-fp32 matrix pipe, no split-K at batch 1 (one workgroup per 16 tiles x 32 couts)
-    L.wino = precision == IDC_FP32 && g_wino && g_tile_policy != 1 && L.blob.w3_off != (size_t)-1 && L.spec->resid == nullptr;
+    L.wino = precision == IDC_FP32 && g_wino && g_tile_policy != 1 && L.blob.w3_off != (size_t)-1 &&
+             (L.spec->kind == kDeconv4x4
+                  ? (g_wino_deconv == 2 || (g_wino_deconv == 1 && a.nkc >= 8 &&
+                                            (long long)((Ws + 7) / 8) * ((Hs + 7) / 8) * n_policy * (a.ncg * 4) <= 1024))
+                  : L.spec->resid == nullptr);
+    // (deconvs: only the small launches of the click path with Cin >= 256 -- the form is transform-bound (one 16-cout block per
+    //  workgroup at the 168-register budget of its 12 waves): model10up (4 chunks) 123 us vs 96 us direct at batch 1, and at N = 32
+    //  model8up / model9up 1.30 / 1.54 ms vs 1.23 / 1.31 ms direct; "winograd_deconv" = 2 forces it everywhere for the tests)
     if (L.wino) { L.v2 = false; L.click = false; a.ksplit = 1; a.kc_per = a.nkc; a.tiles_x = a.tiles_y = 0; return; }
     // large-tile bf16 kernel: 256 couts x (32x8 sites) when the cout groups divide by 4, else
     // 128 couts x (32x16 sites); used when its grid covers at least half of the 256 CUs
@@ -836,7 +882,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
                 (long long)((a.Ws + 31) / 32) * ((a.Hs + 31) / 32) * c->max_batch >= 128)
                 le = launch_conv1_1_bf16(a, s);
             if (L.fused_short >= 0) le = launch_conv_ds(a, s);    // deconv + its shortcut conv in one K loop
-            if (L.wino) le = launch_conv_wino(c->precision, a, s);
+            if (L.wino) le = L.spec->kind == kDeconv4x4 ? launch_deconv_wino(a, s) : launch_conv_wino(c->precision, a, s);
             if (le == hipErrorInvalidConfiguration)
                 le = L.click ? launch_conv_click(c->precision, L.cfg.wp, L.halo, a, s)
                    : L.v2 ? launch_conv_v2(L.cfg, L.halo, a, s) : launch_conv(c->precision, L.cfg, L.halo, a, s);
@@ -976,6 +1022,7 @@ int idc_set_option(const char* name, int value) {
     if (strcmp(name, "click") == 0) { g_click = value; return IDC_OK; }
     if (strcmp(name, "winograd") == 0) { g_wino = value != 0; return IDC_OK; }
     if (strcmp(name, "winograd_bf16") == 0) { g_wino_bf16 = value != 0; return IDC_OK; }
+    if (strcmp(name, "winograd_deconv") == 0) { g_wino_deconv = value; return IDC_OK; }
     if (strcmp(name, "winograd_form") == 0) { set_wino_form(value); return IDC_OK; }     // 0 automatic, 12 / 21 / 22 = <TB,CB> (tests, tuning)
     return fail(nullptr, IDC_ERR_INVALID_ARG, "unknown option '%s'", name);
 }
@@ -1756,7 +1803,7 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
                 if (C.fused_short == layer - 1 || C.fused_next == layer - 1) snprintf(out->kernel, sizeof(out->kernel), "fused into %s", C.spec->name);
             out->flops = 0; out->min_bytes = 0; out->launches = 0;
         } else {
-            snprintf(out->kernel, sizeof(out->kernel), L.wino ? (h->precision == IDC_BF16 ? "conv_wino_bf16" : "conv_wino_f32") : L.click ? (h->precision == IDC_BF16 ? "conv_click<bf16,%d,%d>" : "conv_click<f32,%d,%d>")
+            snprintf(out->kernel, sizeof(out->kernel), L.wino ? (L.spec->kind == kDeconv4x4 ? "conv_wino_deconv_f32" : h->precision == IDC_BF16 ? "conv_wino_bf16" : "conv_wino_f32") : L.click ? (h->precision == IDC_BF16 ? "conv_click<bf16,%d,%d>" : "conv_click<f32,%d,%d>")
                      : L.v2 ? "conv_igemm_v2<%d,%d>" : (h->precision == IDC_BF16 ? "conv_igemm<bf16,%d,%d>" : "conv_igemm<f32,%d,%d>"),
                      L.cfg.wm, L.cfg.wp);
             if (L.fused_head) strncat(out->kernel, "+head", sizeof(out->kernel) - strlen(out->kernel) - 1);
@@ -1882,9 +1929,10 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     L.blob.w_off = 0; L.blob.w2_off = (size_t)-1; L.blob.bias_off = L.blob.bn_scale_off = L.blob.bn_shift_off = L.blob.fbias_off = (size_t)-1;
     const int cpad = cout_pad(spec.cout);
     // fp32 3x3 stride-1 ops without a shortcut sum take the Winograd kernel exactly as inside the network
-    const bool wino_ok = wino_eligible(spec) && spec.cin % kc == 0 && resid == nullptr;
+    const bool wino_dc = precision == IDC_FP32 && wino_deconv_eligible(spec);
+    const bool wino_ok = (wino_eligible(spec) && spec.cin % kc == 0 && resid == nullptr) || wino_dc;
     L.blob.w3_off = wino_ok ? 0 : (size_t)-1;
-    L.blob.w3_bytes = wino_ok ? (size_t)spec.cin * cpad * 16 * eb : 0;
+    L.blob.w3_bytes = wino_ok ? (size_t)spec.cin * cpad * (wino_dc ? 36 : 16) * eb : 0;
     if (wino_ok && L.blob.w3_bytes > L.blob.w_bytes) L.blob.w_bytes = L.blob.w3_bytes;      // one staging buffer serves either image
     std::vector<uint8_t> wimg(L.blob.w_bytes);
     const int Hs = h / spec.in_stride, Ws = w / spec.in_stride;
@@ -1892,7 +1940,8 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     const int Ho = Hs * so, Wo = Ws * so;
     fill_taps(L);
     set_geometry(L, precision, n, n, Hs, Ws);
-    if (L.wino) pack_wino_weights(wimg.data(), precision, spec, L.blob, weight);
+    if (L.wino && wino_dc) pack_wino_deconv_weights(wimg.data(), spec, L.blob, weight);
+    else if (L.wino) pack_wino_weights(wimg.data(), precision, spec, L.blob, weight);
     else {
         if (wino_ok) L.blob.w_bytes = (size_t)weight_taps(spec.kind) * L.blob.nkc * L.blob.ncg * kWBlockBytes;
         pack_layer_weights(wimg.data(), precision, L.v2 ? 2 : 1, spec, L.blob, weight);
@@ -1941,7 +1990,7 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     HIPCHK(nullctx, d_zero.alloc(256));
     HIPCHK(nullctx, hipMemset(d_zero.p, 0, 256));
     a.zeros = d_zero.p;
-    HIPCHK(nullctx, L.wino ? launch_conv_wino(precision, a, nullptr) : L.click ? launch_conv_click(precision, L.cfg.wp, L.halo, a, nullptr)
+    HIPCHK(nullctx, L.wino ? (wino_dc ? launch_deconv_wino(a, nullptr) : launch_conv_wino(precision, a, nullptr)) : L.click ? launch_conv_click(precision, L.cfg.wp, L.halo, a, nullptr)
                     : L.v2 ? launch_conv_v2(L.cfg, L.halo, a, nullptr) : launch_conv(precision, L.cfg, L.halo, a, nullptr));
     if (a.ksplit > 1) HIPCHK(nullctx, launch_splitk_epilogue(precision, a, nullptr));
     HIPCHK(nullctx, launch_nhwc_to_nchw(io_bf16, d_yn.p, (float*)d_y.p, n, spec.cout, Ho, Wo, cpad, nullptr));

@@ -83,6 +83,8 @@ inline int k_channels(const LayerSpec& s) { return s.kind == kConvIm2col ? 36 : 
 // layers the Winograd kernels (idc_wino.hip) can run: 3x3 (the conv itself always has stride 1; in_stride 2 = it reads a strided
 // view of its source), no shortcut sum, 32 | Cin
 inline bool wino_eligible(const LayerSpec& s) { return s.kind == kConv3x3 && s.resid == nullptr && s.cin % 32 == 0; }
+// fp32 deconv layers run as Winograd F(2x2,2x2) over their four phases (conv_wino_deconv_f32): 36 transformed values per (cin, cout)
+inline bool wino_deconv_eligible(const LayerSpec& s) { return s.kind == kDeconv4x4 && s.cin % 32 == 0; }
 // layers the bf16 large-tile kernel (conv_igemm_v2, >= 128 couts per workgroup) can run
 inline bool v2_eligible(const LayerSpec& s) { return s.kind != kConvIm2col && cout_pad(s.cout) >= 128; }
 

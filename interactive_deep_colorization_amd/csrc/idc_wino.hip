@@ -718,6 +718,226 @@ __global__ __launch_bounds__(kWinoNT, 2) void conv_wino_bf16(const ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// conv_wino_deconv_f32<CB>: ConvTranspose2d 4x4 stride 2 pad 1 (model8up / 9up / 10up, model.py:75,87,97) on the fp32 path as
+// Winograd F(2x2,2x2).  Each of the four output phases (r,s) of the deconv is a 2x2-tap correlation over the input grid
+// (out[2m+r,2n+s] uses taps (ky,dy) in T(r) = {(3,-1),(1,0)} | {(2,0),(0,+1)}); for a tile of 2x2 sites:
+//     m1 = (d0-d1) ga, m2 = d1 (ga+gb), m3 = (d2-d1) gb,  y0 = m1+m2, y1 = m2+m3     (3 multiplies per 2 outputs instead of 4)
+// in 2-D 9 multiplies per phase and tile instead of 16, 36 "positions" (phase r,s x i,j) per tile over ONE 4x4 site patch (the
+// phase (r,s) reads its 3x3 sub-patch at offset (r,s)).  Same machinery as conv_wino_f32: workgroup = 16 tiles (an 8x8 block of
+// sites = 16x16 output pixels) x 16*CB couts x 36 positions, 12 waves, wave w = (r, s, i) owns positions 3w .. 3w+2; U image
+// [chunk][pos 36][16 couts][ks][lane][16 B] streamed global -> registers; patch -> LDS -> transform (one item per thread:
+// tile, 16-byte slot, (r,i)) -> V[pos][tile][32 ch]; ONE V buffer of 72 KiB (fragments in registers, next transform under the
+// MFMAs), two patch buffers; the 36 sums of a (tile, cout) meet in LDS, one thread per (tile, phase, cout) forms the 2x2 outputs
+// of its phase, adds bias and the fp32 shortcut sum (model.py:156,170,172), applies the activation and stores.
+// No split-K at batch 1 (the deconvs were the last layers of the fp32 click path that had reduction launches).
+constexpr int kWinoDNT = 768;
+constexpr int kWinoDVBytes = 36 * 16 * kRowBytes;           // 73 728
+constexpr int kWinoDPBytes = 2 * 1024 * kSlotBytes;          // per patch buffer: 100 pixels x 8 slots <= 2 items x 768 threads (first 800 used)
+constexpr int kWinoDLds = kWinoDVBytes + 2 * kWinoDPBytes;
+
+template <int CB>
+__global__ __launch_bounds__(kWinoDNT, 3) void conv_wino_deconv_f32(const ConvArgs a) {
+    constexpr int NT = kWinoDNT, PW = 10, NTILE = 16, PBY = kWinoDPBytes;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Vb = smem;
+    char* const Pb = smem + kWinoDVBytes;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int b = xcd_remap_w(blockIdx.x, gridDim.x);
+    const int bx = b % a.tiles_x; b /= a.tiles_x;
+    const int by = b % a.tiles_y; b /= a.tiles_y;
+    const int n = b % a.N;
+    const int cg = b / a.N;                                    // group of 16*CB couts (slowest: its U slice stays in the XCD's L2)
+    const int Y0 = 8 * by, X0 = 8 * bx;                        // first SITE (input pixel) of the block
+    const int H = a.Hs, W = a.Ws;                              // input (site) resolution; the output is 2H x 2W
+    const int nkc = a.nkc;
+    const int pix_bytes = nkc * kRowBytes;
+    const char* const img = (const char*)a.in + (size_t)n * H * W * pix_bytes;
+
+    int poff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int k = tid + j * NT;
+        const int p = k >> 3, s = k & 7;
+        const int py = p / PW, px = p - py * PW;
+        const int Y = Y0 - 1 + py, X = X0 - 1 + px;
+        const bool inside = k < PW * PW * 8 && (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W;
+        poff[j] = inside ? (Y * W + X) * pix_bytes + s * kSlotBytes : -1;
+    }
+    u32x4 xr[2];
+    auto load_patch = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            xr[j] = *(const u32x4*)((poff[j] >= 0 && c < nkc) ? img + poff[j] + c * kRowBytes : (const char*)a.zeros);
+    };
+    auto store_patch = [&](int pbuf) {
+        *(u32x4*)(Pb + pbuf * PBY + tid * kSlotBytes) = xr[0];
+        if (tid < PW * PW * 8 - NT) *(u32x4*)(Pb + pbuf * PBY + (tid + NT) * kSlotBytes) = xr[1];
+    };
+
+    // transform item = (tile tt, slot ts, (r, i)): rows of B^T d for the phase-row r -- i = 0: P[r] - P[r+1], 1: P[r+1], 2: P[r+2] - P[r+1]
+    const int ts = tid & 7, tq = tid >> 3;                     // tq 0..95
+    const int tt = tq / 6, tri = tq - tt * 6, tr = tri / 3, ti = tri - tr * 3;
+    const int rowA = tr + (ti == 2 ? 2 : (ti == 1 ? 1 : 0)), rowB = tr + 1;
+    const float wB = ti == 1 ? 0.f : -1.f;                    // t = P[rowA] + wB * P[rowB]
+    const int pbase = ((2 * (tt >> 2)) * PW + 2 * (tt & 3)) * kRowBytes + ts * kSlotBytes;
+    auto transform = [&](int pbuf, bool on) {
+        f32x4 t[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 u = *(const f32x4*)(Pb + pbuf * PBY + pbase + (rowA * PW + c) * kRowBytes);
+            const f32x4 v = *(const f32x4*)(Pb + pbuf * PBY + pbase + (rowB * PW + c) * kRowBytes);
+            t[c] = u + wB * v;
+        }
+        if (on) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {                  // pos = ((r*2 + s)*3 + i)*3 + j
+                char* const dst = Vb + ((((tr * 2 + s2) * 3 + ti) * 3) * NTILE + tt) * kRowBytes + ((ts ^ (tt & 7)) * kSlotBytes);
+                *(f32x4*)(dst) = t[s2] - t[s2 + 1];
+                *(f32x4*)(dst + NTILE * kRowBytes) = t[s2 + 1];
+                *(f32x4*)(dst + 2 * NTILE * kRowBytes) = t[s2 + 2] - t[s2 + 1];
+            }
+        }
+    };
+
+    const int p0 = wave * 3;                                   // this wave's positions (r, s, i) x j = 0..2
+    const int ncb = a.ncg * 4;
+    const char* const ubase = (const char*)a.wgt + ((size_t)(cg * CB) * 2 * 64 + lane) * kSlotBytes;
+    const size_t u_pos_stride = (size_t)ncb * 2 * 64 * kSlotBytes;
+    u32x4 areg[2][3][CB][2];
+    auto load_A = [&](int c, auto bufc) {
+        constexpr int B = decltype(bufc)::value;
+        const int cn = c < nkc ? c : nkc - 1;
+        const char* const src0 = ubase + ((size_t)cn * 36 + p0) * u_pos_stride;
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    areg[B][pp][cb][ks] = *(const u32x4*)(src0 + (size_t)pp * u_pos_stride + (cb * 2 + ks) * 64 * kSlotBytes);
+    };
+    const int fn = lane & 15, fg = lane >> 4;
+    f32x4 tot[3][CB];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < CB; ++j) tot[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    load_patch(0);
+    load_A(0, std::integral_constant<int, 0>{});
+    store_patch(0);
+    load_patch(1);
+    __syncthreads();
+    transform(0, true);
+    store_patch(1);
+    load_patch(2);
+    auto chunk = [&](int c, auto curc) {
+        constexpr int CUR = decltype(curc)::value;
+        __syncthreads();                                       // A: V(c) and the patch of chunk c+1 are complete
+        f32x4 bf[3][2];
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                bf[pp][ks] = *(const f32x4*)(Vb + ((p0 + pp) * NTILE + fn) * kRowBytes + (((ks * 4 + fg) ^ (fn & 7)) * kSlotBytes));
+        __syncthreads();                                       // B: every wave holds its fragments, V may be overwritten
+        load_A(c + 1, std::integral_constant<int, CUR ^ 1>{});
+        store_patch(c & 1);
+        load_patch(c + 3);
+        transform((c + 1) & 1, c + 1 < nkc);
+        f32x4 acc[3][CB];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < CB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb)
+                        acc[pp][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(areg[CUR][pp][cb][ks])[e], bf[pp][ks][e], acc[pp][cb], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < CB; ++j) tot[i][j] += acc[i][j];
+    };
+    int c = 0;
+    for (; c + 1 < nkc; c += 2) {
+        chunk(c, std::integral_constant<int, 0>{});
+        chunk(c + 1, std::integral_constant<int, 1>{});
+    }
+    if (c < nkc) chunk(c, std::integral_constant<int, 0>{});
+    __syncthreads();
+
+    char* const Mx = smem;                                     // [pos 36][tile 16][128-B row of couts]
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+            *(f32x4*)(Mx + ((p0 + pp) * NTILE + fn) * kRowBytes + (((cb * 4 + fg) ^ (fn & 7)) * kSlotBytes)) = tot[pp][cb];
+    __syncthreads();
+    const int CoutPad = a.ncg * kCoutGroup;
+    const bool has_bn = a.bn_scale != nullptr;
+    constexpr int NC = 16 * CB, NITEM = NTILE * 4 * NC;
+    const int Ho = 2 * H, Wo = 2 * W;
+    for (int idx = tid; idx < NITEM; idx += NT) {
+        const int oc = idx % NC, rem = idx / NC, ph = rem & 3, ot = rem >> 2;
+        float m[9];
+#pragma unroll
+        for (int p = 0; p < 9; ++p)
+            m[p] = *(const float*)(Mx + ((ph * 9 + p) * NTILE + ot) * kRowBytes + (((oc >> 2) ^ (ot & 7)) * kSlotBytes) + (oc & 3) * 4);
+        float sa[2][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { sa[0][j] = m[0 * 3 + j] + m[1 * 3 + j]; sa[1][j] = m[1 * 3 + j] + m[2 * 3 + j]; }
+        const int co = cg * NC + oc;
+        const float bias = a.bias[co];
+        const float bsc = has_bn ? a.bn_scale[co] : 1.f, bsh = has_bn ? a.bn_shift[co] : 0.f;
+        const int r = ph >> 1, s2 = ph & 1;
+        const int sy = Y0 + 2 * (ot >> 2), sx = X0 + 2 * (ot & 3);
+#pragma unroll
+        for (int ya = 0; ya < 2; ++ya)
+#pragma unroll
+            for (int xb = 0; xb < 2; ++xb) {
+                const int my = sy + ya, mx = sx + xb;
+                if (my < H && mx < W) {
+                    const size_t o = (((size_t)n * Ho + (2 * my + r)) * Wo + (2 * mx + s2)) * CoutPad + co;
+                    float v = sa[ya][xb] + sa[ya][xb + 1] + bias;
+                    if (a.resid != nullptr) v += ((const float*)a.resid)[o];
+                    if (a.act == 1) v = fmaxf(v, 0.f);
+                    else if (a.act == 2) v = v > 0.f ? v : 0.2f * v;
+                    if (has_bn) v = fmaf(v, bsc, bsh);
+                    ((float*)a.out)[o] = v;
+                }
+            }
+    }
+}
+
+// ConvTranspose 4x4 s2 p1, fp32, Winograd F(2x2,2x2).  a.wgt = the layer's 36-position U image, a.Hs / a.Ws = INPUT size,
+// a.resid = optional fp32 shortcut sum at the output resolution.
+hipError_t launch_deconv_wino(const ConvArgs& a0, hipStream_t s) {
+    ConvArgs a = a0;
+    if (a.nphase != 4 || a.so != 2 || a.si != 1 || !a.out_f32 || (a.resid != nullptr && a.resid_bf16) || a.zeros == nullptr || a.nkc < 1 ||
+        a.img_shift != nullptr)
+        return hipErrorInvalidConfiguration;
+    a.tiles_x = (a.Ws + 7) / 8;
+    a.tiles_y = (a.Hs + 7) / 8;
+    const long long tb = (long long)a.tiles_x * a.tiles_y * a.N;
+    const int cb = 1;      // (<2>: 32 couts per workgroup -- 57 spilled registers at the 168-register budget of 12 waves; kept for tuning only)
+    (void)tb;
+    const long long blocks = tb * (a.ncg * 4 / cb);
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (cb == 2) hipLaunchKernelGGL((conv_wino_deconv_f32<2>), dim3((unsigned)blocks), dim3(kWinoDNT), kWinoDLds, s, a);
+    else hipLaunchKernelGGL((conv_wino_deconv_f32<1>), dim3((unsigned)blocks), dim3(kWinoDNT), kWinoDLds, s, a);
+    return hipGetLastError();
+}
+
 int g_wino_form = getenv("IDC_WINO_FORM") ? atoi(getenv("IDC_WINO_FORM")) : 0;      // tuning: 0 automatic, 12 / 21 / 22 = force <TB,CB>
 
 void set_wino_form(int form) { g_wino_form = form; }
@@ -761,6 +981,10 @@ hipError_t init_kernels_wino() {
     e = hipFuncSetAttribute((const void*)conv_wino_f32<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_lds(2));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)conv_wino_f32<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_lds(2));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)conv_wino_deconv_f32<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kWinoDLds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)conv_wino_deconv_f32<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kWinoDLds);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)conv_wino_bf16<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_lds_bf16(1));
     if (e != hipSuccess) return e;

@@ -25,6 +25,7 @@ def _reset_options():
     yield
     engine.set_option("winograd", 1)
     engine.set_option("winograd_bf16", 1)
+    engine.set_option("winograd_deconv", 1)
     engine.set_option("winograd_form", 0)
     engine.set_splitk_policy("auto")
 
@@ -119,6 +120,33 @@ def test_winograd_bf16_click_config(golden, make_sd):
     e.close()
 
 
+@pytest.mark.parametrize("name", ["net64_he_s0_mc05", "net32x48_he_s2"])
+def test_winograd_deconv_fp32_layer_by_layer(golden, make_sd, name):
+    """fp32 ConvTranspose 4x4 s2 layers as Winograd F(2x2,2x2) over their four phases (conv_wino_deconv_f32, forced on every deconv):
+    conv8_1 / conv9_1 / conv10_1 (deconv + fp32 shortcut sum + ReLU) against the float64 oracle at the direct kernels' tolerance."""
+    g = golden(name)
+    style, seed = str(g["weight_style"]), int(g["weight_seed"])
+    n, _, H, W = g["L_mc"].shape
+    _, _, acts = siggraph_torch.forward(make_sd(seed, style), g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]),
+                                        return_acts=True, dtype=torch.float64)
+    engine.set_option("winograd_deconv", 2)
+    e = engine.HipColorizer(H, W, max_batch=n, precision="fp32")
+    e.load_state_dict(make_sd(seed, style))
+    out = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
+    table = {r["name"]: r["kernel"] for r in e.layer_table()}
+    for k in ("conv8_1", "conv9_1", "conv10_1"):
+        assert table[k] == "conv_wino_deconv_f32", table
+        ref = acts[k]
+        err = np.abs(e.activation(k, n) - ref).max()
+        assert err <= 2e-4 * (1 + np.abs(ref).max()), "layer %s: max-abs err %.3e" % (k, err)
+    assert np.abs(out - g["out_ab"]).max() <= 3e-3
+    engine.set_option("winograd_deconv", 0)
+    base = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
+    assert not any(r["kernel"] == "conv_wino_deconv_f32" for r in e.layer_table())
+    assert np.abs(out - base).max() <= 3e-3
+    e.close()
+
+
 def test_winograd_fp32_click_config(golden, make_sd):
     """BASELINE configs[1] (one 256x256 image, 5 hints), fp32 default = Winograd: the reference golden at 1e-3, batch == images alone."""
     g = golden("config2_mortar_5hints_torchinit")
@@ -126,7 +154,7 @@ def test_winograd_fp32_click_config(golden, make_sd):
     e.load_state_dict(make_sd(int(g["weight_seed"]), str(g["weight_style"])))
     out = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
     kernels = [r["kernel"] for r in e.layer_table() if r["launches"] > 0]
-    assert sum(k == "conv_wino_f32" for k in kernels) >= 20 and sum("splitK" in k for k in kernels) <= 3, kernels      # only the deconvs still split K
+    assert sum(k == "conv_wino_f32" for k in kernels) >= 20 and sum("splitK" in k for k in kernels) <= 1, kernels      # no reduction launches left (model10up runs un-split)
     assert np.abs(out - g["out_ab"]).max() <= 1e-3
     e.close()
     L, ab, m = workloads.random_batch(3, 64, seed=9)
