@@ -477,6 +477,7 @@ static int g_fuse_conv1 = !(getenv("IDC_FUSE_CONV1") && atoi(getenv("IDC_FUSE_CO
 // i.e. the batch-1 click path), 1 = never, 2 = always split as far as the cin chunks allow (tests).
 static int g_splitk_policy = 0;
 static int g_wino = !(getenv("IDC_WINO") && atoi(getenv("IDC_WINO")) == 0);   // fp32 3x3 stride-1 layers in Winograd form (idc_set_option "winograd" / env IDC_WINO=0 for A/B)
+static int g_fuse_conv1_small = !(getenv("IDC_FUSE_CONV1_SMALL") && atoi(getenv("IDC_FUSE_CONV1_SMALL")) == 0);   // model1 as one 32x8-tile launch on the bf16 click path
 static int g_wino_deconv = !(getenv("IDC_WINO_DECONV") && atoi(getenv("IDC_WINO_DECONV")) == 0);   // fp32 deconvs as Winograd F(2x2,2x2) (idc_set_option "winograd_deconv")
 static int g_wino_bf16 = !(getenv("IDC_WINO_BF16") && atoi(getenv("IDC_WINO_BF16")) == 0);   // bf16 batch-1 click path: Winograd instead of conv_click + split-K reduction (idc_set_option "winograd_bf16")
 static int g_click = -1;                 // conv_click for small launches: -1 = environment default (on), 0 off, 1 on (idc_set_option "click")
@@ -789,15 +790,20 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
     for (size_t i = 0; i + 1 < c->layers.size(); ++i) {
         Layer& L = c->layers[i];
         if (L.spec->kind != kConvIm2col || c->precision != IDC_BF16 || !g_fuse_conv1 || L.spec->act != 1 || L.spec->bnkey) continue;
-        if ((long long)((c->W + 31) / 32) * ((c->H + 31) / 32) * c->max_batch < 128) continue;
+        // 32x32 tiles when there are >= 128 of them (N = 32); else the 32x8 tile (conv1_block_fused_t<4,2>) when THAT gives >= 128
+        // workgroups -- the batch-1 click path: one launch instead of conv1_1 + conv1_2 and no 8 MB intermediate
+        const long long t32 = (long long)((c->W + 31) / 32) * ((c->H + 31) / 32) * c->max_batch;
+        const long long t8 = (long long)((c->W + 31) / 32) * ((c->H + 7) / 8) * c->max_batch;
+        if (t32 < 128 && (t8 < 128 || !g_fuse_conv1_small)) continue;
+        const int tile_req = t32 >= 128 ? 32 : 8;              // tile height request of launch_conv1_block
         for (size_t j = 0; j < c->layers.size(); ++j) {
             Layer& P = c->layers[j];
             const LayerSpec& ps = *P.spec;
             if (P.src != L.dst || P.v2 || ps.kind != kConv3x3 || ps.cin != 64 || ps.cout != 64 || ps.dilation != 1 ||
-                ps.in_stride != 1 || ps.act != 1 || ps.resid || c->tensors[P.dst].is_f32 || P.args.ksplit > 1 || P.click) continue;
+                ps.in_stride != 1 || ps.act != 1 || ps.resid || c->tensors[P.dst].is_f32 || P.args.ksplit > 1 || P.click || P.wino) continue;
             bool only_consumer = true;
             for (const Layer& Q : c->layers) if (&Q != &P && (Q.src == L.dst || Q.resid == L.dst)) only_consumer = false;
-            if (only_consumer) { L.fused_next = (int)j; P.skip = true; }
+            if (only_consumer) { L.fused_next = (int)j; P.skip = true; L.args.tiles_y = tile_req; }
         }
     }
     for (auto& L : c->layers) {
@@ -1019,6 +1025,7 @@ int idc_set_tile_policy(int policy) {
 int idc_set_option(const char* name, int value) {
     if (!name) return fail(nullptr, IDC_ERR_INVALID_ARG, "null option name");
     if (strcmp(name, "fuse_conv1") == 0) { g_fuse_conv1 = value != 0; return IDC_OK; }
+    if (strcmp(name, "fuse_conv1_small") == 0) { g_fuse_conv1_small = value != 0; return IDC_OK; }
     if (strcmp(name, "click") == 0) { g_click = value; return IDC_OK; }
     if (strcmp(name, "winograd") == 0) { g_wino = value != 0; return IDC_OK; }
     if (strcmp(name, "winograd_bf16") == 0) { g_wino_bf16 = value != 0; return IDC_OK; }

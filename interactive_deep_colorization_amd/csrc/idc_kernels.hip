@@ -2263,7 +2263,8 @@ hipError_t launch_conv1_block(const ConvArgs& a, hipStream_t s) {
     // 32x8 tile / three workgroups per CU: measured -2 % on this kernel (0.229 vs 0.234 ms), nothing on the
     // forward (profiles/r03_conv1_tile8.txt) -- the A fragments of conv1_2 come from global memory per wave and tap, so the smaller
     // tile doubles an L2 -> CU stream that is already 5 TB/s.  Off by default; IDC_C1_TILE8=1 selects it (parity-tested).
-    static const int tile8 = getenv("IDC_C1_TILE8") && atoi(getenv("IDC_C1_TILE8")) != 0;
+    static const int force8 = getenv("IDC_C1_TILE8") && atoi(getenv("IDC_C1_TILE8")) != 0;
+    const bool tile8 = force8 || a.tiles_y == 8;           // a.tiles_y = the engine's request: 8 on the batch-1 click path (too few 32x32 tiles)
     const int th = tile8 ? 8 : 32;
     const long long blocks = (long long)((a.Ws + 31) / 32) * ((a.Hs + th - 1) / th) * a.N;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
