@@ -50,8 +50,8 @@ BlobPlan make_blob_plan(int precision, unsigned flags) {
             lb.w3_bytes = (size_t)s.cin * cout_pad(s.cout) * 16 * elem_bytes(precision);   // 16 transformed values per (cin, cout)
             off = align_up(off, 256); lb.w3_off = off; off += lb.w3_bytes;
         }
-        if (precision == IDC_FP32 && wino_deconv_eligible(s)) {               // fp32 deconvs: F(2x2,2x2) over the four phases
-            lb.w3_bytes = (size_t)s.cin * cout_pad(s.cout) * 36 * 4;
+        if (wino_deconv_eligible(s) && s.cin % kc == 0) {                      // deconvs: F(2x2,2x2) over the four phases (click path)
+            lb.w3_bytes = (size_t)s.cin * cout_pad(s.cout) * 36 * elem_bytes(precision);
             off = align_up(off, 256); lb.w3_off = off; off += lb.w3_bytes;
         }
         off = align_up(off, 256); lb.bias_off = off; off += (size_t)cout_pad(s.cout) * 4;
@@ -181,15 +181,17 @@ static void pack_wino_weights(uint8_t* img, int precision, const LayerSpec& s, c
 // Winograd F(2x2,2x2) image of a ConvTranspose 4x4 s2 p1 layer (fp32, conv_wino_deconv_f32): per output phase (r,s) the 2x2 sub-kernel
 // g[a][b] = W[ci][co][KY[r][a]][KY[s][b]], KY = {{3,1},{2,0}} (taps in ascending input offset: SURVEY.md Appendix C), U = G g G^T
 // with G = [[1,0],[1,1],[0,1]]; position p = ((r*2+s)*3 + i)*3 + j; same fragment order as pack_wino_weights with 36 positions.
-static void pack_wino_deconv_weights(uint8_t* img, const LayerSpec& s, const LayerBlob& lb, const float* w) {
+static void pack_wino_deconv_weights(uint8_t* img, int precision, const LayerSpec& s, const LayerBlob& lb, const float* w) {
     memset(img, 0, lb.w3_bytes);
     static const int KY[2][2] = {{3, 1}, {2, 0}};
     const int ncb = cout_pad(s.cout) / 16;
+    const int kc = kc_elems(precision), eps = kSlotBytes / elem_bytes(precision);
     float* const out = (float*)img;
+    uint16_t* const out16 = (uint16_t*)img;
     for (int ci = 0; ci < s.cin; ++ci)
         for (int co = 0; co < s.cout; ++co) {
             const float* g16 = w + ((size_t)ci * s.cout + co) * 16;             // (Cin, Cout, 4, 4)
-            const int c = ci / 32, within = ci % 32, slot = within / 4, e = within % 4, ks = slot / 4, gq = slot % 4;
+            const int c = ci / kc, within = ci % kc, slot = within / eps, e = within % eps, ks = slot / 4, gq = slot % 4;
             const int cbg = co / 16, m = co % 16, lane = gq * 16 + m;
             for (int r = 0; r < 2; ++r)
                 for (int sx = 0; sx < 2; ++sx) {
@@ -201,8 +203,9 @@ static void pack_wino_deconv_weights(uint8_t* img, const LayerSpec& s, const Lay
                         const double u3[3] = {t[i][0], t[i][0] + t[i][1], t[i][1]};                                       // (G g) G^T
                         for (int j = 0; j < 3; ++j) {
                             const int p = ((r * 2 + sx) * 3 + i) * 3 + j;
-                            const size_t idx = (((((size_t)c * 36 + p) * ncb + cbg) * 2 + ks) * 64 + lane) * 4 + e;
-                            out[idx] = (float)u3[j];
+                            const size_t idx = (((((size_t)c * 36 + p) * ncb + cbg) * 2 + ks) * 64 + lane) * eps + e;
+                            if (precision == IDC_BF16) out16[idx] = f32_to_bf16_rne((float)u3[j]);
+                            else out[idx] = (float)u3[j];
                         }
                     }
                 }
@@ -261,7 +264,7 @@ static int pack_weights_impl(int precision, unsigned flags, const idc_tensor_des
         pack_layer_weights(base + lb.w_off, precision, 1, s, lb, w->data);
         if (lb.w2_off != (size_t)-1) pack_layer_weights(base + lb.w2_off, precision, 2, s, lb, w->data);
         if (lb.w3_off != (size_t)-1) {
-            if (s.kind == kDeconv4x4) pack_wino_deconv_weights(base + lb.w3_off, s, lb, w->data);
+            if (s.kind == kDeconv4x4) pack_wino_deconv_weights(base + lb.w3_off, precision, s, lb, w->data);
             else pack_wino_weights(base + lb.w3_off, precision, s, lb, w->data);
         }
         float* bias = (float*)(base + lb.bias_off);
@@ -623,6 +626,12 @@ static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, i
     // every precision and cout width): conv_igemm's ring loop is the better kernel once the K loop is long and the chip full
     const int wm_big = a.ncg % 4 == 0 ? 4 : (a.ncg % 2 == 0 ? 2 : 1), rows_big = wm_big == 4 ? 8 : 16;
     const long long big_tiles = (long long)((Ws + 31) / 32) * ((Hs + rows_big - 1) / rows_big) * n_policy * (a.ncg / wm_big) * a.nphase;
+    // bf16 click path, deconvs with Cin >= 256 (model8up / model9up): Winograd F(2x2,2x2) instead of conv_click + a reduction launch
+    if (precision == IDC_BF16 && g_wino && g_wino_bf16 && g_wino_deconv && g_tile_policy != 1 && big_tiles < tuning().v2_min_blocks &&
+        L.blob.w3_off != (size_t)-1 && L.spec->kind == kDeconv4x4 && (a.nkc >= 4 || g_wino_deconv == 2)) {
+        L.wino = true; a.ksplit = 1; a.kc_per = a.nkc; a.tiles_x = a.tiles_y = 0;
+        return;
+    }
     // bf16 click path: a 3x3 stride-1 layer that would run conv_click + a split-K reduction launch runs as Winograd instead
     // (16 position-GEMMs fill the chip without split-K: no slabs, no second launch; idc_wino.hip)
     if (precision == IDC_BF16 && g_wino && g_wino_bf16 && g_tile_policy != 1 && big_tiles < tuning().v2_min_blocks &&
@@ -888,7 +897,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
                 (long long)((a.Ws + 31) / 32) * ((a.Hs + 31) / 32) * c->max_batch >= 128)
                 le = launch_conv1_1_bf16(a, s);
             if (L.fused_short >= 0) le = launch_conv_ds(a, s);    // deconv + its shortcut conv in one K loop
-            if (L.wino) le = L.spec->kind == kDeconv4x4 ? launch_deconv_wino(a, s) : launch_conv_wino(c->precision, a, s);
+            if (L.wino) le = L.spec->kind == kDeconv4x4 ? launch_deconv_wino(c->precision, a, s) : launch_conv_wino(c->precision, a, s);
             if (le == hipErrorInvalidConfiguration)
                 le = L.click ? launch_conv_click(c->precision, L.cfg.wp, L.halo, a, s)
                    : L.v2 ? launch_conv_v2(L.cfg, L.halo, a, s) : launch_conv(c->precision, L.cfg, L.halo, a, s);
@@ -1810,7 +1819,7 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
                 if (C.fused_short == layer - 1 || C.fused_next == layer - 1) snprintf(out->kernel, sizeof(out->kernel), "fused into %s", C.spec->name);
             out->flops = 0; out->min_bytes = 0; out->launches = 0;
         } else {
-            snprintf(out->kernel, sizeof(out->kernel), L.wino ? (L.spec->kind == kDeconv4x4 ? "conv_wino_deconv_f32" : h->precision == IDC_BF16 ? "conv_wino_bf16" : "conv_wino_f32") : L.click ? (h->precision == IDC_BF16 ? "conv_click<bf16,%d,%d>" : "conv_click<f32,%d,%d>")
+            snprintf(out->kernel, sizeof(out->kernel), L.wino ? (L.spec->kind == kDeconv4x4 ? (h->precision == IDC_BF16 ? "conv_wino_deconv_bf16" : "conv_wino_deconv_f32") : h->precision == IDC_BF16 ? "conv_wino_bf16" : "conv_wino_f32") : L.click ? (h->precision == IDC_BF16 ? "conv_click<bf16,%d,%d>" : "conv_click<f32,%d,%d>")
                      : L.v2 ? "conv_igemm_v2<%d,%d>" : (h->precision == IDC_BF16 ? "conv_igemm<bf16,%d,%d>" : "conv_igemm<f32,%d,%d>"),
                      L.cfg.wm, L.cfg.wp);
             if (L.fused_head) strncat(out->kernel, "+head", sizeof(out->kernel) - strlen(out->kernel) - 1);
@@ -1936,7 +1945,7 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     L.blob.w_off = 0; L.blob.w2_off = (size_t)-1; L.blob.bias_off = L.blob.bn_scale_off = L.blob.bn_shift_off = L.blob.fbias_off = (size_t)-1;
     const int cpad = cout_pad(spec.cout);
     // fp32 3x3 stride-1 ops without a shortcut sum take the Winograd kernel exactly as inside the network
-    const bool wino_dc = precision == IDC_FP32 && wino_deconv_eligible(spec);
+    const bool wino_dc = wino_deconv_eligible(spec) && spec.cin % kc == 0;
     const bool wino_ok = (wino_eligible(spec) && spec.cin % kc == 0 && resid == nullptr) || wino_dc;
     L.blob.w3_off = wino_ok ? 0 : (size_t)-1;
     L.blob.w3_bytes = wino_ok ? (size_t)spec.cin * cpad * (wino_dc ? 36 : 16) * eb : 0;
@@ -1947,7 +1956,7 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     const int Ho = Hs * so, Wo = Ws * so;
     fill_taps(L);
     set_geometry(L, precision, n, n, Hs, Ws);
-    if (L.wino && wino_dc) pack_wino_deconv_weights(wimg.data(), spec, L.blob, weight);
+    if (L.wino && wino_dc) pack_wino_deconv_weights(wimg.data(), precision, spec, L.blob, weight);
     else if (L.wino) pack_wino_weights(wimg.data(), precision, spec, L.blob, weight);
     else {
         if (wino_ok) L.blob.w_bytes = (size_t)weight_taps(spec.kind) * L.blob.nkc * L.blob.ncg * kWBlockBytes;
@@ -1997,7 +2006,7 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     HIPCHK(nullctx, d_zero.alloc(256));
     HIPCHK(nullctx, hipMemset(d_zero.p, 0, 256));
     a.zeros = d_zero.p;
-    HIPCHK(nullctx, L.wino ? (wino_dc ? launch_deconv_wino(a, nullptr) : launch_conv_wino(precision, a, nullptr)) : L.click ? launch_conv_click(precision, L.cfg.wp, L.halo, a, nullptr)
+    HIPCHK(nullctx, L.wino ? (wino_dc ? launch_deconv_wino(precision, a, nullptr) : launch_conv_wino(precision, a, nullptr)) : L.click ? launch_conv_click(precision, L.cfg.wp, L.halo, a, nullptr)
                     : L.v2 ? launch_conv_v2(L.cfg, L.halo, a, nullptr) : launch_conv(precision, L.cfg, L.halo, a, nullptr));
     if (a.ksplit > 1) HIPCHK(nullctx, launch_splitk_epilogue(precision, a, nullptr));
     HIPCHK(nullctx, launch_nhwc_to_nchw(io_bf16, d_yn.p, (float*)d_y.p, n, spec.cout, Ho, Wo, cpad, nullptr));

@@ -919,12 +919,177 @@ __global__ __launch_bounds__(kWinoDNT, 3) void conv_wino_deconv_f32(const ConvAr
     }
 }
 
+// bf16 twin of conv_wino_deconv_f32 for the batch-1 click path (the last two layers that needed a split-K reduction launch there):
+// 64-channel chunks, transform in fp32 from the bf16 patch and rounded to bf16, 16x16x32 bf16 MFMAs, fp32 accumulation and output
+// transform, bf16 shortcut sum read in the epilogue, bf16 store.  One 16-cout block per workgroup.
+__global__ __launch_bounds__(kWinoDNT, 3) void conv_wino_deconv_bf16(const ConvArgs a) {
+    constexpr int NT = kWinoDNT, PW = 10, NTILE = 16, PBY = kWinoDPBytes;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Vb = smem;
+    char* const Pb = smem + kWinoDVBytes;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int b = xcd_remap_w(blockIdx.x, gridDim.x);
+    const int bx = b % a.tiles_x; b /= a.tiles_x;
+    const int by = b % a.tiles_y; b /= a.tiles_y;
+    const int n = b % a.N;
+    const int cg = b / a.N;
+    const int Y0 = 8 * by, X0 = 8 * bx;
+    const int H = a.Hs, W = a.Ws;
+    const int nkc = a.nkc;
+    const int pix_bytes = nkc * kRowBytes;
+    const char* const img = (const char*)a.in + (size_t)n * H * W * pix_bytes;
+    int poff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int k = tid + j * NT;
+        const int p = k >> 3, s = k & 7;
+        const int py = p / PW, px = p - py * PW;
+        const int Y = Y0 - 1 + py, X = X0 - 1 + px;
+        const bool inside = k < PW * PW * 8 && (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W;
+        poff[j] = inside ? (Y * W + X) * pix_bytes + s * kSlotBytes : -1;
+    }
+    u32x4 xr[2];
+    auto load_patch = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            xr[j] = *(const u32x4*)((poff[j] >= 0 && c < nkc) ? img + poff[j] + c * kRowBytes : (const char*)a.zeros);
+    };
+    auto store_patch = [&](int pbuf) {
+        *(u32x4*)(Pb + pbuf * PBY + tid * kSlotBytes) = xr[0];
+        if (tid < PW * PW * 8 - NT) *(u32x4*)(Pb + pbuf * PBY + (tid + NT) * kSlotBytes) = xr[1];
+    };
+    auto ev = [](const u32x4& v) { return f32x4{__uint_as_float(v.x << 16), __uint_as_float(v.y << 16), __uint_as_float(v.z << 16), __uint_as_float(v.w << 16)}; };
+    auto od = [](const u32x4& v) { return f32x4{__uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y & 0xffff0000u), __uint_as_float(v.z & 0xffff0000u), __uint_as_float(v.w & 0xffff0000u)}; };
+    auto pk = [](const f32x4& e, const f32x4& o) { return u32x4{pack_bf16x2_w(e[0], o[0]), pack_bf16x2_w(e[1], o[1]), pack_bf16x2_w(e[2], o[2]), pack_bf16x2_w(e[3], o[3])}; };
+    const int ts = tid & 7, tq = tid >> 3;
+    const int tt = tq / 6, tri = tq - tt * 6, tr = tri / 3, ti = tri - tr * 3;
+    const int rowA = tr + (ti == 2 ? 2 : (ti == 1 ? 1 : 0)), rowB = tr + 1;
+    const float wB = ti == 1 ? 0.f : -1.f;
+    const int pbase = ((2 * (tt >> 2)) * PW + 2 * (tt & 3)) * kRowBytes + ts * kSlotBytes;
+    auto transform = [&](int pbuf, bool on) {
+        f32x4 te[4], to[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const u32x4 u = *(const u32x4*)(Pb + pbuf * PBY + pbase + (rowA * PW + c) * kRowBytes);
+            const u32x4 v = *(const u32x4*)(Pb + pbuf * PBY + pbase + (rowB * PW + c) * kRowBytes);
+            te[c] = ev(u) + wB * ev(v);
+            to[c] = od(u) + wB * od(v);
+        }
+        if (on) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                char* const dst = Vb + ((((tr * 2 + s2) * 3 + ti) * 3) * NTILE + tt) * kRowBytes + ((ts ^ (tt & 7)) * kSlotBytes);
+                *(u32x4*)(dst) = pk(te[s2] - te[s2 + 1], to[s2] - to[s2 + 1]);
+                *(u32x4*)(dst + NTILE * kRowBytes) = pk(te[s2 + 1], to[s2 + 1]);
+                *(u32x4*)(dst + 2 * NTILE * kRowBytes) = pk(te[s2 + 2] - te[s2 + 1], to[s2 + 2] - to[s2 + 1]);
+            }
+        }
+    };
+    const int p0 = wave * 3;
+    const int ncb = a.ncg * 4;
+    const char* const ubase = (const char*)a.wgt + ((size_t)cg * 2 * 64 + lane) * kSlotBytes;
+    const size_t u_pos_stride = (size_t)ncb * 2 * 64 * kSlotBytes;
+    u32x4 areg[2][3][2];
+    auto load_A = [&](int c, auto bufc) {
+        constexpr int B = decltype(bufc)::value;
+        const int cn = c < nkc ? c : nkc - 1;
+        const char* const src0 = ubase + ((size_t)cn * 36 + p0) * u_pos_stride;
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                areg[B][pp][ks] = *(const u32x4*)(src0 + (size_t)pp * u_pos_stride + ks * 64 * kSlotBytes);
+    };
+    const int fn = lane & 15, fg = lane >> 4;
+    f32x4 tot[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tot[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    load_patch(0);
+    load_A(0, std::integral_constant<int, 0>{});
+    store_patch(0);
+    load_patch(1);
+    __syncthreads();
+    transform(0, true);
+    store_patch(1);
+    load_patch(2);
+    auto chunk = [&](int c, auto curc) {
+        constexpr int CUR = decltype(curc)::value;
+        __syncthreads();
+        u32x4 bf[3][2];
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                bf[pp][ks] = *(const u32x4*)(Vb + ((p0 + pp) * NTILE + fn) * kRowBytes + (((ks * 4 + fg) ^ (fn & 7)) * kSlotBytes));
+        __syncthreads();
+        load_A(c + 1, std::integral_constant<int, CUR ^ 1>{});
+        store_patch(c & 1);
+        load_patch(c + 3);
+        transform((c + 1) & 1, c + 1 < nkc);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp)
+                tot[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_w, areg[CUR][pp][ks]),
+                                                                  __builtin_bit_cast(bf16x8_w, bf[pp][ks]), tot[pp], 0, 0, 0);
+    };
+    int c = 0;
+    for (; c + 1 < nkc; c += 2) {
+        chunk(c, std::integral_constant<int, 0>{});
+        chunk(c + 1, std::integral_constant<int, 1>{});
+    }
+    if (c < nkc) chunk(c, std::integral_constant<int, 0>{});
+    __syncthreads();
+    char* const Mx = smem;
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp)
+        *(f32x4*)(Mx + ((p0 + pp) * NTILE + fn) * kRowBytes + ((fg ^ (fn & 7)) * kSlotBytes)) = tot[pp];
+    __syncthreads();
+    const int CoutPad = a.ncg * kCoutGroup;
+    const bool has_bn = a.bn_scale != nullptr;
+    constexpr int NC = 16, NITEM = NTILE * 4 * NC;
+    const int Ho = 2 * H, Wo = 2 * W;
+    for (int idx = tid; idx < NITEM; idx += NT) {
+        const int oc = idx % NC, rem = idx / NC, ph = rem & 3, ot = rem >> 2;
+        float m[9];
+#pragma unroll
+        for (int p = 0; p < 9; ++p)
+            m[p] = *(const float*)(Mx + ((ph * 9 + p) * NTILE + ot) * kRowBytes + (((oc >> 2) ^ (ot & 7)) * kSlotBytes) + (oc & 3) * 4);
+        float sa[2][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { sa[0][j] = m[0 * 3 + j] + m[1 * 3 + j]; sa[1][j] = m[1 * 3 + j] + m[2 * 3 + j]; }
+        const int co = cg * NC + oc;
+        const float bias = a.bias[co];
+        const float bsc = has_bn ? a.bn_scale[co] : 1.f, bsh = has_bn ? a.bn_shift[co] : 0.f;
+        const int r = ph >> 1, s2 = ph & 1;
+        const int sy = Y0 + 2 * (ot >> 2), sx = X0 + 2 * (ot & 3);
+#pragma unroll
+        for (int ya = 0; ya < 2; ++ya)
+#pragma unroll
+            for (int xb = 0; xb < 2; ++xb) {
+                const int my = sy + ya, mx = sx + xb;
+                if (my < H && mx < W) {
+                    const size_t o = (((size_t)n * Ho + (2 * my + r)) * Wo + (2 * mx + s2)) * CoutPad + co;
+                    float v = sa[ya][xb] + sa[ya][xb + 1] + bias;
+                    if (a.resid != nullptr) v += a.resid_bf16 ? (float)((const __bf16*)a.resid)[o] : ((const float*)a.resid)[o];
+                    if (a.act == 1) v = fmaxf(v, 0.f);
+                    else if (a.act == 2) v = v > 0.f ? v : 0.2f * v;
+                    if (has_bn) v = fmaf(v, bsc, bsh);
+                    if (a.out_f32) ((float*)a.out)[o] = v;
+                    else ((__bf16*)a.out)[o] = (__bf16)v;
+                }
+            }
+    }
+}
+
 // ConvTranspose 4x4 s2 p1, fp32, Winograd F(2x2,2x2).  a.wgt = the layer's 36-position U image, a.Hs / a.Ws = INPUT size,
 // a.resid = optional fp32 shortcut sum at the output resolution.
-hipError_t launch_deconv_wino(const ConvArgs& a0, hipStream_t s) {
+hipError_t launch_deconv_wino(int precision, const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
-    if (a.nphase != 4 || a.so != 2 || a.si != 1 || !a.out_f32 || (a.resid != nullptr && a.resid_bf16) || a.zeros == nullptr || a.nkc < 1 ||
-        a.img_shift != nullptr)
+    if (a.nphase != 4 || a.so != 2 || a.si != 1 || a.zeros == nullptr || a.nkc < 1 || a.img_shift != nullptr ||
+        (precision == 0 && (!a.out_f32 || (a.resid != nullptr && a.resid_bf16))))
         return hipErrorInvalidConfiguration;
     a.tiles_x = (a.Ws + 7) / 8;
     a.tiles_y = (a.Hs + 7) / 8;
@@ -933,7 +1098,8 @@ hipError_t launch_deconv_wino(const ConvArgs& a0, hipStream_t s) {
     (void)tb;
     const long long blocks = tb * (a.ncg * 4 / cb);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (cb == 2) hipLaunchKernelGGL((conv_wino_deconv_f32<2>), dim3((unsigned)blocks), dim3(kWinoDNT), kWinoDLds, s, a);
+    if (precision == 1) hipLaunchKernelGGL(conv_wino_deconv_bf16, dim3((unsigned)blocks), dim3(kWinoDNT), kWinoDLds, s, a);
+    else if (cb == 2) hipLaunchKernelGGL((conv_wino_deconv_f32<2>), dim3((unsigned)blocks), dim3(kWinoDNT), kWinoDLds, s, a);
     else hipLaunchKernelGGL((conv_wino_deconv_f32<1>), dim3((unsigned)blocks), dim3(kWinoDNT), kWinoDLds, s, a);
     return hipGetLastError();
 }
@@ -981,6 +1147,8 @@ hipError_t init_kernels_wino() {
     e = hipFuncSetAttribute((const void*)conv_wino_f32<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_lds(2));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)conv_wino_f32<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_lds(2));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)conv_wino_deconv_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, kWinoDLds);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)conv_wino_deconv_f32<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kWinoDLds);
     if (e != hipSuccess) return e;

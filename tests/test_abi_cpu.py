@@ -99,8 +99,8 @@ def _plan(precision, dist):
             # third image: Winograd F(2x2,3x3) weights U = G g G^T of the 3x3 stride-1 layers (idc_wino.hip; fp32: every
             # batch size, bf16: the batch-1 click path)
             off = _al(off); e["w3_off"] = off; off += cin * cpad * 16 * (2 if precision == "bf16" else 4)
-        if kind == "dc" and precision == "fp32":     # fp32 deconvs: Winograd F(2x2,2x2) over the four phases, 36 values per (cin, cout)
-            off = _al(off); e["w3d_off"] = off; off += cin * cpad * 36 * 4
+        if kind == "dc":                             # deconvs: Winograd F(2x2,2x2) over the four phases, 36 values per (cin, cout)
+            off = _al(off); e["w3d_off"] = off; off += cin * cpad * 36 * (2 if precision == "bf16" else 4)
         off = _al(off); e["b_off"] = off; off += cpad * 4
         if bnkey:
             off = _al(off); e["s_off"] = off; off += cpad * 4
@@ -192,13 +192,18 @@ def test_pack_weights_layout(make_sd, precision, dist):
                 r_, s_, i, j = rs.randint(2), rs.randint(2), rs.randint(3), rs.randint(3)
                 g = np.array([[w[ci, co, KY[r_][a_], KY[s_][b_]] for b_ in (0, 1)] for a_ in (0, 1)], np.float64)
                 U = G2 @ g @ G2.T
-                c, within = divmod(ci, 32)
-                slot, el = divmod(within, 4)
+                kc3, eps3 = (64, 8) if precision == "bf16" else (32, 4)
+                c, within = divmod(ci, kc3)
+                slot, el = divmod(within, eps3)
                 ks, gq = divmod(slot, 4)
                 pidx = ((r_ * 2 + s_) * 3 + i) * 3 + j
-                idx = ((((c * 36 + pidx) * (e["cpad"] // 16) + co // 16) * 2 + ks) * 64 + gq * 16 + co % 16) * 4 + el
-                o3 = e["w3d_off"] + idx * 4
-                assert float(blob[o3:o3 + 4].view(np.float32)[0]) == np.float32(U[i, j]), (e["wkey"], co, ci, r_, s_, i, j)
+                idx = ((((c * 36 + pidx) * (e["cpad"] // 16) + co // 16) * 2 + ks) * 64 + gq * 16 + co % 16) * eps3 + el
+                if precision == "bf16":
+                    o3 = e["w3d_off"] + idx * 2
+                    assert int(blob[o3:o3 + 2].view(np.uint16)[0]) == int(_bf16_bits(np.float32(U[i, j])).ravel()[0]), (e["wkey"], co, ci)
+                else:
+                    o3 = e["w3d_off"] + idx * 4
+                    assert float(blob[o3:o3 + 4].view(np.float32)[0]) == np.float32(U[i, j]), (e["wkey"], co, ci, r_, s_, i, j)
         np.testing.assert_array_equal(blob[e["b_off"]:e["b_off"] + e["cout"] * 4].view(np.float32), sd[e["wkey"] + ".bias"])
         if e["bnkey"]:
             g_, b_ = sd[e["bnkey"] + ".weight"].astype(np.float64), sd[e["bnkey"] + ".bias"].astype(np.float64)

@@ -100,7 +100,7 @@ def test_winograd_bf16_click_path_layer_by_layer(golden, make_sd, name, form):
 
 
 def test_winograd_bf16_click_config(golden, make_sd):
-    """BASELINE configs[1] in bf16: <= 30 launches per click forward (52 with conv_click + split-K), the reference golden inside
+    """BASELINE configs[1] in bf16: <= 28 launches per click forward, none of them a reduction (51 with conv_click + split-K), the reference golden inside
     the torch-init bf16 bound; the N = 32 throughput path never selects the bf16 Winograd form."""
     g = golden("config2_mortar_5hints_torchinit")
     e = engine.HipColorizer(256, 256, max_batch=1, precision="bf16")
@@ -108,7 +108,7 @@ def test_winograd_bf16_click_config(golden, make_sd):
     out = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
     rows = [r for r in e.layer_table() if r["launches"] > 0]
     launches = sum(r["launches"] + (1 if "splitK" in r["kernel"] else 0) for r in rows)
-    assert sum(r["kernel"] == "conv_wino_bf16" for r in rows) >= 20 and launches <= 31, (launches, [r["kernel"] for r in rows])
+    assert sum(r["kernel"] == "conv_wino_bf16" for r in rows) >= 20 and launches <= 28 and not any("splitK" in r["kernel"] for r in rows), (launches, [r["kernel"] for r in rows])
     d = np.abs(out - g["out_ab"])
     assert d.max() <= 0.6 and d.mean() <= 0.06, (d.max(), d.mean())
     e.close()
@@ -144,6 +144,31 @@ def test_winograd_deconv_fp32_layer_by_layer(golden, make_sd, name):
     base = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
     assert not any(r["kernel"] == "conv_wino_deconv_f32" for r in e.layer_table())
     assert np.abs(out - base).max() <= 3e-3
+    e.close()
+
+
+@pytest.mark.parametrize("name", ["net64_he_s0_mc05", "net32x48_he_s2", "net64_torch_s1_mc0"])
+def test_winograd_deconv_bf16_layer_by_layer(golden, make_sd, name):
+    """The bf16 twin (conv_wino_deconv_bf16, forced on every deconv; by default model8up / model9up on the click path): deconv + bf16
+    shortcut sum + ReLU against the float64 oracle at the bf16 per-layer tolerance, the ab map inside the bf16 bounds."""
+    g = golden(name)
+    style, seed = str(g["weight_style"]), int(g["weight_seed"])
+    n, _, H, W = g["L_mc"].shape
+    _, _, acts = siggraph_torch.forward(make_sd(seed, style), g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]),
+                                        return_acts=True, dtype=torch.float64)
+    engine.set_option("winograd_deconv", 2)
+    e = engine.HipColorizer(H, W, max_batch=n, precision="bf16")
+    e.load_state_dict(make_sd(seed, style))
+    out = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
+    table = {r["name"]: r["kernel"] for r in e.layer_table()}
+    for k in ("conv8_1", "conv9_1", "conv10_1"):
+        assert table[k] == "conv_wino_deconv_bf16", table
+        ref = acts[k]
+        err = np.abs(e.activation(k, n) - ref).max()
+        assert err <= 0.04 * (1 + np.abs(ref).max()), "layer %s: max-abs err %.3e" % (k, err)
+    assert not any("splitK" in v for v in table.values()), table
+    d = np.abs(out - g["out_ab"])
+    assert d.max() <= (20.0 if style == "he" else 0.6) and d.mean() <= (2.0 if style == "he" else 0.06), (d.max(), d.mean())
     e.close()
 
 
