@@ -153,10 +153,7 @@ def test_config3_full_size_properties(make_sd):
     assert out.std() > 1.0
     np.testing.assert_array_equal(e.forward(L[7:8], ab[7:8], m[7:8], 0.0)[0], out[7])
     np.testing.assert_array_equal(e.forward(L, ab, m, 0.0), out)
-    # one image of the batch against the oracle at the stated bf16 tolerance
-    ref = siggraph_torch.forward(make_sd(0, "he"), L[7:8], ab[7:8], m[7:8], 0.0)
-    d = np.abs(out[7:8] - ref)
-    assert d.max() <= BF16_MAX["he"] and d.mean() <= BF16_MEAN["he"], "bf16 N=32: max %.3f mean %.4f" % (d.max(), d.mean())
+    # (the comparison with the oracle at this size lives in tests/test_parity_record_gpu.py, several images, measured errors recorded)
 
 
 def test_512_fp32(make_sd):
