@@ -98,6 +98,34 @@ def _wino1d_d1(x, w, round_ops):
     return Y.reshape(N, w.shape[0], H, W)
 
 
+_BT3 = torch.tensor([[1., -1., 0.], [0., 1., 0.], [0., -1., 1.]])
+_G2 = torch.tensor([[1., 0.], [1., 1.], [0., 1.]], dtype=torch.float64)
+_AT2 = torch.tensor([[1., 1., 0.], [0., 1., 1.]])
+_KY = ((3, 1), (2, 0))          # deconv taps of output phase r in ascending input offset
+
+
+def _wino_deconv(x, w, round_ops):
+    """ConvTranspose2d 4x4 s2 p1 without bias as Winograd F(2x2,2x2) over its four output phases (conv_wino_deconv_*):
+    x (N,C,H,W), w (C,Co,4,4) fp32 master weights; operands rounded to bf16 when ``round_ops``."""
+    N, C, H, W = x.shape
+    assert H % 2 == 0 and W % 2 == 0
+    Co = w.shape[1]
+    xp = F.pad(x, (1, 2, 1, 2))                                     # sites -1 .. H+1
+    out = torch.empty((N, Co, 2 * H, 2 * W))
+    for r in range(2):
+        for s in range(2):
+            g = torch.stack([torch.stack([w[:, :, _KY[r][a], _KY[s][b]] for b in range(2)], -1) for a in range(2)], -2)   # (C,Co,2,2)
+            U = torch.einsum("ia,coab,jb->coij", _G2, g.double(), _G2).float()
+            P = xp[:, :, r:r + H + 1, s:s + W + 1].unfold(2, 3, 2).unfold(3, 3, 2)           # (N,C,H/2,W/2,3,3)
+            V = torch.einsum("ik,ncyxkl,jl->ncyxij", _BT3, P, _BT3)
+            if round_ops:
+                U, V = q(U), q(V)
+            M = torch.einsum("coij,ncyxij->noyxij", U, V)
+            Y = torch.einsum("ai,noyxij,bj->noyxab", _AT2, M, _AT2)                             # (N,Co,H/2,W/2,2,2)
+            out[:, :, r::2, s::2] = Y.permute(0, 1, 2, 4, 3, 5).reshape(N, Co, H, W)
+    return out
+
+
 def _conv3(x, w, b, dilation, mode):
     if mode in ("fp32", "bf16"):
         ww = q(w) if mode == "bf16" else w
@@ -143,7 +171,14 @@ def forward(sd, L_mc, ab, mask, maskcent=0.0, modes=None, default="bf16", l_div=
         def up(name, key, x, skip):
             w, b = _w(sd, key)
             ws, bs = _w(sd, SHORT_OF[name])
-            if low(name):
+            if md(name).startswith("wino"):                     # deconv as F(2x2,2x2), shortcut conv as F(2x2,3x3)
+                ro = not md(name).endswith("_fp32")
+                xin, sk = (q(x), q(skip)) if ro else (x, skip)
+                sc = _wino2d_d1(sk, ws, ro) + bs[None, :, None, None]
+                if ro:
+                    sc = q(sc)                                  # the shortcut conv is its own launch on the click path: stored bf16
+                y = _wino_deconv(xin, w, ro) + b[None, :, None, None] + sc
+            elif low(name):
                 y = F.conv_transpose2d(q(x), q(w), b, stride=2, padding=1) + F.conv2d(q(skip), q(ws), bs, padding=1)
             else:
                 y = F.conv_transpose2d(x, w, b, stride=2, padding=1) + F.conv2d(skip, ws, bs, padding=1)

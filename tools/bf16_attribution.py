@@ -47,6 +47,8 @@ def main():
         ("encoder_and_trunk_fp32", {n: "fp32" for n in G["encoder"] + G["trunk"]}),
         ("wino2d_trunk", {n: "wino2d" for n in trunk}),
         ("wino2d_all_3x3_s1", {n: "wino2d" for n in E}),
+        ("click_path_as_shipped (wino2d on conv2_1 .. conv9_2 incl. the strided-view convs, F(2x2,2x2) on conv8_1 / conv9_1)",
+         dict({n: "wino2d" for n in E + ["conv2_1", "conv3_1", "conv4_1"] if n not in ("conv1_2", "conv10_2")}, conv8_1="wino2d", conv9_1="wino2d")),
         ("wino1d_small (conv1_2, conv2_2, conv9_2, conv10_2)", {n: "wino1d" for n in small}),
         ("wino1d_all_3x3_s1", {n: "wino1d" for n in E}),
     ]
