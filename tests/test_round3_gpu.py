@@ -284,3 +284,24 @@ def test_wrapper_getters_fall_back_when_the_engine_lost_the_map(make_sd):
     with pytest.raises(RuntimeError):
         model.get_result_window(np.full((300, 300), 50.0))
     model.net.close()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_winograd_odd_trunk_geometry(make_sd, precision):
+    """40x72 input: the trunk runs at 5x9 pixels (odd in both directions), the dilated layers' parity sub-grids are 3x5 / 2x4 --
+    ragged tiles in every Winograd kernel (conv, strided-view conv, deconv); batch 3 so that image != block boundaries."""
+    sd = make_sd(2, "torch")
+    L, ab, m = workloads.random_batch(3, 72, seed=4)
+    L, ab, m = L[:, :, :40, :], ab[:, :, :40, :], m[:, :, :40, :]
+    L, ab, m = (np.ascontiguousarray(x) for x in (L, ab, m))
+    ref = siggraph_torch.forward(sd, L, ab, m, 0.5)
+    engine.set_option("winograd_deconv", 2)
+    e = engine.HipColorizer(40, 72, max_batch=3, precision=precision)
+    e.load_state_dict(sd)
+    out = e.forward(L, ab, m, 0.5)
+    assert sum(r["kernel"].startswith("conv_wino") for r in e.layer_table()) >= 22
+    d = np.abs(out - ref)
+    assert d.max() <= (1e-3 if precision == "fp32" else 0.6), d.max()
+    for i in range(3):
+        np.testing.assert_array_equal(e.forward(L[i:i + 1], ab[i:i + 1], m[i:i + 1], 0.5)[0], out[i])
+    e.close()
