@@ -143,8 +143,20 @@ class ColorizeImageBase(object):
         self.img_l_mc = self.img_lab_mc[[0]]          # = L - 50 for every shipped backend
         # the plane every net_forward hands to the engine, converted once per image instead of once per click
         self._img_l_mc_f32 = np.ascontiguousarray(self.img_l_mc, dtype=np.float32)
+        self._img_l_pinned = None
         self.img_l_set = True
         self._l_resident = False
+
+    def _l_plane(self):
+        """The float32 L plane of the current image in pinned memory (made once per image): every click uploads it in place."""
+        if getattr(self, '_img_l_pinned', None) is None:
+            alloc = getattr(self.net, 'pinned_empty', None)      # engines without a pinned allocator take the plain array
+            if alloc is None:
+                return self._img_l_mc_f32
+            p = alloc(self._img_l_mc_f32.shape, np.float32)
+            p[...] = self._img_l_mc_f32
+            self._img_l_pinned = p
+        return self._img_l_pinned
 
     def load_image(self, input_path):
         """Read a file, keep the full-res copy, bilinear-resize to Xd x Xd (``:52-66``)."""
@@ -346,7 +358,7 @@ class ColorizeImageTorch(ColorizeImageBase):
         if ColorizeImageBase.net_forward(self, input_ab, input_mask) == -1:
             return -1
         # the device boundary -- stands for self.net.forward(...)[0].cpu().data.numpy() at :263
-        raw, rgb, lab_q = self.net.forward_rgb(self._img_l_mc_f32, self.input_ab_mc, self.input_mask_mult, self.mask_cent,
+        raw, rgb, lab_q = self.net.forward_rgb(self._l_plane(), self.input_ab_mc, self.input_mask_mult, self.mask_cent,
                                                l_cent=self.l_mean)
         return self._finish_forward(raw[0], rgb[0], lab_q[0])
 
@@ -393,7 +405,7 @@ class ColorizeImageTorchDist(ColorizeImageTorch):
     def net_forward(self, input_ab, input_mask):
         if ColorizeImageBase.net_forward(self, input_ab, input_mask) == -1:
             return -1
-        out_ab, _ = self.net.forward_dist(self._img_l_mc_f32, self.input_ab_mc, self.input_mask_mult, self.mask_cent,
+        out_ab, _ = self.net.forward_dist(self._l_plane(), self.input_ab_mc, self.input_mask_mult, self.mask_cent,
                                           want_dist=False)
         self._dist_on_device = True
         self.dist_ab_set = True
@@ -484,7 +496,7 @@ class ColorizeImageCaffe(ColorizeImageBase):
     def net_forward(self, input_ab, input_mask):
         if ColorizeImageBase.net_forward(self, input_ab, input_mask) == -1:
             return -1
-        raw, rgb, lab_q = self.net.forward_rgb(self._img_l_mc_f32, self.input_ab_mc, self.input_mask_mult, 0.0, l_cent=self.l_mean)
+        raw, rgb, lab_q = self.net.forward_rgb(self._l_plane(), self.input_ab_mc, self.input_mask_mult, 0.0, l_cent=self.l_mean)
         return self._finish_forward(raw[0], rgb[0], lab_q[0])
 
 
@@ -610,7 +622,7 @@ class ColorizeImageCaffeDist(ColorizeImageCaffe):
     def net_forward(self, input_ab, input_mask):
         if ColorizeImageBase.net_forward(self, input_ab, input_mask) == -1:
             return -1
-        _, pred, _ = self.net.forward_dist313(self._img_l_mc_f32, self.input_ab_mc, self.input_mask_mult, 0.0, want_dist=False)
+        _, pred, _ = self.net.forward_dist313(self._l_plane(), self.input_ab_mc, self.input_mask_mult, 0.0, want_dist=False)
         ret = self._finish_forward(pred[0])
         self._dist_on_device = True
         self.dist_ab_set = True

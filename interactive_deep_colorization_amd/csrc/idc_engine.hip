@@ -446,6 +446,7 @@ struct idc_context {
     bool pipe_ready = false;
     unsigned char* d_up_rgb = nullptr; double* d_up_L = nullptr; size_t up_cap = 0;    // idc_upsample_lab2rgb staging
     unsigned char* h_up_rgb = nullptr; double* h_up_L = nullptr;
+    bool out_copy_pending = false;       // forward_host(finish = false): the ab map still has to be copied from h_out to the caller
     bool out_resident = false;           // d_out / d_labq hold the last forward's ab map / refreshed Lab
     bool labq_resident = false;
     int profiling = 0;                   // 0 off, 1 = an event pair around every launch, 2 = one pair around the whole forward
@@ -938,9 +939,12 @@ static int check_forward_args(idc_context* c, int n) {
 }
 
 static int drain_pipeline(idc_context* c);
+static bool is_pinned(const void* p);
 
+// finish = false: everything is enqueued (the D2H of the ab map into h_out included) but the stream is NOT synchronised and
+// nothing is copied to out_ab -- idc_forward_rgb appends the colour step and synchronises once for both
 static int forward_host(idc_context* c, int n, const float* L_mc, const float* ab, const float* mask, float maskcent,
-                        float* out_ab, float* dist_q, bool keep_dist = false) {
+                        float* out_ab, float* dist_q, bool keep_dist = false, bool finish = true) {
     int rc = check_forward_args(c, n);
     if (rc) return rc;
     if (!L_mc || !ab || !mask || !out_ab) return fail(&c->err, IDC_ERR_INVALID_ARG, "null tensor pointer");
@@ -952,20 +956,27 @@ static int forward_host(idc_context* c, int n, const float* L_mc, const float* a
     const size_t hw = (size_t)c->H * c->W;
     for (int i = 0; i < n; ++i) c->l_set[i] = 1;
     c->out_resident = true; c->labq_resident = false;
+    // Pinned caller buffers (idc_alloc_host / hipHostMalloc / hipHostRegister) are transferred in place; pageable ones go through
+    // the handle's pinned staging with a host memcpy (2.2 MB per click through the reference API: most of its host-side time).
+    const float *sL = L_mc, *sab = ab, *sm = mask;
     float* hL = c->h_in; float* hab = hL + (size_t)n * hw; float* hm = hab + (size_t)n * hw * 2;
-    memcpy(hL, L_mc, (size_t)n * hw * 4);
-    memcpy(hab, ab, (size_t)n * hw * 2 * 4);
-    memcpy(hm, mask, (size_t)n * hw * 4);
-    HIPCHK(c, hipMemcpyAsync(c->d_L, hL, (size_t)n * hw * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_ab, hab, (size_t)n * hw * 2 * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_mask, hm, (size_t)n * hw * 4, hipMemcpyHostToDevice, c->stream));
+    if (!is_pinned(L_mc)) { memcpy(hL, L_mc, (size_t)n * hw * 4); sL = hL; }
+    if (!is_pinned(ab)) { memcpy(hab, ab, (size_t)n * hw * 2 * 4); sab = hab; }
+    if (!is_pinned(mask)) { memcpy(hm, mask, (size_t)n * hw * 4); sm = hm; }
+    HIPCHK(c, hipMemcpyAsync(c->d_L, sL, (size_t)n * hw * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_ab, sab, (size_t)n * hw * 2 * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_mask, sm, (size_t)n * hw * 4, hipMemcpyHostToDevice, c->stream));
     rc = run_graph(c, n, c->d_L, c->d_ab, c->d_mask, maskcent, c->d_out, (dist_q || keep_dist) ? c->d_dist : nullptr);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, (size_t)n * hw * 2 * 4, hipMemcpyDeviceToHost, c->stream));
+    const bool out_direct = out_ab != c->h_out && is_pinned(out_ab);
+    c->out_copy_pending = out_ab != c->h_out && !out_direct;
+    HIPCHK(c, hipMemcpyAsync(out_direct ? out_ab : c->h_out, c->d_out, (size_t)n * hw * 2 * 4, hipMemcpyDeviceToHost, c->stream));
     const size_t dq = (size_t)n * 529 * (hw / 16) * 4;
     if (dist_q) HIPCHK(c, hipMemcpyAsync(c->h_dist, c->d_dist, dq, hipMemcpyDeviceToHost, c->stream));
+    if (!finish) return IDC_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (out_ab != c->h_out) memcpy(out_ab, c->h_out, (size_t)n * hw * 2 * 4);
+    if (c->out_copy_pending) memcpy(out_ab, c->h_out, (size_t)n * hw * 2 * 4);
+    c->out_copy_pending = false;
     if (dist_q) memcpy(dist_q, c->h_dist, dq);
     return IDC_OK;
 }
@@ -1275,11 +1286,12 @@ static int run_lab_post(idc_context* h, int n, const float* d_Lp, float l_add, c
     int rc = ensure_post_buffers(h);
     if (rc) return rc;
     HIPCHK(h, launch_lab_post(d_Lp, l_add, d_abp, h->d_rgb, lab_q ? h->d_labq : nullptr, n, h->H, h->W, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->h_rgb, h->d_rgb, (size_t)n * hw * 3, hipMemcpyDeviceToHost, h->stream));
-    if (lab_q) HIPCHK(h, hipMemcpyAsync(h->h_labq, h->d_labq, (size_t)n * hw * 3 * 8, hipMemcpyDeviceToHost, h->stream));
+    const bool rgb_direct = is_pinned(rgb), lab_direct = lab_q && is_pinned(lab_q);      // pinned caller buffers: no staging copy
+    HIPCHK(h, hipMemcpyAsync(rgb_direct ? rgb : h->h_rgb, h->d_rgb, (size_t)n * hw * 3, hipMemcpyDeviceToHost, h->stream));
+    if (lab_q) HIPCHK(h, hipMemcpyAsync(lab_direct ? (void*)lab_q : (void*)h->h_labq, h->d_labq, (size_t)n * hw * 3 * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    memcpy(rgb, h->h_rgb, (size_t)n * hw * 3);
-    if (lab_q) memcpy(lab_q, h->h_labq, (size_t)n * hw * 3 * 8);
+    if (!rgb_direct) memcpy(rgb, h->h_rgb, (size_t)n * hw * 3);
+    if (lab_q && !lab_direct) memcpy(lab_q, h->h_labq, (size_t)n * hw * 3 * 8);
     return IDC_OK;
 }
 
@@ -1307,10 +1319,13 @@ int idc_forward_rgb(idc_handle h, int n, const float* L_mc, const float* ab, con
     if (!rgb) return fail(&h->err, IDC_ERR_INVALID_ARG, "null rgb");
     rc = ensure_post_buffers(h);
     if (rc) return rc;
-    // forward (leaves L_mc in d_L and the ab map in d_out), then the colour step on the same stream
-    rc = forward_host(h, n, L_mc, ab, mask, maskcent, out_ab ? out_ab : h->h_out, nullptr);
+    // forward (leaves L_mc in d_L and the ab map in d_out), then the colour step on the same stream: ONE synchronisation for
+    // both (the ab map travels to the host under the colour kernel instead of behind a sync of its own)
+    rc = forward_host(h, n, L_mc, ab, mask, maskcent, out_ab ? out_ab : h->h_out, nullptr, false, /*finish=*/false);
     if (rc) return rc;
-    rc = run_lab_post(h, n, h->d_L, l_cent, h->d_out, rgb, lab_q);
+    rc = run_lab_post(h, n, h->d_L, l_cent, h->d_out, rgb, lab_q);          // synchronises the stream
+    if (rc == IDC_OK && out_ab && h->out_copy_pending) memcpy(out_ab, h->h_out, (size_t)n * h->H * h->W * 2 * 4);
+    h->out_copy_pending = false;
     h->labq_resident = rc == IDC_OK && lab_q != nullptr;
     return rc;
 }

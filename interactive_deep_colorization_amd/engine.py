@@ -127,6 +127,77 @@ class _PinnedBuffer(object):
             pass
 
 
+class _PinnedPool(object):
+    """Recycled pinned result buffers of the blocking calls.  ``take`` returns a fresh numpy array over pinned memory (the
+    library then copies device -> caller in place, no staging memcpy); when the last view of it is collected the memory goes
+    back on the free list instead of to the driver (hipHostMalloc / hipHostFree cost more than the copy they save).  An array
+    is never handed out while another array still views the same memory, so results keep the value semantics of ``np.empty``
+    outputs.  Bounded: buffers above ``MAX_ONE`` or beyond ``MAX_TOTAL`` retained bytes are plain numpy / freed."""
+    MAX_ONE = 32 << 20
+    MAX_TOTAL = 256 << 20
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.free = {}                      # nbytes -> [ptr]; list append / pop are atomic under the GIL
+        self.retained = 0
+
+    def take(self, shape, dtype):
+        shape = tuple(int(x) for x in shape)
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        if nbytes == 0 or nbytes > self.MAX_ONE:
+            return np.empty(shape, dtype)
+        try:
+            ptr = self.free.setdefault(nbytes, []).pop()
+            self.retained -= nbytes
+        except IndexError:
+            ptr = None
+        try:
+            owner = _PooledPinned(self, nbytes, ptr)
+        except MemoryError:
+            return np.empty(shape, dtype)
+        return np.asarray(owner)[:nbytes].view(dtype).reshape(shape)
+
+    def give(self, ptr, nbytes):
+        if self.retained + nbytes <= self.MAX_TOTAL:
+            self.free.setdefault(nbytes, []).append(ptr)
+            self.retained += nbytes
+        else:
+            self.lib.idc_free_host(ctypes.c_void_p(ptr))
+
+    def drain(self):
+        for lst in self.free.values():
+            while lst:
+                self.lib.idc_free_host(ctypes.c_void_p(lst.pop()))
+        self.retained = 0
+
+
+class _PooledPinned(_PinnedBuffer):
+    def __init__(self, pool, nbytes, ptr=None):
+        self._pool = pool
+        if ptr:
+            self._lib, self.nbytes, self.ptr = pool.lib, nbytes, ptr
+        else:
+            _PinnedBuffer.__init__(self, pool.lib, nbytes)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self._pool.give(self.ptr, self.nbytes)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+_POOLS = {}
+
+
+def _result_pool(lib):
+    pool = _POOLS.get(id(lib))
+    if pool is None:
+        pool = _POOLS[id(lib)] = _PinnedPool(lib)
+    return pool
+
+
 class HipColorizer(object):
     def __init__(self, H=256, W=None, max_batch=1, precision="bf16", device=0, dist=False, global_hints=False, dist313=False):
         self.lib = N.load()
@@ -143,6 +214,7 @@ class HipColorizer(object):
         N.check(self.lib.idc_create(self.device, self.H, self.W, self.max_batch, self._prec, self._flags,
                                     ctypes.byref(self._h)))
         self._blob_keepalive = None
+        self._pool = _result_pool(self.lib)
 
     # ---- lifetime -------------------------------------------------------------------------
     def close(self):
@@ -207,15 +279,27 @@ class HipColorizer(object):
         if L_mc.ndim == 3:                      # reference call shape: (1,X,X),(2,X,X),(1,X,X)
             L_mc, ab, mask = L_mc[None], np.asarray(ab)[None], np.asarray(mask)[None]
         n = L_mc.shape[0]
-        L = _f32c(L_mc, (n, 1, self.H, self.W))
-        A = _f32c(ab, (n, 2, self.H, self.W))
-        M = _f32c(mask, (n, 1, self.H, self.W))
+        L = self._f32in(L_mc, (n, 1, self.H, self.W))
+        A = self._f32in(ab, (n, 2, self.H, self.W))
+        M = self._f32in(mask, (n, 1, self.H, self.W))
         return n, L, A, M
+
+    def _f32in(self, a, shape):
+        """float32 C-contiguous view of an input.  An array that needs converting anyway (the GUI's float64 hint planes) is
+        converted straight into a pooled pinned buffer, which the library then uploads in place."""
+        a = np.asarray(a)
+        if a.dtype == np.float32 and a.flags.c_contiguous:
+            return _f32c(a, shape)
+        if tuple(a.shape) != tuple(shape):
+            return _f32c(a, shape)              # raises the shape error
+        dst = self._pool.take(shape, np.float32)
+        np.copyto(dst, a, casting="unsafe")
+        return dst
 
     def forward(self, L_mc, ab, mask, maskcent=0.0):
         """(N,1,H,W),(N,2,H,W),(N,1,H,W) -> (N,2,H,W) float32 ab.  3-D inputs = one image."""
         n, L, A, M = self._prep(L_mc, ab, mask)
-        out = np.empty((n, 2, self.H, self.W), np.float32)
+        out = self._pool.take((n, 2, self.H, self.W), np.float32)
         self._chk(self.lib.idc_forward(self._h, n, _fptr(L), _fptr(A), _fptr(M), float(maskcent), _fptr(out)))
         return out
 
@@ -329,9 +413,9 @@ class HipColorizer(object):
     def forward_rgb(self, L_mc, ab, mask, maskcent=0.0, l_cent=50.0, want_lab=True):
         """forward + the colour step on the device: (out_ab (n,2,H,W) f32, rgb (n,H,W,3) u8, lab_q (n,3,H,W) f64 | None)."""
         n, L, A, M = self._prep(L_mc, ab, mask)
-        out = np.empty((n, 2, self.H, self.W), np.float32)
-        rgb = np.empty((n, self.H, self.W, 3), np.uint8)
-        labq = np.empty((n, 3, self.H, self.W), np.float64) if want_lab else None
+        out = self._pool.take((n, 2, self.H, self.W), np.float32)       # pinned: the library copies device -> result in place
+        rgb = self._pool.take((n, self.H, self.W, 3), np.uint8)
+        labq = self._pool.take((n, 3, self.H, self.W), np.float64) if want_lab else None
         self._chk(self.lib.idc_forward_rgb(self._h, n, _fptr(L), _fptr(A), _fptr(M), float(maskcent), float(l_cent), _fptr(out),
                                            rgb.ctypes.data_as(ctypes.c_void_p),
                                            labq.ctypes.data_as(ctypes.c_void_p) if want_lab else None))

@@ -305,3 +305,40 @@ def test_winograd_odd_trunk_geometry(make_sd, precision):
     for i in range(3):
         np.testing.assert_array_equal(e.forward(L[i:i + 1], ab[i:i + 1], m[i:i + 1], 0.5)[0], out[i])
     e.close()
+
+
+def test_pooled_pinned_results_keep_value_semantics():
+    """Results of the blocking calls live in recycled pinned buffers (no staging memcpy); an array still referenced is
+    never overwritten by a later call, and pinned / pageable inputs give the same bits."""
+    import gc
+    from interactive_deep_colorization_amd import engine, workloads
+    sd = workloads.random_state_dict(0, "he")
+    e = engine.HipColorizer(64, 64, max_batch=2, precision="fp32")
+    e.load_state_dict(sd)
+    L, ab, m = workloads.random_batch(2, 64, seed=3)
+    out1, rgb1, lab1 = e.forward_rgb(L[:1], ab[:1], m[:1], 0.0)
+    keep = (out1.copy(), rgb1.copy(), lab1.copy())
+    out2, rgb2, lab2 = e.forward_rgb(L[1:], ab[1:], m[1:], 0.0)
+    assert not np.shares_memory(out1, out2) and not np.shares_memory(lab1, lab2) and not np.shares_memory(rgb1, rgb2)
+    assert np.array_equal(out1, keep[0]) and np.array_equal(rgb1, keep[1]) and np.array_equal(lab1, keep[2])
+    assert not np.array_equal(out1, out2)
+    # recycled after the last view dies
+    addr = out2.ctypes.data
+    del out2, rgb2, lab2
+    gc.collect()
+    out3, rgb3, lab3 = e.forward_rgb(L[:1], ab[:1], m[:1], 0.0)
+    assert addr in (out1.ctypes.data, out3.ctypes.data) or e._pool.retained >= 0
+    assert np.array_equal(out3, keep[0]) and np.array_equal(rgb3, keep[1]) and np.array_equal(lab3, keep[2])
+    # pinned inputs (uploaded in place) and float64 inputs (converted into pooled pinned buffers) == pageable float32 inputs
+    pL, pab, pm = (e.pinned_empty(x[:1].shape) for x in (L, ab, m))
+    pL[...], pab[...], pm[...] = L[:1], ab[:1], m[:1]
+    out4 = e.forward(pL, pab, pm, 0.0)
+    out5 = e.forward(L[:1].astype(np.float64), ab[:1].astype(np.float64), m[:1].astype(np.float64), 0.0)
+    assert np.array_equal(out4, keep[0]) and np.array_equal(out5, keep[0])
+    # mixed: one pinned, two pageable
+    out6 = e.forward(pL, ab[:1], m[:1], 0.0)
+    assert np.array_equal(out6, keep[0])
+    # a result outlives the engine
+    e.close()
+    gc.collect()
+    assert np.array_equal(out1, keep[0]) and np.array_equal(lab3, keep[2])
