@@ -120,7 +120,8 @@ const void* idc_weights_device_ptr(idc_handle h);
  * L_mc [n,1,H,W] = L-50; ab [n,2,H,W] raw Lab ab hints (0 where none); mask [n,1,H,W] in {0,1};
  * maskcent = the mask_cent argument (0 or .5, colorize_image.py:210,263).
  * out_ab [n,2,H,W] = 110*tanh(.) -- the tensor the reference returns at colorize_image.py:263.
- * Host-pointer form: blocking; returns when out_ab is valid.                                    */
+ * Host-pointer form: blocking; returns when out_ab is valid.  Each pointer that is pinned host memory (idc_alloc_host,
+ * hipHostMalloc, hipHostRegister) is transferred in place; pageable ones go through the handle's pinned staging.      */
 int idc_forward(idc_handle h, int n, const float* L_mc, const float* ab, const float* mask,
                 float maskcent, float* out_ab);
 /* Device-pointer form (same layouts, device memory); enqueued on the handle's stream (see STREAM ORDERING at
