@@ -483,7 +483,9 @@ static int g_splitk_policy = 0;
 static int g_wino = !(getenv("IDC_WINO") && atoi(getenv("IDC_WINO")) == 0);   // fp32 3x3 stride-1 layers in Winograd form (idc_set_option "winograd" / env IDC_WINO=0 for A/B)
 static int g_fuse_conv1_small = !(getenv("IDC_FUSE_CONV1_SMALL") && atoi(getenv("IDC_FUSE_CONV1_SMALL")) == 0);   // model1 as one 32x8-tile launch on the bf16 click path
 static int g_wino_deconv = !(getenv("IDC_WINO_DECONV") && atoi(getenv("IDC_WINO_DECONV")) == 0);   // fp32 deconvs as Winograd F(2x2,2x2) (idc_set_option "winograd_deconv")
-static int g_wino_bf16 = !(getenv("IDC_WINO_BF16") && atoi(getenv("IDC_WINO_BF16")) == 0);   // bf16 batch-1 click path: Winograd instead of conv_click + split-K reduction (idc_set_option "winograd_bf16")
+// bf16 batch-1 click path: Winograd instead of conv_click + split-K reduction (idc_set_option "winograd_bf16"); 2 = every eligible
+// bf16 layer at every batch size (measurement only: slower than the direct kernels at N = 32)
+static int g_wino_bf16 = getenv("IDC_WINO_BF16") ? atoi(getenv("IDC_WINO_BF16")) : 1;
 static int g_click = -1;                 // conv_click for small launches: -1 = environment default (on), 0 off, 1 on (idc_set_option "click")
 // Shortcut fusion (conv_igemm_v2<.,.,1,true>) is correct (parity-tested under tile policy 2) but measured slower
 // than two launches on MI355X (4x re-reads of the skip tensor by the four phase workgroups, VGPR spills around
@@ -592,6 +594,9 @@ static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, i
     // (deconvs: only the small launches of the click path with Cin >= 256 -- the form is transform-bound (one 16-cout block per
     //  workgroup at the 168-register budget of its 12 waves): model10up (4 chunks) 123 us vs 96 us direct at batch 1, and at N = 32
     //  model8up / model9up 1.30 / 1.54 ms vs 1.23 / 1.31 ms direct; "winograd_deconv" = 2 forces it everywhere for the tests)
+    if (precision == IDC_BF16 && g_wino && g_wino_bf16 == 2 && g_tile_policy != 1 && L.blob.w3_off != (size_t)-1 &&
+        L.spec->resid == nullptr && L.spec->kind == kConv3x3)
+        L.wino = true;                               // measurement switch: the click path's Winograd kernel at every batch size
     if (L.wino) { L.v2 = false; L.click = false; a.ksplit = 1; a.kc_per = a.nkc; a.tiles_x = a.tiles_y = 0; return; }
     // large-tile bf16 kernel: 256 couts x (32x8 sites) when the cout groups divide by 4, else
     // 128 couts x (32x16 sites); used when its grid covers at least half of the 256 CUs
@@ -1048,7 +1053,7 @@ int idc_set_option(const char* name, int value) {
     if (strcmp(name, "fuse_conv1_small") == 0) { g_fuse_conv1_small = value != 0; return IDC_OK; }
     if (strcmp(name, "click") == 0) { g_click = value; return IDC_OK; }
     if (strcmp(name, "winograd") == 0) { g_wino = value != 0; return IDC_OK; }
-    if (strcmp(name, "winograd_bf16") == 0) { g_wino_bf16 = value != 0; return IDC_OK; }
+    if (strcmp(name, "winograd_bf16") == 0) { g_wino_bf16 = value; return IDC_OK; }
     if (strcmp(name, "winograd_deconv") == 0) { g_wino_deconv = value; return IDC_OK; }
     if (strcmp(name, "winograd_form") == 0) { set_wino_form(value); return IDC_OK; }     // 0 automatic, 12 / 21 / 22 = <TB,CB> (tests, tuning)
     return fail(nullptr, IDC_ERR_INVALID_ARG, "unknown option '%s'", name);
