@@ -121,3 +121,34 @@ def test_parity_r03_record_is_consistent():
         assert all(d[style][g]["mean_abs"] > 0.4 * base for g in ("encoder_fp32", "trunk_fp32"))
     assert d["he"]["decoder_fp32"]["mean_abs"] > 0.9 * d["he"]["all_bf16"]["mean_abs"]          # he: not the decoder
     assert d["torch"]["decoder_fp32"]["mean_abs"] < 0.5 * d["torch"]["all_bf16"]["mean_abs"]    # torch-init: the decoder
+
+
+def test_result_pool_recycles_only_dead_buffers():
+    """engine._PinnedPool: results of the blocking calls come from recycled pinned buffers.  A buffer goes back on the free
+    list only when no array views it any more; it is never handed out twice at a time; the retained bytes are bounded."""
+    lib = _FakeLib()
+    pool = engine._PinnedPool(lib)
+    a = pool.take((2, 8), np.float32)
+    b = pool.take((2, 8), np.float32)
+    assert a.ctypes.data != b.ctypes.data and len(lib.live) == 2 and pool.retained == 0
+    a[:] = 1.0
+    addr_a = a.ctypes.data
+    view = a[0]                                  # a view keeps the buffer out of the pool
+    del a
+    gc.collect()
+    assert pool.retained == 0 and float(view[0]) == 1.0
+    del view
+    gc.collect()
+    assert pool.retained == 64 and not lib.freed          # recycled, not returned to the driver
+    c = pool.take((16,), np.float32)             # same byte size -> the recycled buffer
+    assert c.ctypes.data == addr_a and pool.retained == 0
+    assert pool.take((0, 4), np.float32).shape == (0, 4)  # empty and oversized requests are plain numpy
+    big = pool.take((engine._PinnedPool.MAX_ONE // 4 + 1,), np.float32)
+    assert len(lib.live) == 2 and big.nbytes > engine._PinnedPool.MAX_ONE
+    # beyond MAX_TOTAL retained bytes a dead buffer is freed instead of kept
+    pool.MAX_TOTAL = 64
+    del b, c
+    gc.collect()
+    assert pool.retained == 64 and len(lib.freed) == 1
+    pool.drain()
+    assert pool.retained == 0 and len(lib.freed) == 2 and not lib.live
