@@ -198,6 +198,13 @@ def _result_pool(lib):
     return pool
 
 
+def trim_pinned_pool():
+    """Return the recycled pinned result buffers nobody views any more to the driver (at most ``_PinnedPool.MAX_TOTAL`` bytes
+    are ever retained; buffers still viewed by a live array are untouched)."""
+    for pool in _POOLS.values():
+        pool.drain()
+
+
 class HipColorizer(object):
     def __init__(self, H=256, W=None, max_batch=1, precision="bf16", device=0, dist=False, global_hints=False, dist313=False):
         self.lib = N.load()
