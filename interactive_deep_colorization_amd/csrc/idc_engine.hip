@@ -386,6 +386,7 @@ struct Layer {
     int halo = 0;
     ConvConfig cfg{2, 2};
     bool v2 = false;                     // bf16 large-tile kernel (layout-2 weights)
+    bool m16 = false;                    // ... its 16x16x32-MFMA build (conv_igemm_v2m, layout-1 weights): set per launch in run_graph
     bool click = false;                  // batch-1 click-path kernel (conv_click: whole K slice by LDS-DMA)
     bool wino = false;                   // fp32 Winograd F(2x2,3x3) kernel (conv_wino_f32, idc_wino.hip)
     bool fused_head = false;             // conv10_2 only: model_out + tanh run in this layer's epilogue
@@ -486,6 +487,8 @@ static int g_wino_deconv = !(getenv("IDC_WINO_DECONV") && atoi(getenv("IDC_WINO_
 // bf16 batch-1 click path: Winograd instead of conv_click + split-K reduction (idc_set_option "winograd_bf16"); 2 = every eligible
 // bf16 layer at every batch size (measurement only: slower than the direct kernels at N = 32)
 static int g_wino_bf16 = getenv("IDC_WINO_BF16") ? atoi(getenv("IDC_WINO_BF16")) : 1;
+// conv_igemm_v2 launches that qualify run as conv_igemm_v2m (16x16x32 MFMA: fewer joules per FLOP at the power cap; idc_set_option "mfma16")
+static int g_mfma16 = getenv("IDC_MFMA16") ? atoi(getenv("IDC_MFMA16")) : 1;
 static int g_click = -1;                 // conv_click for small launches: -1 = environment default (on), 0 off, 1 on (idc_set_option "click")
 // Shortcut fusion (conv_igemm_v2<.,.,1,true>) is correct (parity-tested under tile policy 2) but measured slower
 // than two launches on MI355X (4x re-reads of the skip tensor by the four phase workgroups, VGPR spills around
@@ -892,6 +895,8 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             }
             a.partial = c->d_partial;
         }
+        L.m16 = L.v2 && g_mfma16 && L.fused_short < 0 && L.fused_next < 0 && !L.wino && !L.click && conv_v2m_applies(a);
+        if (L.m16) a.wgt = c->d_blob + L.blob.w_off;            // the layout-1 image (the one conv_igemm / conv_click read)
         tic();
         {
             hipError_t le = hipErrorInvalidConfiguration;
@@ -906,7 +911,8 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             if (L.wino) le = L.spec->kind == kDeconv4x4 ? launch_deconv_wino(c->precision, a, s) : launch_conv_wino(c->precision, a, s);
             if (le == hipErrorInvalidConfiguration)
                 le = L.click ? launch_conv_click(c->precision, L.cfg.wp, L.halo, a, s)
-                   : L.v2 ? launch_conv_v2(L.cfg, L.halo, a, s) : launch_conv(c->precision, L.cfg, L.halo, a, s);
+                   : L.v2 ? (L.m16 ? launch_conv_v2m(L.cfg, L.halo, a, s) : launch_conv_v2(L.cfg, L.halo, a, s))
+                          : launch_conv(c->precision, L.cfg, L.halo, a, s);
             HIPCHK(c, le);
         }
         if (a.ksplit > 1) HIPCHK(c, launch_splitk_epilogue(c->precision, a, s));
@@ -1053,6 +1059,7 @@ int idc_set_option(const char* name, int value) {
     if (strcmp(name, "fuse_conv1_small") == 0) { g_fuse_conv1_small = value != 0; return IDC_OK; }
     if (strcmp(name, "click") == 0) { g_click = value; return IDC_OK; }
     if (strcmp(name, "winograd") == 0) { g_wino = value != 0; return IDC_OK; }
+    if (strcmp(name, "mfma16") == 0) { g_mfma16 = value != 0; return IDC_OK; }
     if (strcmp(name, "winograd_bf16") == 0) { g_wino_bf16 = value; return IDC_OK; }
     if (strcmp(name, "winograd_deconv") == 0) { g_wino_deconv = value; return IDC_OK; }
     if (strcmp(name, "winograd_form") == 0) { set_wino_form(value); return IDC_OK; }     // 0 automatic, 12 / 21 / 22 = <TB,CB> (tests, tuning)
@@ -1842,6 +1849,7 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
             snprintf(out->kernel, sizeof(out->kernel), L.wino ? (L.spec->kind == kDeconv4x4 ? (h->precision == IDC_BF16 ? "conv_wino_deconv_bf16" : "conv_wino_deconv_f32") : h->precision == IDC_BF16 ? "conv_wino_bf16" : "conv_wino_f32") : L.click ? (h->precision == IDC_BF16 ? "conv_click<bf16,%d,%d>" : "conv_click<f32,%d,%d>")
                      : L.v2 ? "conv_igemm_v2<%d,%d>" : (h->precision == IDC_BF16 ? "conv_igemm<bf16,%d,%d>" : "conv_igemm<f32,%d,%d>"),
                      L.cfg.wm, L.cfg.wp);
+            if (L.m16) strncat(out->kernel, "+m16", sizeof(out->kernel) - strlen(out->kernel) - 1);
             if (L.fused_head) strncat(out->kernel, "+head", sizeof(out->kernel) - strlen(out->kernel) - 1);
             if (L.args.ksplit > 1) {
                 char sk[16]; snprintf(sk, sizeof(sk), " splitK%d", L.args.ksplit);
@@ -1980,7 +1988,8 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     else if (L.wino) pack_wino_weights(wimg.data(), precision, spec, L.blob, weight);
     else {
         if (wino_ok) L.blob.w_bytes = (size_t)weight_taps(spec.kind) * L.blob.nkc * L.blob.ncg * kWBlockBytes;
-        pack_layer_weights(wimg.data(), precision, L.v2 ? 2 : 1, spec, L.blob, weight);
+        L.m16 = L.v2 && g_mfma16 && resid == nullptr && spec.act != 2;       // as in the network: conv_igemm_v2m where it applies
+        pack_layer_weights(wimg.data(), precision, (L.v2 && !L.m16) ? 2 : 1, spec, L.blob, weight);
     }
     std::vector<float> hb(cpad, 0.f), hs(cpad, 1.f), ht(cpad, 0.f);
     for (int c = 0; c < spec.cout; ++c) {
@@ -2027,7 +2036,8 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     HIPCHK(nullctx, hipMemset(d_zero.p, 0, 256));
     a.zeros = d_zero.p;
     HIPCHK(nullctx, L.wino ? (wino_dc ? launch_deconv_wino(precision, a, nullptr) : launch_conv_wino(precision, a, nullptr)) : L.click ? launch_conv_click(precision, L.cfg.wp, L.halo, a, nullptr)
-                    : L.v2 ? launch_conv_v2(L.cfg, L.halo, a, nullptr) : launch_conv(precision, L.cfg, L.halo, a, nullptr));
+                    : L.v2 ? (L.m16 ? launch_conv_v2m(L.cfg, L.halo, a, nullptr) : launch_conv_v2(L.cfg, L.halo, a, nullptr))
+                           : launch_conv(precision, L.cfg, L.halo, a, nullptr));
     if (a.ksplit > 1) HIPCHK(nullctx, launch_splitk_epilogue(precision, a, nullptr));
     HIPCHK(nullctx, launch_nhwc_to_nchw(io_bf16, d_yn.p, (float*)d_y.p, n, spec.cout, Ho, Wo, cpad, nullptr));
     HIPCHK(nullctx, hipMemcpy(y, d_y.p, yout * 4, hipMemcpyDeviceToHost));

@@ -73,6 +73,12 @@ hipError_t launch_conv(int precision, ConvConfig cfg, int halo, const ConvArgs& 
 // {4,2} = 256 couts x (32x8 sites), {2,4} = 128 couts x (32x16 sites).  a.wgt must point at the
 // layer's layout-2 weight image (idc_layout.h); tiles_x/tiles_y count 32 x 4*WPX tiles.
 hipError_t launch_conv_v2(ConvConfig cfg, int halo, const ConvArgs& a, hipStream_t s);
+// The same tile from v_mfma_f32_16x16x32_bf16 (idc_v2m.hip: the more energy-efficient MFMA shape on a power-capped chip).  a.wgt must
+// point at the layer's LAYOUT-1 image; bf16-output launches without shortcut sum / per-image shift only (conv_v2m_applies), else
+// hipErrorInvalidConfiguration.
+hipError_t launch_conv_v2m(ConvConfig cfg, int halo, const ConvArgs& a, hipStream_t s);
+bool conv_v2m_applies(const ConvArgs& a);
+hipError_t init_kernels_v2m();
 // ConvTranspose 4x4 s2 + the 3x3 shortcut conv it is summed with, one K loop (conv_ds_fused); a.in2 / wgt2 / nkc2 = the
 // shortcut's input, layout-2 weights and channel chunks, a.bias = the two biases added.  hipErrorInvalidConfiguration if
 // the launch does not qualify.

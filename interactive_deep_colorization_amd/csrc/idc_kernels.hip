@@ -814,6 +814,8 @@ hipError_t init_kernels() {
     if (e != hipSuccess) return e;
     e = init_kernels_wino();
     if (e != hipSuccess) return e;
+    e = init_kernels_v2m();
+    if (e != hipSuccess) return e;
     return init_kernels_v2();
 }
 

@@ -1,6 +1,6 @@
 // MFMA issue-rate microbenchmark for MI355X: what v_mfma_f32_32x32x16_bf16 sustains on this box, by operand data.
 //
-//   mfma_peak [seconds-per-arm] [zeros|ones|random]     (default 10 s, all three arms)
+//   mfma_peak [seconds-per-arm] [zeros|ones|random|all] [32|16]     (default 10 s, all three arms, the 32x32x16 instruction)
 //
 // Arms: operand fill = zeros | constant 1.0 | uniform random [-1,1) bf16 (per lane, per register; the accumulators
 // see a random walk), each held for `seconds` of back-to-back launches of 256 CUs x 8 waves x 8 independent
@@ -47,6 +47,36 @@ __global__ __launch_bounds__(512) void k32(const u32x4* __restrict__ ops, float*
     if (threadIdx.x == 0) { clk[blockIdx.x * 2] = c1 - c0; clk[blockIdx.x * 2 + 1] = w1 - w0; }
 }
 
+// the same loop on v_mfma_f32_16x16x32_bf16 (half the FLOPs per instruction, twice the operand bytes per FLOP): argv[3] = 16
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+template <int NACC>
+__global__ __launch_bounds__(512) void k16(const u32x4* __restrict__ ops, float* out, long long* clk, int iters) {
+    f32x4 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    u32x4 a[2], b[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = ops[t * 6 + i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = ops[t * 6 + 2 + i];
+    const long long c0 = clock64(), w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i & 1]),
+                                                             __builtin_bit_cast(bf16x8, b[i & 3]), acc[i], 0, 0, 0);
+    }
+    const long long c1 = clock64(), w1 = wall_clock64();
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += acc[i][r];
+    out[t] = s;
+    if (threadIdx.x == 0) { clk[blockIdx.x * 2] = c1 - c0; clk[blockIdx.x * 2 + 1] = w1 - w0; }
+}
+
 static unsigned short bf16_of(float f) {
     unsigned u; __builtin_memcpy(&u, &f, 4);
     u += 0x7fffu + ((u >> 16) & 1u);
@@ -55,13 +85,18 @@ static unsigned short bf16_of(float f) {
 
 int main(int argc, char** argv) {
     const double seconds = argc > 1 ? atof(argv[1]) : 10.0;
-    const int only = argc > 2 ? (argv[2][0] == 'z' ? 0 : argv[2][0] == 'o' ? 1 : 2) : -1;
-    const int blocks = 256, threads = 512, iters = 20000;
+    const int only = argc > 2 ? (argv[2][0] == 'z' ? 0 : argv[2][0] == 'o' ? 1 : argv[2][0] == 'a' ? -1 : 2) : -1;
+    const bool v16 = argc > 3 && atoi(argv[3]) == 16;
+    const int blocks = 256, threads = 512, iters = v16 ? 40000 : 20000;
+    auto launch = [&](u32x4* ops, float* out, long long* clk) {
+        if (v16) hipLaunchKernelGGL(k16<8>, dim3(blocks), dim3(threads), 0, 0, ops, out, clk, iters);
+        else hipLaunchKernelGGL(k32<8>, dim3(blocks), dim3(threads), 0, 0, ops, out, clk, iters);
+    };
     const size_t nthr = (size_t)blocks * threads;
     u32x4* d_ops; float* d_out; long long* d_clk;
     hipMalloc(&d_ops, nthr * 6 * sizeof(u32x4)); hipMalloc(&d_out, nthr * 4); hipMalloc(&d_clk, blocks * 16);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const double flop_per_launch = 8.0 * 2 * 32 * 32 * 16 * (double)iters * (threads / 64) * blocks;
+    const double flop_per_launch = 8.0 * 2 * (v16 ? 16 * 16 * 32 : 32 * 32 * 16) * (double)iters * (threads / 64) * blocks;
     const char* names[3] = {"zeros", "constant 1.0", "uniform random [-1,1)"};
     for (int fill = 0; fill < 3; ++fill) {
         if (only >= 0 && fill != only) continue;
@@ -73,21 +108,21 @@ int main(int argc, char** argv) {
             v = fill == 0 ? 0 : fill == 1 ? 0x3f80 : bf16_of(r);
         }
         hipMemcpy(d_ops, h.data(), h.size() * 2, hipMemcpyHostToDevice);
-        hipLaunchKernelGGL(k32<8>, dim3(blocks), dim3(threads), 0, 0, d_ops, d_out, d_clk, iters);
+        launch(d_ops, d_out, d_clk);
         hipDeviceSynchronize();
-        printf("== operands: %s, %.0f s sustained, %d x %d threads, 8 accumulators per wave\n", names[fill], seconds, blocks, threads);
+        printf("== %s, operands: %s, %.0f s sustained, %d x %d threads, 8 accumulators per wave\n", v16 ? "v_mfma_f32_16x16x32_bf16" : "v_mfma_f32_32x32x16_bf16", names[fill], seconds, blocks, threads);
         double elapsed = 0, best = 0, sum_tf = 0; int nwin = 0;
         while (elapsed < seconds) {
             // one ~1 s window of back-to-back launches
             int n = 0; float ms = 0;
             hipEventRecord(e0, 0);
-            do { for (int k = 0; k < 8; ++k) hipLaunchKernelGGL(k32<8>, dim3(blocks), dim3(threads), 0, 0, d_ops, d_out, d_clk, iters);
+            do { for (int k = 0; k < 8; ++k) launch(d_ops, d_out, d_clk);
                  n += 8; hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); } while (ms < 1000.f);
             long long hc[512]; hipMemcpy(hc, d_clk, blocks * 16, hipMemcpyDeviceToHost);
             double cyc = 0, wall = 0; for (int b = 0; b < blocks; ++b) { cyc += hc[2 * b]; wall += hc[2 * b + 1]; }
             const double ghz = cyc / wall * 0.1;                                        // wall_clock64 = 100 MHz
             const double tf = flop_per_launch * n / ms / 1e9;
-            const double interval = ghz * 1e9 * 1024.0 * 32768.0 / (tf * 1e12);          // shader cycles between MFMAs on one SIMD (32 = issue-bound)
+            const double interval = ghz * 1e9 * 1024.0 * (v16 ? 16384.0 : 32768.0) / (tf * 1e12);          // shader cycles between MFMAs on one SIMD (32 = issue-bound)
             printf("  t=%5.1fs  %7.1f TFLOP/s  shader clock %.3f GHz  MFMA issue interval %.1f cycles per SIMD\n", elapsed + ms / 1e3, tf, ghz, interval);
             elapsed += ms / 1e3; sum_tf += tf; ++nwin; if (tf > best) best = tf;
         }
