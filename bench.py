@@ -14,7 +14,7 @@ With N ranks every rank runs its own 32 images (weak scaling, no data-path colle
 weights are packed on rank 0 and broadcast once over RCCL before the timed region.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      : the conv stack (kernels conv_igemm_v2 / conv_ds_fused / conv_igemm / conv1_1_bf16) against the dense bf16 MFMA peak,
+  roofline      : the conv stack (kernels conv_igemm_v2m / conv_igemm_v2 / conv_ds_fused / conv_igemm / conv1_1_bf16) against the dense bf16 MFMA peak,
                   from per-layer HIP events recorded on the engine's stream inside the timed region;
   cpu_baseline  : the torch-CPU oracle (same ATen kernels as the reference's PyTorch backend)
                   timed on this box's host cores on a bounded sample (rank 0, N=1 only);
@@ -282,7 +282,7 @@ def main():
                      "frac": round(achieved_tflops / peak, 4), "traffic": traffic.get("conv_family_bytes_per_forward"),
                      "traffic_source": "profiles/pmc_traffic.json: rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command run by "
                                        "the builder (%s), replayed here -- not measured in this process" % traffic.get("tag", "r01j"),
-                     "kernel": "conv kernel family (conv_igemm_v2 / conv_ds_fused / conv_igemm / conv1_1, %s): the %d conv/deconv launches of one "
+                     "kernel": "conv kernel family (conv_igemm_v2m / conv_igemm_v2 / conv_ds_fused / conv_igemm / conv1_1, %s): the %d conv/deconv launches of one "
                                "forward taken together" % (args.precision, len(conv_rows)),
                      "launches_per_forward": len(conv_rows),
                      "algorithmic_flop_per_forward": conv_flops,
@@ -459,7 +459,7 @@ def _spread(values, steps):
             "note": "`value` is values[0] (the contract's timed region); boxes of the pool differ by up to 7 % on one binary"}
 
 
-def mfma_peak_probe(seconds=3.0):
+def mfma_peak_probe(seconds=2.0):
     """What the matrix pipes of THIS box sustain on full-range random bf16 operands (no memory traffic at all): the
     chip clocks to its power budget, so the nominal 2.5 PFLOP/s (2.4 GHz) is not reachable on real data
     (profiles/r02_mfma_peak.txt: zeros 2484, uniform random 1813 TFLOP/s at 1.78 GHz).  Runs tools/ubench/mfma_peak
@@ -469,18 +469,26 @@ def mfma_peak_probe(seconds=3.0):
     if not os.path.exists(exe):
         return None
     try:
-        out = subprocess.run([exe, str(seconds), "random"], capture_output=True, text=True, timeout=60).stdout
-        tf = ghz = None
-        for line in out.splitlines():
-            if line.strip().startswith("mean"):
-                tf = float(line.split()[1])
-            if "shader clock" in line:
-                ghz = float(line.split("shader clock")[1].split()[0])
-        if tf is None:
+        def one(shape):
+            out = subprocess.run([exe, str(seconds), "random", shape], capture_output=True, text=True, timeout=60).stdout
+            tf = ghz = None
+            for line in out.splitlines():
+                if line.strip().startswith("mean"):
+                    tf = float(line.split()[1])
+                if "shader clock" in line:
+                    ghz = float(line.split("shader clock")[1].split()[0])
+            return tf, ghz
+        tf32, ghz32 = one("32")
+        tf16, ghz16 = one("16")
+        if tf32 is None:
             return None
-        return {"tflops_random_operands": round(tf, 1), "shader_clock_ghz": ghz, "seconds": seconds,
-                "how": "tools/ubench/mfma_peak: 256 CUs x 8 waves x 8 independent v_mfma_f32_32x32x16_bf16 accumulators, uniform "
-                       "random [-1,1) bf16 operands, back-to-back launches; measured in this bench run"}
+        best = max(tf32, tf16 or 0.0)
+        return {"tflops_random_operands": round(best, 1), "tflops_32x32x16": round(tf32, 1),
+                "tflops_16x16x32": round(tf16, 1) if tf16 else None, "shader_clock_ghz": ghz16 if (tf16 or 0) >= tf32 else ghz32,
+                "seconds": seconds,
+                "how": "tools/ubench/mfma_peak: 256 CUs x 8 waves x 8 independent accumulators, uniform random [-1,1) bf16 operands, "
+                       "back-to-back launches, once per MFMA shape (v_mfma_f32_32x32x16_bf16: conv_ds_fused / conv1_block_fused; "
+                       "v_mfma_f32_16x16x32_bf16: conv_igemm_v2m); `tflops_random_operands` is the better of the two; measured in this bench run"}
     except Exception:
         return None
 
