@@ -27,6 +27,8 @@ def _reset_options():
     engine.set_option("winograd_bf16", 1)
     engine.set_option("winograd_deconv", 1)
     engine.set_option("winograd_form", 0)
+    engine.set_option("mfma16", 1)
+    engine.set_tile_policy("auto")
     engine.set_splitk_policy("auto")
 
 
@@ -342,3 +344,35 @@ def test_pooled_pinned_results_keep_value_semantics():
     e.close()
     gc.collect()
     assert np.array_equal(out1, keep[0]) and np.array_equal(lab3, keep[2])
+
+
+# ------------------------------------------------------------------------------------------------ the two MFMA shapes of the throughput tile
+@pytest.mark.parametrize("mfma16", [1, 0])
+@pytest.mark.parametrize("name", ["net64_he_s0_mc05", "net32x48_he_s2"])
+def test_throughput_tile_in_both_mfma_shapes(golden, make_sd, name, mfma16):
+    """conv_igemm_v2m (16x16x32 MFMA, the default where it applies) and conv_igemm_v2 (32x32x16, `mfma16` = 0) compute the same
+    layers: both within the bf16 bound of the reference's golden output and within bf16 rounding of each other."""
+    g = golden(name)
+    style, seed = str(g["weight_style"]), int(g["weight_seed"])
+    n, _, H, W = g["L_mc"].shape
+    sd = make_sd(seed, style)
+    outs = {}
+    for shape in (mfma16, 1 - mfma16):
+        engine.set_tile_policy("large")
+        engine.set_option("mfma16", shape)
+        e = engine.HipColorizer(H, W, max_batch=n, precision="bf16")
+        e.load_state_dict(sd)
+        outs[shape] = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
+        kernels = [r["kernel"] for r in e.layer_table() if r["kernel"].startswith("conv_igemm_v2")]
+        assert kernels, e.layer_table()
+        assert any("+m16" in k for k in kernels) == bool(shape), kernels
+        if shape:                                    # what stays on the 32x32 kernel: launches with a shortcut sum
+            assert all("+m16" in k or "+shortcut" in k for k in kernels), kernels
+        e.close()
+    ref = g["out_ab"]
+    bound = (20.0, 2.0) if style == "he" else (0.6, 0.06)
+    for shape, out in outs.items():
+        d = np.abs(out - ref)
+        assert d.max() <= bound[0] and d.mean() <= bound[1], (shape, d.max(), d.mean())
+    d = np.abs(outs[1] - outs[0])
+    assert d.mean() <= bound[1] / 2, (d.max(), d.mean())
