@@ -63,8 +63,11 @@ int idc_set_tile_policy(int policy);
 /* Process-wide switches for the parity tests (speed only).  "fuse_conv1" (default 1): model1 = conv1_1 + conv1_2 as one
  * launch on the bf16 throughput path -- 0 keeps the two launches apart, so that conv1_1's own output exists and can be
  * read with idc_get_activation.  "click" (default -1 = on unless IDC_CLICK=0): small launches (the batch-1 click path) run
- * conv_click (weight tiles streamed by LDS-DMA, fragments prefetched across steps); 0 keeps them on conv_igemm.  Take effect
- * on the next forward. */
+ * conv_click (weight tiles streamed by LDS-DMA, fragments prefetched across steps); 0 keeps them on conv_igemm.
+ * "mfma16" (default 1): the bf16 throughput tile runs as conv_igemm_v2m (v_mfma_f32_16x16x32_bf16, fewer joules per FLOP at the
+ * power cap) wherever it applies; 0 = conv_igemm_v2 (v_mfma_f32_32x32x16_bf16) everywhere.  "winograd" / "winograd_bf16" /
+ * "winograd_deconv" / "winograd_form" / "fuse_conv1_small": kernel choice on the fp32 path and the batch-1 click path.
+ * Take effect on the next forward; unknown names return IDC_ERR_INVALID_ARG. */
 int idc_set_option(const char* name, int value);
 /* Split-K policy of the small-tile kernels (speed only): 0 automatic (launches too small to fill the chip: the
  * batch-1 click path), 1 never, 2 always (tests).  The slice sums are added in a fixed order: results stay

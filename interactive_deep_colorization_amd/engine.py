@@ -80,7 +80,8 @@ def set_option(name, value):
     """Process-wide switches (``idc_set_option``; speed / kernel choice only): 'fuse_conv1' 0/1, 'fuse_conv1_small' 0/1
     (model1 as one 32x8-tile launch on the bf16 click path), 'click' -1/0/1, 'winograd_deconv' 0/1/2,
     'winograd' 0/1 (3x3 stride-1 layers as Winograd F(2x2,3x3): fp32 at every batch size, bf16 on the batch-1 click path;
-    default on; 0 switches both off), 'winograd_bf16' 0/1 (the bf16 half alone), 'winograd_form' 0/12/21/22."""
+    default on; 0 switches both off), 'winograd_bf16' 0/1 (the bf16 half alone), 'winograd_form' 0/12/21/22, 'mfma16' 0/1 (the bf16
+    throughput tile from the 16x16x32 MFMA -- conv_igemm_v2m, default -- or from the 32x32x16 one)."""
     N.check(N.load().idc_set_option(name.encode(), int(value)))
 
 
