@@ -37,6 +37,7 @@ if REPO not in sys.path:
 
 FLOP_PER_IMAGE_256 = 150.391e9          # 75.1955 GMAC, conv/deconv MACs x 2
 PEAK_BF16_DENSE_TFLOPS = 2500.0         # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+LAYER_PASS_FORWARDS = 20                # per-launch event pass (untimed): forwards recorded, median / min per layer reported
 PEAK_FP32_MFMA_TFLOPS = 157.3
 PER_GPU_BATCH = 32
 H = W = 256
@@ -186,10 +187,13 @@ def main():
     nb = args.batch
 
     # ---- engine + weights (rank 0 packs, RCCL broadcast of the packed blob) --------------------------
-    e = engine.HipColorizer(H, W, max_batch=nb, precision=args.precision, device=local_rank)
+    # bf16 throughput job: the blob without the Winograd images of the batch-1 / fp32 kernels (IDC_FLAG_THROUGHPUT_BLOB) -- the
+    # N = 32 bf16 handle never selects those kernels, and the broadcast then moves 136 MB instead of 260 MB
+    tblob = args.precision == "bf16" and nb >= 8
+    e = engine.HipColorizer(H, W, max_batch=nb, precision=args.precision, device=local_rank, throughput_blob=tblob)
     sc = sharded.ShardedColorizer(e, rank=rank, world_size=world)
     sd = seeded_weights() if rank == 0 else None
-    blob = engine.pack_weights(sd, args.precision) if rank == 0 else None
+    blob = engine.pack_weights(sd, args.precision, throughput_blob=tblob) if rank == 0 else None
     sc.broadcast_weights(blob, transport=args.transport)
 
     # ---- synthetic inputs, resident in HBM (each rank owns its own contiguous shard of the job) -----
@@ -222,11 +226,11 @@ def main():
     forward_ms = float(e.layer_times_ms()[0])
     my_elapsed = elapsed
     extra = [timed_region() for _ in range(max(args.repeats, 1) - 1)]     # spread only, never `value`
-    e.set_profiling(True)                       # untimed: per-launch events, 5 forwards
-    for _ in range(5):
+    e.set_profiling(True)                       # untimed: per-launch events, LAYER_PASS_FORWARDS forwards (median per layer)
+    for _ in range(LAYER_PASS_FORWARDS):
         e.forward_device(nb, dL, dab, dm, dout, 0.0, sync=False)
     e.sync()
-    layer_ms = e.layer_times_ms()
+    layer_min, layer_ms, layer_max = e.layer_times_stats()
     e.set_profiling(False)
 
     per_rank = [my_elapsed]
@@ -276,7 +280,9 @@ def main():
                                "hint masks per GPU, %s MFMA conv path, Local-Hints SIGGRAPHGenerator forward "
                                "(dist=False), seeded random-init weights" % (nb, args.precision),
                    "global_batch": world * nb, "per_gpu_batch": nb, "height": H, "width": W,
-                   "parallelism": "independent images sharded over %d GPU(s); one RCCL weight broadcast (transport: %s)" % (world, args.transport),
+                   "parallelism": "independent images sharded over %d GPU(s); one RCCL weight broadcast (transport: %s%s)" % (
+                       world, sc.transport_used or args.transport, ", c_abi fell back: " + sc.transport_fallback_reason if sc.transport_fallback_reason else ""),
+                   "weights_blob_bytes": int(e.blob_bytes()),
                    "weights_broadcast_ms": sc.weights_broadcast_ms},
         "roofline": {"bound": "mfma", "achieved": round(achieved_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved_tflops / peak, 4), "traffic": traffic.get("conv_family_bytes_per_forward"),
@@ -298,7 +304,16 @@ def main():
         "scaling_note": "no hardware scaling curve exists from the builder (1-GPU boxes only): per-N values are whatever the "
                         "driver's 8-GPU run of this command measures; the path has no data-path collective",
         "layers_ms": {r["name"]: round(float(layer_ms[r["index"]]), 4) for r in table},
-        "layers_ms_note": "separate untimed pass of 5 forwards with an event pair around every launch (these pairs cost ~4 %)",
+        "layers_ms_min": {r["name"]: round(float(layer_min[r["index"]]), 4) for r in table if r["launches"] > 0},
+        # same-shape layers that differ (conv5_1 / conv3_2 on the driver's boxes): median vs min over the
+        # pass says whether a layer is slow on every forward or was slow on a few of them
+        "layers_unsteady": {r["name"]: {"min": round(float(layer_min[r["index"]]), 4), "median": round(float(layer_ms[r["index"]]), 4),
+                                         "max": round(float(layer_max[r["index"]]), 4)}
+                            for r in table if r["launches"] > 0 and layer_min[r["index"]] > 0.02
+                            and layer_max[r["index"]] > 1.10 * layer_min[r["index"]]},
+        "layers_ms_note": "separate untimed pass of %d forwards with an event pair around every launch (these pairs cost ~4 %%): "
+                          "`layers_ms` is the per-layer MEDIAN, `layers_ms_min` the minimum, `layers_unsteady` lists launches whose "
+                          "max exceeds their min by more than 10 %%" % LAYER_PASS_FORWARDS,
     }
     if world == 1 and not args.no_end_to_end:
         result["end_to_end"] = measure_end_to_end(e, nb, args.steps, args.warmup, value)
@@ -413,8 +428,17 @@ def measure_end_to_end(e, nb, steps, warmup, device_resident_value):
             "period_ms": round(float(tl[3] - tp[3]), 3),
             "h2d_of_k_under_compute_of_k_minus_1_ms": round(max(0.0, float(min(tl[1], tp[3]) - max(tl[0], tp[2]))), 3),
             "d2h_of_k_minus_1_under_compute_of_k_ms": round(max(0.0, float(min(tp[5], tl[3]) - max(tp[4], tl[2]))), 3),
-            "note": "compute_ms well above the device-resident ms_per_step = the copies slowed the kernels they ran beside; "
-                    "period_ms ~ h2d + compute + d2h = the box ran the stages one after the other"}
+            "legend": "compute_ms well above the device-resident ms_per_step would mean the copies slowed the kernels they ran "
+                      "beside; period_ms ~ h2d + compute + d2h would mean the box ran the stages one after the other"}
+        st = res["stages_ms"]
+        serial = st["h2d_ms"] + st["compute_ms"] + st["d2h_ms"]
+        dev_ms = nb / device_resident_value * 1e3
+        st["diagnosis"] = ("stages serialised (period %.2f ms ~ h2d + compute + d2h %.2f ms)" % (st["period_ms"], serial)
+                           if st["period_ms"] > 0.95 * serial else
+                           "copies slowed the kernels (compute %.2f ms vs %.2f ms device-resident)" % (st["compute_ms"], dev_ms)
+                           if st["compute_ms"] > 1.05 * dev_ms else
+                           "copies ran under the other slot's kernels (period %.2f ms, compute %.2f ms, device-resident %.2f ms)"
+                           % (st["period_ms"], st["compute_ms"], dev_ms))
     except Exception as ex:
         res["stages_ms"] = {"error": str(ex)[:200]}
     ref_out = np.array(bufs[(steps - 1) & 1][3], copy=True)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define IDC_VERSION 1
+#define IDC_VERSION 2   /* 2: blob header flags may carry IDC_FLAG_THROUGHPUT_BLOB; round-3 blobs (Winograd images added without a bump) were 1 */
 
 typedef struct idc_context* idc_handle;
 
@@ -52,6 +52,12 @@ typedef enum idc_precision { IDC_FP32 = 0, IDC_BF16 = 1 } idc_precision;
                                       models/reference_model/deploy_nopred.prototxt:650-850 (needs the pred.* tensors, see idc_forward_dist313) */
 #define IDC_FLAG_GLOBAL_HINTS 0x4u /* also build the Global-Hints branch of models/global_model/deploy_nodist.prototxt:37-172,
                                       501-518 (needs the glob.* tensors, see idc_set_global_hints) */
+#define IDC_FLAG_THROUGHPUT_BLOB 0x10u /* weight blob WITHOUT the Winograd images (U = G g G^T of the 3x3 layers and the deconvs): those
+                                        * serve the batch-1 click path (bf16) and the fp32 path; a bf16 throughput handle (large batches)
+                                        * never reads them, and they are half of the blob -- 136 MB instead of 260 MB to pack, upload and
+                                        * broadcast (sharded.py / bench.py use it for the N = 32 bf16 job).  With the flag those kernel
+                                        * variants are simply not selected (direct kernels run instead: same results within tolerance, slower
+                                        * at batch 1 and in fp32). */
 
 /* ---- library ------------------------------------------------------------------------------- */
 int idc_version(void);
@@ -312,6 +318,9 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out);
  * the other entries 0) -- the per-launch pairs of mode 1 slow a batch-32 forward by about 4 %. */
 int idc_set_profiling(idc_handle h, int on);
 int idc_layer_times_ms(idc_handle h, float* ms, int capacity);
+/* The same recorded forwards as per-layer min / median / max (ms) instead of the mean: tells a layer that is slow on every forward
+ * from one that was slow once (first launch of a kernel variant, a clock step) -- bench.py's `layers_ms` is the median of 20. */
+int idc_layer_times_stats(idc_handle h, float* ms_min, float* ms_median, float* ms_max, int capacity);
 /* Copy an intermediate activation of the LAST forward to the host as NCHW fp32.
  * name = idc_layer_info.name; out must hold n*C*H*W floats; *C,*H,*W are returned.            */
 int idc_get_activation(idc_handle h, const char* name, int n, float* out, size_t capacity_floats,

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libideepcolor_hip.so")
 
 IDC_FP32, IDC_BF16 = 0, 1
-IDC_FLAG_DIST_HEAD, IDC_FLAG_GLOBAL_HINTS, IDC_FLAG_DIST313 = 0x1, 0x4, 0x8
+IDC_FLAG_DIST_HEAD, IDC_FLAG_GLOBAL_HINTS, IDC_FLAG_DIST313, IDC_FLAG_THROUGHPUT_BLOB = 0x1, 0x4, 0x8, 0x10
 IDC_OK = 0
 STATUS_NAMES = {0: "IDC_OK", -1: "IDC_ERR_INVALID_ARG", -2: "IDC_ERR_NO_DEVICE", -3: "IDC_ERR_HIP",
                 -4: "IDC_ERR_NO_WEIGHTS", -5: "IDC_ERR_MISSING_KEY", -6: "IDC_ERR_BATCH",
@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     "idc_weights_blob_bytes", "idc_pack_weights", "idc_set_weights_host", "idc_set_weights_device",
     "idc_load_weights", "idc_weights_device_ptr", "idc_forward", "idc_forward_device", "idc_forward_dist",
     "idc_lab2rgb", "idc_forward_rgb", "idc_global_histogram", "idc_forward_dist313", "idc_set_dist_temperature", "idc_set_global_hints", "idc_clear_global_hints", "idc_sync", "idc_stream", "idc_num_layers", "idc_layer_info_get", "idc_set_profiling",
-    "idc_layer_times_ms", "idc_get_activation", "idc_op_conv2d", "idc_op_deconv4x4s2",
+    "idc_layer_times_ms", "idc_layer_times_stats", "idc_get_activation", "idc_op_conv2d", "idc_op_deconv4x4s2",
     "idc_set_image_l", "idc_set_hints", "idc_get_hint_planes", "idc_forward_resident",
     "idc_dist_bins", "idc_keep_dist", "idc_dist_at", "idc_get_dist", "idc_suggest_colors",
     "idc_stream_wait", "idc_stream_signal", "idc_alloc_host", "idc_free_host", "idc_forward_async", "idc_wait", "idc_pipeline_times",
@@ -111,6 +111,7 @@ def load():
     proto("idc_layer_info_get", ci, [vp, ci, ctypes.POINTER(LayerInfo)])
     proto("idc_set_profiling", ci, [vp, ci])
     proto("idc_layer_times_ms", ci, [vp, c_float_p, ci])
+    proto("idc_layer_times_stats", ci, [vp, c_float_p, c_float_p, c_float_p, ci])
     proto("idc_get_activation", ci, [vp, ctypes.c_char_p, ci, c_float_p, csz,
                                      ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci)])
     proto("idc_op_conv2d", ci, [ci, ci, ci, ci, ci, ci, c_float_p, ci, ci, ci, ci, c_float_p, c_float_p, ci,

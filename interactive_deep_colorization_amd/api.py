@@ -33,6 +33,12 @@ from .workloads import put_point  # noqa: F401  notebook helper (DemoInteractive
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
+# every public name of the reference's data/colorize_image.py (:10-36 helpers, :39-558 classes) + the notebook helper:
+# `from interactive_deep_colorization_amd.api import *` and the `colorize_image` shim export exactly these
+__all__ = ['create_temp_directory', 'lab2rgb_transpose', 'rgb2lab_transpose', 'put_point', 'read_state_dict',
+           'ColorizeImageBase', 'ColorizeImageTorch', 'ColorizeImageTorchDist', 'ColorizeImageCaffe',
+           'ColorizeImageCaffeGlobDist', 'ColorizeImageCaffeDist']
+
 
 def create_temp_directory(path_template, N=1e8):
     """Make a fresh ``path_template % random_int`` directory (reference helper, ``:10-17``)."""

@@ -13,6 +13,7 @@
 
 #include <map>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/ideepcolor.h"
@@ -29,7 +30,8 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 BlobPlan make_blob_plan(int precision, unsigned flags) {
     BlobPlan p;
     p.precision = precision;
-    p.flags = flags & (IDC_FLAG_DIST_HEAD | IDC_FLAG_GLOBAL_HINTS | IDC_FLAG_DIST313);
+    p.flags = flags & (IDC_FLAG_DIST_HEAD | IDC_FLAG_GLOBAL_HINTS | IDC_FLAG_DIST313 | IDC_FLAG_THROUGHPUT_BLOB);
+    const bool wino_images = !(flags & IDC_FLAG_THROUGHPUT_BLOB);
     const auto& specs = layer_specs();
     size_t off = sizeof(BlobHeader);
     const int kc = kc_elems(precision);
@@ -46,11 +48,11 @@ BlobPlan make_blob_plan(int precision, unsigned flags) {
         lb.w2_off = (size_t)-1;
         if (precision == IDC_BF16 && v2_eligible(s)) { off = align_up(off, 256); lb.w2_off = off; off += lb.w_bytes; }
         lb.w3_off = (size_t)-1; lb.w3_bytes = 0;
-        if (wino_eligible(s) && s.cin % kc == 0) {                            // fp32: every batch size; bf16: the batch-1 click path
+        if (wino_images && wino_eligible(s) && s.cin % kc == 0) {                            // fp32: every batch size; bf16: the batch-1 click path
             lb.w3_bytes = (size_t)s.cin * cout_pad(s.cout) * 16 * elem_bytes(precision);   // 16 transformed values per (cin, cout)
             off = align_up(off, 256); lb.w3_off = off; off += lb.w3_bytes;
         }
-        if (wino_deconv_eligible(s) && s.cin % kc == 0) {                      // deconvs: F(2x2,2x2) over the four phases (click path)
+        if (wino_images && wino_deconv_eligible(s) && s.cin % kc == 0) {                      // deconvs: F(2x2,2x2) over the four phases (click path)
             lb.w3_bytes = (size_t)s.cin * cout_pad(s.cout) * 36 * elem_bytes(precision);
             off = align_up(off, 256); lb.w3_off = off; off += lb.w3_bytes;
         }
@@ -1864,7 +1866,8 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
             }
             if (L.fused_short >= 0) {
                 const Layer& P = h->layers[L.fused_short];
-                strncat(out->kernel, "+shortcut", sizeof(out->kernel) - strlen(out->kernel) - 1);
+                // the name rocprofv3 shows for this launch (the deconv and its 3x3 shortcut conv in one K loop)
+                snprintf(out->kernel, sizeof(out->kernel), "conv_ds_fused+shortcut");
                 out->flops += P.flops;
                 out->min_bytes += P.min_bytes - 2.0 * (double)h->tensors[P.dst].H * h->tensors[P.dst].W * h->tensors[P.dst].Cpad * eb;
             }
@@ -1911,6 +1914,29 @@ int idc_layer_times_ms(idc_handle h, float* ms, int capacity) {
             sum += t;
         }
         ms[i] = (float)(sum / slots);
+    }
+    return IDC_OK;
+}
+
+int idc_layer_times_stats(idc_handle h, float* ms_min, float* ms_median, float* ms_max, int capacity) {
+    if (!h || !ms_min || !ms_median || !ms_max) return fail(h ? &h->err : nullptr, IDC_ERR_INVALID_ARG, "null argument");
+    if (h->ev.empty()) return fail(&h->err, IDC_ERR_INVALID_ARG, "no forward was recorded with profiling on");
+    if (capacity < h->n_timed) return fail(&h->err, IDC_ERR_INVALID_ARG, "capacity %d < %d", capacity, h->n_timed);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int slots = (int)(h->prof_count < kProfRing ? h->prof_count : kProfRing);
+    if (slots == 0) return fail(&h->err, IDC_ERR_INVALID_ARG, "no forward was recorded with profiling on");
+    std::vector<float> v((size_t)slots);
+    for (int i = 0; i < h->n_timed; ++i) {
+        if (h->profiling == 2 && i > 0) { ms_min[i] = ms_median[i] = ms_max[i] = 0.f; continue; }
+        for (int sl = 0; sl < slots; ++sl) {
+            float t = 0.f;
+            const size_t base = (size_t)sl * h->n_timed * 2;
+            if (hipEventElapsedTime(&t, h->ev[base + i * 2], h->ev[base + i * 2 + 1]) != hipSuccess) { t = 0.f; (void)hipGetLastError(); }
+            v[(size_t)sl] = t;
+        }
+        std::sort(v.begin(), v.end());
+        ms_min[i] = v.front(); ms_max[i] = v.back();
+        ms_median[i] = (slots & 1) ? v[(size_t)slots / 2] : 0.5f * (v[(size_t)slots / 2 - 1] + v[(size_t)slots / 2]);
     }
     return IDC_OK;
 }

@@ -68,9 +68,9 @@ def set_tile_policy(policy="auto"):
     N.check(N.load().idc_set_tile_policy(TILE_POLICIES[policy] if isinstance(policy, str) else int(policy)))
 
 
-def _flags(dist=False, global_hints=False, dist313=False):
+def _flags(dist=False, global_hints=False, dist313=False, throughput_blob=False):
     return ((N.IDC_FLAG_DIST_HEAD if dist else 0) | (N.IDC_FLAG_GLOBAL_HINTS if global_hints else 0) |
-            (N.IDC_FLAG_DIST313 if dist313 else 0))
+            (N.IDC_FLAG_DIST313 if dist313 else 0) | (N.IDC_FLAG_THROUGHPUT_BLOB if throughput_blob else 0))
 
 
 SPLITK_POLICIES = {"auto": 0, "never": 1, "always": 2}
@@ -90,12 +90,13 @@ def set_splitk_policy(policy="auto"):
     N.check(N.load().idc_set_splitk_policy(SPLITK_POLICIES[policy] if isinstance(policy, str) else int(policy)))
 
 
-def pack_weights(sd, precision="bf16", dist=False, global_hints=False, dist313=False):
+def pack_weights(sd, precision="bf16", dist=False, global_hints=False, dist313=False, throughput_blob=False):
     """Host-only: reference ``state_dict`` -> packed device-ready blob (uint8 ndarray).
-    Needs no GPU (used by rank 0 before the RCCL broadcast)."""
+    Needs no GPU (used by rank 0 before the RCCL broadcast).  ``throughput_blob``: without the Winograd images of the
+    batch-1 / fp32 kernels (IDC_FLAG_THROUGHPUT_BLOB: 136 MB instead of 260 MB in bf16) -- must match the handle's."""
     lib = N.load()
     prec = _PREC[precision]
-    flags = _flags(dist, global_hints, dist313)
+    flags = _flags(dist, global_hints, dist313, throughput_blob)
     nbytes = lib.idc_weights_blob_bytes(prec, flags)
     blob = np.zeros(nbytes, dtype=np.uint8)
     arr, n, keep = _tensor_descs(sd)
@@ -207,7 +208,8 @@ def trim_pinned_pool():
 
 
 class HipColorizer(object):
-    def __init__(self, H=256, W=None, max_batch=1, precision="bf16", device=0, dist=False, global_hints=False, dist313=False):
+    def __init__(self, H=256, W=None, max_batch=1, precision="bf16", device=0, dist=False, global_hints=False, dist313=False,
+                 throughput_blob=False):
         self.lib = N.load()
         self.H, self.W = int(H), int(H if W is None else W)
         self.max_batch = int(max_batch)
@@ -217,7 +219,8 @@ class HipColorizer(object):
         self.device = int(device)
         self.global_hints = bool(global_hints)
         self.dist313 = bool(dist313)
-        self._flags = _flags(dist, global_hints, dist313)
+        self.throughput_blob = bool(throughput_blob)
+        self._flags = _flags(dist, global_hints, dist313, throughput_blob)
         self._h = ctypes.c_void_p()
         N.check(self.lib.idc_create(self.device, self.H, self.W, self.max_batch, self._prec, self._flags,
                                     ctypes.byref(self._h)))
@@ -547,6 +550,13 @@ class HipColorizer(object):
         ms = np.zeros(n, np.float32)
         self._chk(self.lib.idc_layer_times_ms(self._h, _fptr(ms), n))
         return ms
+
+    def layer_times_stats(self):
+        """(min, median, max) per layer over the forwards recorded since profiling was switched on (at most the last 32)."""
+        n = self.lib.idc_num_layers(self._h)
+        lo, med, hi = (np.zeros(n, np.float32) for _ in range(3))
+        self._chk(self.lib.idc_layer_times_stats(self._h, _fptr(lo), _fptr(med), _fptr(hi), n))
+        return lo, med, hi
 
     def activation(self, name, n=1):
         """NCHW fp32 copy of an intermediate tensor of the last forward (parity tests)."""

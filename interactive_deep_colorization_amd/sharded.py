@@ -5,8 +5,9 @@ eval-mode BatchNorm uses fixed statistics (``data/colorize_image.py:232``) and n
 So:
 
 * images are split into contiguous shards, one per rank -- no data-path collective;
-* the ONLY collective is a one-time broadcast of the packed weight blob (68 MB bf16 / 136 MB
-  fp32) from rank 0: RCCL over xGMI when the process group is ``nccl``, ``gloo`` in the CPU tests.
+* the ONLY collective is a one-time broadcast of the packed weight blob from rank 0 (bf16: 136 MB for a throughput
+  handle -- ``throughput_blob=True``, both MFMA layouts of every layer -- or 260 MB with the Winograd images of the
+  batch-1 click path; fp32: 136 / 384 MB; ``engine.blob_bytes()`` is the exact figure): RCCL over xGMI when the process group is ``nccl``, ``gloo`` in the CPU tests.
   Rank 0 packs once on the host; every other rank receives device-ready bytes straight into the
   memory its engine then adopts (no re-packing, no host copy on the receivers);
 * results stay on the rank that produced them unless ``gather_to_rank0`` is asked for.
@@ -61,6 +62,8 @@ class ShardedColorizer(object):
         self.rank = env_rank if rank is None else int(rank)
         self.world_size = env_world if world_size is None else int(world_size)
         self.weights_broadcast_ms = None
+        self.transport_used = None                 # 'torch' | 'c_abi' after broadcast_weights (c_abi falls back to torch, logged)
+        self.transport_fallback_reason = None
 
     # ---- the one collective -------------------------------------------------------------------
     def broadcast_weights(self, packed_blob=None, src=0, transport="torch"):
@@ -83,18 +86,45 @@ class ShardedColorizer(object):
             self.engine.set_weights_blob(packed_blob)
             self.weights_broadcast_ms = 0.0
             return
+        self.transport_used = transport
         if transport == "c_abi":
+            # idc_broadcast_weights has only ever run with one rank on hardware: every way it can fail
+            # without hanging -- librccl not found beside the HIP runtime, communicator init, the broadcast itself -- is agreed on
+            # by ALL ranks through the existing process group and answered by the torch transport below, with the reason logged,
+            # instead of sinking the job.
             if self.rank == src:
                 if packed_blob is None or int(packed_blob.size) != nbytes:
                     raise ValueError("rank %d must provide a %d-byte packed blob" % (src, nbytes))
                 self.engine.set_weights_blob(packed_blob)
-            box = [self.engine.comm_unique_id() if self.rank == src else None]
+            box = [None, None]
+            if self.rank == src:
+                try:
+                    box[0] = self.engine.comm_unique_id()
+                except Exception as ex:
+                    box[1] = "idc_comm_unique_id failed on rank %d: %s" % (src, str(ex)[:200])
             dist.broadcast_object_list(box, src=src)
-            dist.barrier()
-            t0 = time.perf_counter()
-            self.engine.broadcast_weights(box[0], self.rank, self.world_size, src)
-            self.weights_broadcast_ms = (time.perf_counter() - t0) * 1e3
-            return
+            why = box[1]
+            if why is None:
+                dist.barrier()
+                t0 = time.perf_counter()
+                mine = None
+                try:
+                    self.engine.broadcast_weights(box[0], self.rank, self.world_size, src)
+                except Exception as ex:
+                    mine = "idc_broadcast_weights failed on rank %d: %s" % (self.rank, str(ex)[:200])
+                reasons = [None] * self.world_size
+                dist.all_gather_object(reasons, mine)
+                bad = [r for r in reasons if r]
+                if not bad:
+                    self.weights_broadcast_ms = (time.perf_counter() - t0) * 1e3
+                    return
+                why = bad[0]
+            self.transport_used = "torch"
+            self.transport_fallback_reason = why
+            if self.rank == 0:
+                import sys
+                print("sharded.broadcast_weights: transport 'c_abi' unavailable (%s) -- falling back to torch.distributed.broadcast"
+                      % why, file=sys.stderr)
         on_gpu = dist.get_backend() == "nccl"
         gpu_dev = torch.device("cuda", int(getattr(self.engine, "device", 0))) if on_gpu else None
         if self.rank == src:

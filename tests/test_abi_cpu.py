@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(N.EXPORTED_SYMBOLS), declared ^ set(N.EXPORTED_SYMBOLS)
     for sym in declared:
         assert hasattr(lib, sym), "libideepcolor_hip.so does not export %s" % sym
-    assert lib.idc_version() == 1
+    assert lib.idc_version() == 2
 
 
 @pytest.mark.skipif(N.load().idc_device_count() > 0, reason="a GPU is present")

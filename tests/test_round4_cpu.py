@@ -1,0 +1,89 @@
+"""Round-4 CPU tests: the one-line import swap a maintainer of the reference makes, checked name by name and
+signature by signature against the reference's own source."""
+import ast
+import importlib
+import inspect
+import json
+import os
+import re
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SURFACE = os.path.join(REPO, "tests", "golden", "reference_ci_surface.json")
+REF = "/root/reference"
+
+ROUTES = ("interactive_deep_colorization_amd.colorize_image", "interactive_deep_colorization_amd.api")
+
+
+def _surface():
+    with open(SURFACE) as f:
+        return json.load(f)
+
+
+def test_fixture_matches_the_reference_source_when_it_is_present():
+    """tests/golden/reference_ci_surface.json (oracle/make_reference_names.py) is what data/colorize_image.py and its callers
+    say today; the GPU box has no /root/reference, the build container does."""
+    if not os.path.isdir(REF):
+        pytest.skip("no /root/reference here: the committed fixture stands in")
+    s = _surface()
+    tree = ast.parse(open(os.path.join(REF, "data", "colorize_image.py")).read())
+    classes = [n.name for n in tree.body if isinstance(n, ast.ClassDef)]
+    assert sorted(classes) == sorted(s["classes"])
+    used = set()
+    for f in ["ideepcolor.py"] + [x for x in os.listdir(REF) if x.endswith(".ipynb")]:
+        used.update(re.findall(r"\bCI\.([A-Za-z_][A-Za-z0-9_]*)", open(os.path.join(REF, f)).read()))
+    assert sorted(used) == s["names_used_by_callers"]
+    # ideepcolor.py:39 defaults to the caffe backend and :62-66 constructs these two
+    assert "ColorizeImageCaffeDist" in used and "ColorizeImageCaffe" in used
+
+
+@pytest.mark.parametrize("route", ROUTES)
+def test_every_name_the_reference_callers_touch_resolves(route):
+    """`from data import colorize_image as CI` -> `from interactive_deep_colorization_amd import colorize_image as CI` (or `api`):
+    every CI.<name> of ideepcolor.py:62-72 and the notebooks, every class and module-level helper of data/colorize_image.py."""
+    s = _surface()
+    CI = importlib.import_module(route)
+    for name in s["names_used_by_callers"] + list(s["classes"]) + s["functions"]:
+        assert hasattr(CI, name), "%s.%s is missing" % (route, name)
+    for name, spec in s["classes"].items():
+        cls = getattr(CI, name)
+        assert inspect.isclass(cls)
+        for b in spec["bases"]:
+            assert issubclass(cls, getattr(CI, b)), "%s must derive from %s as in the reference" % (name, b)
+
+
+@pytest.mark.parametrize("route", ROUTES)
+def test_reference_signatures_are_a_prefix_of_ours(route):
+    """Every method of every reference class exists here, takes the reference's parameters in the reference's order with the
+    reference's defaults (ideepcolor.py calls prep_net positionally AND by keyword), and anything this package adds
+    (precision=, state_dict=, color_bins_dir=) comes after them with a default."""
+    s = _surface()
+    CI = importlib.import_module(route)
+    for cname, spec in s["classes"].items():
+        cls = getattr(CI, cname)
+        for mname, ref_params in spec["methods"].items():
+            # the reference's private `_set_img_*_` staging helpers are only called from its own set_image / load_image
+            # (no caller outside data/colorize_image.py touches them); here that staging is `_ingest`
+            if mname.startswith("_") and mname != "__init__" and not hasattr(cls, mname):
+                continue
+            assert hasattr(cls, mname), "%s.%s missing" % (cname, mname)
+            ours = list(inspect.signature(getattr(cls, mname)).parameters.values())
+            assert len(ours) >= len(ref_params), "%s.%s takes fewer parameters than the reference" % (cname, mname)
+            for p, (rname, rdefault) in zip(ours, ref_params):
+                assert p.name == rname, "%s.%s: parameter %s where the reference has %s" % (cname, mname, p.name, rname)
+                if rdefault is None:
+                    assert p.default is inspect.Parameter.empty or rname == "self", "%s.%s(%s) must stay required" % (cname, mname, rname)
+                else:
+                    assert p.default is not inspect.Parameter.empty, "%s.%s(%s) lost its default" % (cname, mname, rname)
+                    assert p.default == ast.literal_eval(rdefault), "%s.%s(%s=%r), reference %s" % (cname, mname, rname, p.default, rdefault)
+            for p in ours[len(ref_params):]:
+                assert p.default is not inspect.Parameter.empty, "%s.%s: extra parameter %s needs a default" % (cname, mname, p.name)
+
+
+def test_shim_and_api_export_the_same_objects():
+    a = importlib.import_module(ROUTES[0])
+    b = importlib.import_module(ROUTES[1])
+    assert sorted(a.__all__) == sorted(b.__all__)
+    for name in b.__all__:
+        assert getattr(a, name) is getattr(b, name)
