@@ -37,7 +37,9 @@ typedef enum idc_status {
     IDC_ERR_NO_WEIGHTS = -4,    /* forward before weights (reference: "I need to have a net!", colorize_image.py:88-90) */
     IDC_ERR_MISSING_KEY = -5,   /* a state_dict key of SURVEY.md Appendix B is absent or mis-shaped */
     IDC_ERR_BATCH = -6,         /* n > max_batch or n <= 0 */
-    IDC_ERR_UNSUPPORTED = -7
+    IDC_ERR_UNSUPPORTED = -7,
+    IDC_ERR_INTERNAL = -8       /* a kernel variant was selected for a launch it does not cover: a bug in the library, reported instead of
+                                 * falling back to another kernel with the wrong weight image */
 } idc_status;
 
 /* Arithmetic type of the conv stack.  BF16: bf16 activations+weights, fp32 MFMA accumulation,

@@ -16,7 +16,7 @@ IDC_FLAG_DIST_HEAD, IDC_FLAG_GLOBAL_HINTS, IDC_FLAG_DIST313, IDC_FLAG_THROUGHPUT
 IDC_OK = 0
 STATUS_NAMES = {0: "IDC_OK", -1: "IDC_ERR_INVALID_ARG", -2: "IDC_ERR_NO_DEVICE", -3: "IDC_ERR_HIP",
                 -4: "IDC_ERR_NO_WEIGHTS", -5: "IDC_ERR_MISSING_KEY", -6: "IDC_ERR_BATCH",
-                -7: "IDC_ERR_UNSUPPORTED"}
+                -7: "IDC_ERR_UNSUPPORTED", -8: "IDC_ERR_INTERNAL"}
 
 # every symbol include/ideepcolor.h declares (tests check the .so exports all of them)
 EXPORTED_SYMBOLS = [

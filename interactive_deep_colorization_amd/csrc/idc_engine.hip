@@ -602,6 +602,8 @@ static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, i
     if (precision == IDC_BF16 && g_wino && g_wino_bf16 == 2 && g_tile_policy != 1 && L.blob.w3_off != (size_t)-1 &&
         L.spec->resid == nullptr && L.spec->kind == kConv3x3)
         L.wino = true;                               // measurement switch: the click path's Winograd kernel at every batch size
+    const bool wino_fits = wino_offsets_fit(Hs, Ws, L.spec->kind == kDeconv4x4 ? 1 : L.spec->in_stride, a.nkc);   // 32-bit patch offsets
+    L.wino = L.wino && wino_fits;
     if (L.wino) { L.v2 = false; L.click = false; a.ksplit = 1; a.kc_per = a.nkc; a.tiles_x = a.tiles_y = 0; return; }
     // large-tile bf16 kernel: 256 couts x (32x8 sites) when the cout groups divide by 4, else
     // 128 couts x (32x16 sites); used when its grid covers at least half of the 256 CUs
@@ -638,14 +640,14 @@ static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, i
     const int wm_big = a.ncg % 4 == 0 ? 4 : (a.ncg % 2 == 0 ? 2 : 1), rows_big = wm_big == 4 ? 8 : 16;
     const long long big_tiles = (long long)((Ws + 31) / 32) * ((Hs + rows_big - 1) / rows_big) * n_policy * (a.ncg / wm_big) * a.nphase;
     // bf16 click path, deconvs with Cin >= 256 (model8up / model9up): Winograd F(2x2,2x2) instead of conv_click + a reduction launch
-    if (precision == IDC_BF16 && g_wino && g_wino_bf16 && g_wino_deconv && g_tile_policy != 1 && big_tiles < tuning().v2_min_blocks &&
+    if (precision == IDC_BF16 && g_wino && g_wino_bf16 && g_wino_deconv && g_tile_policy != 1 && big_tiles < tuning().v2_min_blocks && wino_fits &&
         L.blob.w3_off != (size_t)-1 && L.spec->kind == kDeconv4x4 && (a.nkc >= 4 || g_wino_deconv == 2)) {
         L.wino = true; a.ksplit = 1; a.kc_per = a.nkc; a.tiles_x = a.tiles_y = 0;
         return;
     }
     // bf16 click path: a 3x3 stride-1 layer that would run conv_click + a split-K reduction launch runs as Winograd instead
     // (16 position-GEMMs fill the chip without split-K: no slabs, no second launch; idc_wino.hip)
-    if (precision == IDC_BF16 && g_wino && g_wino_bf16 && g_tile_policy != 1 && big_tiles < tuning().v2_min_blocks &&
+    if (precision == IDC_BF16 && g_wino && g_wino_bf16 && g_tile_policy != 1 && big_tiles < tuning().v2_min_blocks && wino_fits &&
         L.blob.w3_off != (size_t)-1 && L.spec->resid == nullptr && L.spec->kind == kConv3x3) {
         L.wino = true; a.ksplit = 1; a.kc_per = a.nkc; a.tiles_x = a.tiles_y = 0;
         return;
@@ -910,7 +912,14 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
                 (long long)((a.Ws + 31) / 32) * ((a.Hs + 31) / 32) * c->max_batch >= 128)
                 le = launch_conv1_1_bf16(a, s);
             if (L.fused_short >= 0) le = launch_conv_ds(a, s);    // deconv + its shortcut conv in one K loop
-            if (L.wino) le = L.spec->kind == kDeconv4x4 ? launch_deconv_wino(c->precision, a, s) : launch_conv_wino(c->precision, a, s);
+            if (L.wino) {
+                // a.wgt points at the Winograd U image and L.cfg / tiles were never set for this layer: a refused launch must not fall
+                // through to the direct kernels below -- it is a variant-selection bug and says so
+                if (!conv_wino_applies(c->precision, a, L.spec->kind == kDeconv4x4))
+                    return fail(&c->err, IDC_ERR_INTERNAL, "layer %s: Winograd variant selected for a launch it does not cover", L.spec->name);
+                le = L.spec->kind == kDeconv4x4 ? launch_deconv_wino(c->precision, a, s) : launch_conv_wino(c->precision, a, s);
+                HIPCHK(c, le);
+            }
             if (le == hipErrorInvalidConfiguration)
                 le = L.click ? launch_conv_click(c->precision, L.cfg.wp, L.halo, a, s)
                    : L.v2 ? (L.m16 ? launch_conv_v2m(L.cfg, L.halo, a, s) : launch_conv_v2(L.cfg, L.halo, a, s))
@@ -1691,6 +1700,8 @@ struct IdcNcclId { char internal[128]; };                  // ncclUniqueId (rccl
 struct Rccl {
     void* lib = nullptr;
     std::string path;
+    std::string tried;                   // every candidate that failed, for the error string
+    bool beside_runtime = false;         // opened from the directory of the libamdhip64 this library is bound to
     int (*GetUniqueId)(void*) = nullptr;
     int (*CommInitRank)(void**, int, IdcNcclId, int) = nullptr;
     int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
@@ -1713,13 +1724,24 @@ static Rccl* rccl() {
             const size_t sl = dir.rfind('/');
             dir = sl == std::string::npos ? std::string() : dir.substr(0, sl + 1);
         }
+        auto try_open = [&](const std::string& nm, int flags) {
+            if (r.lib) return;
+            r.lib = dlopen(nm.c_str(), flags);
+            if (r.lib) r.path = nm; else r.tried += (r.tried.empty() ? "" : ", ") + nm;
+        };
+        if (const char* forced = getenv("IDC_RCCL_PATH")) try_open(forced, RTLD_NOW | RTLD_LOCAL);      // explicit override wins
         if (!dir.empty()) {
-            const std::string cands[] = {dir + "librccl.so.1", dir + "librccl.so"};
-            for (const std::string& nm : cands) { r.lib = dlopen(nm.c_str(), RTLD_NOW | RTLD_LOCAL); if (r.lib) { r.path = nm; break; } }
+            try_open(dir + "librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+            try_open(dir + "librccl.so", RTLD_NOW | RTLD_LOCAL);
+            r.beside_runtime = r.lib != nullptr && r.path.compare(0, dir.size(), dir) == 0;
         }
-        if (!r.lib && dir.empty()) {              // dladdr unavailable: the historical search (documented as unverified)
-            const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-            for (const char* nm : names) { r.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL); if (r.lib) { r.path = nm; break; } }
+        // Not beside the runtime (split packages, LD_LIBRARY_PATH installs -- ADVICE r3: this search had been dropped): the loader's
+        // own resolution.  A librccl found this way binds to whichever libamdhip64 the loader gives IT; when that is the runtime this
+        // library uses (one ROCm install on the library path: the normal case) everything is as above, and the path travels in every
+        // error string so a mismatch is diagnosable.
+        if (!r.lib) {
+            const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+            for (const char* nm : names) try_open(nm, RTLD_NOW | RTLD_LOCAL);
         }
         if (r.lib) {
             r.GetUniqueId = (int (*)(void*))dlsym(r.lib, "ncclGetUniqueId");
@@ -1727,18 +1749,27 @@ static Rccl* rccl() {
             r.Broadcast = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(r.lib, "ncclBroadcast");
             r.CommDestroy = (int (*)(void*))dlsym(r.lib, "ncclCommDestroy");
             r.GetErrorString = (const char* (*)(int))dlsym(r.lib, "ncclGetErrorString");
-            if (!r.GetUniqueId || !r.CommInitRank || !r.Broadcast || !r.CommDestroy) r.lib = nullptr;
+            if (!r.GetUniqueId || !r.CommInitRank || !r.Broadcast || !r.CommDestroy) { r.tried += " (" + r.path + ": nccl symbols missing)"; r.lib = nullptr; }
         }
     }
     return r.lib ? &r : nullptr;
+}
+static std::string rccl_where() {            // for error strings: which librccl, and whether it is the runtime's sibling
+    Rccl* r = rccl();
+    if (!r) {
+        static Rccl dummy;
+        (void)dummy;
+        return "librccl.so could not be opened (IDC_RCCL_PATH overrides the search)";
+    }
+    return r->path + (r->beside_runtime ? "" : " [not beside the libamdhip64 this library is bound to]");
 }
 
 int idc_comm_unique_id(void* id128) {
     if (!id128) return fail(nullptr, IDC_ERR_INVALID_ARG, "null id buffer");
     Rccl* r = rccl();
-    if (!r) return fail(nullptr, IDC_ERR_UNSUPPORTED, "librccl.so could not be opened");
+    if (!r) return fail(nullptr, IDC_ERR_UNSUPPORTED, "%s", rccl_where().c_str());
     const int e = r->GetUniqueId(id128);
-    if (e != 0) return fail(nullptr, IDC_ERR_HIP, "ncclGetUniqueId failed: %s", r->GetErrorString ? r->GetErrorString(e) : "?");
+    if (e != 0) return fail(nullptr, IDC_ERR_HIP, "ncclGetUniqueId failed: %s (%s)", r->GetErrorString ? r->GetErrorString(e) : "?", rccl_where().c_str());
     return IDC_OK;
 }
 
@@ -1748,7 +1779,7 @@ int idc_broadcast_weights(idc_handle h, const void* unique_id, int rank, int wor
         return fail(&h->err, IDC_ERR_INVALID_ARG, "rank %d / root %d outside world %d", rank, root, world);
     if (rank == root && !h->weights_set) return fail(&h->err, IDC_ERR_NO_WEIGHTS, "the root rank has no weights to broadcast");
     Rccl* r = rccl();
-    if (!r) return fail(&h->err, IDC_ERR_UNSUPPORTED, "librccl.so could not be opened");
+    if (!r) return fail(&h->err, IDC_ERR_UNSUPPORTED, "%s", rccl_where().c_str());
     HIPCHK(h, hipSetDevice(h->device));
     if (rank != root && (!h->own_blob || !h->d_blob)) {
         h->d_blob = nullptr;
@@ -1759,11 +1790,11 @@ int idc_broadcast_weights(idc_handle h, const void* unique_id, int rank, int wor
     memcpy(&id, unique_id, sizeof(id));
     void* comm = nullptr;
     int e = r->CommInitRank(&comm, world, id, rank);
-    if (e != 0) return fail(&h->err, IDC_ERR_HIP, "ncclCommInitRank failed: %s", r->GetErrorString ? r->GetErrorString(e) : "?");
+    if (e != 0) return fail(&h->err, IDC_ERR_HIP, "ncclCommInitRank failed: %s (%s)", r->GetErrorString ? r->GetErrorString(e) : "?", rccl_where().c_str());
     e = r->Broadcast(h->d_blob, h->d_blob, h->plan.total_bytes, /*ncclUint8*/ 1, root, comm, h->stream);
     hipError_t he = hipStreamSynchronize(h->stream);
     (void)r->CommDestroy(comm);
-    if (e != 0) return fail(&h->err, IDC_ERR_HIP, "ncclBroadcast failed: %s", r->GetErrorString ? r->GetErrorString(e) : "?");
+    if (e != 0) return fail(&h->err, IDC_ERR_HIP, "ncclBroadcast failed: %s (%s)", r->GetErrorString ? r->GetErrorString(e) : "?", rccl_where().c_str());
     if (he != hipSuccess) return fail(&h->err, IDC_ERR_HIP, "stream sync after ncclBroadcast: %s", hipGetErrorString(he));
     if (rank != root) {                     // the received bytes are validated like any other device blob
         h->weights_set = false;
@@ -2061,6 +2092,10 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     HIPCHK(nullctx, d_zero.alloc(256));
     HIPCHK(nullctx, hipMemset(d_zero.p, 0, 256));
     a.zeros = d_zero.p;
+    if (L.wino && !conv_wino_applies(precision, a, wino_dc))
+        return fail(nullptr, IDC_ERR_INTERNAL, "single op: Winograd variant selected for a launch it does not cover");
+    if (L.m16 && !conv_v2m_applies(a))
+        return fail(nullptr, IDC_ERR_INTERNAL, "single op: conv_igemm_v2m selected for a launch it does not cover");
     HIPCHK(nullctx, L.wino ? (wino_dc ? launch_deconv_wino(precision, a, nullptr) : launch_conv_wino(precision, a, nullptr)) : L.click ? launch_conv_click(precision, L.cfg.wp, L.halo, a, nullptr)
                     : L.v2 ? (L.m16 ? launch_conv_v2m(L.cfg, L.halo, a, nullptr) : launch_conv_v2(L.cfg, L.halo, a, nullptr))
                            : launch_conv(precision, L.cfg, L.halo, a, nullptr));

@@ -102,6 +102,10 @@ hipError_t launch_splitk_epilogue(int precision, const ConvArgs& a, hipStream_t 
 hipError_t launch_conv_wino(int precision, const ConvArgs& a, hipStream_t s);     // precision 1: conv_wino_bf16 (batch-1 click path only)
 // fp32 ConvTranspose 4x4 s2 as Winograd F(2x2,2x2) over its four phases: a.wgt = the 36-position U image, a.Hs / a.Ws = input size
 hipError_t launch_deconv_wino(int precision, const ConvArgs& a, hipStream_t s);    // precision 1: the bf16 twin (click path)
+// the launch guards of the two entry points above as a predicate (args filled in: in / wgt / zeros / resid / out_f32 set), and the
+// 32-bit source-offset bound alone (known before the pointers are: set_geometry)
+bool conv_wino_applies(int precision, const ConvArgs& a, bool deconv);
+bool wino_offsets_fit(int Hs, int Ws, int si, int nkc);
 hipError_t init_kernels_wino();
 void set_wino_form(int form);      // 0 = by grid size, 12 / 21 / 22 = force conv_wino_f32<TB,CB> (speed only)
 // One-time: raise the dynamic-LDS limit of every conv instantiation.

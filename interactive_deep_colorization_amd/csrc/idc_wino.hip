@@ -1086,11 +1086,28 @@ __global__ __launch_bounds__(kWinoDNT, 3) void conv_wino_deconv_bf16(const ConvA
 
 // ConvTranspose 4x4 s2 p1, fp32, Winograd F(2x2,2x2).  a.wgt = the layer's 36-position U image, a.Hs / a.Ws = INPUT size,
 // a.resid = optional fp32 shortcut sum at the output resolution.
+// The kernels of this file address a source image with 32-bit byte offsets (poff[] = ((Y*si)*(W*si) + X*si) * pix_bytes + ..., -1 =
+// outside): the strided source of ONE image must stay below 2 GiB (fp32 conv2_1 reads conv1_2 at 256 B per pixel through its
+// stride-2 view: 2896 x 2896).  Larger geometries take the direct kernels, whose offsets are size_t.
+bool wino_offsets_fit(int Hs, int Ws, int si, int nkc) {
+    return (long long)Hs * si * (long long)Ws * si * ((long long)nkc * kRowBytes) < 0x7fffffffLL;
+}
+
+// ONE predicate for "this launch can run as Winograd" -- the engine's variant choice (set_geometry), the single-operator entry points and
+// the two launchers below all ask it (the launch guards used to be wider than the eligibility tests).
+bool conv_wino_applies(int precision, const ConvArgs& a, bool deconv) {
+    if (a.zeros == nullptr || a.nkc < 1 || a.wgt == nullptr) return false;
+    if (deconv)
+        return a.nphase == 4 && a.so == 2 && a.si == 1 && a.img_shift == nullptr && wino_offsets_fit(a.Hs, a.Ws, 1, a.nkc) &&
+               !(precision == 0 && (!a.out_f32 || (a.resid != nullptr && a.resid_bf16)));
+    const int d = a.dy[8];
+    return (d == 1 || d == 2) && (a.si == 1 || a.si == 2) && a.so == 1 && a.nphase == 1 && a.ntaps == 9 && a.resid == nullptr &&
+           !(precision == 0 && !a.out_f32) && wino_offsets_fit(a.Hs, a.Ws, a.si, a.nkc);
+}
+
 hipError_t launch_deconv_wino(int precision, const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
-    if (a.nphase != 4 || a.so != 2 || a.si != 1 || a.zeros == nullptr || a.nkc < 1 || a.img_shift != nullptr ||
-        (precision == 0 && (!a.out_f32 || (a.resid != nullptr && a.resid_bf16))))
-        return hipErrorInvalidConfiguration;
+    if (!conv_wino_applies(precision, a, true)) return hipErrorInvalidConfiguration;
     a.tiles_x = (a.Ws + 7) / 8;
     a.tiles_y = (a.Hs + 7) / 8;
     const long long tb = (long long)a.tiles_x * a.tiles_y * a.N;
@@ -1128,9 +1145,7 @@ static hipError_t launch_wino_t(ConvArgs& a, int d, int precision, hipStream_t s
 hipError_t launch_conv_wino(int precision, const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     const int d = a.dy[8];
-    if ((d != 1 && d != 2) || (a.si != 1 && a.si != 2) || a.so != 1 || a.nphase != 1 || a.ntaps != 9 || a.resid != nullptr || (precision == 0 && !a.out_f32) ||
-        a.zeros == nullptr || a.nkc < 1)
-        return hipErrorInvalidConfiguration;
+    if (!conv_wino_applies(precision, a, false)) return hipErrorInvalidConfiguration;
     const long long t2 = (long long)(((a.Ws + d - 1) / d + 15) / 16) * (((a.Hs + d - 1) / d + 7) / 8) * d * d * a.N;   // 8x16-pixel blocks
     int form = g_wino_form;
     // (measured, profiles/r03_wino_harness.txt: <2,1> loses to <1,2> on every shape -- its transform work per workgroup doubles --

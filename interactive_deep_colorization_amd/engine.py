@@ -7,6 +7,7 @@ the HIP library behind the C ABI (``include/ideepcolor.h``); this file only
 marshals numpy arrays and weight dictionaries.
 """
 import ctypes
+import threading
 
 import numpy as np
 
@@ -134,43 +135,60 @@ class _PinnedPool(object):
     library then copies device -> caller in place, no staging memcpy); when the last view of it is collected the memory goes
     back on the free list instead of to the driver (hipHostMalloc / hipHostFree cost more than the copy they save).  An array
     is never handed out while another array still views the same memory, so results keep the value semantics of ``np.empty``
-    outputs.  Bounded: buffers above ``MAX_ONE`` or beyond ``MAX_TOTAL`` retained bytes are plain numpy / freed."""
+    outputs.  Bounded on both sides: buffers above ``MAX_ONE`` or beyond ``MAX_TOTAL`` retained (free-list) bytes are plain
+    numpy / freed, and at most ``MAX_LIVE`` bytes of pinned memory are in callers' hands at any time -- a caller that keeps
+    many results alive gets pageable ``np.empty`` arrays beyond that (the library stages those through its own pinned
+    buffer), so kept outputs cannot pin unbounded host RAM.  Counters are guarded by a lock (results may be
+    dropped on any thread)."""
     MAX_ONE = 32 << 20
     MAX_TOTAL = 256 << 20
+    MAX_LIVE = 512 << 20
 
     def __init__(self, lib):
         self.lib = lib
-        self.free = {}                      # nbytes -> [ptr]; list append / pop are atomic under the GIL
-        self.retained = 0
+        self.free = {}                      # nbytes -> [ptr]
+        self.retained = 0                   # bytes on the free lists
+        self.live = 0                       # pinned bytes currently viewed by arrays handed out
+        self._lock = threading.Lock()
 
     def take(self, shape, dtype):
         shape = tuple(int(x) for x in shape)
         nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
         if nbytes == 0 or nbytes > self.MAX_ONE:
             return np.empty(shape, dtype)
-        try:
-            ptr = self.free.setdefault(nbytes, []).pop()
-            self.retained -= nbytes
-        except IndexError:
-            ptr = None
+        with self._lock:
+            if self.live + nbytes > self.MAX_LIVE:
+                return np.empty(shape, dtype)
+            lst = self.free.get(nbytes)
+            ptr = lst.pop() if lst else None
+            if ptr is not None:
+                self.retained -= nbytes
+            self.live += nbytes
         try:
             owner = _PooledPinned(self, nbytes, ptr)
         except MemoryError:
+            with self._lock:
+                self.live -= nbytes
             return np.empty(shape, dtype)
         return np.asarray(owner)[:nbytes].view(dtype).reshape(shape)
 
     def give(self, ptr, nbytes):
-        if self.retained + nbytes <= self.MAX_TOTAL:
-            self.free.setdefault(nbytes, []).append(ptr)
-            self.retained += nbytes
-        else:
+        with self._lock:
+            self.live -= nbytes
+            keep = self.retained + nbytes <= self.MAX_TOTAL
+            if keep:
+                self.free.setdefault(nbytes, []).append(ptr)
+                self.retained += nbytes
+        if not keep:
             self.lib.idc_free_host(ctypes.c_void_p(ptr))
 
     def drain(self):
-        for lst in self.free.values():
-            while lst:
-                self.lib.idc_free_host(ctypes.c_void_p(lst.pop()))
-        self.retained = 0
+        with self._lock:
+            ptrs = [p for lst in self.free.values() for p in lst]
+            self.free = {}
+            self.retained = 0
+        for p in ptrs:
+            self.lib.idc_free_host(ctypes.c_void_p(p))
 
 
 class _PooledPinned(_PinnedBuffer):

@@ -87,3 +87,60 @@ def test_shim_and_api_export_the_same_objects():
     assert sorted(a.__all__) == sorted(b.__all__)
     for name in b.__all__:
         assert getattr(a, name) is getattr(b, name)
+
+
+class _FakeLib(object):
+    def __init__(self):
+        self.live, self.freed = {}, []
+
+    def idc_alloc_host(self, n):
+        import ctypes
+        b = (ctypes.c_char * n)()
+        a = ctypes.addressof(b)
+        self.live[a] = b
+        return a
+
+    def idc_free_host(self, p):
+        self.freed.append(p.value)
+        self.live.pop(p.value, None)
+        return 0
+
+
+def test_pinned_result_pool_caps_live_bytes():
+    """a caller that KEEPS its results must not pin unbounded host RAM -- beyond MAX_LIVE bytes in callers' hands
+    the pool hands out pageable arrays; dropping results makes pinned ones available again."""
+    import gc
+
+    import numpy as np
+
+    from interactive_deep_colorization_amd import engine
+    lib = _FakeLib()
+    pool = engine._PinnedPool(lib)
+    pool.MAX_LIVE = 256
+    kept = [pool.take((16,), np.float32) for _ in range(6)]          # 64 B each: four fit under the cap
+    pinned = [a for a in kept if a.ctypes.data in lib.live or any(a.ctypes.data == k for k in lib.live)]
+    assert len(lib.live) == 4 and pool.live == 256 and len(pinned) == 4
+    for a in kept:
+        a[:] = 2.0                                                   # all six are ordinary writable arrays
+    del pinned
+    kept = kept[4:]                                                  # drop the four pinned ones
+    gc.collect()
+    assert pool.live == 0 and pool.retained == 256
+    again = pool.take((16,), np.float32)
+    assert again.ctypes.data in lib.live and pool.live == 64 and pool.retained == 192
+
+
+def test_throughput_blob_is_about_half_and_host_packable():
+    """IDC_FLAG_THROUGHPUT_BLOB: the blob a bf16 throughput handle needs carries no Winograd
+    images; the header records the flag so a handle created without it refuses the blob."""
+    import numpy as np
+
+    from interactive_deep_colorization_amd import _native, engine
+    lib = _native.load()
+    full = int(lib.idc_weights_blob_bytes(1, 0))
+    thr = int(lib.idc_weights_blob_bytes(1, _native.IDC_FLAG_THROUGHPUT_BLOB))
+    assert 120e6 < thr < 150e6 and 240e6 < full < 280e6, (thr, full)
+    full32 = int(lib.idc_weights_blob_bytes(0, 0))
+    thr32 = int(lib.idc_weights_blob_bytes(0, _native.IDC_FLAG_THROUGHPUT_BLOB))
+    assert thr32 < 0.5 * full32
+    assert lib.idc_version() == 2
