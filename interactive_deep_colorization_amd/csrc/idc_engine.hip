@@ -491,6 +491,8 @@ static int g_wino_deconv = !(getenv("IDC_WINO_DECONV") && atoi(getenv("IDC_WINO_
 static int g_wino_bf16 = getenv("IDC_WINO_BF16") ? atoi(getenv("IDC_WINO_BF16")) : 1;
 // conv_igemm_v2 launches that qualify run as conv_igemm_v2m (16x16x32 MFMA: fewer joules per FLOP at the power cap; idc_set_option "mfma16")
 static int g_mfma16 = getenv("IDC_MFMA16") ? atoi(getenv("IDC_MFMA16")) : 1;
+// ... and so do the three deconv + shortcut launches (conv_ds_fused_m, idc_dsm.hip; idc_set_option "ds_mfma16" / env IDC_DS_M16=0 for A/B)
+static int g_ds_m16 = getenv("IDC_DS_M16") ? atoi(getenv("IDC_DS_M16")) : 1;
 static int g_click = -1;                 // conv_click for small launches: -1 = environment default (on), 0 off, 1 on (idc_set_option "click")
 // Shortcut fusion (conv_igemm_v2<.,.,1,true>) is correct (parity-tested under tile policy 2) but measured slower
 // than two launches on MI355X (4x re-reads of the skip tensor by the four phase workgroups, VGPR spills around
@@ -868,6 +870,8 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             a.resid = nullptr; a.resid_bf16 = 0;
             a.in2 = c->tensors[P.src].ptr; a.wgt2 = c->d_blob + P.blob.w2_off; a.nkc2 = P.blob.nkc;
             a.bias = (const float*)(c->d_blob + L.blob.fbias_off);
+            L.m16 = g_ds_m16 != 0;
+            if (L.m16) { a.wgt = c->d_blob + L.blob.w_off; a.wgt2 = c->d_blob + P.blob.w_off; }   // conv_ds_fused_m reads the layout-1 images
         } else {
             a.resid = L.resid >= 0 ? c->tensors[L.resid].ptr : nullptr;
             a.resid_bf16 = (L.resid >= 0 && !c->tensors[L.resid].is_f32) ? 1 : 0;
@@ -899,8 +903,10 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             }
             a.partial = c->d_partial;
         }
-        L.m16 = L.v2 && g_mfma16 && L.fused_short < 0 && L.fused_next < 0 && !L.wino && !L.click && conv_v2m_applies(a);
-        if (L.m16) a.wgt = c->d_blob + L.blob.w_off;            // the layout-1 image (the one conv_igemm / conv_click read)
+        if (L.fused_short < 0) {
+            L.m16 = L.v2 && g_mfma16 && L.fused_next < 0 && !L.wino && !L.click && conv_v2m_applies(a);
+            if (L.m16) a.wgt = c->d_blob + L.blob.w_off;            // the layout-1 image (the one conv_igemm / conv_click read)
+        }
         tic();
         {
             hipError_t le = hipErrorInvalidConfiguration;
@@ -911,7 +917,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             else if (L.spec->kind == kConvIm2col && c->precision == IDC_BF16 && a.ksplit <= 1 &&
                 (long long)((a.Ws + 31) / 32) * ((a.Hs + 31) / 32) * c->max_batch >= 128)
                 le = launch_conv1_1_bf16(a, s);
-            if (L.fused_short >= 0) le = launch_conv_ds(a, s);    // deconv + its shortcut conv in one K loop
+            if (L.fused_short >= 0) le = L.m16 ? launch_conv_ds_m(a, s) : launch_conv_ds(a, s);    // deconv + its shortcut conv in one K loop
             if (L.wino) {
                 // a.wgt points at the Winograd U image and L.cfg / tiles were never set for this layer: a refused launch must not fall
                 // through to the direct kernels below -- it is a variant-selection bug and says so
@@ -1071,6 +1077,7 @@ int idc_set_option(const char* name, int value) {
     if (strcmp(name, "click") == 0) { g_click = value; return IDC_OK; }
     if (strcmp(name, "winograd") == 0) { g_wino = value != 0; return IDC_OK; }
     if (strcmp(name, "mfma16") == 0) { g_mfma16 = value != 0; return IDC_OK; }
+    if (strcmp(name, "ds_mfma16") == 0) { g_ds_m16 = value != 0; return IDC_OK; }
     if (strcmp(name, "winograd_bf16") == 0) { g_wino_bf16 = value; return IDC_OK; }
     if (strcmp(name, "winograd_deconv") == 0) { g_wino_deconv = value; return IDC_OK; }
     if (strcmp(name, "winograd_form") == 0) { set_wino_form(value); return IDC_OK; }     // 0 automatic, 12 / 21 / 22 = <TB,CB> (tests, tuning)
@@ -1898,7 +1905,7 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
             if (L.fused_short >= 0) {
                 const Layer& P = h->layers[L.fused_short];
                 // the name rocprofv3 shows for this launch (the deconv and its 3x3 shortcut conv in one K loop)
-                snprintf(out->kernel, sizeof(out->kernel), "conv_ds_fused+shortcut");
+                snprintf(out->kernel, sizeof(out->kernel), L.m16 ? "conv_ds_fused_m+shortcut" : "conv_ds_fused+shortcut");
                 out->flops += P.flops;
                 out->min_bytes += P.min_bytes - 2.0 * (double)h->tensors[P.dst].H * h->tensors[P.dst].W * h->tensors[P.dst].Cpad * eb;
             }

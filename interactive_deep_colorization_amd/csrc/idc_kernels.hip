@@ -816,6 +816,8 @@ hipError_t init_kernels() {
     if (e != hipSuccess) return e;
     e = init_kernels_v2m();
     if (e != hipSuccess) return e;
+    e = init_kernels_dsm();
+    if (e != hipSuccess) return e;
     return init_kernels_v2();
 }
 

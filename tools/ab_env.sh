@@ -11,6 +11,7 @@ envs = sys.argv[1:]
 runs = [[json.load(open('gpurun_out/abenv_%d_%d.json' % (i, r))) for r in (1, 2)] for i in range(len(envs))]
 print("ms/forward: " + " | ".join("%s %s" % (e, [x['ms_per_forward'] for x in rr]) for e, rr in zip(envs, runs)))
 for k in runs[0][0]['layers']:
-    vals = [min(x['layers'].get(k, 0) for x in rr) for rr in runs]
+    ms = lambda v: v[0] if isinstance(v, list) else v
+    vals = [min(ms(x['layers'].get(k, 0)) for x in rr) for rr in runs]
     print("%-14s " % k + "  ".join("%.4f" % v for v in vals) + "   " + "  ".join("%+5.1f%%" % (100 * (v - vals[0]) / vals[0]) if vals[0] else "" for v in vals[1:]))
 PY

@@ -6,6 +6,7 @@ import json
 o=[json.load(open('gpurun_out/ab_old_%d.json'%r)) for r in (1,2)]; n=[json.load(open('gpurun_out/ab_new_%d.json'%r)) for r in (1,2)]
 print("ms/forward old %s new %s" % ([x['ms_per_forward'] for x in o], [x['ms_per_forward'] for x in n]))
 for k in o[0]['layers']:
-    a=min(x['layers'][k] for x in o); b=min(x['layers'].get(k,0) for x in n)
+    ms=lambda v: v[0] if isinstance(v,list) else v
+    a=min(ms(x['layers'][k]) for x in o); b=min(ms(x['layers'].get(k,0)) for x in n)
     print("%-14s %.4f -> %.4f  %+5.1f%%" % (k, a, b, 100*(b-a)/a if a else 0))
 PY

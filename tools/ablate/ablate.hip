@@ -11,6 +11,8 @@
 #endif
 #include ABL_KERNELS
 #include "../../interactive_deep_colorization_amd/csrc/idc_wino.hip"
+#include "../../interactive_deep_colorization_amd/csrc/idc_v2m.hip"
+#include "../../interactive_deep_colorization_amd/csrc/idc_dsm.hip"
 
 __global__ void fill_bf16(unsigned short* p, size_t n, unsigned seed) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -86,7 +88,7 @@ int main(int argc, char** argv) {
     }
     idc::ConvConfig cfg{wm, wp};
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-#define LAUNCH() (v2 == 6 ? idc::launch_conv_wino(prec, a, 0) : v2 == 4 ? idc::launch_conv_click(prec, wp, halo, a, 0) : v2 == 5 ? idc::launch_conv(prec, cfg, halo, a, 0) : v2 == 2 ? idc::launch_conv_ds(a, 0) : v2 ? idc::launch_conv_v2(cfg, halo, a, 0) : idc::launch_conv(prec, cfg, halo, a, 0))
+#define LAUNCH() (v2 == 6 ? idc::launch_conv_wino(prec, a, 0) : v2 == 4 ? idc::launch_conv_click(prec, wp, halo, a, 0) : v2 == 5 ? idc::launch_conv(prec, cfg, halo, a, 0) : v2 == 2 ? (getenv("IDC_DS_M16") && atoi(getenv("IDC_DS_M16")) ? idc::launch_conv_ds_m(a, 0) : idc::launch_conv_ds(a, 0)) : v2 ? idc::launch_conv_v2(cfg, halo, a, 0) : idc::launch_conv(prec, cfg, halo, a, 0))
 #ifdef IDC_TIMING
     int nb = v2 == 6 ? (int)(((HW + halo - 1) / halo + 7) / 8) * (((HW + halo - 1) / halo + 7) / 8) * halo * halo * N * (C / 32) : v2 == 2 ? ((HW + 31) / 32) * ((HW + 3) / 4) * N * (a.ncg / 2) : a.tiles_x * a.tiles_y * N * (a.ncg / wm) * a.nphase * (a.ksplit > 1 ? a.ksplit : 1);
     long long* dbg; CK(hipMalloc(&dbg, (size_t)nb * 128)); CK(hipMemset(dbg, 0, (size_t)nb * 128));
