@@ -47,6 +47,13 @@ BlobPlan make_blob_plan(int precision, unsigned flags) {
         off = align_up(off, 256); lb.w_off = off; off += lb.w_bytes;
         lb.w2_off = (size_t)-1;
         if (precision == IDC_BF16 && v2_eligible(s)) { off = align_up(off, 256); lb.w2_off = off; off += lb.w_bytes; }
+        lb.w4_off = (size_t)-1;
+        if (precision == IDC_BF16 && v2_eligible(s)) {
+            bool ds_pair = s.kind == kDeconv4x4 && s.resid != nullptr;                   // model8up / 9up / 10up ...
+            for (const LayerSpec& q : specs)                                              // ... and the shortcut convs they are summed with
+                if (q.kind == kDeconv4x4 && q.resid != nullptr && s.kind == kConv3x3 && strcmp(q.resid, s.name) == 0) ds_pair = true;
+            if (ds_pair) { off = align_up(off, 256); lb.w4_off = off; off += lb.w_bytes; }
+        }
         lb.w3_off = (size_t)-1; lb.w3_bytes = 0;
         if (wino_images && wino_eligible(s) && s.cin % kc == 0) {                            // fp32: every batch size; bf16: the batch-1 click path
             lb.w3_bytes = (size_t)s.cin * cout_pad(s.cout) * 16 * elem_bytes(precision);   // 16 transformed values per (cin, cout)
@@ -104,6 +111,16 @@ static inline void put_w(uint8_t* wimg, int precision, int layout, int nkc, int 
     const int s = kin / eps, e = kin % eps;
     const int cg = co / kCoutGroup, col = co % kCoutGroup;
     int lam, sig;
+    if (layout == 3) {                        // k32-major 4 KiB tiles: [tw][kc][kk][cg][64 rows][4 slots]
+        const int gq = col >> 4, ci = (col >> 2) & 3, reg = col & 3;
+        lam = ci * 16 + gq * 4 + reg;
+        const int kk = s >> 2, g = s & 3;
+        const size_t off3 = (((size_t)(tw * nkc + kc) * 2 + kk) * ncg + cg) * kW3BlockBytes + (size_t)lam * 64 +
+                            (size_t)((g ^ swz3(lam)) * kSlotBytes) + (size_t)e * eb;
+        const uint16_t b = f32_to_bf16_rne(v);
+        memcpy(wimg + off3, &b, 2);
+        return;
+    }
     if (layout == 2) {
         lam = cg_cout_to_row2(col);
         sig = s ^ swz2(lam);
@@ -265,6 +282,7 @@ static int pack_weights_impl(int precision, unsigned flags, const idc_tensor_des
         if (!dims_are(*b, {s.cout})) return fail(err, IDC_ERR_MISSING_KEY, "key '%s' has the wrong shape", bk.c_str());
         pack_layer_weights(base + lb.w_off, precision, 1, s, lb, w->data);
         if (lb.w2_off != (size_t)-1) pack_layer_weights(base + lb.w2_off, precision, 2, s, lb, w->data);
+        if (lb.w4_off != (size_t)-1) pack_layer_weights(base + lb.w4_off, precision, 3, s, lb, w->data);
         if (lb.w3_off != (size_t)-1) {
             if (s.kind == kDeconv4x4) pack_wino_deconv_weights(base + lb.w3_off, precision, s, lb, w->data);
             else pack_wino_weights(base + lb.w3_off, precision, s, lb, w->data);
@@ -389,6 +407,7 @@ struct Layer {
     ConvConfig cfg{2, 2};
     bool v2 = false;                     // bf16 large-tile kernel (layout-2 weights)
     bool m16 = false;                    // ... its 16x16x32-MFMA build (conv_igemm_v2m, layout-1 weights): set per launch in run_graph
+    bool ds_q = false;                   // deconv + shortcut launch as conv_ds_fused_q (layout-3 weights): set per launch in run_graph
     bool click = false;                  // batch-1 click-path kernel (conv_click: whole K slice by LDS-DMA)
     bool wino = false;                   // fp32 Winograd F(2x2,3x3) kernel (conv_wino_f32, idc_wino.hip)
     bool fused_head = false;             // conv10_2 only: model_out + tanh run in this layer's epilogue
@@ -872,6 +891,8 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             a.bias = (const float*)(c->d_blob + L.blob.fbias_off);
             L.m16 = g_ds_m16 != 0;
             if (L.m16) { a.wgt = c->d_blob + L.blob.w_off; a.wgt2 = c->d_blob + P.blob.w_off; }   // conv_ds_fused_m reads the layout-1 images
+            L.ds_q = L.m16 && g_ds_m16 == 2 && L.blob.w4_off != (size_t)-1 && P.blob.w4_off != (size_t)-1;
+            if (L.ds_q) { a.wgt = c->d_blob + L.blob.w4_off; a.wgt2 = c->d_blob + P.blob.w4_off; }   // conv_ds_fused_q: the k32-major tiles (layout 3)
         } else {
             a.resid = L.resid >= 0 ? c->tensors[L.resid].ptr : nullptr;
             a.resid_bf16 = (L.resid >= 0 && !c->tensors[L.resid].is_f32) ? 1 : 0;
@@ -917,7 +938,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             else if (L.spec->kind == kConvIm2col && c->precision == IDC_BF16 && a.ksplit <= 1 &&
                 (long long)((a.Ws + 31) / 32) * ((a.Hs + 31) / 32) * c->max_batch >= 128)
                 le = launch_conv1_1_bf16(a, s);
-            if (L.fused_short >= 0) le = L.m16 ? launch_conv_ds_m(a, s) : launch_conv_ds(a, s);    // deconv + its shortcut conv in one K loop
+            if (L.fused_short >= 0) le = !L.m16 ? launch_conv_ds(a, s) : L.ds_q ? launch_conv_ds_q(a, s) : launch_conv_ds_m(a, s);    // deconv + its shortcut conv in one K loop
             if (L.wino) {
                 // a.wgt points at the Winograd U image and L.cfg / tiles were never set for this layer: a refused launch must not fall
                 // through to the direct kernels below -- it is a variant-selection bug and says so
@@ -1077,7 +1098,7 @@ int idc_set_option(const char* name, int value) {
     if (strcmp(name, "click") == 0) { g_click = value; return IDC_OK; }
     if (strcmp(name, "winograd") == 0) { g_wino = value != 0; return IDC_OK; }
     if (strcmp(name, "mfma16") == 0) { g_mfma16 = value != 0; return IDC_OK; }
-    if (strcmp(name, "ds_mfma16") == 0) { g_ds_m16 = value != 0; return IDC_OK; }
+    if (strcmp(name, "ds_mfma16") == 0) { g_ds_m16 = value < 0 ? 0 : value > 2 ? 2 : value; return IDC_OK; }   // 0: conv_ds_fused, 1: _m, 2: _q
     if (strcmp(name, "winograd_bf16") == 0) { g_wino_bf16 = value; return IDC_OK; }
     if (strcmp(name, "winograd_deconv") == 0) { g_wino_deconv = value; return IDC_OK; }
     if (strcmp(name, "winograd_form") == 0) { set_wino_form(value); return IDC_OK; }     // 0 automatic, 12 / 21 / 22 = <TB,CB> (tests, tuning)
@@ -1905,7 +1926,7 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
             if (L.fused_short >= 0) {
                 const Layer& P = h->layers[L.fused_short];
                 // the name rocprofv3 shows for this launch (the deconv and its 3x3 shortcut conv in one K loop)
-                snprintf(out->kernel, sizeof(out->kernel), L.m16 ? "conv_ds_fused_m+shortcut" : "conv_ds_fused+shortcut");
+                snprintf(out->kernel, sizeof(out->kernel), !L.m16 ? "conv_ds_fused+shortcut" : L.ds_q ? "conv_ds_fused_q+shortcut" : "conv_ds_fused_m+shortcut");
                 out->flops += P.flops;
                 out->min_bytes += P.min_bytes - 2.0 * (double)h->tensors[P.dst].H * h->tensors[P.dst].W * h->tensors[P.dst].Cpad * eb;
             }
@@ -2034,7 +2055,7 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     L.spec = &spec;
     L.blob.nkc = spec.cin / kc; L.blob.ncg = cout_pad(spec.cout) / kCoutGroup;
     L.blob.w_bytes = (size_t)weight_taps(spec.kind) * L.blob.nkc * L.blob.ncg * kWBlockBytes;
-    L.blob.w_off = 0; L.blob.w2_off = (size_t)-1; L.blob.bias_off = L.blob.bn_scale_off = L.blob.bn_shift_off = L.blob.fbias_off = (size_t)-1;
+    L.blob.w_off = 0; L.blob.w2_off = (size_t)-1; L.blob.w4_off = (size_t)-1; L.blob.bias_off = L.blob.bn_scale_off = L.blob.bn_shift_off = L.blob.fbias_off = (size_t)-1;
     const int cpad = cout_pad(spec.cout);
     // fp32 3x3 stride-1 ops without a shortcut sum take the Winograd kernel exactly as inside the network
     const bool wino_dc = wino_deconv_eligible(spec) && spec.cin % kc == 0;
