@@ -407,6 +407,7 @@ struct Layer {
     ConvConfig cfg{2, 2};
     bool v2 = false;                     // bf16 large-tile kernel (layout-2 weights)
     bool m16 = false;                    // ... its 16x16x32-MFMA build (conv_igemm_v2m, layout-1 weights): set per launch in run_graph
+    bool v2p = false;                    // ... conv_igemm_v2p (padded halo rows, unrolled taps): set per launch in run_graph
     bool ds_q = false;                   // deconv + shortcut launch as conv_ds_fused_q (layout-3 weights): set per launch in run_graph
     bool click = false;                  // batch-1 click-path kernel (conv_click: whole K slice by LDS-DMA)
     bool wino = false;                   // fp32 Winograd F(2x2,3x3) kernel (conv_wino_f32, idc_wino.hip)
@@ -512,6 +513,8 @@ static int g_wino_bf16 = getenv("IDC_WINO_BF16") ? atoi(getenv("IDC_WINO_BF16"))
 static int g_mfma16 = getenv("IDC_MFMA16") ? atoi(getenv("IDC_MFMA16")) : 1;
 // ... and so do the three deconv + shortcut launches (conv_ds_fused_m, idc_dsm.hip; idc_set_option "ds_mfma16" / env IDC_DS_M16=0 for A/B)
 static int g_ds_m16 = getenv("IDC_DS_M16") ? atoi(getenv("IDC_DS_M16")) : 1;
+// ... and the 3x3 convs among them as conv_igemm_v2p (no address arithmetic in the K loop; idc_set_option "v2p" / env IDC_V2P=0 for A/B)
+static int g_v2p = getenv("IDC_V2P") ? atoi(getenv("IDC_V2P")) : 1;
 static int g_click = -1;                 // conv_click for small launches: -1 = environment default (on), 0 off, 1 on (idc_set_option "click")
 // Shortcut fusion (conv_igemm_v2<.,.,1,true>) is correct (parity-tested under tile policy 2) but measured slower
 // than two launches on MI355X (4x re-reads of the skip tensor by the four phase workgroups, VGPR spills around
@@ -927,6 +930,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
         if (L.fused_short < 0) {
             L.m16 = L.v2 && g_mfma16 && L.fused_next < 0 && !L.wino && !L.click && conv_v2m_applies(a);
             if (L.m16) a.wgt = c->d_blob + L.blob.w_off;            // the layout-1 image (the one conv_igemm / conv_click read)
+            L.v2p = L.m16 && g_v2p && conv_v2p_applies(L.cfg, L.halo, a);
         }
         tic();
         {
@@ -949,7 +953,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             }
             if (le == hipErrorInvalidConfiguration)
                 le = L.click ? launch_conv_click(c->precision, L.cfg.wp, L.halo, a, s)
-                   : L.v2 ? (L.m16 ? launch_conv_v2m(L.cfg, L.halo, a, s) : launch_conv_v2(L.cfg, L.halo, a, s))
+                   : L.v2 ? (L.v2p ? launch_conv_v2p(L.cfg, L.halo, a, s) : L.m16 ? launch_conv_v2m(L.cfg, L.halo, a, s) : launch_conv_v2(L.cfg, L.halo, a, s))
                           : launch_conv(c->precision, L.cfg, L.halo, a, s);
             HIPCHK(c, le);
         }
@@ -1098,6 +1102,7 @@ int idc_set_option(const char* name, int value) {
     if (strcmp(name, "click") == 0) { g_click = value; return IDC_OK; }
     if (strcmp(name, "winograd") == 0) { g_wino = value != 0; return IDC_OK; }
     if (strcmp(name, "mfma16") == 0) { g_mfma16 = value != 0; return IDC_OK; }
+    if (strcmp(name, "v2p") == 0) { g_v2p = value != 0; return IDC_OK; }
     if (strcmp(name, "ds_mfma16") == 0) { g_ds_m16 = value < 0 ? 0 : value > 2 ? 2 : value; return IDC_OK; }   // 0: conv_ds_fused, 1: _m, 2: _q
     if (strcmp(name, "winograd_bf16") == 0) { g_wino_bf16 = value; return IDC_OK; }
     if (strcmp(name, "winograd_deconv") == 0) { g_wino_deconv = value; return IDC_OK; }
@@ -1910,7 +1915,7 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
             snprintf(out->kernel, sizeof(out->kernel), L.wino ? (L.spec->kind == kDeconv4x4 ? (h->precision == IDC_BF16 ? "conv_wino_deconv_bf16" : "conv_wino_deconv_f32") : h->precision == IDC_BF16 ? "conv_wino_bf16" : "conv_wino_f32") : L.click ? (h->precision == IDC_BF16 ? "conv_click<bf16,%d,%d>" : "conv_click<f32,%d,%d>")
                      : L.v2 ? "conv_igemm_v2<%d,%d>" : (h->precision == IDC_BF16 ? "conv_igemm<bf16,%d,%d>" : "conv_igemm<f32,%d,%d>"),
                      L.cfg.wm, L.cfg.wp);
-            if (L.m16) strncat(out->kernel, "+m16", sizeof(out->kernel) - strlen(out->kernel) - 1);
+            if (L.m16) strncat(out->kernel, L.v2p ? "+m16p" : "+m16", sizeof(out->kernel) - strlen(out->kernel) - 1);
             if (L.fused_head) strncat(out->kernel, "+head", sizeof(out->kernel) - strlen(out->kernel) - 1);
             if (L.args.ksplit > 1) {
                 char sk[16]; snprintf(sk, sizeof(sk), " splitK%d", L.args.ksplit);
@@ -2124,8 +2129,9 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
         return fail(nullptr, IDC_ERR_INTERNAL, "single op: Winograd variant selected for a launch it does not cover");
     if (L.m16 && !conv_v2m_applies(a))
         return fail(nullptr, IDC_ERR_INTERNAL, "single op: conv_igemm_v2m selected for a launch it does not cover");
+    L.v2p = L.m16 && g_v2p && conv_v2p_applies(L.cfg, L.halo, a);
     HIPCHK(nullctx, L.wino ? (wino_dc ? launch_deconv_wino(precision, a, nullptr) : launch_conv_wino(precision, a, nullptr)) : L.click ? launch_conv_click(precision, L.cfg.wp, L.halo, a, nullptr)
-                    : L.v2 ? (L.m16 ? launch_conv_v2m(L.cfg, L.halo, a, nullptr) : launch_conv_v2(L.cfg, L.halo, a, nullptr))
+                    : L.v2 ? (L.v2p ? launch_conv_v2p(L.cfg, L.halo, a, nullptr) : L.m16 ? launch_conv_v2m(L.cfg, L.halo, a, nullptr) : launch_conv_v2(L.cfg, L.halo, a, nullptr))
                            : launch_conv(precision, L.cfg, L.halo, a, nullptr));
     if (a.ksplit > 1) HIPCHK(nullctx, launch_splitk_epilogue(precision, a, nullptr));
     HIPCHK(nullctx, launch_nhwc_to_nchw(io_bf16, d_yn.p, (float*)d_y.p, n, spec.cout, Ho, Wo, cpad, nullptr));

@@ -78,6 +78,9 @@ hipError_t launch_conv_v2(ConvConfig cfg, int halo, const ConvArgs& a, hipStream
 // hipErrorInvalidConfiguration.
 hipError_t launch_conv_v2m(ConvConfig cfg, int halo, const ConvArgs& a, hipStream_t s);
 bool conv_v2m_applies(const ConvArgs& a);
+// ... and its 3x3 form without address arithmetic in the K loop (conv_igemm_v2p: padded halo rows, unrolled taps, buffer loads)
+hipError_t launch_conv_v2p(ConvConfig cfg, int halo, const ConvArgs& a, hipStream_t s);
+bool conv_v2p_applies(ConvConfig cfg, int halo, const ConvArgs& a);
 hipError_t init_kernels_v2m();
 // ConvTranspose 4x4 s2 + the 3x3 shortcut conv it is summed with, one K loop (conv_ds_fused); a.in2 / wgt2 / nkc2 = the
 // shortcut's input, layout-2 weights and channel chunks, a.bias = the two biases added.  hipErrorInvalidConfiguration if

@@ -341,6 +341,330 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2m(const ConvArg
     }
 }
 
+// ================================================================================================
+// conv_igemm_v2p<WCO, WPX, D> -- conv_igemm_v2m for the 3x3 convolutions (dilation D = 1 | 2) with NO address arithmetic in the K loop
+// (the per-tap address update and re-swizzle priced at 3 % of the loop at the power cap, profiles/r03_mix_probe_mfma16.txt).
+//   * halo rows (128 bytes of channels) sit at a 144-BYTE PITCH instead of being XOR-swizzled: 144 = 9 x 16 with 9 odd, so the 16
+//     consecutive rows of a B fragment fall on 16 different 16-byte bank groups whatever row they start at -- conflict-free like the
+//     swizzled tile, but the address of (tap, pixel row, 16-site half, k32 half) is ONE lane base plus a compile-time offset
+//     (ds_read_b128's immediate field): the nine taps are unrolled and set_xb / xaddr ^ kk disappear;
+//   * halo rows come through buffer loads: 32-bit offsets, the hardware bounds check returns zeros for out-of-image rows (offset
+//     2^31) -- no zero page select, no 64-bit address pairs, no branch per row;
+//   * A fragments: two lane constants (k32 halves) plus the ring slot's base.
+// Everything else is conv_igemm_v2m: tile, LDS-DMA weight ring (2 slots, one tap ahead), stage plan, epilogues.  LDS: +12.5 % for the
+// halo tile (<2,2>, D = 1: 79.8 KiB -- still two workgroups per CU).
+// ================================================================================================
+constexpr int kV2pPitch = 144;
+
+template <int WCO, int WPX, int D>
+__global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArgs a) {
+    constexpr int NT = WCO * WPX * 64;
+    constexpr int TW = 32, TH = 4 * WPX, HALO = D;
+    constexpr int HWP = TW + 2 * HALO, HHP = TH + 2 * HALO, HROWS = HWP * HHP, HP = kV2pPitch;
+    constexpr int BN = 64 * WCO;
+    constexpr int W_BYTES = BN * kRowBytes;
+    constexpr int N_HITEMS = (HROWS * kSlots + NT - 1) / NT;
+    constexpr int HALO_BYTES = HROWS * HP;
+    constexpr int N_WITEMS = (W_BYTES / kSlotBytes) / NT;
+    static_assert((W_BYTES / kSlotBytes) % NT == 0, "weight tile must split evenly");
+    static_assert(NT % 8 == 0, "halo items: 8 slots per row");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const halo = smem;
+    char* const wbuf = smem + HALO_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave % WCO, wpx = wave / WCO;
+    const int r16 = lane & 15, g16 = lane >> 4;
+
+    int b = xcd_remap_m(blockIdx.x, gridDim.x);
+    const int nct = a.ncg / WCO;
+    const int ct = b % nct; b /= nct;
+    const int txi = b % a.tiles_x; b /= a.tiles_x;
+    const int tyi = b % a.tiles_y;
+    const int n = b / a.tiles_y;
+    const int ty0 = tyi * TH, tx0 = txi * TW;
+    const int Hs = a.Hs, Ws = a.Ws;
+    const int nkc = a.nkc, si = a.si;
+    const size_t w_kc_stride = (size_t)a.ncg * kWBlockBytes;
+    const size_t w_tap_stride = (size_t)nkc * w_kc_stride;
+    const char* const wb = (const char*)a.wgt + (size_t)(ct * WCO) * kWBlockBytes + (size_t)tid * kSlotBytes;
+    const int pix_bytes = nkc * kRowBytes, Win = Ws * si;
+    const char* const img = (const char*)a.in + (size_t)n * (size_t)(Hs * si) * Win * (size_t)pix_bytes;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)img, 0, (Hs * si) * Win * pix_bytes, 0x00020000);
+
+    f32x4 acc[4][8];
+    {
+        const float* const bp = a.bias + (ct * WCO + wco) * kCoutGroup + g16 * 16;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const float4 bq = *(const float4*)(bp + mi * 4);
+            const f32x4 b4 = f32x4{bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+            for (int pt = 0; pt < 8; ++pt) acc[mi][pt] = b4;
+        }
+    }
+
+    auto dma_w = [&](int t, int kc, int slot_byte) {           // slot_byte: 0 | W_BYTES
+        const char* src = wb + (size_t)t * w_tap_stride + (size_t)kc * w_kc_stride;
+        char* dst = wbuf + slot_byte + wave * 64 * kSlotBytes;
+#pragma unroll
+        for (int j = 0; j < N_WITEMS; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)j * NT * kSlotBytes),
+                                             (__attribute__((address_space(3))) void*)(dst + j * NT * kSlotBytes), 16, 0, 0);
+    };
+    u32x4 hreg[N_HITEMS];
+    auto load_halo = [&](int kc) {                             // row (tid >> 3) + j*NT/8 of the halo tile, 16-byte slot tid & 7 of chunk kc
+        int tid_ = tid;
+        asm volatile("" : "+v"(tid_));
+#pragma unroll
+        for (int j = 0; j < N_HITEMS; ++j) {
+            const int hr = (tid_ >> 3) + j * (NT / 8), sig = tid_ & 7;
+            const int hy = hr / HWP, hx = hr - hy * HWP;
+            const int sy = ty0 - HALO + hy, sx = tx0 - HALO + hx;
+            const bool inside = (unsigned)sy < (unsigned)Hs && (unsigned)sx < (unsigned)Ws && hr < HROWS;
+            const int off = ((sy * si) * Win + sx * si) * pix_bytes + (sig + kc * kSlots) * kSlotBytes;
+            hreg[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, inside ? off : (int)0x80000000, 0, 0));
+        }
+    };
+    auto store_halo = [&]() {
+        char* const dst = halo + (tid >> 3) * HP + (tid & 7) * kSlotBytes;
+#pragma unroll
+        for (int j = 0; j < N_HITEMS; ++j)
+            if (j + 1 < N_HITEMS || tid < HROWS * 8 - (N_HITEMS - 1) * NT) *(u32x4*)(dst + j * (NT / 8) * HP) = hreg[j];
+    };
+
+    load_halo(0);
+    dma_w(0, 0, 0);
+
+    // lane bases: B rows of the wave's first pixel row (+ compile-time (tap, row, half, k32) offsets), A rows of the two k32 halves
+    const int xbase = ((wpx * 4) * HWP + r16) * HP + g16 * kSlotBytes;
+    const int wa0 = (wco * 64 + r16) * kRowBytes + ((g16 ^ swz(r16)) * kSlotBytes);
+    const int wa1 = wa0 ^ (4 * kSlotBytes);
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);              // second-dispatched half of an 8-wave workgroup (as conv_igemm_v2)
+    int buf_off = 0;                                           // byte offset of the ring slot holding the current tap's tile
+
+    for (int kc = 0; kc < nkc; ++kc) {
+        __syncthreads();                                       // previous chunk's halo reads are done
+        store_halo();
+        const bool last_kc = kc + 1 == nkc;
+        auto tap_body = [&](auto t_tag) {
+            constexpr int t = decltype(t_tag)::value;
+            constexpr bool LAST = t == 8;
+            constexpr int dy = (t / 3 - 1) * D, dx = (t % 3 - 1) * D;
+            constexpr int tn = LAST ? 0 : t + 1;
+            const char* const wcur = wbuf + buf_off;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // my pieces of this tap's weight tile landed
+            __syncthreads();                                        // everybody's landed; everybody left the other buffer
+            const char* const a0 = wcur + wa0;
+            const char* const a1 = wcur + wa1;
+            u32x4 wf[4], xlo[4], xhi[4];
+            auto read_b = [&](int kk, int half, u32x4 (&xf)[4]) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    xf[q] = *(const u32x4*)(halo + xbase + ((half * 2 + (q >> 1) + HALO + dy) * HWP + HALO + dx + (q & 1) * 16) * HP + kk * 64);
+            };
+            auto mma4 = [&](int mi, int half, const u32x4 (&xf)[4]) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[mi][half * 4 + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_m, wf[mi]),
+                                                                                    __builtin_bit_cast(bf16x8_m, xf[q]),
+                                                                                    acc[mi][half * 4 + q], 0, 0, 0);
+            };
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) wf[mi] = *(const u32x4*)(a0 + mi * 16 * kRowBytes);
+            read_b(0, 0, xlo);
+            __builtin_amdgcn_sched_barrier(0);
+            // the NEXT step's loads behind this tap's first fragment reads (as conv_igemm_v2m)
+            if constexpr (!LAST) {
+                dma_w(tn, kc, buf_off ^ W_BYTES);
+            } else {
+                if (!last_kc) dma_w(0, kc + 1, buf_off ^ W_BYTES);
+                load_halo(last_kc ? kc : kc + 1);              // (unconditional: every halo register has one definition per trip -- a value
+            }                                                  //  that might survive "in case" would stay live through all nine taps)
+            __builtin_amdgcn_sched_barrier(0);
+            // stage (k32 step 0, pixel rows 0-1): 16 MFMAs over the reads of rows 2-3
+            read_b(0, 1, xhi);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) mma4(mi, 0, xlo);
+#pragma unroll
+            for (int q_ = 0; q_ < 4; ++q_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            // stage (0, rows 2-3): cout block by cout block, its A registers reloaded for step 1 behind its last four MFMAs
+            read_b(1, 0, xlo);
+            mma4(0, 1, xhi); wf[0] = *(const u32x4*)(a1);
+            mma4(1, 1, xhi); wf[1] = *(const u32x4*)(a1 + 16 * kRowBytes);
+            mma4(2, 1, xhi); wf[2] = *(const u32x4*)(a1 + 32 * kRowBytes);
+            mma4(3, 1, xhi); wf[3] = *(const u32x4*)(a1 + 48 * kRowBytes);
+#pragma unroll
+            for (int q_ = 0; q_ < 4; ++q_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int q_ = 0; q_ < 3; ++q_) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            // stage (1, rows 0-1)
+            read_b(1, 1, xhi);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) mma4(mi, 0, xlo);
+#pragma unroll
+            for (int q_ = 0; q_ < 4; ++q_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            // stage (1, rows 2-3)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) mma4(mi, 1, xhi);
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            buf_off ^= W_BYTES;
+        };
+        tap_body(std::integral_constant<int, 0>{}); tap_body(std::integral_constant<int, 1>{}); tap_body(std::integral_constant<int, 2>{});
+        tap_body(std::integral_constant<int, 3>{}); tap_body(std::integral_constant<int, 4>{}); tap_body(std::integral_constant<int, 5>{});
+        tap_body(std::integral_constant<int, 6>{}); tap_body(std::integral_constant<int, 7>{}); tap_body(std::integral_constant<int, 8>{});
+    }
+
+    // ---- epilogue (conv_igemm_v2m's): lane (site r16, group g16) owns couts g16*16 + mi*4 + j of its wave's 64 ----------------------
+    const int CoutPad = a.ncg * kCoutGroup;
+    const bool has_bn = a.bn_scale != nullptr;
+    const int cow = (ct * WCO + wco) * kCoutGroup;
+    __syncthreads();                                           // every wave left the halo / weight tiles
+    if (WCO == 2 && a.head_w != nullptr) {
+        f32x4 w0[4], w1[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const float4 u = *(const float4*)(a.head_w + cow + g16 * 16 + mi * 4);
+            const float4 v = *(const float4*)(a.head_w + 128 + cow + g16 * 16 + mi * 4);
+            w0[mi] = f32x4{u.x, u.y, u.z, u.w};
+            w1[mi] = f32x4{v.x, v.y, v.z, v.w};
+        }
+        float* const hp = (float*)smem;                        // [wave][pt 8][group 4][16 sites][2]
+#pragma unroll
+        for (int pt = 0; pt < 8; ++pt) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = acc[mi][pt][j];
+                    if (a.act == 1) v = fmaxf(v, 0.f);
+                    else if (a.act == 2) v = fmaxf(v, 0.2f * v);
+                    s0 = fmaf(v, w0[mi][j], s0);
+                    s1 = fmaf(v, w1[mi][j], s1);
+                }
+            *(float2*)(hp + ((((wave * 8 + pt) * 4 + g16) * 16 + r16) * 2)) = float2{s0, s1};
+        }
+        __syncthreads();
+        if (wco == 0) {
+            const int px = lane & 31, ch = lane >> 5;
+            const float hb = a.head_b[ch];
+#pragma unroll
+            for (int pj = 0; pj < 4; ++pj) {
+                float p = hb;
+#pragma unroll
+                for (int w2 = 0; w2 < 2; ++w2)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        p += hp[(((((wave + w2) * 8 + pj * 2 + (px >> 4)) * 4 + g) * 16 + (px & 15)) * 2) + ch];
+                const int sy = ty0 + wpx * 4 + pj, sx = tx0 + px;
+                if (sy < Hs && sx < Ws) a.head_out[(((size_t)n * 2 + ch) * Hs + sy) * Ws + sx] = tanhf(p) * a.head_mul;
+            }
+        }
+        return;
+    }
+    char* const tb16 = smem + wave * 4096;
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    const int rr = lane >> 3, cc = lane & 7;
+    const int co8 = cow + cc * 8;
+    f32x4 bsc[4], bsh[4];
+    if (has_bn) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const float4 s4 = *(const float4*)(a.bn_scale + cow + g16 * 16 + mi * 4);
+            const float4 t4 = *(const float4*)(a.bn_shift + cow + g16 * 16 + mi * 4);
+            bsc[mi] = f32x4{s4.x, s4.y, s4.z, s4.w};
+            bsh[mi] = f32x4{t4.x, t4.y, t4.z, t4.w};
+        }
+    }
+#pragma unroll
+    for (int pj = 0; pj < 4; ++pj) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int pt = pj * 2 + hf, site = hf * 16 + r16;
+            unsigned pk[8];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    float v0 = acc[mi][pt][2 * e], v1 = acc[mi][pt][2 * e + 1];
+                    if (has_bn) {
+                        if (a.act == 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                        pk[mi * 2 + e] = pack_bf16x2_m(fmaf(v0, bsc[mi][2 * e], bsh[mi][2 * e]), fmaf(v1, bsc[mi][2 * e + 1], bsh[mi][2 * e + 1]));
+                    } else {
+                        unsigned p = pack_bf16x2_m(v0, v1);
+                        if (a.act == 1) p = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), s16x2{0, 0}));
+                        pk[mi * 2 + e] = p;
+                    }
+                }
+            const int s0 = g16 * 2;
+            *(uint4*)(tb16 + site * 128 + ((s0 ^ (site & 7)) * 16)) = uint4{pk[0], pk[1], pk[2], pk[3]};
+            *(uint4*)(tb16 + site * 128 + (((s0 + 1) ^ (site & 7)) * 16)) = uint4{pk[4], pk[5], pk[6], pk[7]};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int sy = ty0 + wpx * 4 + pj;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = i * 8 + rr;
+            const uint4 o = *(const uint4*)(tb16 + row * 128 + ((cc ^ (row & 7)) * 16));
+            const int sx = tx0 + row;
+            if (sy < Hs && sx < Ws) {
+                const size_t oidx = (((size_t)n * Hs + sy) * Ws + sx) * CoutPad + co8;
+                *(uint4*)((unsigned short*)a.out + oidx) = o;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+static constexpr size_t conv_v2p_lds_bytes_c(int wco, int wpx, int d) {
+    return (size_t)(32 + 2 * d) * (4 * wpx + 2 * d) * kV2pPitch + 2 * (size_t)(64 * wco) * kRowBytes;
+}
+
+#define IDC_FOR_EACH_CONV_V2P(X) X(4, 2, 1) X(4, 2, 2) X(2, 2, 1)
+
+// 3x3 convs (so = 1, one phase, nine taps in ky*3 + kx order with offsets (ky-1, kx-1) * D) that conv_igemm_v2m covers
+bool conv_v2p_applies(ConvConfig cfg, int halo, const ConvArgs& a) {
+    if (!conv_v2m_applies(a) || a.nphase != 1 || a.ntaps != 9 || a.so != 1 || (halo != 1 && halo != 2)) return false;
+    if (!((cfg.wm == 4 && cfg.wp == 2) || (cfg.wm == 2 && cfg.wp == 2 && halo == 1))) return false;
+    for (int t = 0; t < 9; ++t)
+        if (a.dy[t] != (t / 3 - 1) * halo || a.dx[t] != (t % 3 - 1) * halo || a.tw[t] != t) return false;
+    // buffer loads address one image with 32-bit offsets; out-of-image rows use offset 2^31
+    return (long long)a.Hs * a.si * (long long)a.Ws * a.si * ((long long)a.nkc * kRowBytes) < 0x7fffffffLL;
+}
+
+hipError_t launch_conv_v2p(ConvConfig cfg, int halo, const ConvArgs& a, hipStream_t s) {
+    if (!conv_v2p_applies(cfg, halo, a)) return hipErrorInvalidConfiguration;
+    const int nct = a.ncg / cfg.wm;
+    const long long blocks = (long long)a.tiles_x * a.tiles_y * a.N * nct;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+#define X(WCO, WPX, DD)                                                                                                          \
+    if (cfg.wm == WCO && cfg.wp == WPX && halo == DD) {                                                                          \
+        hipLaunchKernelGGL((conv_igemm_v2p<WCO, WPX, DD>), dim3((unsigned)blocks), dim3(WCO * WPX * 64),                         \
+                           conv_v2p_lds_bytes_c(WCO, WPX, DD), s, a);                                                            \
+        return hipGetLastError();                                                                                                \
+    }
+    IDC_FOR_EACH_CONV_V2P(X)
+#undef X
+    return hipErrorInvalidConfiguration;
+}
+
 static constexpr size_t conv_v2m_lds_bytes_c(int wco, int wpx, int halo) {
     const int nt = wco * wpx * 64;
     const int hrows = (32 + 2 * halo) * (4 * wpx + 2 * halo);
@@ -373,6 +697,12 @@ hipError_t launch_conv_v2m(ConvConfig cfg, int halo, const ConvArgs& a, hipStrea
 
 hipError_t init_kernels_v2m() {
     hipError_t e;
+#define X(WCO, WPX, DD)                                                                                                          \
+    e = hipFuncSetAttribute((const void*)conv_igemm_v2p<WCO, WPX, DD>, hipFuncAttributeMaxDynamicSharedMemorySize,               \
+                            (int)conv_v2p_lds_bytes_c(WCO, WPX, DD));                                                            \
+    if (e != hipSuccess) return e;
+    IDC_FOR_EACH_CONV_V2P(X)
+#undef X
 #define X(WCO, WPX, HL)                                                                                                          \
     e = hipFuncSetAttribute((const void*)conv_igemm_v2m<WCO, WPX, HL>, hipFuncAttributeMaxDynamicSharedMemorySize,               \
                             (int)conv_v2m_lds_bytes_c(WCO, WPX, HL));                                                            \

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _reset_options():
     yield
-    for k, v in (("mfma16", 1), ("ds_mfma16", 1), ("conv1_mfma16", 1), ("fuse_conv1", 1)):
+    for k, v in (("mfma16", 1), ("ds_mfma16", 1), ("v2p", 1), ("fuse_conv1", 1)):
         try:
             engine.set_option(k, v)
         except Exception:
@@ -77,3 +77,41 @@ def test_deconv_shortcut_m16_batch_is_per_image(make_sd, shape):
     for i in range(3):
         np.testing.assert_array_equal(e.forward(L[i:i + 1], ab[i:i + 1], m[i:i + 1], 0.0)[0], full[i])
     e.close()
+
+
+V2_LAYERS = ["conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3", "conv4_1", "conv4_2", "conv4_3", "conv5_1", "conv5_2", "conv5_3",
+             "conv6_1", "conv6_2", "conv6_3", "conv7_1", "conv7_2", "conv7_3", "conv8_2", "conv8_3", "conv9_2"]
+
+
+@pytest.mark.parametrize("name", ["net64_he_s0_mc05", "net32x48_he_s2", "net64_torch_s1_mc0"])
+def test_throughput_3x3_tile_without_address_arithmetic(golden, make_sd, name):
+    """conv_igemm_v2p (padded halo rows, nine unrolled taps, buffer loads; default for the 3x3 convs of the large-tile bf16 path:
+    dilation 1 and 2, the stride-2 first-of-block reads, conv10_2's fused head) issues conv_igemm_v2m's MFMAs in conv_igemm_v2m's
+    order on the same operands: every layer and the ab map BIT-identical to `v2p` = 0, both inside the bf16 bounds of the golden."""
+    g = golden(name)
+    style, seed = str(g["weight_style"]), int(g["weight_seed"])
+    n, _, H, W = g["L_mc"].shape
+    sd = make_sd(seed, style)
+    outs, layers = {}, {}
+    for v2p in (1, 0):
+        engine.set_tile_policy("large")
+        engine.set_option("v2p", v2p)
+        e = engine.HipColorizer(H, W, max_batch=n, precision="bf16")
+        e.load_state_dict(sd)
+        outs[v2p] = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
+        table = {r["name"]: r["kernel"] for r in e.layer_table()}
+        # the 256-cout x (32 x 8) and the 4-wave 128-cout tiles have the form (the 8-wave 128-cout tile of tiny grids keeps conv_igemm_v2m)
+        for k in V2_LAYERS + ["conv10_2"]:
+            assert table[k].startswith("conv_igemm_v2<"), (k, table[k])
+            if table[k].startswith("conv_igemm_v2<4,2>") or table[k].startswith("conv_igemm_v2<2,2>"):
+                assert ("+m16p" in table[k]) == bool(v2p), (k, table[k])
+        assert sum("+m16p" in table[k] for k in V2_LAYERS) >= (11 if v2p else 0), table
+        layers[v2p] = {k: e.activation(k, n) for k in V2_LAYERS}
+        e.close()
+    engine.set_option("v2p", 1)
+    for k in V2_LAYERS:
+        np.testing.assert_array_equal(layers[1][k], layers[0][k], err_msg=k)
+    np.testing.assert_array_equal(outs[1], outs[0])
+    bound = (20.0, 2.0) if style == "he" else (0.6, 0.06)
+    d = np.abs(outs[1] - g["out_ab"])
+    assert d.max() <= bound[0] and d.mean() <= bound[1], (d.max(), d.mean())
