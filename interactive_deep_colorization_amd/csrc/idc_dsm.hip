@@ -403,371 +403,6 @@ __global__ __launch_bounds__(512, 2) void conv_ds_fused_m(const ConvArgs a) {
 #endif
 }
 
-// ================================================================================================
-// conv_ds_fused_q -- the same launch as FOUR-wave workgroups of 64 couts, two of them co-resident on a CU.
-//
-// Why: conv_ds_fused(_m) needs all 160 KiB of LDS, so a CU holds ONE workgroup and nothing runs under its prologue (first halo
-// fetch: ~10 k cycles), its S -> D hand-over (~4.5 k) and its store epilogue (~9 k): 28 % of a 69 k-cycle tile at conv10_1's shape
-// (in-kernel stamps, profiles/r02_ds_fused_anatomy_after.txt), on 26 % of the forward.  conv_igemm_v2's 4-wave tile bought 9.5 % on
-// conv10_2 that way (profiles/r02_tile22_ab.txt).  Here the LDS plan has to halve first:
-//   * workgroup = 64 x 8 OUTPUT pixels x 64 couts = 4 PHASE waves (wave ph owns the 32 x 4 sites whose output pixel is (2y + ro,
-//     2x + cof), all 64 couts: the same 4 x 8 accumulator tiles of 16 x 16 as conv_ds_fused_m); grid = tiles x cout groups, cout
-//     group fastest, so the workgroups that share a halo run next to each other on one XCD's L2;
-//   * S part (shortcut conv): the skip tensor's 66 x 10 halo is staged per HALF chunk (32 channels = one k32 MFMA step): 64-byte
-//     rows at an 80-byte pitch -- 16 consecutive rows then fall on 16 different 16-byte bank groups (80 = 5 x 16, 5 odd), so a
-//     B fragment read needs NO swizzle and its address is lane base + compile-time offset for every (tap, pixel row): the K loop
-//     has no address arithmetic at all.  One step = the three kx taps of a kernel row for one half chunk = 96 MFMAs per wave
-//     between workgroup barriers; its three 4 KiB weight tiles ([64 couts][64 B], slot ^ (row >> 2) & 3, gathered out of the
-//     ordinary layout-1 blob by the LDS-DMA's per-lane addresses) sit in a 2-slot ring requested one step ahead;
-//   * D part (deconv): chunk halo in 128-byte rows at a 144-byte pitch (9 x 16: same property), wave-private 4 KiB weight tiles per
-//     (tap, k32 half) on a 3-slot ring requested two steps ahead, no workgroup barrier inside a chunk, waits by counted vmcnt;
-//   * 78.5 KiB of LDS, 256 registers: two workgroups per CU, one wave of each per SIMD, running out of step.
-// Costs accepted: the halo of a pixel tile is staged once per 64 couts (not per 128), and a half-chunk change every 288 MFMAs.
-// ================================================================================================
-constexpr int kDsqSP = 80, kDsqDP = 144;
-constexpr int kDsqSHalo = 660 * kDsqSP, kDsqSTap = 64 * 64, kDsqSTile = 3 * kDsqSTap;
-constexpr int kDsqDHalo = 204 * kDsqDP, kDsqDTile = 64 * 64, kDsqDRing = 3;
-constexpr int kDsqLds = (kDsqSHalo + 2 * kDsqSTile) > (kDsqDHalo + 4 * kDsqDRing * kDsqDTile) ? (kDsqSHalo + 2 * kDsqSTile)
-                                                                                            : (kDsqDHalo + 4 * kDsqDRing * kDsqDTile);
-static_assert(2 * kDsqLds <= 160 * 1024, "two workgroups per CU");
-
-template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-__global__ __launch_bounds__(256, 2) void conv_ds_fused_q(const ConvArgs a) {
-    constexpr int NT = 256;
-    constexpr int SW = 66, SROWS = 10 * SW, SP = kDsqSP, S_ITEMS = (SROWS * 4 + NT - 1) / NT;     // 11 x 16 B per thread and half chunk
-    constexpr int DW = 34, DROWS = 6 * DW, DP = kDsqDP, D_ITEMS = (DROWS * 8 + NT - 1) / NT;     // 7
-    constexpr int S_TAP = kDsqSTap, S_TILE = kDsqSTile, D_TILE = kDsqDTile;
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const halo = smem;
-    char* const ringS = smem + kDsqSHalo;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int ph = __builtin_amdgcn_readfirstlane(tid >> 6);
-    char* const ringD = smem + kDsqDHalo + ph * (kDsqDRing * D_TILE);
-    const int r16 = lane & 15, g16 = lane >> 4;
-    const int Hs = a.Hs, Ws = a.Ws;                            // deconv input (= site) resolution; output is 2x
-    const int ntx = (Ws + 31) >> 5, nty = (Hs + 3) >> 2, ncg = a.ncg;
-    int b = xcd_remap_d(blockIdx.x, gridDim.x);
-    const int cg = b % ncg; b /= ncg;
-    const int txi = b % ntx; b /= ntx;
-    const int tyi = b % nty;
-    const int n = b / nty;
-    const int y0 = tyi * 4, x0 = txi * 32;
-    const int ro = a.ro[ph], cof = a.co[ph];
-    const int nkc = a.nkc, nkc2 = a.nkc2, nhc2 = 2 * nkc2;
-    const int pixD = nkc * kRowBytes, pixS = nkc2 * kRowBytes;
-    const char* const imgD = (const char*)a.in + (size_t)n * Hs * Ws * pixD;
-    const char* const imgS = (const char*)a.in2 + (size_t)n * (4 * (size_t)Hs * Ws) * pixS;
-    IDC_DSTAMP(0);
-
-    f32x4 acc[4][8];
-    {
-        const float* const bp = a.bias + cg * kCoutGroup + g16 * 16;
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const float4 bq = *(const float4*)(bp + mi * 4);
-            const f32x4 b4 = f32x4{bq.x, bq.y, bq.z, bq.w};
-#pragma unroll
-            for (int pt = 0; pt < 8; ++pt) acc[mi][pt] = b4;
-        }
-    }
-
-    u32x4 hreg[S_ITEMS], hregD[D_ITEMS];                      // (two arrays: two sets of live ranges for the register allocator)
-    // Halo rows come through buffer loads: a 32-bit byte offset into ONE image per descriptor, and the hardware's bounds check returns
-    // zeros for the offset 2^31 given to out-of-image rows -- no zero page, no 64-bit address pairs, no branch per row.
-    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)imgS, 0, 4 * Hs * Ws * pixS, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)imgD, 0, Hs * Ws * pixD, 0x00020000);
-    // half chunk `hc2` (0 .. 2*nkc2-1: 32 channels) of the skip tensor's halo -> registers; row hr = (tid >> 2) + 64 j, 16-byte slot tid & 3
-    auto load_halo_S = [&](int hc2) {
-        int tid_ = tid;
-        asm volatile("" : "+v"(tid_));
-#pragma unroll
-        for (int j = 0; j < S_ITEMS; ++j) {
-            const int hr = (tid_ >> 2) + j * (NT / 4), g = tid_ & 3;
-            const int hy = hr / SW, rem = hr - hy * SW;
-            const int par = rem >= 33 ? 1 : 0, hx = 2 * (rem - par * 33) + par;
-            const int Y = 2 * y0 - 1 + hy, X = 2 * x0 - 1 + hx;
-            const bool inside = (unsigned)Y < (unsigned)(2 * Hs) && (unsigned)X < (unsigned)(2 * Ws) && hr < SROWS;
-            const int off = (Y * (2 * Ws) + X) * pixS + (hc2 * 4 + g) * kSlotBytes;
-            hreg[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsS, inside ? off : (int)0x80000000, 0, 0));
-        }
-    };
-    auto store_halo_S = [&]() {
-        char* const dst = halo + (tid >> 2) * SP + (tid & 3) * kSlotBytes;
-#pragma unroll
-        for (int j = 0; j < S_ITEMS; ++j)
-            if (j + 1 < S_ITEMS || tid < SROWS * 4 - (S_ITEMS - 1) * NT) *(u32x4*)(dst + j * (NT / 4) * SP) = hreg[j];
-    };
-    // chunk kc of the deconv input's 34 x 6 halo -> registers (real = false: nothing but zeros, so that the vmcnt counts of the D loop
-    // do not depend on whether a next chunk exists); row (tid >> 3) + 32 j, slot tid & 7
-    auto load_halo_D = [&](int kc, bool real) {
-        int tid_ = tid;
-        asm volatile("" : "+v"(tid_));
-#pragma unroll
-        for (int j = 0; j < D_ITEMS; ++j) {
-            const int hr = (tid_ >> 3) + j * (NT / 8), sig = tid_ & 7;
-            const int hy = hr / DW, hx = hr - hy * DW;
-            const int Y = y0 - 1 + hy, X = x0 - 1 + hx;
-            const bool inside = real && (unsigned)Y < (unsigned)Hs && (unsigned)X < (unsigned)Ws && hr < DROWS;
-            const int off = (Y * Ws + X) * pixD + (sig + kc * kSlots) * kSlotBytes;
-            hregD[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsD, inside ? off : (int)0x80000000, 0, 0));
-        }
-    };
-    auto store_halo_D = [&]() {
-        char* const dst = halo + (tid >> 3) * DP + (tid & 7) * kSlotBytes;
-#pragma unroll
-        for (int j = 0; j < D_ITEMS; ++j)
-            if (j + 1 < D_ITEMS || tid < DROWS * 8 - (D_ITEMS - 1) * NT) *(u32x4*)(dst + j * (NT / 8) * DP) = hregD[j];
-    };
-
-    // A fragment of cout block mi out of a [64 rows][64 B] tile whose 16-byte slots are swizzled by (row >> 2) & 3: lane constant + mi KiB
-    const int aoff = r16 * 64 + ((g16 ^ (r16 >> 2)) * kSlotBytes);
-    u32x4 wf[4], xlo[4], xhi[4];
-    auto mma4 = [&](int mi, int half, const u32x4 (&xf)[4]) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            acc[mi][half * 4 + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_d, wf[mi]),
-                                                                            __builtin_bit_cast(bf16x8_d, xf[q]),
-                                                                            acc[mi][half * 4 + q], 0, 0, 0);
-    };
-#define IDC_DSQ_STAGE_A()                                                             \
-    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                               \
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                            \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
-    }
-#define IDC_DSQ_STAGE_B()                                                             \
-    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                               \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
-    }                                                                                 \
-    _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_) {                               \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                            \
-    }                                                                                 \
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-
-    // ---------------------------------------------------------------- S part: 3x3 conv of the skip tensor, half chunk by half chunk
-    // weight tile of (tap, half chunk hc2) = one contiguous 4 KiB block of the layout-3 image (idc_layout.h): every thread brings 16 bytes
-    auto dma_S = [&](int ky, int hc2, int slot, bool real) {
-        int tid_ = tid;
-        asm volatile("" : "+v"(tid_));                         // (keeps the per-step 64-bit source addresses out of the loop-invariant set)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const char* src = real ? (const char*)a.wgt2 + (((size_t)(ky * 3 + kx) * nhc2 + hc2) * ncg + cg) * kW3BlockBytes + tid_ * kSlotBytes
-                                   : (const char*)a.zeros + (tid_ & 15) * kSlotBytes;
-            char* dst = ringS + slot * S_TILE + kx * S_TAP + ph * 64 * kSlotBytes;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        }
-    };
-    // B rows: output x = 2*xs + cof reads skip x + kx - 1 = halo column 2*xs + c, c = cof + kx: parity section c & 1, shift c >> 1
-    int xb[3];
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-        const int c = cof + kx;
-        xb[kx] = (ro * SW + (c & 1) * 33 + (c >> 1) + r16) * SP + g16 * kSlotBytes;
-    }
-    auto read_b_S = [&](int ky, int kx, int half, u32x4 (&xf)[4]) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            xf[q] = *(const u32x4*)(halo + xb[kx] + ((2 * (half * 2 + (q >> 1)) + ky) * SW + (q & 1) * 16) * SP);
-    };
-
-    load_halo_S(0);
-    dma_S(0, 0, 0, true);
-    store_halo_S();
-    IDC_DSTAMP(1);
-    // one step = kernel row ky (three kx taps) of half chunk hc2; step index hc2*3 + ky -> ring slot (hc2 + ky) & 1.  The last half
-    // chunk is a second instance (MORE = false): its rows' successor is the deconv input's first chunk, and nothing is stored after it
-    // (as two instances every halo register has ONE definition per path: no value has to survive a half chunk "just in case").
-    auto half_chunk = [&](int hc2, auto more_tag) {
-        constexpr bool MORE = decltype(more_tag)::value;
-        auto step = [&](auto ky_tag) {
-            constexpr int ky = decltype(ky_tag)::value;
-            const int slot = (hc2 + ky) & 1;
-            const char* const wcur = ringS + slot * S_TILE + aoff;
-            // my pieces of this step's tile: everything but the halo loads issued at the end of step ky = 1
-            if constexpr (ky == 2) wait_vm<MORE ? S_ITEMS : D_ITEMS>();
-            else wait_vm<0>();
-            __syncthreads();                                    // everybody's: tile (and new halo rows) visible; everybody left the other slot
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) wf[mi] = *(const u32x4*)(wcur + mi * 1024);
-            read_b_S(ky, 0, 0, xlo);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (ky < 2) dma_S(ky + 1, hc2, slot ^ 1, true);   // next step's tile
-            else dma_S(0, hc2 + 1, slot ^ 1, MORE);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                read_b_S(ky, kx, 1, xhi);
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi) mma4(mi, 0, xlo);
-                IDC_DSQ_STAGE_A()
-                if (kx < 2) {
-                    read_b_S(ky, kx + 1, 0, xlo);
-                    const char* const wn = wcur + (kx + 1) * S_TAP;
-                    mma4(0, 1, xhi); wf[0] = *(const u32x4*)(wn);
-                    mma4(1, 1, xhi); wf[1] = *(const u32x4*)(wn + 1024);
-                    mma4(2, 1, xhi); wf[2] = *(const u32x4*)(wn + 2048);
-                    mma4(3, 1, xhi); wf[3] = *(const u32x4*)(wn + 3072);
-                    IDC_DSQ_STAGE_B()
-                } else {
-#pragma unroll
-                    for (int mi = 0; mi < 4; ++mi) mma4(mi, 1, xhi);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (ky == 1) {
-                // the next half chunk's rows (or the deconv input's first chunk), requested behind this step's last MFMAs -- no
-                // fragment register is live here -- and stored after the next step (counted waits)
-                if constexpr (MORE) load_halo_S(hc2 + 1);
-                else load_halo_D(0, true);
-            }
-            if constexpr (ky == 2 && MORE) {
-                __syncthreads();                                // everybody is done with this half chunk's rows
-                store_halo_S();                                 // (published by the next step's barrier)
-            }
-        };
-        step(std::integral_constant<int, 0>{});
-        step(std::integral_constant<int, 1>{});
-        step(std::integral_constant<int, 2>{});
-    };
-    for (int hc2 = 0; hc2 + 1 < nhc2; ++hc2) half_chunk(hc2, std::true_type{});
-    half_chunk(nhc2 - 1, std::false_type{});
-    wait_vm<0>();                                              // the trailing zero-page request targets LDS the D part reuses
-    // ---------------------------------------------------------------- hand-over: the D part reuses the LDS
-    IDC_DSTAMP(8);
-    const int* const tdy = a.dy + ph * 9;
-    const int* const tdx = a.dx + ph * 9;
-    const int* const ttw = a.tw + ph * 9;
-    // B rows of the phase's four taps (lane base per tap; pixel row / k32 half / 16-site half are compile-time offsets)
-    int xa[4], twt[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        xa[t] = ((1 + tdy[t]) * DW + 1 + tdx[t] + r16) * DP + g16 * kSlotBytes;
-        twt[t] = ttw[t];
-    }
-    // wave-private weight tile of (tap, chunk, k32 half kk): 4 KiB of the layout-3 image, four 1 KiB requests
-    auto dma_D = [&](int st, int slot_byte) {                  // step st = (kc, t, kk) = (st >> 3, (st >> 1) & 3, st & 1)
-        const bool real = st < 8 * nkc;
-        const int kc = st >> 3, t = (st >> 1) & 3, kk = st & 1;
-        const int tw = t == 0 ? twt[0] : t == 1 ? twt[1] : t == 2 ? twt[2] : twt[3];
-        int lane_ = lane;
-        asm volatile("" : "+v"(lane_));
-        const char* src = real ? (const char*)a.wgt + ((((size_t)tw * nkc + kc) * 2 + kk) * ncg + cg) * kW3BlockBytes + lane_ * kSlotBytes
-                               : (const char*)a.zeros + (lane_ & 15) * kSlotBytes;
-        const int jstep = real ? 64 * kSlotBytes : 0;
-        char* dst = ringD + slot_byte;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * jstep),
-                                             (__attribute__((address_space(3))) void*)(dst + j * 64 * kSlotBytes), 16, 0, 0);
-    };
-    auto read_b_D = [&](int t, int kk, int half, u32x4 (&xf)[4]) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            xf[q] = *(const u32x4*)(halo + xa[t] + ((half * 2 + (q >> 1)) * DW + (q & 1) * 16) * DP + kk * 64);
-    };
-    __syncthreads();                                           // every wave left the S halo and ring
-    store_halo_D();
-    int s_cur = 0, s_nxt = D_TILE, s_free = 2 * D_TILE;        // ring slots (byte offsets) of steps st, st+1, st+2
-    dma_D(0, s_cur);
-    dma_D(1, s_nxt);
-    wait_vm<4>();                                              // tile 0 landed (tile 1 may still be in flight)
-    __syncthreads();                                           // halo chunk 0 visible
-    IDC_DSTAMP(9);
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) wf[mi] = *(const u32x4*)(ringD + s_cur + aoff + mi * 1024);
-    read_b_D(0, 0, 0, xlo);
-    // ---------------------------------------------------------------- D part: the wave's deconv phase, 2x2 taps x k32 halves
-    for (int kc = 0; kc < nkc; ++kc) {
-        const bool more = kc + 1 < nkc;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int st = kc * 8 + t * 2 + kk;
-                dma_D(st + 2, s_free);                          // (slot of step st-1: all of its fragments were consumed a step ago)
-                if (t == 3 && kk == 0) load_halo_D(kc + 1, more);   // next chunk's rows wait in registers (zero page when there is none)
-                read_b_D(t, kk, 1, xhi);
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi) mma4(mi, 0, xlo);
-                IDC_DSQ_STAGE_A()
-                // tile st+1 landed?  issued after it: this step's request (4) and, in the chunk's last two steps, the D_ITEMS halo loads
-                if (t == 3) wait_vm<4 + D_ITEMS>(); else wait_vm<4>();
-                {
-                    const int tn = kk == 1 ? (t + 1) & 3 : t, kn = kk ^ 1;
-                    read_b_D(tn, kn, 0, xlo);                   // (across a chunk change: read again below)
-                    const char* const wn = ringD + s_nxt + aoff;
-                    mma4(0, 1, xhi); wf[0] = *(const u32x4*)(wn);
-                    mma4(1, 1, xhi); wf[1] = *(const u32x4*)(wn + 1024);
-                    mma4(2, 1, xhi); wf[2] = *(const u32x4*)(wn + 2048);
-                    mma4(3, 1, xhi); wf[3] = *(const u32x4*)(wn + 3072);
-                    IDC_DSQ_STAGE_B()
-                }
-                { const int o_ = s_cur; s_cur = s_nxt; s_nxt = s_free; s_free = o_; }
-                if (t == 3 && kk == 1 && more) {
-                    wait_vm<4>();                               // the halo rows landed (the one request issued after them may fly on)
-                    __syncthreads();                            // every wave is done with halo chunk kc
-                    store_halo_D();
-                    __syncthreads();
-                    read_b_D(0, 0, 0, xlo);
-                }
-            }
-        }
-    }
-    wait_vm<0>();                                              // (the zero-page requests of the last two steps target this ring)
-#undef IDC_DSQ_STAGE_A
-#undef IDC_DSQ_STAGE_B
-    // ---------------------------------------------------------------- epilogue: (ReLU,) round, transpose, whole-line stores
-    IDC_DSTAMP(2);
-    __syncthreads();
-    char* const tb16 = smem + ph * 4096;
-    typedef short s16x2 __attribute__((ext_vector_type(2)));
-    const int rr = lane >> 3, cc = lane & 7;
-    const int CoutPad = ncg * kCoutGroup;
-    const int co8 = cg * kCoutGroup + cc * 8;
-    const int Wout = 2 * Ws, Hout = 2 * Hs;
-#pragma unroll
-    for (int pj = 0; pj < 4; ++pj) {
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            const int pt = pj * 2 + hf, site = hf * 16 + r16;
-            unsigned pk[8];
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    unsigned p = pack_bf16x2_d(acc[mi][pt][2 * e], acc[mi][pt][2 * e + 1]);
-                    if (a.act == 1) p = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), s16x2{0, 0}));
-                    pk[mi * 2 + e] = p;
-                }
-            const int s0 = g16 * 2;
-            *(uint4*)(tb16 + site * 128 + ((s0 ^ (site & 7)) * 16)) = uint4{pk[0], pk[1], pk[2], pk[3]};
-            *(uint4*)(tb16 + site * 128 + (((s0 + 1) ^ (site & 7)) * 16)) = uint4{pk[4], pk[5], pk[6], pk[7]};
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int sy = y0 + pj;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = i * 8 + rr;
-            const uint4 o = *(const uint4*)(tb16 + row * 128 + ((cc ^ (row & 7)) * 16));
-            const int sx = x0 + row;
-            if (sy < Hs && sx < Ws)
-                *(uint4*)((unsigned short*)a.out + (((size_t)n * Hout + (2 * sy + ro)) * Wout + (2 * sx + cof)) * CoutPad + co8) = o;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    IDC_DSTAMP(3);
-#ifdef IDC_TIMING
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    IDC_DSTAMP(4);
-#endif
-}
-
 // deconv 4x4 s2 + its 3x3 shortcut conv in one launch, 16x16x32 MFMA: bf16, Cout a multiple of 128, (ReLU | none), no BN.
 // a.wgt / a.wgt2 = the LAYOUT-1 images of the deconv / the shortcut conv.
 hipError_t launch_conv_ds_m(const ConvArgs& a, hipStream_t s) {
@@ -780,20 +415,7 @@ hipError_t launch_conv_ds_m(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// the four-wave form (conv_ds_fused_q): Cout a multiple of 64; a.wgt / a.wgt2 = the LAYOUT-3 images (k32-major 4 KiB tiles)
-hipError_t launch_conv_ds_q(const ConvArgs& a, hipStream_t s) {
-    if (a.in2 == nullptr || a.wgt2 == nullptr || a.zeros == nullptr || a.nphase != 4 || a.so != 2 || a.si != 1 || a.out_f32 ||
-        a.bn_scale != nullptr || a.act == 2 || a.img_shift != nullptr || a.resid != nullptr || a.head_w != nullptr || a.nkc < 1 || a.nkc2 < 1)
-        return hipErrorInvalidConfiguration;
-    const long long blocks = (long long)((a.Ws + 31) / 32) * ((a.Hs + 3) / 4) * a.N * a.ncg;
-    if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(conv_ds_fused_q, dim3((unsigned)blocks), dim3(256), kDsqLds, s, a);
-    return hipGetLastError();
-}
-
 hipError_t init_kernels_dsm() {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_ds_fused_q, hipFuncAttributeMaxDynamicSharedMemorySize, kDsqLds);
-    if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void*)conv_ds_fused_m, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 

@@ -88,8 +88,6 @@ hipError_t init_kernels_v2m();
 hipError_t launch_conv_ds(const ConvArgs& a, hipStream_t s);
 // The same launch from v_mfma_f32_16x16x32_bf16 (idc_dsm.hip: conv_ds_fused_m); a.wgt / a.wgt2 = the LAYOUT-1 images
 hipError_t launch_conv_ds_m(const ConvArgs& a, hipStream_t s);
-// ... as four-wave workgroups of 64 couts, two per CU (conv_ds_fused_q): same arguments as launch_conv_ds_m
-hipError_t launch_conv_ds_q(const ConvArgs& a, hipStream_t s);
 hipError_t init_kernels_dsm();
 // model1 = conv1_1 + conv1_2 of a 32x32 tile in one workgroup (conv1_block_fused): `a` = conv1_1's arguments with conv1_2's
 // riding in (wgt2 = its layout-1 weights, head_b = its bias, bn_scale/bn_shift, out = its output)

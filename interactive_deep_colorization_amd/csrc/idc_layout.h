@@ -49,14 +49,6 @@ __host__ __device__ inline int cg_cout_to_row2(int col) {
     return mi * 32 + (r >> 2) * 8 + hh * 4 + (r & 3);
 }
 
-// ---- layout 3 (bf16, conv_ds_fused_q): k32-major half-chunk tiles ---------------------------------
-// [tap][cin-chunk][k32 half kk][cout group][64 rows][4 slots of 16 B]: one 4 KiB block = 64 couts x 32 cin, the unit conv_ds_fused_q
-// stages per (tap, half chunk) -- contiguous, so its LDS-DMA reads whole 128-byte lines (gathering the same bytes out of a layout-1
-// block touches half of every line).  Rows in layout-1 order (cg_row_to_cout); slot g of row r sits at g ^ swz3(r): the 16 rows of an
-// MFMA A fragment (64-byte pitch) then cover all 16 sixteen-byte bank groups.
-constexpr int kW3BlockBytes = kCoutGroup * 64;               // 4096
-__host__ __device__ inline int swz3(int row) { return (row >> 2) & 3; }
-
 inline int elem_bytes(int precision) { return precision == 1 ? 2 : 4; }       // IDC_BF16 == 1
 inline int kc_elems(int precision) { return kRowBytes / elem_bytes(precision); }  // 64 or 32
 

@@ -92,8 +92,6 @@ inline bool v2_eligible(const LayerSpec& s) { return s.kind != kConvIm2col && co
 struct LayerBlob {
     size_t w_off, w_bytes;        // [tap][kc][cg][64][128B]
     size_t w2_off;                // same size, layout 2 (bf16 large-tile kernel) or (size_t)-1
-    size_t w4_off;                // same size, layout 3 (bf16: k32-major 4 KiB tiles of conv_ds_fused_q, idc_layout.h) -- the deconvs with a
-                                  // shortcut sum and the shortcut convs only -- or (size_t)-1
     size_t w3_off, w3_bytes;      // fp32 only: Winograd F(2x2,3x3) image U = G g G^T, [chunk][pos 16][cout/16][ks 2][64 lanes][16 B]
                                   // (idc_wino.hip), or (size_t)-1 / 0
     size_t bias_off;              // fp32 [cout_pad]

@@ -354,17 +354,16 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2m(const ConvArg
 // Everything else is conv_igemm_v2m: tile, LDS-DMA weight ring (2 slots, one tap ahead), stage plan, epilogues.  LDS: +12.5 % for the
 // halo tile (<2,2>, D = 1: 79.8 KiB -- still two workgroups per CU).
 // ================================================================================================
-constexpr int kV2pPitch = 144;
 
 template <int WCO, int WPX, int D>
 __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArgs a) {
     constexpr int NT = WCO * WPX * 64;
     constexpr int TW = 32, TH = 4 * WPX, HALO = D;
-    constexpr int HWP = TW + 2 * HALO, HHP = TH + 2 * HALO, HROWS = HWP * HHP, HP = kV2pPitch;
+    constexpr int HWP = TW + 2 * HALO, HHP = TH + 2 * HALO, HROWS = HWP * HHP, HP = kRowBytes;
     constexpr int BN = 64 * WCO;
     constexpr int W_BYTES = BN * kRowBytes;
     constexpr int N_HITEMS = (HROWS * kSlots + NT - 1) / NT;
-    constexpr int HALO_BYTES = HROWS * HP;
+    constexpr int HALO_BYTES = N_HITEMS * NT * kSlotBytes;
     constexpr int N_WITEMS = (W_BYTES / kSlotBytes) / NT;
     static_assert((W_BYTES / kSlotBytes) % NT == 0, "weight tile must split evenly");
     static_assert(NT % 8 == 0, "halo items: 8 slots per row");
@@ -425,22 +424,28 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArg
             const int hy = hr / HWP, hx = hr - hy * HWP;
             const int sy = ty0 - HALO + hy, sx = tx0 - HALO + hx;
             const bool inside = (unsigned)sy < (unsigned)Hs && (unsigned)sx < (unsigned)Ws && hr < HROWS;
-            const int off = ((sy * si) * Win + sx * si) * pix_bytes + (sig + kc * kSlots) * kSlotBytes;
+            const int off = ((sy * si) * Win + sx * si) * pix_bytes + ((sig ^ (hx & 7)) + kc * kSlots) * kSlotBytes;   // LDS slot sig holds logical slot sig ^ (hx & 7)
             hreg[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, inside ? off : (int)0x80000000, 0, 0));
         }
     };
     auto store_halo = [&]() {
-        char* const dst = halo + (tid >> 3) * HP + (tid & 7) * kSlotBytes;
 #pragma unroll
-        for (int j = 0; j < N_HITEMS; ++j)
-            if (j + 1 < N_HITEMS || tid < HROWS * 8 - (N_HITEMS - 1) * NT) *(u32x4*)(dst + j * (NT / 8) * HP) = hreg[j];
+        for (int j = 0; j < N_HITEMS; ++j) *(u32x4*)(halo + (tid + j * NT) * kSlotBytes) = hreg[j];
     };
 
     load_halo(0);
     dma_w(0, 0, 0);
 
-    // lane bases: B rows of the wave's first pixel row (+ compile-time (tap, row, half, k32) offsets), A rows of the two k32 halves
-    const int xbase = ((wpx * 4) * HWP + r16) * HP + g16 * kSlotBytes;
+    // lane bases: B rows of the wave's first pixel row for each column shift dx and k32 half (the swizzle term depends on the halo COLUMN
+    // only, so pixel-row / kernel-row / 16-site offsets are whole rows: compile-time immediates), A rows of the two k32 halves
+    int xb[3][2];
+#pragma unroll
+    for (int dxi = 0; dxi < 3; ++dxi)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int hx = r16 + HALO + (dxi - 1) * D;
+            xb[dxi][kk] = ((wpx * 4) * HWP + hx) * HP + (((kk * 4 + g16) ^ (hx & 7)) * kSlotBytes);
+        }
     const int wa0 = (wco * 64 + r16) * kRowBytes + ((g16 ^ swz(r16)) * kSlotBytes);
     const int wa1 = wa0 ^ (4 * kSlotBytes);
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);              // second-dispatched half of an 8-wave workgroup (as conv_igemm_v2)
@@ -453,7 +458,7 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArg
         auto tap_body = [&](auto t_tag) {
             constexpr int t = decltype(t_tag)::value;
             constexpr bool LAST = t == 8;
-            constexpr int dy = (t / 3 - 1) * D, dx = (t % 3 - 1) * D;
+            constexpr int dy = (t / 3 - 1) * D;
             constexpr int tn = LAST ? 0 : t + 1;
             const char* const wcur = wbuf + buf_off;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // my pieces of this tap's weight tile landed
@@ -464,7 +469,7 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArg
             auto read_b = [&](int kk, int half, u32x4 (&xf)[4]) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    xf[q] = *(const u32x4*)(halo + xbase + ((half * 2 + (q >> 1) + HALO + dy) * HWP + HALO + dx + (q & 1) * 16) * HP + kk * 64);
+                    xf[q] = *(const u32x4*)(halo + xb[t % 3][kk] + ((half * 2 + (q >> 1) + HALO + dy) * HWP + (q & 1) * 16) * HP);
             };
             auto mma4 = [&](int mi, int half, const u32x4 (&xf)[4]) {
 #pragma unroll
@@ -633,8 +638,12 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArg
     }
 }
 
-static constexpr size_t conv_v2p_lds_bytes_c(int wco, int wpx, int d) {
-    return (size_t)(32 + 2 * d) * (4 * wpx + 2 * d) * kV2pPitch + 2 * (size_t)(64 * wco) * kRowBytes;
+
+static constexpr size_t conv_v2p_lds_bytes_c(int wco, int wpx, int d) {            // = conv_igemm_v2m's
+    const int nt = wco * wpx * 64;
+    const int hrows = (32 + 2 * d) * (4 * wpx + 2 * d);
+    const int items = (hrows * kSlots + nt - 1) / nt;
+    return (size_t)items * nt * kSlotBytes + 2 * (size_t)(64 * wco) * kRowBytes;
 }
 
 #define IDC_FOR_EACH_CONV_V2P(X) X(4, 2, 1) X(4, 2, 2) X(2, 2, 1)

@@ -95,9 +95,6 @@ def _plan(precision, dist):
         off = _al(off); e["w_off"] = off; off += ntap * nkc * e["ncg"] * 8192
         if precision == "bf16" and kind != "im2col" and cpad >= 128:   # second image: layout 2 (conv_igemm_v2)
             off = _al(off); e["w2_off"] = off; off += ntap * nkc * e["ncg"] * 8192
-            # layout 3 (round 4, conv_ds_fused_q): k32-major 4 KiB tiles, only for the deconvs and the shortcut convs they are summed with
-            if kind == "dc" or "short" in wkey:
-                off = _al(off); e["w4_off"] = off; off += ntap * nkc * e["ncg"] * 8192
         if kind == "c3":
             # third image: Winograd F(2x2,3x3) weights U = G g G^T of the 3x3 stride-1 layers (idc_wino.hip; fp32: every
             # batch size, bf16: the batch-1 click path)
@@ -170,16 +167,6 @@ def test_pack_weights_layout(make_sd, precision, dist):
                 assert got == int(_bf16_bits(np.float32(val)).ravel()[0]), (e["wkey"], co, ci)
                 if "w2_off" in e:
                     assert _read_w(blob, e, precision, tw, co, k, layout=2) == got, (e["wkey"], co, ci, "layout 2")
-                if "w4_off" in e:
-                    # [tap][chunk][k32 half][cout group][row = layout-1 row][slot g ^ (row >> 2 & 3)][8 bf16]
-                    kcc, kin = divmod(k, 64)
-                    sl, el = divmod(kin, 8)
-                    kk, g = divmod(sl, 4)
-                    cgi, col = divmod(co, 64)
-                    lam = ((col >> 2) & 3) * 16 + (col >> 4) * 4 + (col & 3)
-                    o4 = e["w4_off"] + ((((tw * e["nkc"] + kcc) * 2 + kk) * e["ncg"] + cgi) * 4096 + lam * 64 +
-                                        ((g ^ ((lam >> 2) & 3)) * 16) + el * 2)
-                    assert int(blob[o4:o4 + 2].view(np.uint16)[0]) == got, (e["wkey"], co, ci, "layout 3")
             else:
                 assert got == float(val), (e["wkey"], co, ci)
             if "w3_off" in e:

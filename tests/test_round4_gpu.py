@@ -27,8 +27,7 @@ DS_LAYERS = ["conv8_1", "conv9_1", "conv10_1"]
 
 @pytest.mark.parametrize("name", ["net64_he_s0_mc05", "net32x48_he_s2", "net64_torch_s1_mc0"])
 def test_deconv_shortcut_launch_in_both_mfma_shapes(golden, make_sd, name):
-    """conv_ds_fused_q (four-wave workgroups of 64 couts, two per CU, `ds_mfma16` = 2), conv_ds_fused_m (16x16x32 MFMA, 8 waves, = 1)
-    and conv_ds_fused (32x32x16, = 0): model8up + model3short8, model9up +
+    """conv_ds_fused_m (16x16x32 MFMA, default) and conv_ds_fused (32x32x16, `ds_mfma16` = 0): model8up + model3short8, model9up +
     model2short9, model10up + model1short10 (model.py:156,170,172) of the large-tile bf16 path -- each launch's output against the
     float64 oracle at the bf16 per-layer tolerance (4 % of the layer's range), the ab map inside the bf16 bounds of the reference's
     golden output, and the two shapes within bf16 rounding of each other.  32x48 = ragged tiles (site grids of 4x6, 8x12, 16x24)."""
@@ -38,8 +37,8 @@ def test_deconv_shortcut_launch_in_both_mfma_shapes(golden, make_sd, name):
     sd = make_sd(seed, style)
     _, _, acts = siggraph_torch.forward(sd, g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]), return_acts=True, dtype=torch.float64)
     outs, layers = {}, {}
-    names = {0: "conv_ds_fused+shortcut", 1: "conv_ds_fused_m+shortcut", 2: "conv_ds_fused_q+shortcut"}
-    for shape in (2, 1, 0):
+    names = {0: "conv_ds_fused+shortcut", 1: "conv_ds_fused_m+shortcut"}
+    for shape in (1, 0):
         engine.set_tile_policy("large")
         engine.set_option("ds_mfma16", shape)
         e = engine.HipColorizer(H, W, max_batch=n, precision="bf16")
@@ -51,29 +50,26 @@ def test_deconv_shortcut_launch_in_both_mfma_shapes(golden, make_sd, name):
         np.testing.assert_array_equal(e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"])), outs[shape])   # deterministic
         e.close()
     bound = (20.0, 2.0) if style == "he" else (0.6, 0.06)
-    for shape in (2, 1, 0):
+    for shape in (1, 0):
         for k in DS_LAYERS:
             err = np.abs(layers[shape][k] - acts[k]).max()
             assert err <= 0.04 * (1 + np.abs(acts[k]).max()), "layer %s (ds_mfma16=%d): max-abs err %.3e" % (k, shape, err)
         d = np.abs(outs[shape] - g["out_ab"])
         assert d.max() <= bound[0] and d.mean() <= bound[1], (shape, d.max(), d.mean())
-    for shape in (2, 1):
-        for k in DS_LAYERS:                                   # same sums in a different order: a bf16 ulp here and there
-            a, b = layers[shape][k], layers[0][k]
-            assert np.abs(a - b).max() <= 2.0 ** -6 * (1 + np.abs(b).max()), (shape, k)
-        assert np.abs(outs[shape] - outs[0]).mean() <= bound[1] / 2
+    for k in DS_LAYERS:                                       # same sums in a different order: a bf16 ulp here and there
+        a, b = layers[1][k], layers[0][k]
+        assert np.abs(a - b).max() <= 2.0 ** -6 * (1 + np.abs(b).max()), k
+    assert np.abs(outs[1] - outs[0]).mean() <= bound[1] / 2
 
 
-@pytest.mark.parametrize("shape", [2, 1])
-def test_deconv_shortcut_m16_batch_is_per_image(make_sd, shape):
-    """A batch through conv_ds_fused_m / _q equals its images run alone, bit for bit (no op mixes images; variant chosen per handle)."""
+def test_deconv_shortcut_m16_batch_is_per_image(make_sd):
+    """A batch through conv_ds_fused_m equals its images run alone, bit for bit (no op mixes images; variant chosen per handle)."""
     engine.set_tile_policy("large")
-    engine.set_option("ds_mfma16", shape)
     L, ab, m = workloads.random_batch(3, 64, seed=11)
     e = engine.HipColorizer(64, 64, max_batch=3, precision="bf16")
     e.load_state_dict(make_sd(0, "he"))
     full = e.forward(L, ab, m, 0.0)
-    assert any(r["kernel"].startswith("conv_ds_fused_q" if shape == 2 else "conv_ds_fused_m") for r in e.layer_table())
+    assert any(r["kernel"].startswith("conv_ds_fused_m") for r in e.layer_table())
     for i in range(3):
         np.testing.assert_array_equal(e.forward(L[i:i + 1], ab[i:i + 1], m[i:i + 1], 0.0)[0], full[i])
     e.close()
