@@ -1,7 +1,7 @@
 """Parity on the configurations the bench times, with the MEASURED errors written down.
 
 Every case appends {config, precision, weights, images, max_abs, mean_abs, rms, rel_rms, q999} to
-gpurun_out/parity_r03_gpu.json (copied to profiles/parity_r03_gpu.json after a GPU run; round 2: profiles/parity_r02.json), so headroom against the stated
+gpurun_out/parity_r04_gpu.json (copied to profiles/parity_r04_gpu.json after a GPU run; rounds 2 / 3: profiles/parity_r02.json, parity_r03_gpu.json), so headroom against the stated
 bounds is visible, not just pass/fail:
   * BASELINE configs[2] itself -- N=32, 256x256, bf16, the large-tile kernels at their real 4096-workgroup geometry --
     with torch-init weights, FOUR images of the batch against the oracle at the tight bf16 bound 0.6 / 0.06;
@@ -21,7 +21,7 @@ from oracle import siggraph_torch, weights
 
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(REPO, "gpurun_out", "parity_r03_gpu.json")
+OUT = os.path.join(REPO, "gpurun_out", "parity_r04_gpu.json")
 
 
 def record(config, precision, style, images, out, ref):
@@ -122,3 +122,31 @@ def test_config2_click_path_against_the_oracle(make_sd, precision, style, bound)
     assert row["max_abs"] <= bound[0], row
     if bound[1] is not None:
         assert row["mean_abs"] <= bound[1], row
+
+
+@pytest.mark.parametrize("style,wino,bound", [
+    ("torch", 1, (0.6, 0.06, 0.6)), ("torch", 0, (0.6, 0.06, 0.6)),
+    ("he", 1, (45.0, 2.0, 20.0)), ("he", 0, (45.0, 2.0, 20.0)),
+])
+def test_click_path_bf16_at_512_winograd_margin(make_sd, style, wino, bound):
+    """the bf16 click path (Winograd F(2x2,3x3) / F(2x2,2x2), `winograd_bf16` = 1, and the direct conv_click kernels,
+    = 0) at BASELINE configs[4]'s geometry -- ONE 512x512 image -- against the oracle, both weight styles, measured error recorded.
+    Bounds as for the N = 8 512x512 bf16 case (max / mean / q99.9): the 256x256 bounds (20 / 2.0) are stated for 4x fewer pixels, the
+    maximum over 524k values of a 30-layer bf16 network is a tail statistic (mean and q99.9 carry the claim)."""
+    sd = make_sd(0, style)
+    L = workloads.random_batch(1, 512, seed=13)[0].astype(np.float32)
+    hab, hm = workloads.hints_config2(512, 5, 3, 0)
+    ab, m = hab[None].astype(np.float32), hm[None].astype(np.float32)
+    engine.set_option("winograd_bf16", wino)
+    try:
+        e = engine.HipColorizer(512, 512, max_batch=1, precision="bf16")
+        e.load_state_dict(sd)
+        out = e.forward(L, ab, m, 0.0)
+        n_wino = sum(r["kernel"].startswith("conv_wino") for r in e.layer_table())
+        e.close()
+    finally:
+        engine.set_option("winograd_bf16", 1)
+    assert (n_wino >= 8) if wino else (n_wino == 0), n_wino
+    ref = siggraph_torch.forward(sd, L, ab, m, 0.0)
+    row = record("configs[4] geometry N=1 512x512 (click path, %s)" % ("Winograd" if wino else "direct"), "bf16", style, (0,), out, ref)
+    assert row["max_abs"] <= bound[0] and row["mean_abs"] <= bound[1] and row["q999"] <= bound[2], row
