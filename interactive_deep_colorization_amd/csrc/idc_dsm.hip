@@ -79,6 +79,9 @@ __global__ __launch_bounds__(512, 2) void conv_ds_fused_m(const ConvArgs a) {
     const char* const imgD = (const char*)a.in + (size_t)n * Hs * Ws * pixD;
     const char* const imgS = (const char*)a.in2 + (size_t)n * (4 * (size_t)Hs * Ws) * pixS;
     const int cg0 = ct * 2;
+    // halo rows come through buffer loads: 32-bit offsets into one image, the bounds check returns zeros for out-of-image rows (offset 2^31)
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)imgS, 0, 4 * Hs * Ws * pixS, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)imgD, 0, Hs * Ws * pixD, 0x00020000);
     IDC_DSTAMP(0);
 
     // accumulators start at the (summed) bias: lane (site r16, group g16) register j of acc[mi][.] is cout g16*16 + mi*4 + j
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(512, 2) void conv_ds_fused_m(const ConvArgs a) {
             const int Y = 2 * y0 - 1 + hy, X = 2 * x0 - 1 + hx;
             const bool inside = (unsigned)Y < (unsigned)(2 * Hs) && (unsigned)X < (unsigned)(2 * Ws) && hr < SROWS;
             const int off = (Y * (2 * Ws) + X) * pixS + ((sig ^ swz(hr)) + kc2 * kSlots) * kSlotBytes;
-            hreg[j] = *(const u32x4*)(inside ? imgS + off : (const char*)a.zeros);
+            hreg[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsS, inside ? off : (int)0x80000000, 0, 0));
         }
     };
     auto load_halo_D = [&](int kc) {
@@ -122,8 +125,10 @@ __global__ __launch_bounds__(512, 2) void conv_ds_fused_m(const ConvArgs a) {
             const int Y = y0 - 1 + hy, X = x0 - 1 + hx;
             const bool inside = (unsigned)Y < (unsigned)Hs && (unsigned)X < (unsigned)Ws && hr < DROWS;
             const int off = (Y * Ws + X) * pixD + ((sig ^ swz(hr)) + kc * kSlots) * kSlotBytes;
-            hreg[j] = *(const u32x4*)(inside ? imgD + off : (const char*)a.zeros);
+            hreg[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsD, inside ? off : (int)0x80000000, 0, 0));
         }
+#pragma unroll
+        for (int j = D_ITEMS; j < S_ITEMS; ++j) hreg[j] = u32x4{0u, 0u, 0u, 0u};   // (one definition per path for every halo register)
     };
     auto dma_S = [&](int tap, int kc2, int buf) {              // 128 couts x 64 cin, shared: every wave brings 2 KiB
         const char* src = (const char*)a.wgt2 + (((size_t)tap * nkc2 + kc2) * ncg + cg0) * kWBlockBytes + (size_t)tid * kSlotBytes;
@@ -407,7 +412,8 @@ __global__ __launch_bounds__(512, 2) void conv_ds_fused_m(const ConvArgs a) {
 // a.wgt / a.wgt2 = the LAYOUT-1 images of the deconv / the shortcut conv.
 hipError_t launch_conv_ds_m(const ConvArgs& a, hipStream_t s) {
     if (a.in2 == nullptr || a.wgt2 == nullptr || a.zeros == nullptr || a.nphase != 4 || a.so != 2 || a.si != 1 || (a.ncg & 1) || a.out_f32 ||
-        a.bn_scale != nullptr || a.act == 2 || a.img_shift != nullptr || a.resid != nullptr || a.head_w != nullptr)
+        a.bn_scale != nullptr || a.act == 2 || a.img_shift != nullptr || a.resid != nullptr || a.head_w != nullptr ||
+        (long long)4 * a.Hs * a.Ws * ((long long)(a.nkc2 > a.nkc ? a.nkc2 : a.nkc) * kRowBytes) >= 0x7fffffffLL)    // 32-bit buffer offsets per image
         return hipErrorInvalidConfiguration;
     const long long blocks = (long long)((a.Ws + 31) / 32) * ((a.Hs + 3) / 4) * a.N * (a.ncg / 2);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;

@@ -939,7 +939,9 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             else if (L.spec->kind == kConvIm2col && c->precision == IDC_BF16 && a.ksplit <= 1 &&
                 (long long)((a.Ws + 31) / 32) * ((a.Hs + 31) / 32) * c->max_batch >= 128)
                 le = launch_conv1_1_bf16(a, s);
-            if (L.fused_short >= 0) le = L.m16 ? launch_conv_ds_m(a, s) : launch_conv_ds(a, s);    // deconv + its shortcut conv in one K loop
+            if (L.fused_short >= 0) le = L.m16 ? launch_conv_ds_m(a, s) : launch_conv_ds(a, s);
+            if (L.fused_short >= 0 && L.m16 && le == hipErrorInvalidConfiguration)
+                return fail(&c->err, IDC_ERR_UNSUPPORTED, "layer %s: image too large for conv_ds_fused_m's 32-bit offsets (idc_set_option(\"ds_mfma16\", 0) selects conv_ds_fused)", L.spec->name);    // deconv + its shortcut conv in one K loop
             if (L.wino) {
                 // a.wgt points at the Winograd U image and L.cfg / tiles were never set for this layer: a refused launch must not fall
                 // through to the direct kernels below -- it is a variant-selection bug and says so
