@@ -288,7 +288,7 @@ def main():
                      "frac": round(achieved_tflops / peak, 4), "traffic": traffic.get("conv_family_bytes_per_forward"),
                      "traffic_source": "profiles/pmc_traffic.json: rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command run by "
                                        "the builder (%s), replayed here -- not measured in this process" % traffic.get("tag", "r01j"),
-                     "kernel": "conv kernel family (conv_igemm_v2m / conv_igemm_v2 / conv_ds_fused / conv_igemm / conv1_1, %s): the %d conv/deconv launches of one "
+                     "kernel": "conv kernel family (conv_igemm_v2p / conv_igemm_v2m / conv_igemm_v2 / conv_ds_fused_m / conv1_block_fused / conv_igemm, %s): the %d conv/deconv launches of one "
                                "forward taken together" % (args.precision, len(conv_rows)),
                      "launches_per_forward": len(conv_rows),
                      "algorithmic_flop_per_forward": conv_flops,

@@ -1111,12 +1111,11 @@ hipError_t launch_deconv_wino(int precision, const ConvArgs& a0, hipStream_t s) 
     a.tiles_x = (a.Ws + 7) / 8;
     a.tiles_y = (a.Hs + 7) / 8;
     const long long tb = (long long)a.tiles_x * a.tiles_y * a.N;
-    const int cb = 1;      // (<2>: 32 couts per workgroup -- 57 spilled registers at the 168-register budget of 12 waves; kept for tuning only)
+    const int cb = 1;      // (a <2> form -- 32 couts per workgroup -- spills 57-96 registers at the 168-register budget of 12 waves: not instantiated)
     (void)tb;
     const long long blocks = tb * (a.ncg * 4 / cb);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     if (precision == 1) hipLaunchKernelGGL(conv_wino_deconv_bf16, dim3((unsigned)blocks), dim3(kWinoDNT), kWinoDLds, s, a);
-    else if (cb == 2) hipLaunchKernelGGL((conv_wino_deconv_f32<2>), dim3((unsigned)blocks), dim3(kWinoDNT), kWinoDLds, s, a);
     else hipLaunchKernelGGL((conv_wino_deconv_f32<1>), dim3((unsigned)blocks), dim3(kWinoDNT), kWinoDLds, s, a);
     return hipGetLastError();
 }
@@ -1166,8 +1165,6 @@ hipError_t init_kernels_wino() {
     e = hipFuncSetAttribute((const void*)conv_wino_deconv_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, kWinoDLds);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)conv_wino_deconv_f32<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kWinoDLds);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)conv_wino_deconv_f32<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kWinoDLds);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)conv_wino_bf16<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_lds_bf16(1));
     if (e != hipSuccess) return e;
