@@ -1104,6 +1104,7 @@ int idc_set_option(const char* name, int value) {
     if (strcmp(name, "winograd") == 0) { g_wino = value != 0; return IDC_OK; }
     if (strcmp(name, "mfma16") == 0) { g_mfma16 = value != 0; return IDC_OK; }
     if (strcmp(name, "v2p") == 0) { g_v2p = value != 0; return IDC_OK; }
+    if (strcmp(name, "conv1_lw") == 0) { set_conv1_lw(value); return IDC_OK; }
     if (strcmp(name, "ds_mfma16") == 0) { g_ds_m16 = value != 0; return IDC_OK; }
     if (strcmp(name, "winograd_bf16") == 0) { g_wino_bf16 = value; return IDC_OK; }
     if (strcmp(name, "winograd_deconv") == 0) { g_wino_deconv = value; return IDC_OK; }

@@ -1494,7 +1494,8 @@ static hipError_t launch_conv_v2_t(const ConvArgs& a, hipStream_t s) {
 #define IDC_FOR_EACH_CONV_V2(X) X(4, 2, 0) X(4, 2, 1) X(4, 2, 2) X(2, 4, 0) X(2, 4, 1) X(2, 4, 2) X(2, 2, 0) X(2, 2, 1) X(2, 2, 2)
 
 __global__ void conv_ds_fused(const ConvArgs a);
-template <int NW, int RPW> __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 3) void conv1_block_fused_t(const ConvArgs a);
+template <int NW, int RPW, bool LW> __global__ __launch_bounds__(NW * 64, (NW == 8 || LW) ? 2 : 3) void conv1_block_fused_t(const ConvArgs a);
+constexpr int conv1_block_lds(int nw, int rpw, bool lw) { return 34 * (nw * rpw + 2) * 128 + 36 * (nw * rpw + 4) * 8 + (lw ? 2 * kWBlockBytes : 0); }
 
 hipError_t init_kernels_v2() {
     hipError_t e;
@@ -1507,9 +1508,13 @@ hipError_t init_kernels_v2() {
     // the two fused kernels use more than the default 64 KiB of dynamic LDS (set per device: this runs for every handle)
     e = hipFuncSetAttribute((const void*)conv_ds_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)conv1_block_fused_t<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 34 * 10 * 128 + 36 * 12 * 8);
+    e = hipFuncSetAttribute((const void*)conv1_block_fused_t<4, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, conv1_block_lds(4, 2, false));
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)conv1_block_fused_t<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 34 * 34 * 128 + 36 * 36 * 8);
+    e = hipFuncSetAttribute((const void*)conv1_block_fused_t<4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv1_block_lds(4, 2, true));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)conv1_block_fused_t<4, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv1_block_lds(4, 3, true));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)conv1_block_fused_t<8, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, conv1_block_lds(8, 4, false));
 }
 
 // v2 tile = 32 sites wide, 4*wpx rows; cfg.wm = WCO (x64 couts), cfg.wp = WPX.
@@ -2034,14 +2039,19 @@ hipError_t launch_conv1_1_bf16(const ConvArgs& a, hipStream_t s) {
 // NW waves x RPW pixel rows each: <8,4> = the 32x32 tile (one workgroup per CU), <4,2> = a 32x8 tile whose 46 KiB of LDS and
 // <= 168 registers let THREE workgroups share a CU, so that one's patch / conv1_1 / store phases run under another's conv1_2 MFMAs
 // (conv1_1 is recomputed on 34x10 sites per 32x8 outputs: 33 % extra instead of 13 %, of a conv that is 2 % of the block's MACs).
-template <int NW, int RPW>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 3) void conv1_block_fused_t(const ConvArgs a) {
+// LW (round 4): conv1_2's weight tiles go through a 2-slot LDS ring by LDS-DMA (one 8 KiB tile per tap, shared by the workgroup's
+// waves, requested one tap ahead, one barrier per tap) instead of global -> registers per wave: the L2 -> CU stream of the phase drops
+// by the number of waves, which is what kept the small tiles from paying (profiles/r03_conv1_tile8.txt); <4,3,true> = 32x12 tile at
+// exactly 80 KiB and <4,2,true> = 32x8 at 62 KiB: two workgroups per CU.
+template <int NW, int RPW, bool LW>
+__global__ __launch_bounds__(NW * 64, (NW == 8 || LW) ? 2 : 3) void conv1_block_fused_t(const ConvArgs a) {
     constexpr int NT = NW * 64, TH = NW * RPW;
     constexpr int HW_ = 34, HH_ = TH + 2, PW = 36, PH = TH + 4, NSITE = HW_ * HH_;
     constexpr int HALO_BYTES = NSITE * kRowBytes;              // 147,968
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const halo = smem;
     uint2* const patch = (uint2*)(smem + HALO_BYTES);          // [TH + 4][36] x 4 bf16
+    char* const wring = smem + HALO_BYTES + PW * PH * 8;       // LW: 2 x 8 KiB weight tiles of conv1_2
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2053,6 +2063,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 3) void conv1_block_fused_t(
     const int tyi = b % nty;
     const int n = b / nty;
     const int ty0 = tyi * TH, tx0 = txi * 32;
+    auto dma_w2 = [&](int t, int slot) {                       // conv1_2's tap-t tile (64 couts x 64 cin, layout 1) -> ring slot
+        static_assert(!LW || kWBlockBytes % (NT * kSlotBytes) == 0, "tile must split evenly");
+        const char* src = (const char*)a.wgt2 + (size_t)t * kWBlockBytes + (size_t)tid * kSlotBytes;
+        char* dst = wring + slot * kWBlockBytes + wave * 64 * kSlotBytes;
+#pragma unroll
+        for (int j = 0; j < kWBlockBytes / (NT * kSlotBytes); ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)j * NT * kSlotBytes),
+                                             (__attribute__((address_space(3))) void*)(dst + j * NT * kSlotBytes), 16, 0, 0);
+    };
+    if constexpr (LW) dma_w2(0, 0);                            // lands under phases 0 and 1
     // ---- phase 0 -------------------------------------------------------------------------------
     {
         const size_t hw = (size_t)Hs * Ws;
@@ -2148,6 +2168,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 3) void conv1_block_fused_t(
 #pragma unroll
         for (int pj = 0; pj < RPW; ++pj) acc[mi][pj] = b16;
     }
+  if constexpr (!LW) {
     u32x4 wcur[4][2], wnxt[4][2];
     auto load_w = [&](int t, u32x4 (&w)[4][2]) {
         const char* const base = (const char*)a.wgt2 + (size_t)t * kWBlockBytes;
@@ -2211,6 +2232,61 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 3) void conv1_block_fused_t(
                 for (int mi = 0; mi < 2; ++mi) wcur[kk][mi] = wnxt[kk][mi];
         }
     }
+  } else {
+    // LW: per tap one vmcnt(0) + barrier publishes the tile requested a tap ago; A fragments (2 per k16 step) and B fragments (RPW) are
+    // read a step ahead of their MFMAs, as above
+    const int wlam0 = lam[0] * kRowBytes + ((h ^ swz(lam[0])) * kSlotBytes), wlam1 = lam[1] * kRowBytes + ((h ^ swz(lam[1])) * kSlotBytes);
+#pragma unroll 1
+    for (int t = 0; t < 9; ++t) {
+        const char* const wcur_ = wring + (t & 1) * kWBlockBytes;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // my pieces of this tap's tile
+        __syncthreads();                                        // everybody's (t = 0: also the conv1_1 tile); everybody left the other slot
+        if (t + 1 < 9) dma_w2(t + 1, (t + 1) & 1);
+        const int dy = t / 3 - 1, dx = t - (t / 3) * 3 - 1;
+        int xaddr[RPW];
+#pragma unroll
+        for (int pj = 0; pj < RPW; ++pj) {
+            const int xr = (wave * RPW + pj + 1 + dy) * HW_ + (px + 1 + dx);
+            xaddr[pj] = xr * kRowBytes + ((h ^ swz2(xr)) * kSlotBytes);
+        }
+        u32x4 xfA[RPW], xfB[RPW], wA[2], wB[2];
+        auto read_f = [&](int kk, u32x4 (&xf)[RPW], u32x4 (&wf)[2]) {
+            wf[0] = *(const u32x4*)(wcur_ + (wlam0 ^ (kk * 2 * kSlotBytes)));
+            wf[1] = *(const u32x4*)(wcur_ + (wlam1 ^ (kk * 2 * kSlotBytes)));
+#pragma unroll
+            for (int pj = 0; pj < RPW; ++pj) xf[pj] = *(const u32x4*)(halo + (xaddr[pj] ^ (kk * 2 * kSlotBytes)));
+        };
+        auto mmaL = [&](const u32x4 (&wf)[2], const u32x4 (&xf)[RPW]) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int pj = 0; pj < RPW; ++pj)
+                    acc[mi][pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[mi]),
+                                                                          __builtin_bit_cast(bf16x8, xf[pj]), acc[mi][pj], 0, 0, 0);
+        };
+#define IDC_C1L_INTERLEAVE()                                                          \
+    _Pragma("unroll") for (int q_ = 0; q_ < RPW + 2; ++q_) {                         \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
+    }                                                                                 \
+    if constexpr (RPW > 2) __builtin_amdgcn_sched_group_barrier(0x008, RPW - 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_f(0, xfA, wA);
+        __builtin_amdgcn_sched_group_barrier(0x100, RPW + 2, 0);
+        read_f(1, xfB, wB);
+        mmaL(wA, xfA);
+        IDC_C1L_INTERLEAVE()
+        read_f(2, xfA, wA);
+        mmaL(wB, xfB);
+        IDC_C1L_INTERLEAVE()
+        read_f(3, xfB, wB);
+        mmaL(wA, xfA);
+        IDC_C1L_INTERLEAVE()
+        mmaL(wB, xfB);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * RPW, 0);
+#undef IDC_C1L_INTERLEAVE
+    }
+  }
     // ---- phase 3 -------------------------------------------------------------------------------
     __syncthreads();                                           // every wave left the halo tile
     char* const tb16 = smem + wave * 4096;
@@ -2261,6 +2337,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 3) void conv1_block_fused_t(
 // model1 (conv1_1 + conv1_2) in one launch.  `a` = conv1_1's arguments (fused-pack planes, layout-1 weights, bias, act)
 // with conv1_2's riding in: wgt2 = its layout-1 weights (9 taps x 8 KiB), head_b = its bias, bn_scale/bn_shift = its
 // eval-BN affine, out = its output.  conv1_2 is ReLU + (optional) BN, 64 -> 64.
+// default 3: same-box A/B of the N = 32 forward, conv1 block 0.2315 -> 0.2121 ms (-8.4 %) and 0.2106 -> 0.2001 (-5 %) on two boxes; 2 (32x8): +7 %
+int g_c1_lw = getenv("IDC_C1_LW") ? atoi(getenv("IDC_C1_LW")) : 3;
+void set_conv1_lw(int v) { g_c1_lw = v == 2 || v == 3 ? v : 0; }
+
 hipError_t launch_conv1_block(const ConvArgs& a, hipStream_t s) {
     if (a.pk_L == nullptr || a.wgt2 == nullptr || a.head_b == nullptr || a.ncg != 1 || a.out_f32 || a.resid != nullptr)
         return hipErrorInvalidConfiguration;
@@ -2268,12 +2348,16 @@ hipError_t launch_conv1_block(const ConvArgs& a, hipStream_t s) {
     // forward (profiles/r03_conv1_tile8.txt) -- the A fragments of conv1_2 come from global memory per wave and tap, so the smaller
     // tile doubles an L2 -> CU stream that is already 5 TB/s.  Off by default; IDC_C1_TILE8=1 selects it (parity-tested).
     static const int force8 = getenv("IDC_C1_TILE8") && atoi(getenv("IDC_C1_TILE8")) != 0;
-    const bool tile8 = force8 || a.tiles_y == 8;           // a.tiles_y = the engine's request: 8 on the batch-1 click path (too few 32x32 tiles)
-    const int th = tile8 ? 8 : 32;
+    // round 4: weight tiles through an LDS ring, two workgroups per CU (g_c1_lw = 2: 32x8 tile, 3: 32x12 tile; 0: the 32x32 tile above)
+    const bool big = !(force8 || a.tiles_y == 8);           // a.tiles_y = the engine's request: 8 on the batch-1 click path (too few 32x32 tiles)
+    const int lw = big ? g_c1_lw : 0;
+    const int th = lw == 3 ? 12 : (lw == 2 || !big) ? 8 : 32;
     const long long blocks = (long long)((a.Ws + 31) / 32) * ((a.Hs + th - 1) / th) * a.N;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (tile8) hipLaunchKernelGGL((conv1_block_fused_t<4, 2>), dim3((unsigned)blocks), dim3(256), 34 * 10 * 128 + 36 * 12 * 8, s, a);
-    else hipLaunchKernelGGL((conv1_block_fused_t<8, 4>), dim3((unsigned)blocks), dim3(512), 34 * 34 * 128 + 36 * 36 * 8, s, a);
+    if (lw == 3) hipLaunchKernelGGL((conv1_block_fused_t<4, 3, true>), dim3((unsigned)blocks), dim3(256), conv1_block_lds(4, 3, true), s, a);
+    else if (lw == 2) hipLaunchKernelGGL((conv1_block_fused_t<4, 2, true>), dim3((unsigned)blocks), dim3(256), conv1_block_lds(4, 2, true), s, a);
+    else if (!big) hipLaunchKernelGGL((conv1_block_fused_t<4, 2, false>), dim3((unsigned)blocks), dim3(256), conv1_block_lds(4, 2, false), s, a);
+    else hipLaunchKernelGGL((conv1_block_fused_t<8, 4, false>), dim3((unsigned)blocks), dim3(512), conv1_block_lds(8, 4, false), s, a);
     return hipGetLastError();
 }
 

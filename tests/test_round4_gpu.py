@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _reset_options():
     yield
-    for k, v in (("mfma16", 1), ("ds_mfma16", 1), ("v2p", 1), ("fuse_conv1", 1)):
+    for k, v in (("mfma16", 1), ("ds_mfma16", 1), ("v2p", 1), ("fuse_conv1", 1), ("conv1_lw", 3)):
         try:
             engine.set_option(k, v)
         except Exception:
@@ -111,3 +111,32 @@ def test_throughput_3x3_tile_without_address_arithmetic(golden, make_sd, name):
     bound = (20.0, 2.0) if style == "he" else (0.6, 0.06)
     d = np.abs(outs[1] - g["out_ab"])
     assert d.max() <= bound[0] and d.mean() <= bound[1], (d.max(), d.mean())
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 256), (3, 208, 240)])
+def test_model1_block_with_lds_weight_ring(make_sd, shape):
+    """conv1_block_fused_t<4,2,true> / <4,3,true> (`conv1_lw` = 2 / 3: 32x8 / 32x12 tiles, conv1_2's weight tiles through an LDS ring,
+    two workgroups per CU) against the 32x32-tile form (itself checked per layer against the oracle in test_net_gpu / test_parity_record):
+    conv1_2's output (model.py:13-17) and the ab map bit-identical -- the same MFMAs in the same order per accumulator -- ragged
+    tile edges included (208 = 17 x 12 + 4 rows, 240 = 7.5 x 32 columns)."""
+    n, H, W = shape
+    sd = make_sd(0, "he")
+    L, ab, m = workloads.random_batch(n, max(H, W), seed=3)
+    L, ab, m = L[:, :, :H, :W].copy(), ab[:, :, :H, :W].copy(), m[:, :, :H, :W].copy()
+    got = {}
+    try:
+        for lw in (0, 2, 3):
+            engine.set_option("conv1_lw", lw)
+            e = engine.HipColorizer(H, W, max_batch=n, precision="bf16")
+            e.load_state_dict(sd)
+            out = e.forward(L, ab, m, 0.0)
+            table = {r["name"]: r["kernel"] for r in e.layer_table()}
+            assert table["conv1_1"] == "conv1_block_fused", table
+            got[lw] = (e.activation("conv1_2", n), out)
+            e.close()
+    finally:
+        engine.set_option("conv1_lw", 3)
+    assert np.isfinite(got[0][1]).all() and np.abs(got[0][0]).max() > 0.1
+    for lw in (2, 3):
+        np.testing.assert_array_equal(got[lw][0], got[0][0], err_msg="conv1_2, conv1_lw=%d" % lw)
+        np.testing.assert_array_equal(got[lw][1], got[0][1], err_msg="ab map, conv1_lw=%d" % lw)
