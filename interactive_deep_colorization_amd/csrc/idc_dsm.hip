@@ -189,6 +189,8 @@ __global__ __launch_bounds__(512, 2) void conv_ds_fused_m(const ConvArgs a) {
     load_halo_S(0);
     dma_S(0, 0, 0);
     dma_S(1, 0, 1);
+    if (a.warm && wave == 0) idc_warm_own_code(halo + SROWS * kRowBytes, lane, 2);   // own code (16.7 KB) -> L2; scratch: the halo area's unread tail
+    static_assert(S_HALO_BYTES - SROWS * kRowBytes >= 256, "scratch for the code warm-up");
     int rt = 2, rkc = 0;                                       // request cursor: (tap, chunk) of tile s+2
     auto dma_S_req = [&](int slot_off) {
         const bool real = rkc < nkc2;

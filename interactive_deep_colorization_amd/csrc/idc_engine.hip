@@ -497,6 +497,8 @@ static int g_mfma16 = getenv("IDC_MFMA16") ? atoi(getenv("IDC_MFMA16")) : 1;
 static int g_ds_m16 = getenv("IDC_DS_M16") ? atoi(getenv("IDC_DS_M16")) : 1;
 // ... and the 3x3 convs among them as conv_igemm_v2p (no address arithmetic in the K loop; idc_set_option "v2p" / env IDC_V2P=0 for A/B)
 static int g_v2p = getenv("IDC_V2P") ? atoi(getenv("IDC_V2P")) : 1;
+// throughput kernels touch their own code at entry (idc_warm_own_code, idc_kernels.h; idc_set_option "code_warm" / env IDC_CODE_WARM=0 for A/B)
+static int g_code_warm = getenv("IDC_CODE_WARM") ? atoi(getenv("IDC_CODE_WARM")) : 1;
 static int g_click = -1;                 // conv_click for small launches: -1 = environment default (on), 0 off, 1 on (idc_set_option "click")
 // Shortcut fusion (conv_igemm_v2<.,.,1,true>) is correct (parity-tested under tile policy 2) but measured slower
 // than two launches on MI355X (4x re-reads of the skip tensor by the four phase workgroups, VGPR spills around
@@ -870,6 +872,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
         ConvArgs& a = L.args;
         a.in = ti.ptr; a.out = to.ptr;
         a.zeros = c->d_zeros;
+        a.warm = g_code_warm;
         a.out_f32 = to.is_f32;
         a.img_shift = ((c->flags & IDC_FLAG_GLOBAL_HINTS) && L.dst == c->t_conv4_3) ? c->d_glob_vec : nullptr;
         if (L.spec->kind == kConvIm2col) {          // model.py:139-148 input pack, fused into the operand staging
@@ -1104,6 +1107,7 @@ int idc_set_option(const char* name, int value) {
     if (strcmp(name, "winograd") == 0) { g_wino = value != 0; return IDC_OK; }
     if (strcmp(name, "mfma16") == 0) { g_mfma16 = value != 0; return IDC_OK; }
     if (strcmp(name, "v2p") == 0) { g_v2p = value != 0; return IDC_OK; }
+    if (strcmp(name, "code_warm") == 0) { g_code_warm = value != 0; return IDC_OK; }
     if (strcmp(name, "conv1_lw") == 0) { set_conv1_lw(value); return IDC_OK; }
     if (strcmp(name, "ds_mfma16") == 0) { g_ds_m16 = value != 0; return IDC_OK; }
     if (strcmp(name, "winograd_bf16") == 0) { g_wino_bf16 = value; return IDC_OK; }
@@ -2118,6 +2122,7 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     a.resid_bf16 = io_bf16;
     a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_mul = 0.f;
     a.in2 = nullptr; a.wgt2 = nullptr; a.nkc2 = 0;
+    a.warm = g_code_warm;
     a.out_f32 = io_bf16 ? 0 : 1;
     DevBuf d_part, d_zero;
     if (a.ksplit > 1) {

@@ -60,10 +60,27 @@ struct ConvArgs {
     const float* head_b;    // [2]
     float* head_out;        // NCHW fp32 [N][2][Hs][Ws]
     float head_mul;
+    int warm;               // != 0: the throughput kernels pull their own code into L2 at entry (idc_warm_own_code below)
     const void* zeros;      // >= 16 zero bytes in device memory: LDS-DMA source of out-of-image halo rows (conv_click)
     int dy[36], dx[36], tw[36];   // [phase*9 + t]: tap offset in sites, packed-weight tap index
     int ro[4], co[4];
 };
+
+#ifdef __HIPCC__
+// First-use cost of a kernel: on some boxes the first launch of a kernel after other kernels have run is
+// 25-35 % (up to 36 us) slower on EVERY forward -- the launch fetches 17-37 KB of instructions it has not executed for ~1 GB of
+// traffic, line after line (or page after page) as the wave reaches them.  One wave per workgroup therefore touches every 128-byte
+// line of the kernel's own code at entry -- as DATA, by LDS-DMA into `lds_scratch` (256 bytes nobody reads; no destination register
+// to keep alive) -- so that the lines are on their way into this XCD's L2, and their pages walked, all at once and under the prologue's
+// own memory latency.  `blocks8k` x 8 KiB from the current PC; callers stay inside the kernel's code (or inside code that follows it
+// in the same code object).  The requests retire with the prologue's first vmcnt(0).
+__device__ __forceinline__ void idc_warm_own_code(char* lds_scratch, int lane, int blocks8k) {
+    const char* const pc = (const char*)(__builtin_amdgcn_s_getpc() & ~(unsigned long long)127);
+    for (int j = 0; j < blocks8k; ++j)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pc + (size_t)(j * 64 + lane) * 128),
+                                         (__attribute__((address_space(3))) void*)lds_scratch, 4, 0, 0);
+}
+#endif
 
 struct ConvConfig { int wm, wp; };     // waves along cout (x64) and along pixel rows (x4 rows of 16)
 

@@ -2072,7 +2072,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || LW) ? 2 : 3) void conv1_block_
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)j * NT * kSlotBytes),
                                              (__attribute__((address_space(3))) void*)(dst + j * NT * kSlotBytes), 16, 0, 0);
     };
-    if constexpr (LW) dma_w2(0, 0);                            // lands under phases 0 and 1
+    if constexpr (LW) {
+        dma_w2(0, 0);                                          // lands under phases 0 and 1
+        if (a.warm && wave == 0) idc_warm_own_code(wring + kWBlockBytes, lane, 1);   // own code (9.7 KB) -> L2; scratch: ring slot 1 (rewritten by tap 1's tile)
+    }
     // ---- phase 0 -------------------------------------------------------------------------------
     {
         const size_t hw = (size_t)Hs * Ws;

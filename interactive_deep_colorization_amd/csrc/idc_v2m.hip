@@ -435,6 +435,9 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArg
 
     load_halo(0);
     dma_w(0, 0, 0);
+    // own code -> L2 (idc_kernels.h): 23-37 KB; the scratch is the tail of the halo area that no fragment read reaches
+    if (a.warm && wave == 0) idc_warm_own_code(halo + HROWS * HP, lane, (WCO == 2 ? 5 : 3));
+    static_assert(HALO_BYTES - HROWS * HP >= 256, "scratch for the code warm-up");
 
     // lane bases: B rows of the wave's first pixel row for each column shift dx and k32 half (the swizzle term depends on the halo COLUMN
     // only, so pixel-row / kernel-row / 16-site offsets are whole rows: compile-time immediates), A rows of the two k32 halves

@@ -89,6 +89,7 @@ int main(int argc, char** argv) {
     idc::ConvConfig cfg{wm, wp};
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 #define LAUNCH() (v2 == 6 ? idc::launch_conv_wino(prec, a, 0) : v2 == 4 ? idc::launch_conv_click(prec, wp, halo, a, 0) : v2 == 5 ? idc::launch_conv(prec, cfg, halo, a, 0) : v2 == 2 ? (dsm ? idc::launch_conv_ds_m(a, 0) : idc::launch_conv_ds(a, 0)) : v2 ? (ablv == 1 ? idc::launch_conv_v2p(cfg, halo, a, 0) : ablv == 2 ? idc::launch_conv_v2m(cfg, halo, a, 0) : idc::launch_conv_v2(cfg, halo, a, 0)) : idc::launch_conv(prec, cfg, halo, a, 0))
+    a.warm = getenv("IDC_CODE_WARM") ? atoi(getenv("IDC_CODE_WARM")) : 1;
     const int dsm = getenv("IDC_DS_M16") ? atoi(getenv("IDC_DS_M16")) : 0;
     const int ablv = getenv("IDC_ABL_V2") ? atoi(getenv("IDC_ABL_V2")) : 0;      // 0: conv_igemm_v2 (32x32 MFMA), 1: conv_igemm_v2p, 2: conv_igemm_v2m
     if (v2 == 1 && ablv) { void* z; CK(hipMalloc(&z, 256)); CK(hipMemset(z, 0, 256)); a.zeros = z; }
