@@ -2063,13 +2063,26 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || LW) ? 2 : 3) void conv1_block_
     const int tyi = b % nty;
     const int n = b / nty;
     const int ty0 = tyi * TH, tx0 = txi * 32;
-    auto dma_w2 = [&](int t, int slot) {                       // conv1_2's tap-t tile (64 couts x 64 cin, layout 1) -> ring slot
-        static_assert(!LW || kWBlockBytes % (NT * kSlotBytes) == 0, "tile must split evenly");
-        const char* src = (const char*)a.wgt2 + (size_t)t * kWBlockBytes + (size_t)tid * kSlotBytes;
+    // conv1_2's tap-t tile (64 couts x 64 cin) -> ring slot, RE-LAID on the way: the blob holds the layout-1 image (rows in the 16x16
+    // MFMA's order, slot ^ (row & 7)), whose rows a 32x32 A fragment reads 8-way bank-conflicted (50 % of this kernel's LDS cycles in its
+    // first form, profiles/r04b_pmc_sq_summary.txt); the LDS-DMA's per-lane source addresses gather it into conv_igemm_v2's layout instead --
+    // LDS row rho = the MFMA row (mi*32 + px), slot ^ ((rho >> 1) & 7) -- still one whole 128-byte line per 8 lanes.
+    constexpr int W2_ITEMS = kWBlockBytes / (NT * kSlotBytes);
+    static_assert(!LW || kWBlockBytes % (NT * kSlotBytes) == 0, "tile must split evenly");
+    int w2_src[W2_ITEMS];
+#pragma unroll
+    for (int j = 0; j < W2_ITEMS; ++j) {
+        const int i = tid + j * NT, rho = i >> 3, sphys = i & 7, px_ = rho & 31, mi_ = rho >> 5;
+        const int c = ((px_ >> 2) & 1) * 32 + mi_ * 16 + (px_ >> 3) * 4 + (px_ & 3);         // cout of MFMA row rho (as lam[] below)
+        const int lr = ((c >> 2) & 3) * 16 + (c >> 4) * 4 + (c & 3);                          // its row in the layout-1 block
+        w2_src[j] = lr * kRowBytes + (((sphys ^ swz2(rho)) ^ swz(lr)) * kSlotBytes);
+    }
+    auto dma_w2 = [&](int t, int slot) {
+        const char* const src = (const char*)a.wgt2 + (size_t)t * kWBlockBytes;
         char* dst = wring + slot * kWBlockBytes + wave * 64 * kSlotBytes;
 #pragma unroll
-        for (int j = 0; j < kWBlockBytes / (NT * kSlotBytes); ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)j * NT * kSlotBytes),
+        for (int j = 0; j < W2_ITEMS; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + w2_src[j]),
                                              (__attribute__((address_space(3))) void*)(dst + j * NT * kSlotBytes), 16, 0, 0);
     };
     if constexpr (LW) {
@@ -2238,7 +2251,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || LW) ? 2 : 3) void conv1_block_
   } else {
     // LW: per tap one vmcnt(0) + barrier publishes the tile requested a tap ago; A fragments (2 per k16 step) and B fragments (RPW) are
     // read a step ahead of their MFMAs, as above
-    const int wlam0 = lam[0] * kRowBytes + ((h ^ swz(lam[0])) * kSlotBytes), wlam1 = lam[1] * kRowBytes + ((h ^ swz(lam[1])) * kSlotBytes);
+    const int wlam0 = px * kRowBytes + ((h ^ swz2(px)) * kSlotBytes), wlam1 = wlam0 + 32 * kRowBytes;   // rows mi*32 + px of the re-laid tile
 #pragma unroll 1
     for (int t = 0; t < 9; ++t) {
         const char* const wcur_ = wring + (t & 1) * kWBlockBytes;
