@@ -75,6 +75,11 @@ int idc_set_tile_policy(int policy);
  * "mfma16" (default 1): the bf16 throughput tile runs as conv_igemm_v2m (v_mfma_f32_16x16x32_bf16, fewer joules per FLOP at the
  * power cap) wherever it applies; 0 = conv_igemm_v2 (v_mfma_f32_32x32x16_bf16) everywhere.  "winograd" / "winograd_bf16" /
  * "winograd_deconv" / "winograd_form" / "fuse_conv1_small": kernel choice on the fp32 path and the batch-1 click path.
+ * Round 4: "v2p" (default 1): the 3x3 convs among the conv_igemm_v2m launches run as conv_igemm_v2p (column-swizzled halo tile, unrolled
+ * taps, immediates; bit-identical results); "ds_mfma16" (default 1): the deconv + shortcut launches run as conv_ds_fused_m (16x16x32 MFMA),
+ * 0 = conv_ds_fused; "conv1_lw" (default 3): model1 on 32x12 tiles with conv1_2's weight tiles through an LDS ring, two workgroups per CU
+ * (2: 32x8 tiles; 0: the 32x32 tile, weights global -> registers; bit-identical results); "code_warm" (default 1): the throughput kernels
+ * pull their own code into L2 at entry (first-use cost of a kernel on some boxes).
  * Take effect on the next forward; unknown names return IDC_ERR_INVALID_ARG. */
 int idc_set_option(const char* name, int value);
 /* Split-K policy of the small-tile kernels (speed only): 0 automatic (launches too small to fill the chip: the

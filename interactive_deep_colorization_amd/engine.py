@@ -82,7 +82,10 @@ def set_option(name, value):
     (model1 as one 32x8-tile launch on the bf16 click path), 'click' -1/0/1, 'winograd_deconv' 0/1/2,
     'winograd' 0/1 (3x3 stride-1 layers as Winograd F(2x2,3x3): fp32 at every batch size, bf16 on the batch-1 click path;
     default on; 0 switches both off), 'winograd_bf16' 0/1 (the bf16 half alone), 'winograd_form' 0/12/21/22, 'mfma16' 0/1 (the bf16
-    throughput tile from the 16x16x32 MFMA -- conv_igemm_v2m, default -- or from the 32x32x16 one)."""
+    throughput tile from the 16x16x32 MFMA -- conv_igemm_v2m, default -- or from the 32x32x16 one), 'v2p' 0/1 (its 3x3 form without
+    address arithmetic in the K loop, conv_igemm_v2p, default on), 'ds_mfma16' 0/1 (deconv + shortcut launches as conv_ds_fused_m),
+    'conv1_lw' 0/2/3 (model1: 32x32 tile / 32x8 / 32x12 tiles with an LDS weight ring; default 3), 'code_warm' 0/1 (own-code
+    warm-up at kernel entry)."""
     N.check(N.load().idc_set_option(name.encode(), int(value)))
 
 
