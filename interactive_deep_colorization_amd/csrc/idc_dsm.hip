@@ -189,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void conv_ds_fused_m(const ConvArgs a) {
     load_halo_S(0);
     dma_S(0, 0, 0);
     dma_S(1, 0, 1);
-    if (a.warm && wave == 0) idc_warm_own_code(halo + SROWS * kRowBytes, lane, 2);   // own code (16.7 KB) -> L2; scratch: the halo area's unread tail
+    if (a.warm && wave == 0) idc_warm_own_code(halo + SROWS * kRowBytes, lane, 112);   // 14 of this kernel's 16.7 KB (the only kernel of its code object: stay inside); scratch: the halo area's unread tail
     static_assert(S_HALO_BYTES - SROWS * kRowBytes >= 256, "scratch for the code warm-up");
     int rt = 2, rkc = 0;                                       // request cursor: (tap, chunk) of tile s+2
     auto dma_S_req = [&](int slot_off) {
@@ -412,10 +412,15 @@ __global__ __launch_bounds__(512, 2) void conv_ds_fused_m(const ConvArgs a) {
 
 // deconv 4x4 s2 + its 3x3 shortcut conv in one launch, 16x16x32 MFMA: bf16, Cout a multiple of 128, (ReLU | none), no BN.
 // a.wgt / a.wgt2 = the LAYOUT-1 images of the deconv / the shortcut conv.
+// buffer loads address ONE image with 32-bit offsets (out-of-image rows: offset 2^31)
+bool conv_ds_m_fits(int Hs, int Ws, int nkc, int nkc2) {
+    return (long long)4 * Hs * Ws * ((long long)(nkc2 > nkc ? nkc2 : nkc) * kRowBytes) < 0x7fffffffLL;
+}
+
 hipError_t launch_conv_ds_m(const ConvArgs& a, hipStream_t s) {
     if (a.in2 == nullptr || a.wgt2 == nullptr || a.zeros == nullptr || a.nphase != 4 || a.so != 2 || a.si != 1 || (a.ncg & 1) || a.out_f32 ||
         a.bn_scale != nullptr || a.act == 2 || a.img_shift != nullptr || a.resid != nullptr || a.head_w != nullptr ||
-        (long long)4 * a.Hs * a.Ws * ((long long)(a.nkc2 > a.nkc ? a.nkc2 : a.nkc) * kRowBytes) >= 0x7fffffffLL)    // 32-bit buffer offsets per image
+        !conv_ds_m_fits(a.Hs, a.Ws, a.nkc, a.nkc2))
         return hipErrorInvalidConfiguration;
     const long long blocks = (long long)((a.Ws + 31) / 32) * ((a.Hs + 3) / 4) * a.N * (a.ncg / 2);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;

@@ -890,7 +890,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             a.resid = nullptr; a.resid_bf16 = 0;
             a.in2 = c->tensors[P.src].ptr; a.wgt2 = c->d_blob + P.blob.w2_off; a.nkc2 = P.blob.nkc;
             a.bias = (const float*)(c->d_blob + L.blob.fbias_off);
-            L.m16 = g_ds_m16 != 0;
+            L.m16 = g_ds_m16 != 0 && conv_ds_m_fits(a.Hs, a.Ws, a.nkc, P.blob.nkc);   // (huge images: conv_ds_fused, 64-bit addressing)
             if (L.m16) { a.wgt = c->d_blob + L.blob.w_off; a.wgt2 = c->d_blob + P.blob.w_off; }   // conv_ds_fused_m reads the layout-1 images
         } else {
             a.resid = L.resid >= 0 ? c->tensors[L.resid].ptr : nullptr;
@@ -943,8 +943,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
                 (long long)((a.Ws + 31) / 32) * ((a.Hs + 31) / 32) * c->max_batch >= 128)
                 le = launch_conv1_1_bf16(a, s);
             if (L.fused_short >= 0) le = L.m16 ? launch_conv_ds_m(a, s) : launch_conv_ds(a, s);
-            if (L.fused_short >= 0 && L.m16 && le == hipErrorInvalidConfiguration)
-                return fail(&c->err, IDC_ERR_UNSUPPORTED, "layer %s: image too large for conv_ds_fused_m's 32-bit offsets (idc_set_option(\"ds_mfma16\", 0) selects conv_ds_fused)", L.spec->name);    // deconv + its shortcut conv in one K loop
+    // deconv + its shortcut conv in one K loop
             if (L.wino) {
                 // a.wgt points at the Winograd U image and L.cfg / tiles were never set for this layer: a refused launch must not fall
                 // through to the direct kernels below -- it is a variant-selection bug and says so

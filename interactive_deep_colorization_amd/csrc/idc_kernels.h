@@ -72,13 +72,15 @@ struct ConvArgs {
 // traffic, line after line (or page after page) as the wave reaches them.  One wave per workgroup therefore touches every 128-byte
 // line of the kernel's own code at entry -- as DATA, by LDS-DMA into `lds_scratch` (256 bytes nobody reads; no destination register
 // to keep alive) -- so that the lines are on their way into this XCD's L2, and their pages walked, all at once and under the prologue's
-// own memory latency.  `blocks8k` x 8 KiB from the current PC; callers stay inside the kernel's code (or inside code that follows it
-// in the same code object).  The requests retire with the prologue's first vmcnt(0).
-__device__ __forceinline__ void idc_warm_own_code(char* lds_scratch, int lane, int blocks8k) {
+// own memory latency.  `lines` x 128 bytes from the current PC: callers pass LESS than their kernel's code size (codeLenInByte of the
+// build, profiles/r04_kernel_resources.txt lists the kernels) unless other kernels follow it in the same code object.  The requests
+// retire with the prologue's first vmcnt(0).
+__device__ __forceinline__ void idc_warm_own_code(char* lds_scratch, int lane, int lines) {
     const char* const pc = (const char*)(__builtin_amdgcn_s_getpc() & ~(unsigned long long)127);
-    for (int j = 0; j < blocks8k; ++j)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pc + (size_t)(j * 64 + lane) * 128),
-                                         (__attribute__((address_space(3))) void*)lds_scratch, 4, 0, 0);
+    for (int j = 0; j * 64 < lines; ++j)
+        if (j * 64 + lane < lines)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pc + (size_t)(j * 64 + lane) * 128),
+                                             (__attribute__((address_space(3))) void*)lds_scratch, 4, 0, 0);
 }
 #endif
 
@@ -105,6 +107,7 @@ hipError_t init_kernels_v2m();
 hipError_t launch_conv_ds(const ConvArgs& a, hipStream_t s);
 // The same launch from v_mfma_f32_16x16x32_bf16 (idc_dsm.hip: conv_ds_fused_m); a.wgt / a.wgt2 = the LAYOUT-1 images
 hipError_t launch_conv_ds_m(const ConvArgs& a, hipStream_t s);
+bool conv_ds_m_fits(int Hs, int Ws, int nkc, int nkc2);   // (else conv_ds_fused, which addresses with 64-bit pointers)
 hipError_t init_kernels_dsm();
 // model1 = conv1_1 + conv1_2 of a 32x32 tile in one workgroup (conv1_block_fused): `a` = conv1_1's arguments with conv1_2's
 // riding in (wgt2 = its layout-1 weights, head_b = its bias, bn_scale/bn_shift, out = its output)

@@ -2087,7 +2087,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || LW) ? 2 : 3) void conv1_block_
     };
     if constexpr (LW) {
         dma_w2(0, 0);                                          // lands under phases 0 and 1
-        if (a.warm && wave == 0) idc_warm_own_code(wring + kWBlockBytes, lane, 1);   // own code (9.7 KB) -> L2; scratch: ring slot 1 (rewritten by tap 1's tile)
+        if (a.warm && wave == 0) idc_warm_own_code(wring + kWBlockBytes, lane, 64);   // 8 of this kernel's 7.6-9.7 KB (other kernels follow in this code object); scratch: ring slot 1 (rewritten by tap 1's tile)
     }
     // ---- phase 0 -------------------------------------------------------------------------------
     {

@@ -436,7 +436,7 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArg
     load_halo(0);
     dma_w(0, 0, 0);
     // own code -> L2 (idc_kernels.h): 23-37 KB; the scratch is the tail of the halo area that no fragment read reaches
-    if (a.warm && wave == 0) idc_warm_own_code(halo + HROWS * HP, lane, (WCO == 2 ? 5 : 3));
+    if (a.warm && wave == 0) idc_warm_own_code(halo + HROWS * HP, lane, (WCO == 2 ? 288 : 180));   // 36.9 / 23.1-23.4 KB; conv_igemm_v2m's kernels follow in this code object
     static_assert(HALO_BYTES - HROWS * HP >= 256, "scratch for the code warm-up");
 
     // lane bases: B rows of the wave's first pixel row for each column shift dx and k32 half (the swizzle term depends on the halo COLUMN
