@@ -79,7 +79,9 @@ int idc_set_tile_policy(int policy);
  * taps, immediates; bit-identical results); "ds_mfma16" (default 1): the deconv + shortcut launches run as conv_ds_fused_m (16x16x32 MFMA),
  * 0 = conv_ds_fused; "conv1_lw" (default 3): model1 on 32x12 tiles with conv1_2's weight tiles through an LDS ring, two workgroups per CU
  * (2: 32x8 tiles; 0: the 32x32 tile, weights global -> registers; bit-identical results); "code_warm" (default 1): the throughput kernels
- * pull their own code into L2 at entry (first-use cost of a kernel on some boxes).
+ * pull their own code into L2 at entry (first-use cost of a kernel on some boxes); "kwave" (default 1): on the bf16
+ * batch-1 click path the 3x3 stride-1 layers run as conv_kwave_bf16 (direct form, K split over the waves of a workgroup, layout-1 weights),
+ * 0 = the Winograd form conv_wino_bf16 of round 3.
  * Take effect on the next forward; unknown names return IDC_ERR_INVALID_ARG. */
 int idc_set_option(const char* name, int value);
 /* Split-K policy of the small-tile kernels (speed only): 0 automatic (launches too small to fill the chip: the

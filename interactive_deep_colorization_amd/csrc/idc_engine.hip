@@ -392,6 +392,7 @@ struct Layer {
     bool v2p = false;                    // ... conv_igemm_v2p (padded halo rows, unrolled taps): set per launch in run_graph
     bool click = false;                  // batch-1 click-path kernel (conv_click: whole K slice by LDS-DMA)
     bool wino = false;                   // fp32 Winograd F(2x2,3x3) kernel (conv_wino_f32, idc_wino.hip)
+    bool kw = false;                     // bf16 click path: conv_kwave_bf16 (idc_kw.hip: K split over the waves of a workgroup, layout-1 weights)
     bool fused_head = false;             // conv10_2 only: model_out + tanh run in this layer's epilogue
     int fused_short = -1;                // deconv layers: index of the shortcut conv layer riding in this launch's K loop
     bool skip = false;                   // layer fused into another launch: not launched itself
@@ -499,6 +500,8 @@ static int g_ds_m16 = getenv("IDC_DS_M16") ? atoi(getenv("IDC_DS_M16")) : 1;
 static int g_v2p = getenv("IDC_V2P") ? atoi(getenv("IDC_V2P")) : 1;
 // throughput kernels touch their own code at entry (idc_warm_own_code, idc_kernels.h; idc_set_option "code_warm" / env IDC_CODE_WARM=0 for A/B)
 static int g_code_warm = getenv("IDC_CODE_WARM") ? atoi(getenv("IDC_CODE_WARM")) : 1;
+// bf16 click path: the 3x3 stride-1 layers as conv_kwave_bf16 instead of conv_wino_bf16 ("kwave" / IDC_KWAVE)
+static int g_kwave = getenv("IDC_KWAVE") ? atoi(getenv("IDC_KWAVE")) : 1;
 static int g_click = -1;                 // conv_click for small launches: -1 = environment default (on), 0 off, 1 on (idc_set_option "click")
 // Shortcut fusion (conv_igemm_v2<.,.,1,true>) is correct (parity-tested under tile policy 2) but measured slower
 // than two launches on MI355X (4x re-reads of the skip tensor by the four phase workgroups, VGPR spills around
@@ -612,6 +615,7 @@ static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, i
         L.wino = true;                               // measurement switch: the click path's Winograd kernel at every batch size
     const bool wino_fits = wino_offsets_fit(Hs, Ws, L.spec->kind == kDeconv4x4 ? 1 : L.spec->in_stride, a.nkc);   // 32-bit patch offsets
     L.wino = L.wino && wino_fits;
+    L.kw = false;
     if (L.wino) { L.v2 = false; L.click = false; a.ksplit = 1; a.kc_per = a.nkc; a.tiles_x = a.tiles_y = 0; return; }
     // large-tile bf16 kernel: 256 couts x (32x8 sites) when the cout groups divide by 4, else
     // 128 couts x (32x16 sites); used when its grid covers at least half of the 256 CUs
@@ -651,6 +655,14 @@ static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, i
     if (precision == IDC_BF16 && g_wino && g_wino_bf16 && g_wino_deconv && g_tile_policy != 1 && big_tiles < tuning().v2_min_blocks && wino_fits &&
         L.blob.w3_off != (size_t)-1 && L.spec->kind == kDeconv4x4 && (a.nkc >= 4 || g_wino_deconv == 2)) {
         L.wino = true; a.ksplit = 1; a.kc_per = a.nkc; a.tiles_x = a.tiles_y = 0;
+        return;
+    }
+    // bf16 click path, 3x3 stride-1 layers: the direct form with K split over the waves of a workgroup (idc_kw.hip) -- 9/16 of the Winograd
+    // form's weight stream, no reduction launch either
+    L.kw = false;
+    if (precision == IDC_BF16 && g_kwave && g_tile_policy != 1 && big_tiles < tuning().v2_min_blocks && wino_fits && L.spec->resid == nullptr &&
+        L.spec->kind == kConv3x3 && (a.nkc == 1 || a.nkc == 2 || a.nkc == 4 || a.nkc == 8)) {
+        L.kw = true; a.ksplit = 1; a.kc_per = a.nkc; a.tiles_x = a.tiles_y = 0;
         return;
     }
     // bf16 click path: a 3x3 stride-1 layer that would run conv_click + a split-K reduction launch runs as Winograd instead
@@ -952,6 +964,12 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
                 le = L.spec->kind == kDeconv4x4 ? launch_deconv_wino(c->precision, a, s) : launch_conv_wino(c->precision, a, s);
                 HIPCHK(c, le);
             }
+            if (L.kw) {
+                if (!conv_kwave_applies(a))
+                    return fail(&c->err, IDC_ERR_INTERNAL, "layer %s: conv_kwave_bf16 selected for a launch it does not cover", L.spec->name);
+                le = launch_conv_kwave(a, s);
+                HIPCHK(c, le);
+            }
             if (le == hipErrorInvalidConfiguration)
                 le = L.click ? launch_conv_click(c->precision, L.cfg.wp, L.halo, a, s)
                    : L.v2 ? (L.v2p ? launch_conv_v2p(L.cfg, L.halo, a, s) : L.m16 ? launch_conv_v2m(L.cfg, L.halo, a, s) : launch_conv_v2(L.cfg, L.halo, a, s))
@@ -1107,6 +1125,7 @@ int idc_set_option(const char* name, int value) {
     if (strcmp(name, "mfma16") == 0) { g_mfma16 = value != 0; return IDC_OK; }
     if (strcmp(name, "v2p") == 0) { g_v2p = value != 0; return IDC_OK; }
     if (strcmp(name, "code_warm") == 0) { g_code_warm = value != 0; return IDC_OK; }
+    if (strcmp(name, "kwave") == 0) { g_kwave = value != 0; return IDC_OK; }
     if (strcmp(name, "conv1_lw") == 0) { set_conv1_lw(value); return IDC_OK; }
     if (strcmp(name, "ds_mfma16") == 0) { g_ds_m16 = value != 0; return IDC_OK; }
     if (strcmp(name, "winograd_bf16") == 0) { g_wino_bf16 = value; return IDC_OK; }
@@ -1917,7 +1936,7 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
                 if (C.fused_short == layer - 1 || C.fused_next == layer - 1) snprintf(out->kernel, sizeof(out->kernel), "fused into %s", C.spec->name);
             out->flops = 0; out->min_bytes = 0; out->launches = 0;
         } else {
-            snprintf(out->kernel, sizeof(out->kernel), L.wino ? (L.spec->kind == kDeconv4x4 ? (h->precision == IDC_BF16 ? "conv_wino_deconv_bf16" : "conv_wino_deconv_f32") : h->precision == IDC_BF16 ? "conv_wino_bf16" : "conv_wino_f32") : L.click ? (h->precision == IDC_BF16 ? "conv_click<bf16,%d,%d>" : "conv_click<f32,%d,%d>")
+            snprintf(out->kernel, sizeof(out->kernel), L.kw ? "conv_kwave_bf16" : L.wino ? (L.spec->kind == kDeconv4x4 ? (h->precision == IDC_BF16 ? "conv_wino_deconv_bf16" : "conv_wino_deconv_f32") : h->precision == IDC_BF16 ? "conv_wino_bf16" : "conv_wino_f32") : L.click ? (h->precision == IDC_BF16 ? "conv_click<bf16,%d,%d>" : "conv_click<f32,%d,%d>")
                      : L.v2 ? "conv_igemm_v2<%d,%d>" : (h->precision == IDC_BF16 ? "conv_igemm<bf16,%d,%d>" : "conv_igemm<f32,%d,%d>"),
                      L.cfg.wm, L.cfg.wp);
             if (L.m16) strncat(out->kernel, L.v2p ? "+m16p" : "+m16", sizeof(out->kernel) - strlen(out->kernel) - 1);
@@ -2136,7 +2155,9 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     if (L.m16 && !conv_v2m_applies(a))
         return fail(nullptr, IDC_ERR_INTERNAL, "single op: conv_igemm_v2m selected for a launch it does not cover");
     L.v2p = L.m16 && g_v2p && conv_v2p_applies(L.cfg, L.halo, a);
-    HIPCHK(nullctx, L.wino ? (wino_dc ? launch_deconv_wino(precision, a, nullptr) : launch_conv_wino(precision, a, nullptr)) : L.click ? launch_conv_click(precision, L.cfg.wp, L.halo, a, nullptr)
+    if (L.kw && !conv_kwave_applies(a))
+        return fail(nullptr, IDC_ERR_INTERNAL, "single op: conv_kwave_bf16 selected for a launch it does not cover");
+    HIPCHK(nullctx, L.kw ? launch_conv_kwave(a, nullptr) : L.wino ? (wino_dc ? launch_deconv_wino(precision, a, nullptr) : launch_conv_wino(precision, a, nullptr)) : L.click ? launch_conv_click(precision, L.cfg.wp, L.halo, a, nullptr)
                     : L.v2 ? (L.v2p ? launch_conv_v2p(L.cfg, L.halo, a, nullptr) : L.m16 ? launch_conv_v2m(L.cfg, L.halo, a, nullptr) : launch_conv_v2(L.cfg, L.halo, a, nullptr))
                            : launch_conv(precision, L.cfg, L.halo, a, nullptr));
     if (a.ksplit > 1) HIPCHK(nullctx, launch_splitk_epilogue(precision, a, nullptr));

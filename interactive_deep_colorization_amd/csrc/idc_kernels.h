@@ -132,6 +132,11 @@ hipError_t launch_deconv_wino(int precision, const ConvArgs& a, hipStream_t s); 
 // the launch guards of the two entry points above as a predicate (args filled in: in / wgt / zeros / resid / out_f32 set), and the
 // 32-bit source-offset bound alone (known before the pointers are: set_geometry)
 bool conv_wino_applies(int precision, const ConvArgs& a, bool deconv);
+// bf16 click path (idc_kw.hip): a 3x3 stride-1 conv with K split over the waves of a workgroup, no reduction launch; a.wgt = the
+// layer's LAYOUT-1 image, a.dy[8] = dilation, a.zeros set; hipErrorInvalidConfiguration if the launch does not qualify
+hipError_t launch_conv_kwave(const ConvArgs& a, hipStream_t s);
+bool conv_kwave_applies(const ConvArgs& a);
+hipError_t init_kernels_kw();
 bool wino_offsets_fit(int Hs, int Ws, int si, int nkc);
 hipError_t init_kernels_wino();
 void set_wino_form(int form);      // 0 = by grid size, 12 / 21 / 22 = force conv_wino_f32<TB,CB> (speed only)

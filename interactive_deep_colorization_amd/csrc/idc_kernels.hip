@@ -818,6 +818,8 @@ hipError_t init_kernels() {
     if (e != hipSuccess) return e;
     e = init_kernels_dsm();
     if (e != hipSuccess) return e;
+    e = init_kernels_kw();
+    if (e != hipSuccess) return e;
     return init_kernels_v2();
 }
 

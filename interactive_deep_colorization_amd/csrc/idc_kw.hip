@@ -1,0 +1,267 @@
+// idc_kw.hip -- conv_kwave_bf16: the 3x3 stride-1 convolutions of the bf16 BATCH-1 CLICK PATH (BASELINE configs[1]; ui/gui_draw.py:272-286
+// fires the forward on every drag pixel; model.py:13-102), K split over the WAVES of a workgroup (gfx950).
+//
+// What bounds a batch-1 layer (profiles/r04d_click_bf16_trace.txt): 256 workgroups, one per CU, each pulling
+// its operands L2 -> CU at the ~29-32 B/clk a CU gets.  The Winograd kernel this replaces (conv_wino_bf16) streams 16 positions x Cin x
+// 32 couts x 2 B of U per workgroup (512 KiB at Cin = 512) + the patch; touching U early (L2 residency) made it slower, so the stream
+// itself is the bound, not its latency.  The direct form needs 9/16 of the weight bytes; what it lacked at batch 1 was parallelism
+// without a split-K reduction LAUNCH.  Here the K split lives inside the workgroup:
+//   * workgroup = 8 x (8*TWB) pixels of one dilation sub-grid (d = 2: four independent d = 1 problems on the parity grids, as in the
+//     Winograd kernels) x 32 couts x the WHOLE K; NW waves, wave w = (cin chunk w % NKC, tap range w / NKC): NKC = 8 -> a wave owns
+//     one 64-channel chunk and all nine taps; NKC = 4 -> two waves per chunk split the taps 4 : 5; ...
+//   * the whole-K halo tile (NKC x 10 x (8*TWB+2) pixels x 128 B) goes global -> LDS by LDS-DMA once (source-side XOR swizzle, zero
+//     page outside the image), ONE barrier; after it the waves run independently -- no barrier in the K loop at all;
+//   * weights: the layout-1 blocks conv_click / conv_igemm_v2m read ([tap][chunk][64 couts][128 B], slot ^ (row & 7)), streamed
+//     global -> registers as MFMA A fragments (a wave's 16-byte pieces of a tap = one 4 KiB run), four taps ahead;
+//   * v_mfma_f32_16x16x32_bf16, fp32 accumulation; the NW partial sums of a (pixel, cout) meet in LDS in a fixed order (deterministic),
+//     then bias, activation, eval-BN, per-image shift, bf16 (or fp32) store -- the epilogue arithmetic of conv_wino_bf16.
+// Per workgroup at Cin = 512, 32 x 32 pixels: 288 KiB of weights + 100 KiB of halo instead of 512 + 100.
+// Numerics: plain bf16 products, fp32 sums (no transform): the error of the direct kernels (conv_click), below conv_wino_bf16's.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "idc_kernels.h"
+
+#include "idc_layout.h"
+
+namespace idc {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4_k;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_k;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_k;
+
+__device__ __forceinline__ int xcd_remap_k(int b, int nb) {
+    const int xcd = b & 7, q = nb >> 3, r = nb & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (b >> 3);
+}
+
+constexpr int kw_halo_items(int nkc, int twb) { return nkc * 10 * (8 * twb + 2) * 8; }
+constexpr int kw_lds_bytes(int nkc, int twb, int nw) {
+    const int nt = nw * 64;
+    const int halo = ((kw_halo_items(nkc, twb) + nt - 1) / nt) * nt * kSlotBytes;
+    const int red = nw * 8192;                                 // one round of partial sums: [wave][64 pixels][32 couts] fp32
+    return halo > red ? halo : red;
+}
+
+template <int NKC, int TWB, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_kwave_bf16(const ConvArgs a) {
+    static_assert(NW % NKC == 0, "waves = chunks x tap ranges");
+    constexpr int NT = NW * 64, NS = NW / NKC;
+    constexpr int MAXT = (9 + NS - 1) / NS;                    // taps of the longest range
+    constexpr int PWD = 8 * TWB + 2, HR = 10 * PWD;            // halo pixels of one chunk
+    constexpr int ITEMS = kw_halo_items(NKC, TWB);
+    constexpr int NH = (ITEMS + NT - 1) / NT;
+    constexpr int PB = 4 * TWB;                                // 16-pixel blocks of the tile
+    constexpr int PD = MAXT < 4 ? MAXT : 4;                    // taps of weights in flight
+    static_assert(NH + PD * 4 <= 63, "vmcnt field");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 15, g = lane >> 4;
+
+    int b = xcd_remap_k(blockIdx.x, gridDim.x);               // tile blocks fastest, the cout group slowest: an XCD's L2 sees few weight slices
+    const int d = a.dy[8];
+    const int bx = b % a.tiles_x; b /= a.tiles_x;
+    const int by = b % a.tiles_y; b /= a.tiles_y;
+    const int par = b % (d * d); b /= d * d;
+    const int n = b % a.N;
+    const int cg = b / a.N;                                    // group of 32 couts
+    const int Y0 = par / d + d * 8 * by, X0 = par % d + d * 8 * TWB * bx;      // the tile's pixels are (Y0 + d*r, X0 + d*c)
+    const int H = a.Hs, W = a.Ws, si = a.si;
+    const int pix_bytes = NKC * kRowBytes;
+    const char* const img = (const char*)a.in + (size_t)n * (H * si) * (W * si) * pix_bytes;
+
+    // ---- the whole-K halo tile: global -> LDS, 16-byte pieces, item = (chunk, halo pixel, slot) in LDS order ----------------
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+        const int item = tid + j * NT;
+        const int kc = item / (HR * 8), rem = item - kc * (HR * 8);
+        const int hr = rem >> 3, sig = rem & 7;
+        const int hy = hr / PWD, hx = hr - hy * PWD;
+        const int Y = Y0 + d * (hy - 1), X = X0 + d * (hx - 1);
+        const bool inside = item < ITEMS && (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W;
+        const char* const src = inside ? img + (((Y * si) * (W * si) + X * si) * pix_bytes + kc * kRowBytes + ((sig ^ (hr & 7)) * kSlotBytes))
+                                       : (const char*)a.zeros;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(smem + (j * NT + wave * 64) * kSlotBytes), 16, 0, 0);
+    }
+
+    // ---- this wave's share of K: chunk kcw, taps [t0, t1) -------------------------------------------------------------------
+    const int kcw = wave % NKC, split = wave / NKC;
+    const int t0 = (split * 9) / NS, t1 = ((split + 1) * 9) / NS;
+    const size_t w_kc_stride = (size_t)a.ncg * kWBlockBytes;
+    const size_t w_tap_stride = w_kc_stride * NKC;
+    // the workgroup's 32 rows of the 64-row block: rows (cg & 1) * 32 + cb * 16 + m, m = the MFMA row = this lane's px; row lam holds
+    // cout cg_row_to_cout(lam) (idc_layout.h): accumulator register r of lane group g in block cb = cout g*16 + ((cg&1)*2 + cb)*4 + r
+    const char* const wl = (const char*)a.wgt + (size_t)kcw * w_kc_stride + (size_t)(cg >> 1) * kWBlockBytes + (cg & 1) * 32 * kRowBytes;
+    int wo[2][2];                                              // logical slots g (ks 0) and 4 + g (ks 1) of row px (+ 16 for the second block)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            wo[cb][ks] = (cb * 16 + px) * kRowBytes + (((ks * 4 + g) ^ (px & 7)) * kSlotBytes);
+    u32x4_k areg[PD][2][2];
+    auto load_A = [&](auto slotc, int t) {
+        constexpr int S = decltype(slotc)::value;
+        const char* const src = wl + (size_t)(t < 8 ? t : 8) * w_tap_stride;         // past the range: a harmless re-read (same count on every wave)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            areg[S][cb][0] = *(const u32x4_k*)(src + wo[cb][0]);
+            areg[S][cb][1] = *(const u32x4_k*)(src + wo[cb][1]);
+        }
+    };
+    if constexpr (PD > 0) load_A(std::integral_constant<int, 0>{}, t0);
+    if constexpr (PD > 1) load_A(std::integral_constant<int, 1>{}, t0 + 1);
+    if constexpr (PD > 2) load_A(std::integral_constant<int, 2>{}, t0 + 2);
+    if constexpr (PD > 3) load_A(std::integral_constant<int, 3>{}, t0 + 3);
+
+    f32x4_k acc[2][PB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < PB; ++j) acc[i][j] = f32x4_k{0.f, 0.f, 0.f, 0.f};
+    // the lane's pixel in each 16-pixel block, as a halo pixel index (tap (1,1))
+    int hbase[PB];
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+        const int row = TWB == 1 ? pb * 2 + (px >> 3) : pb, col = TWB == 1 ? (px & 7) : px;
+        hbase[pb] = (row + 1) * PWD + col + 1;
+    }
+
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD * 4) : "memory");      // the halo pieces are older than the weight loads
+    __builtin_amdgcn_s_barrier();
+
+    const char* const hchunk = smem + kcw * (HR * kRowBytes);
+    auto tap = [&](auto ic) {
+        constexpr int I = decltype(ic)::value;
+        const int t = t0 + I;
+        if (t < t1) {                                          // wave-uniform
+            const int ty = t / 3, tx = t - ty * 3;
+            const int toff = (ty - 1) * PWD + (tx - 1);
+            u32x4_k bf[PB][2];
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) {
+                const int hr = hbase[pb] + toff;
+                const int o0 = hr * kRowBytes + ((g ^ (hr & 7)) * kSlotBytes);
+                bf[pb][0] = *(const u32x4_k*)(hchunk + o0);
+                bf[pb][1] = *(const u32x4_k*)(hchunk + (o0 ^ (4 * kSlotBytes)));
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb)
+                        acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_k, areg[I % PD][cb][ks]),
+                                                                              __builtin_bit_cast(bf16x8_k, bf[pb][ks]), acc[cb][pb], 0, 0, 0);
+        }
+        if constexpr (I + PD < MAXT) load_A(std::integral_constant<int, I % PD>{}, t0 + I + PD);
+    };
+    tap(std::integral_constant<int, 0>{});
+    if constexpr (MAXT > 1) tap(std::integral_constant<int, 1>{});
+    if constexpr (MAXT > 2) tap(std::integral_constant<int, 2>{});
+    if constexpr (MAXT > 3) tap(std::integral_constant<int, 3>{});
+    if constexpr (MAXT > 4) tap(std::integral_constant<int, 4>{});
+    if constexpr (MAXT > 5) tap(std::integral_constant<int, 5>{});
+    if constexpr (MAXT > 6) tap(std::integral_constant<int, 6>{});
+    if constexpr (MAXT > 7) tap(std::integral_constant<int, 7>{});
+    if constexpr (MAXT > 8) tap(std::integral_constant<int, 8>{});
+
+    // ---- the NW partial sums of a (pixel, cout) meet in LDS, 64 pixels per round; fixed summation order --------------------
+    const int CoutPad = a.ncg * kCoutGroup;
+    const bool has_bn = a.bn_scale != nullptr;
+#pragma unroll
+    for (int h = 0; h < TWB; ++h) {
+        __syncthreads();                                       // every wave is done with the halo (h = 0) / the previous round's sums are read
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const int p64 = q * 16 + px;
+                *(f32x4_k*)(smem + wave * 8192 + p64 * kRowBytes + (((g * 2 + cb) ^ (p64 & 7)) * kSlotBytes)) = acc[cb][h * 4 + q];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < (64 * 8) / NT; ++k) {
+            const int idx = tid + k * NT;
+            const int p64 = idx >> 3, slot = idx & 7;
+            f32x4_k s = *(const f32x4_k*)(smem + p64 * kRowBytes + ((slot ^ (p64 & 7)) * kSlotBytes));
+#pragma unroll
+            for (int w = 1; w < NW; ++w) s += *(const f32x4_k*)(smem + w * 8192 + p64 * kRowBytes + ((slot ^ (p64 & 7)) * kSlotBytes));
+            const int P = h * 64 + p64, pb = P >> 4, pp = P & 15;
+            const int row = TWB == 1 ? pb * 2 + (pp >> 3) : pb, col = TWB == 1 ? (pp & 7) : pp;
+            const int yy = Y0 + d * row, xx = X0 + d * col;
+            const int co = (cg >> 1) * kCoutGroup + (slot >> 1) * 16 + (cg & 1) * 8 + (slot & 1) * 4;      // slot = g*2 + cb (see the weight rows above)
+            const f32x4_k bias = *(const f32x4_k*)(a.bias + co);
+            f32x4_k v = s + bias;
+            if (a.act == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            else if (a.act == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.2f * v[r];
+            }
+            if (has_bn) {
+                const f32x4_k sc = *(const f32x4_k*)(a.bn_scale + co), sh = *(const f32x4_k*)(a.bn_shift + co);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaf(v[r], sc[r], sh[r]);
+            }
+            if (a.img_shift) v += *(const f32x4_k*)(a.img_shift + (size_t)n * CoutPad + co);
+            if (yy < H && xx < W) {
+                const size_t o = (((size_t)n * H + yy) * W + xx) * CoutPad + co;
+                if (a.out_f32) *(f32x4_k*)((float*)a.out + o) = v;
+                else {
+                    const __bf16 q0 = (__bf16)v[0], q1 = (__bf16)v[1], q2 = (__bf16)v[2], q3 = (__bf16)v[3];
+                    uint2 pk;
+                    pk.x = (unsigned)__builtin_bit_cast(unsigned short, q0) | ((unsigned)__builtin_bit_cast(unsigned short, q1) << 16);
+                    pk.y = (unsigned)__builtin_bit_cast(unsigned short, q2) | ((unsigned)__builtin_bit_cast(unsigned short, q3) << 16);
+                    *(uint2*)((__bf16*)a.out + o) = pk;
+                }
+            }
+        }
+    }
+}
+
+// the launches this kernel takes: a bf16 3x3 conv (pad = dilation 1 | 2, reading x or x[::2, ::2]) with 64 / 128 / 256 / 512 input
+// channels, no shortcut sum; 32-bit source offsets (as the Winograd kernels)
+bool conv_kwave_applies(const ConvArgs& a) {
+    if (a.zeros == nullptr || a.wgt == nullptr) return false;
+    const int d = a.dy[8];
+    return (a.nkc == 1 || a.nkc == 2 || a.nkc == 4 || a.nkc == 8) && (d == 1 || d == 2) && (a.si == 1 || a.si == 2) && a.so == 1 &&
+           a.nphase == 1 && a.ntaps == 9 && a.resid == nullptr && a.head_w == nullptr && a.in2 == nullptr && a.pk_L == nullptr &&
+           wino_offsets_fit(a.Hs, a.Ws, a.si, a.nkc);
+}
+
+template <int NKC, int TWB, int NW>
+static hipError_t launch_kw_t(ConvArgs& a, int d, hipStream_t s) {
+    a.tiles_x = ((a.Ws + d - 1) / d + 8 * TWB - 1) / (8 * TWB);
+    a.tiles_y = ((a.Hs + d - 1) / d + 7) / 8;
+    const long long blocks = (long long)a.tiles_x * a.tiles_y * d * d * a.N * (a.ncg * 2);
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((conv_kwave_bf16<NKC, TWB, NW>), dim3((unsigned)blocks), dim3(NW * 64), kw_lds_bytes(NKC, TWB, NW), s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_kwave(const ConvArgs& a0, hipStream_t s) {
+    ConvArgs a = a0;
+    if (!conv_kwave_applies(a)) return hipErrorInvalidConfiguration;
+    const int d = a.dy[8];
+    if (a.nkc == 8) return launch_kw_t<8, 1, 8>(a, d, s);
+    if (a.nkc == 4) return launch_kw_t<4, 2, 8>(a, d, s);
+    if (a.nkc == 2) return launch_kw_t<2, 2, 4>(a, d, s);
+    return launch_kw_t<1, 2, 4>(a, d, s);
+}
+
+hipError_t init_kernels_kw() {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_kwave_bf16<8, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kw_lds_bytes(8, 1, 8));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)conv_kwave_bf16<4, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kw_lds_bytes(4, 2, 8));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)conv_kwave_bf16<2, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kw_lds_bytes(2, 2, 4));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)conv_kwave_bf16<1, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kw_lds_bytes(1, 2, 4));
+}
+
+}  // namespace idc

@@ -106,8 +106,8 @@ def test_config5_512_global_hints_against_the_oracle(precision, style):
     ("bf16", "torch", (0.6, 0.06)), ("bf16", "he", (20.0, 2.0)), ("fp32", "torch", (1e-3, None)), ("fp32", "he", (3e-3, None)),
 ])
 def test_config2_click_path_against_the_oracle(make_sd, precision, style, bound):
-    """BASELINE configs[1] -- ONE 256x256 image, 5 hints: the click path's kernels (round 3: Winograd F(2x2,3x3) for the 3x3
-    stride-1 layers in both precisions, conv_click + split-K for the stride-2 convs and the deconvs), measured error recorded."""
+    """BASELINE configs[1] -- ONE 256x256 image, 5 hints: the click path's kernels (fp32: Winograd F(2x2,3x3) for the 3x3 stride-1
+    layers; bf16, round 4: conv_kwave_bf16 for them, Winograd F(2x2,2x2) for model8up / model9up), measured error recorded."""
     sd = make_sd(0, style)
     L = workloads.random_batch(1, 256, seed=7)[0].astype(np.float32)
     hab, hm = workloads.hints_config2(256, 5, 3, 0)
@@ -115,18 +115,22 @@ def test_config2_click_path_against_the_oracle(make_sd, precision, style, bound)
     e = engine.HipColorizer(256, 256, max_batch=1, precision=precision)
     e.load_state_dict(sd)
     out = e.forward(L, ab, m, 0.0)
-    assert sum(r["kernel"].startswith("conv_wino") for r in e.layer_table()) >= 17
+    table = [r["kernel"] for r in e.layer_table()]
+    if precision == "bf16":                                     # round 4: conv_kwave_bf16 on the 3x3 layers, Winograd F(2x2,2x2) on model8up / model9up
+        assert sum(k == "conv_kwave_bf16" for k in table) == 22 and sum(k == "conv_wino_deconv_bf16" for k in table) == 2, table
+    else:
+        assert sum(k.startswith("conv_wino") for k in table) >= 17, table
     e.close()
     ref = siggraph_torch.forward(sd, L, ab, m, 0.0)
-    row = record("configs[1] N=1 256x256 (click path, Winograd)", precision, style, (0,), out, ref)
+    row = record("configs[1] N=1 256x256 (click path, %s)" % ("conv_kwave_bf16" if precision == "bf16" else "Winograd"), precision, style, (0,), out, ref)
     assert row["max_abs"] <= bound[0], row
     if bound[1] is not None:
         assert row["mean_abs"] <= bound[1], row
 
 
 @pytest.mark.parametrize("style,wino,bound", [
-    ("torch", 1, (0.6, 0.06, 0.6)), ("torch", 0, (0.6, 0.06, 0.6)),
-    ("he", 1, (45.0, 2.0, 20.0)), ("he", 0, (45.0, 2.0, 20.0)),
+    ("torch", 2, (0.6, 0.06, 0.6)), ("torch", 1, (0.6, 0.06, 0.6)), ("torch", 0, (0.6, 0.06, 0.6)),
+    ("he", 2, (45.0, 2.0, 20.0)), ("he", 1, (45.0, 2.0, 20.0)), ("he", 0, (45.0, 2.0, 20.0)),
 ])
 def test_click_path_bf16_at_512_winograd_margin(make_sd, style, wino, bound):
     """the bf16 click path (Winograd F(2x2,3x3) / F(2x2,2x2), `winograd_bf16` = 1, and the direct conv_click kernels,
@@ -137,16 +141,19 @@ def test_click_path_bf16_at_512_winograd_margin(make_sd, style, wino, bound):
     L = workloads.random_batch(1, 512, seed=13)[0].astype(np.float32)
     hab, hm = workloads.hints_config2(512, 5, 3, 0)
     ab, m = hab[None].astype(np.float32), hm[None].astype(np.float32)
-    engine.set_option("winograd_bf16", wino)
+    engine.set_option("winograd_bf16", 1 if wino else 0)       # wino = 2: the round-4 default (conv_kwave_bf16 on the 3x3 layers, `kwave` = 1)
+    engine.set_option("kwave", 1 if wino == 2 else 0)
     try:
         e = engine.HipColorizer(512, 512, max_batch=1, precision="bf16")
         e.load_state_dict(sd)
         out = e.forward(L, ab, m, 0.0)
         n_wino = sum(r["kernel"].startswith("conv_wino") for r in e.layer_table())
+        n_kw = sum(r["kernel"].startswith("conv_kwave") for r in e.layer_table())
         e.close()
     finally:
         engine.set_option("winograd_bf16", 1)
-    assert (n_wino >= 8) if wino else (n_wino == 0), n_wino
+        engine.set_option("kwave", 1)
+    assert (n_kw >= 8 and n_wino <= 3) if wino == 2 else ((n_wino >= 8 and n_kw == 0) if wino else (n_wino == 0 and n_kw == 0)), (n_wino, n_kw)
     ref = siggraph_torch.forward(sd, L, ab, m, 0.0)
-    row = record("configs[4] geometry N=1 512x512 (click path, %s)" % ("Winograd" if wino else "direct"), "bf16", style, (0,), out, ref)
+    row = record("configs[4] geometry N=1 512x512 (click path, %s)" % ("conv_kwave_bf16" if wino == 2 else "Winograd" if wino else "direct"), "bf16", style, (0,), out, ref)
     assert row["max_abs"] <= bound[0] and row["mean_abs"] <= bound[1] and row["q999"] <= bound[2], row

@@ -25,6 +25,7 @@ def _reset_options():
     yield
     engine.set_option("winograd", 1)
     engine.set_option("winograd_bf16", 1)
+    engine.set_option("kwave", 1)
     engine.set_option("winograd_deconv", 1)
     engine.set_option("winograd_form", 0)
     engine.set_option("mfma16", 1)
@@ -79,6 +80,7 @@ def test_winograd_bf16_click_path_layer_by_layer(golden, make_sd, name, form):
     _, _, acts = siggraph_torch.forward(make_sd(seed, style), g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]),
                                         return_acts=True, dtype=torch.float64)
     engine.set_option("winograd_form", form)
+    engine.set_option("kwave", 0)                               # (round 4: conv_kwave_bf16 is the default on these layers; this is the Winograd form's test)
     e = engine.HipColorizer(H, W, max_batch=n, precision="bf16")
     e.load_state_dict(make_sd(seed, style))
     out = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
@@ -105,6 +107,7 @@ def test_winograd_bf16_click_config(golden, make_sd):
     """BASELINE configs[1] in bf16: <= 28 launches per click forward, none of them a reduction (51 with conv_click + split-K), the reference golden inside
     the torch-init bf16 bound; the N = 32 throughput path never selects the bf16 Winograd form."""
     g = golden("config2_mortar_5hints_torchinit")
+    engine.set_option("kwave", 0)                               # (the round-4 default is tested in tests/test_round4_gpu.py::test_kwave_click_config)
     e = engine.HipColorizer(256, 256, max_batch=1, precision="bf16")
     e.load_state_dict(make_sd(int(g["weight_seed"]), str(g["weight_style"])))
     out = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
@@ -301,7 +304,9 @@ def test_winograd_odd_trunk_geometry(make_sd, precision):
     e = engine.HipColorizer(40, 72, max_batch=3, precision=precision)
     e.load_state_dict(sd)
     out = e.forward(L, ab, m, 0.5)
-    assert sum(r["kernel"].startswith("conv_wino") for r in e.layer_table()) >= 22
+    assert sum(r["kernel"].startswith("conv_wino") or r["kernel"].startswith("conv_kwave") for r in e.layer_table()) >= 22
+    if precision == "bf16":                                     # round 4: the 3x3 layers of the bf16 click path are conv_kwave_bf16, the deconvs stay Winograd
+        assert sum(r["kernel"].startswith("conv_kwave") for r in e.layer_table()) >= 19
     d = np.abs(out - ref)
     assert d.max() <= (1e-3 if precision == "fp32" else 0.6), d.max()
     for i in range(3):

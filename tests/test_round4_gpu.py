@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 import torch
+import torch.nn.functional as F
 
 from interactive_deep_colorization_amd import engine, workloads
 from oracle import siggraph_torch
@@ -14,7 +15,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _reset_options():
     yield
-    for k, v in (("mfma16", 1), ("ds_mfma16", 1), ("v2p", 1), ("fuse_conv1", 1), ("conv1_lw", 3)):
+    for k, v in (("mfma16", 1), ("ds_mfma16", 1), ("v2p", 1), ("fuse_conv1", 1), ("conv1_lw", 3), ("kwave", 1), ("winograd_bf16", 1)):
         try:
             engine.set_option(k, v)
         except Exception:
@@ -140,3 +141,107 @@ def test_model1_block_with_lds_weight_ring(make_sd, shape):
     for lw in (2, 3):
         np.testing.assert_array_equal(got[lw][0], got[0][0], err_msg="conv1_2, conv1_lw=%d" % lw)
         np.testing.assert_array_equal(got[lw][1], got[0][1], err_msg="ab map, conv1_lw=%d" % lw)
+
+
+# ------------------------------------------------------------------------------------------------ bf16 click path: conv_kwave_bf16
+KW_LAYERS = ["conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3", "conv4_1", "conv4_2", "conv4_3", "conv5_1", "conv5_2", "conv5_3", "conv6_1", "conv6_2",
+             "conv6_3", "conv7_1", "conv7_2", "conv7_3", "conv3_3_short", "conv8_2", "conv8_3", "conv2_2_short", "conv9_2"]
+
+
+@pytest.mark.parametrize("name", ["net64_he_s0_mc05", "net32x48_he_s2", "net64_torch_s1_mc0"])
+def test_kwave_click_path_layer_by_layer(golden, make_sd, name):
+    """bf16, small launches (the batch-1 click path's kernel choice): every 3x3 stride-1 layer with 64 / 128 / 256 / 512 input channels
+    (model.py:19-102; dilation 1 and 2, the x[::2, ::2] reads of conv2_1 / conv3_1 / conv4_1, ragged 32x48 geometry, batch 2) runs as
+    conv_kwave_bf16 -- K split over the waves of a workgroup, no split-K launch.  Each layer against the float64 oracle at the bf16
+    per-layer tolerance (4 % of the layer's range) and NOT worse than the Winograd form it replaces (`kwave` = 0), the ab map inside the
+    stated bf16 bounds of the reference's golden output, deterministic, a batch equal to its images run alone."""
+    g = golden(name)
+    style, seed = str(g["weight_style"]), int(g["weight_seed"])
+    n, _, H, W = g["L_mc"].shape
+    sd = make_sd(seed, style)
+    _, _, acts = siggraph_torch.forward(sd, g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]), return_acts=True, dtype=torch.float64)
+    err = {}
+    for kw in (1, 0):
+        engine.set_option("kwave", kw)
+        e = engine.HipColorizer(H, W, max_batch=n, precision="bf16")
+        e.load_state_dict(sd)
+        out = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
+        table = {r["name"]: r["kernel"] for r in e.layer_table()}
+        want = "conv_kwave_bf16" if kw else "conv_wino_bf16"
+        assert [k for k in KW_LAYERS if table[k] != want] == [], table
+        assert not any("splitK" in table[k] for k in KW_LAYERS)
+        err[kw] = {k: float(np.abs(e.activation(k, n) - acts[k]).mean()) for k in KW_LAYERS}
+        for k in KW_LAYERS:
+            mx = np.abs(e.activation(k, n) - acts[k]).max()
+            assert mx <= 0.04 * (1 + np.abs(acts[k]).max()), "layer %s (kwave=%d): max-abs err %.3e" % (k, kw, mx)
+        d = np.abs(out - g["out_ab"])
+        assert d.max() <= (20.0 if style == "he" else 0.6) and d.mean() <= (2.0 if style == "he" else 0.06), (kw, d.max(), d.mean())
+        np.testing.assert_array_equal(e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"])), out)       # deterministic
+        if kw:
+            for i in range(n):
+                one = e.forward(g["L_mc"][i:i + 1], g["ab"][i:i + 1], g["mask"][i:i + 1], float(g["maskcent"]))
+                np.testing.assert_array_equal(one[0], out[i])
+        e.close()
+    # plain bf16 products against transformed ones: the mean error over the layers does not exceed the Winograd form's
+    assert np.mean([err[1][k] for k in KW_LAYERS]) <= 1.05 * np.mean([err[0][k] for k in KW_LAYERS]), (err[1], err[0])
+
+
+def test_kwave_click_config(golden, make_sd):
+    """BASELINE configs[1] in bf16: 22 of the <= 28 launches of a click forward are conv_kwave_bf16, none a reduction, the reference golden
+    inside the torch-init bf16 bound; the N = 32 throughput path never selects the form."""
+    g = golden("config2_mortar_5hints_torchinit")
+    e = engine.HipColorizer(256, 256, max_batch=1, precision="bf16")
+    e.load_state_dict(make_sd(int(g["weight_seed"]), str(g["weight_style"])))
+    out = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
+    rows = [r for r in e.layer_table() if r["launches"] > 0]
+    launches = sum(r["launches"] + (1 if "splitK" in r["kernel"] else 0) for r in rows)
+    assert sum(r["kernel"] == "conv_kwave_bf16" for r in rows) == 22 and launches <= 28 and not any("splitK" in r["kernel"] for r in rows), (launches, [r["kernel"] for r in rows])
+    d = np.abs(out - g["out_ab"])
+    assert d.max() <= 0.6 and d.mean() <= 0.06, (d.max(), d.mean())
+    e.close()
+    e = engine.HipColorizer(256, 256, max_batch=32, precision="bf16")
+    e.load_state_dict(make_sd(0, "he"))
+    L, ab, m = workloads.random_batch(1, 256, seed=3)
+    e.forward(L, ab, m, 0.0)
+    assert not any(r["kernel"].startswith("conv_kwave") for r in e.layer_table())
+    e.close()
+
+
+KW_OPS = [
+    # n, cin, cout, h,  w,  dil, stride, act, bn
+    (1, 64, 128, 32, 48, 1, 2, 1, False),      # one chunk (conv2_1's read of x[::2, ::2]): four waves = four tap ranges (2, 2, 2, 3 taps)
+    (2, 128, 128, 24, 40, 1, 1, 0, False),     # two chunks x two tap ranges; ragged 16-pixel tile edges (40 = 2.5 tiles), no activation
+    (1, 256, 256, 20, 36, 1, 1, 1, True),      # four chunks x (4 | 5 taps); eval-BN after the ReLU
+    (1, 256, 512, 24, 24, 1, 2, 1, False),     # conv4_1: strided read, 512 couts
+    (3, 512, 512, 8, 12, 2, 1, 1, True),       # dilated (model5 / model6): parity sub-grids of 4 x 6 pixels, batch 3
+    (1, 512, 512, 5, 9, 2, 1, 2, False),       # odd sizes: parity sub-grids 3x5 / 2x4; LeakyReLU
+    (1, 512, 256, 4, 4, 1, 1, 1, False),       # one partial tile
+    (1, 256, 128, 3, 3, 2, 1, 1, False),       # image smaller than the dilation halo
+]
+
+
+@pytest.mark.parametrize("case", KW_OPS)
+def test_kwave_single_conv(case):
+    """conv_kwave_bf16 as a single operator (the launch the network would make at this size: tile policy auto, small grid) against
+    torch float64 conv2d on the bf16-rounded operands' fp32 originals, at the bf16 operator tolerance of tests/test_ops_gpu.py
+    (2.5e-2 * (1 + max|ref|)); `kwave` = 0 gives the Winograd launch -- a different kernel, hence (almost surely) different bits."""
+    n, cin, cout, h, w, dil, stride, act, bn = case
+    rs = np.random.RandomState(abs(hash(case)) % (2 ** 31))
+    x = rs.standard_normal((n, cin, h * stride, w * stride)).astype(np.float32)
+    wt = (rs.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    b = rs.uniform(-0.5, 0.5, cout).astype(np.float32)
+    bn_s = rs.uniform(0.5, 2.0, cout).astype(np.float32) if bn else None
+    bn_t = rs.uniform(-1, 1, cout).astype(np.float32) if bn else None
+    y = F.conv2d(torch.from_numpy(x).double()[:, :, ::stride, ::stride], torch.from_numpy(wt).double(), torch.from_numpy(b).double(), padding=dil, dilation=dil)
+    y = F.relu(y) if act == 1 else (F.leaky_relu(y, 0.2) if act == 2 else y)
+    if bn:
+        y = y * torch.from_numpy(bn_s).double()[None, :, None, None] + torch.from_numpy(bn_t).double()[None, :, None, None]
+    ref = y.numpy()
+    got = {}
+    for kw in (1, 0):
+        engine.set_option("kwave", kw)
+        got[kw] = engine.op_conv2d(x, wt, b, dilation=dil, in_stride=stride, act=act, bn_scale=bn_s, bn_shift=bn_t, precision="bf16")
+        errv = np.abs(got[kw] - ref).max()
+        assert np.isfinite(got[kw]).all() and errv <= 2.5e-2 * (1 + np.abs(ref).max()), (case, kw, errv)
+    assert not np.array_equal(got[1], got[0])
+    assert np.abs(got[1] - ref).mean() <= 1.1 * np.abs(got[0] - ref).mean()
