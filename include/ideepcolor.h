@@ -81,7 +81,8 @@ int idc_set_tile_policy(int policy);
  * (2: 32x8 tiles; 0: the 32x32 tile, weights global -> registers; bit-identical results); "code_warm" (default 1): the throughput kernels
  * pull their own code into L2 at entry (first-use cost of a kernel on some boxes); "kwave" (default 1): on the bf16
  * batch-1 click path the 3x3 stride-1 layers run as conv_kwave_bf16 (direct form, K split over the waves of a workgroup, layout-1 weights),
- * 0 = the Winograd form conv_wino_bf16 of round 3.
+ * 0 = the Winograd form conv_wino_bf16 of round 3; "kwave_deconv" (default 1): likewise the ConvTranspose 4x4 s2 launches of that path as
+ * conv_kwave_deconv_bf16 (0 = conv_wino_deconv_bf16 / conv_click).
  * Take effect on the next forward; unknown names return IDC_ERR_INVALID_ARG. */
 int idc_set_option(const char* name, int value);
 /* Split-K policy of the small-tile kernels (speed only): 0 automatic (launches too small to fill the chip: the

@@ -502,6 +502,7 @@ static int g_v2p = getenv("IDC_V2P") ? atoi(getenv("IDC_V2P")) : 1;
 static int g_code_warm = getenv("IDC_CODE_WARM") ? atoi(getenv("IDC_CODE_WARM")) : 1;
 // bf16 click path: the 3x3 stride-1 layers as conv_kwave_bf16 instead of conv_wino_bf16 ("kwave" / IDC_KWAVE)
 static int g_kwave = getenv("IDC_KWAVE") ? atoi(getenv("IDC_KWAVE")) : 1;
+static int g_kwave_deconv = getenv("IDC_KWAVE_DECONV") ? atoi(getenv("IDC_KWAVE_DECONV")) : 1;      // ... and the deconvs ("kwave_deconv")
 static int g_click = -1;                 // conv_click for small launches: -1 = environment default (on), 0 off, 1 on (idc_set_option "click")
 // Shortcut fusion (conv_igemm_v2<.,.,1,true>) is correct (parity-tested under tile policy 2) but measured slower
 // than two launches on MI355X (4x re-reads of the skip tensor by the four phase workgroups, VGPR spills around
@@ -651,6 +652,12 @@ static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, i
     // every precision and cout width): conv_igemm's ring loop is the better kernel once the K loop is long and the chip full
     const int wm_big = a.ncg % 4 == 0 ? 4 : (a.ncg % 2 == 0 ? 2 : 1), rows_big = wm_big == 4 ? 8 : 16;
     const long long big_tiles = (long long)((Ws + 31) / 32) * ((Hs + rows_big - 1) / rows_big) * n_policy * (a.ncg / wm_big) * a.nphase;
+    // bf16 click path, deconvs: the direct form with K split over the waves of a workgroup (conv_kwave_deconv_bf16, idc_kw.hip)
+    if (precision == IDC_BF16 && g_kwave && g_kwave_deconv && g_tile_policy != 1 && big_tiles < tuning().v2_min_blocks && wino_fits &&
+        L.spec->kind == kDeconv4x4 && (a.nkc == 2 || a.nkc == 4 || a.nkc == 8)) {
+        L.kw = true; a.ksplit = 1; a.kc_per = a.nkc; a.tiles_x = a.tiles_y = 0;
+        return;
+    }
     // bf16 click path, deconvs with Cin >= 256 (model8up / model9up): Winograd F(2x2,2x2) instead of conv_click + a reduction launch
     if (precision == IDC_BF16 && g_wino && g_wino_bf16 && g_wino_deconv && g_tile_policy != 1 && big_tiles < tuning().v2_min_blocks && wino_fits &&
         L.blob.w3_off != (size_t)-1 && L.spec->kind == kDeconv4x4 && (a.nkc >= 4 || g_wino_deconv == 2)) {
@@ -1126,6 +1133,7 @@ int idc_set_option(const char* name, int value) {
     if (strcmp(name, "v2p") == 0) { g_v2p = value != 0; return IDC_OK; }
     if (strcmp(name, "code_warm") == 0) { g_code_warm = value != 0; return IDC_OK; }
     if (strcmp(name, "kwave") == 0) { g_kwave = value != 0; return IDC_OK; }
+    if (strcmp(name, "kwave_deconv") == 0) { g_kwave_deconv = value != 0; return IDC_OK; }
     if (strcmp(name, "conv1_lw") == 0) { set_conv1_lw(value); return IDC_OK; }
     if (strcmp(name, "ds_mfma16") == 0) { g_ds_m16 = value != 0; return IDC_OK; }
     if (strcmp(name, "winograd_bf16") == 0) { g_wino_bf16 = value; return IDC_OK; }
@@ -1936,7 +1944,7 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
                 if (C.fused_short == layer - 1 || C.fused_next == layer - 1) snprintf(out->kernel, sizeof(out->kernel), "fused into %s", C.spec->name);
             out->flops = 0; out->min_bytes = 0; out->launches = 0;
         } else {
-            snprintf(out->kernel, sizeof(out->kernel), L.kw ? "conv_kwave_bf16" : L.wino ? (L.spec->kind == kDeconv4x4 ? (h->precision == IDC_BF16 ? "conv_wino_deconv_bf16" : "conv_wino_deconv_f32") : h->precision == IDC_BF16 ? "conv_wino_bf16" : "conv_wino_f32") : L.click ? (h->precision == IDC_BF16 ? "conv_click<bf16,%d,%d>" : "conv_click<f32,%d,%d>")
+            snprintf(out->kernel, sizeof(out->kernel), L.kw ? (L.spec->kind == kDeconv4x4 ? "conv_kwave_deconv_bf16" : "conv_kwave_bf16") : L.wino ? (L.spec->kind == kDeconv4x4 ? (h->precision == IDC_BF16 ? "conv_wino_deconv_bf16" : "conv_wino_deconv_f32") : h->precision == IDC_BF16 ? "conv_wino_bf16" : "conv_wino_f32") : L.click ? (h->precision == IDC_BF16 ? "conv_click<bf16,%d,%d>" : "conv_click<f32,%d,%d>")
                      : L.v2 ? "conv_igemm_v2<%d,%d>" : (h->precision == IDC_BF16 ? "conv_igemm<bf16,%d,%d>" : "conv_igemm<f32,%d,%d>"),
                      L.cfg.wm, L.cfg.wp);
             if (L.m16) strncat(out->kernel, L.v2p ? "+m16p" : "+m16", sizeof(out->kernel) - strlen(out->kernel) - 1);

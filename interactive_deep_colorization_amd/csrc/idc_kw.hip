@@ -46,7 +46,7 @@ constexpr int kw_lds_bytes(int nkc, int twb, int nw) {
 }
 
 template <int NKC, int TWB, int NW>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_kwave_bf16(const ConvArgs a) {
+__global__ __launch_bounds__(NW * 64, 2) void conv_kwave_bf16(const ConvArgs a) {
     static_assert(NW % NKC == 0, "waves = chunks x tap ranges");
     constexpr int NT = NW * 64, NS = NW / NKC;
     constexpr int MAXT = (9 + NS - 1) / NS;                    // taps of the longest range
@@ -224,10 +224,196 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_kwave_bf16(cons
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// conv_kwave_deconv_bf16<NKC>: ConvTranspose2d 4x4 stride 2 pad 1 (model8up / model9up / model10up, model.py:75,87,97) of the bf16
+// click path in the same form.  out[co, 2m+r, 2n+s] = b + sum over (ky,dy) in T(r), (kx,dx) in T(s), ci of in[ci, m+dy, n+dx] W[ci,co,ky,kx],
+// T(0) = {(1,0),(3,-1)}, T(1) = {(0,+1),(2,0)}: four phases (r,s) x four taps (i,j), ky = (1-r) + 2i, dy = r - i.
+// Workgroup = 8 x 8 input sites (16 x 16 output pixels) x 16 couts (one MFMA row block of the layout-1 weight block: couts g*16 + q*4 + reg)
+// x the whole K; 8 waves, wave w = (cin chunk w % NKC, phases [(w / NKC) * PHW, +PHW)): every (phase, tap) weight tile (16 rows x 128 B)
+// is read by exactly one wave, two taps... four items ahead; the halo tile is the 3x3 kernel's (10 x 10 sites x NKC chunks, one barrier).
+// The NKC partial sums of a (phase, site, cout) meet in LDS in chunk order; + bias + the shortcut sum (model.py:156,170), activation,
+// store at (2m+r, 2n+s).  The Winograd F(2x2,2x2) form it replaces on model8up / model9up streams 36/16 of these weight bytes.
+template <int NKC>
+__global__ __launch_bounds__(512, NKC == 8 ? 2 : 4) void conv_kwave_deconv_bf16(const ConvArgs a) {
+    constexpr int NW = 8, NT = NW * 64, NS = NW / NKC, PHW = 4 / NS;     // phases per wave
+    static_assert(NS == 1 || NS == 2 || NS == 4, "8 waves = chunks x phase groups");
+    constexpr int MAXI = PHW * 4;                              // (phase, tap) items of a wave
+    constexpr int PWD = 10, HR = 100;
+    constexpr int ITEMS = NKC * HR * 8;
+    constexpr int NH = (ITEMS + NT - 1) / NT;
+    constexpr int PD = MAXI < 4 ? MAXI : 4;
+    static_assert(NH + PD * 2 <= 63, "vmcnt field");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 15, g = lane >> 4;
+
+    int b = xcd_remap_k(blockIdx.x, gridDim.x);
+    const int bx = b % a.tiles_x; b /= a.tiles_x;
+    const int by = b % a.tiles_y; b /= a.tiles_y;
+    const int n = b % a.N;
+    const int cq = b / a.N;                                    // group of 16 couts: row block cq & 3 of weight block cq >> 2
+    const int Y0 = 8 * by, X0 = 8 * bx;
+    const int H = a.Hs, W = a.Ws;                              // INPUT sites; the output is 2H x 2W
+    const int pix_bytes = NKC * kRowBytes;
+    const char* const img = (const char*)a.in + (size_t)n * H * W * pix_bytes;
+
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+        const int item = tid + j * NT;
+        const int kc = item / (HR * 8), rem = item - kc * (HR * 8);
+        const int hr = rem >> 3, sig = rem & 7;
+        const int hy = hr / PWD, hx = hr - hy * PWD;
+        const int Y = Y0 + hy - 1, X = X0 + hx - 1;
+        const bool inside = item < ITEMS && (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W;
+        const char* const src = inside ? img + ((Y * W + X) * pix_bytes + kc * kRowBytes + ((sig ^ (hr & 7)) * kSlotBytes)) : (const char*)a.zeros;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(smem + (j * NT + wave * 64) * kSlotBytes), 16, 0, 0);
+    }
+
+    const int kcw = wave % NKC, split = wave / NKC;
+    const size_t w_kc_stride = (size_t)a.ncg * kWBlockBytes;
+    const size_t w_tap_stride = w_kc_stride * NKC;
+    const char* const wl = (const char*)a.wgt + (size_t)kcw * w_kc_stride + (size_t)(cq >> 2) * kWBlockBytes + ((cq & 3) * 16 + px) * kRowBytes;
+    const int wo0 = (g ^ (px & 7)) * kSlotBytes, wo1 = wo0 ^ (4 * kSlotBytes);
+    // item I of this wave: phase ph = split * PHW + I / 4 = (r, s), tap (i, j) = ((I >> 1) & 1, I & 1)
+    auto item_tw = [&](int I) {
+        const int ph = split * PHW + (I >> 2), r = ph >> 1, sx = ph & 1, i = (I >> 1) & 1, j = I & 1;
+        return ((1 - r) + 2 * i) * 4 + (1 - sx) + 2 * j;
+    };
+    u32x4_k areg[PD][2];
+    auto load_A = [&](auto slotc, int I) {
+        constexpr int S = decltype(slotc)::value;
+        const char* const src = wl + (size_t)item_tw(I) * w_tap_stride;
+        areg[S][0] = *(const u32x4_k*)(src + wo0);
+        areg[S][1] = *(const u32x4_k*)(src + wo1);
+    };
+    if constexpr (PD > 0) load_A(std::integral_constant<int, 0>{}, 0);
+    if constexpr (PD > 1) load_A(std::integral_constant<int, 1>{}, 1);
+    if constexpr (PD > 2) load_A(std::integral_constant<int, 2>{}, 2);
+    if constexpr (PD > 3) load_A(std::integral_constant<int, 3>{}, 3);
+
+    f32x4_k acc[PHW][4];
+#pragma unroll
+    for (int i = 0; i < PHW; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_k{0.f, 0.f, 0.f, 0.f};
+    int hbase[4];
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) hbase[pb] = (pb * 2 + (px >> 3) + 1) * PWD + (px & 7) + 1;
+
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD * 2) : "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const char* const hchunk = smem + kcw * (HR * kRowBytes);
+    auto item = [&](auto ic) {
+        constexpr int I = decltype(ic)::value;
+        const int ph = split * PHW + (I >> 2), r = ph >> 1, sx = ph & 1;
+        constexpr int i = (I >> 1) & 1, j = I & 1;
+        const int toff = (r - i) * PWD + (sx - j);
+        u32x4_k bf[4][2];
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) {
+            const int hr = hbase[pb] + toff;
+            const int o0 = hr * kRowBytes + ((g ^ (hr & 7)) * kSlotBytes);
+            bf[pb][0] = *(const u32x4_k*)(hchunk + o0);
+            bf[pb][1] = *(const u32x4_k*)(hchunk + (o0 ^ (4 * kSlotBytes)));
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb)
+                acc[I >> 2][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_k, areg[I % PD][ks]),
+                                                                          __builtin_bit_cast(bf16x8_k, bf[pb][ks]), acc[I >> 2][pb], 0, 0, 0);
+        if constexpr (I + PD < MAXI) load_A(std::integral_constant<int, I % PD>{}, I + PD);
+    };
+    item(std::integral_constant<int, 0>{}); item(std::integral_constant<int, 1>{});
+    item(std::integral_constant<int, 2>{}); item(std::integral_constant<int, 3>{});
+    if constexpr (MAXI > 4) {
+        item(std::integral_constant<int, 4>{}); item(std::integral_constant<int, 5>{});
+        item(std::integral_constant<int, 6>{}); item(std::integral_constant<int, 7>{});
+    }
+    if constexpr (MAXI > 8) {
+        item(std::integral_constant<int, 8>{}); item(std::integral_constant<int, 9>{});
+        item(std::integral_constant<int, 10>{}); item(std::integral_constant<int, 11>{});
+        item(std::integral_constant<int, 12>{}); item(std::integral_constant<int, 13>{});
+        item(std::integral_constant<int, 14>{}); item(std::integral_constant<int, 15>{});
+    }
+
+    // ---- partial sums: [wave][local phase][site 64][16 couts] fp32, 64-byte rows, slot g ^ ((site >> 1) & 3) ---------------------
+    __syncthreads();                                           // every wave is done with the halo
+#pragma unroll
+    for (int pl = 0; pl < PHW; ++pl)
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) {
+            const int site = pb * 16 + px;
+            *(f32x4_k*)(smem + (wave * PHW + pl) * 4096 + site * 64 + ((g ^ ((site >> 1) & 3)) * kSlotBytes)) = acc[pl][pb];
+        }
+    __syncthreads();
+    const int CoutPad = a.ncg * kCoutGroup;
+    const bool has_bn = a.bn_scale != nullptr;
+    const int Ho = 2 * H, Wo = 2 * W;
+#pragma unroll
+    for (int k = 0; k < (4 * 64 * 4) / NT; ++k) {
+        const int idx = tid + k * NT;
+        const int slot = idx & 3, site = (idx >> 2) & 63, ph = idx >> 8;
+        const int sp = ph / PHW, pl = ph - sp * PHW;
+        const char* const base = smem + ((sp * NKC) * PHW + pl) * 4096 + site * 64 + ((slot ^ ((site >> 1) & 3)) * kSlotBytes);
+        f32x4_k v = *(const f32x4_k*)base;
+#pragma unroll
+        for (int kc = 1; kc < NKC; ++kc) v += *(const f32x4_k*)(base + kc * PHW * 4096);
+        const int pb = site >> 4, pp = site & 15;
+        const int sy = Y0 + pb * 2 + (pp >> 3), sxx = X0 + (pp & 7);
+        const int co = (cq >> 2) * kCoutGroup + slot * 16 + (cq & 3) * 4;
+        v += *(const f32x4_k*)(a.bias + co);
+        if (sy < H && sxx < W) {
+            const size_t o = (((size_t)n * Ho + (2 * sy + (ph >> 1))) * Wo + (2 * sxx + (ph & 1))) * CoutPad + co;
+            if (a.resid) {
+                if (a.resid_bf16) {
+                    const uint2 rr = *(const uint2*)((const __bf16*)a.resid + o);
+                    v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+                    v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+                } else {
+                    v += *(const f32x4_k*)((const float*)a.resid + o);
+                }
+            }
+            if (a.act == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            else if (a.act == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.2f * v[r];
+            }
+            if (has_bn) {
+                const f32x4_k sc = *(const f32x4_k*)(a.bn_scale + co), sh = *(const f32x4_k*)(a.bn_shift + co);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaf(v[r], sc[r], sh[r]);
+            }
+            if (a.out_f32) *(f32x4_k*)((float*)a.out + o) = v;
+            else {
+                const __bf16 q0 = (__bf16)v[0], q1 = (__bf16)v[1], q2 = (__bf16)v[2], q3 = (__bf16)v[3];
+                uint2 pk;
+                pk.x = (unsigned)__builtin_bit_cast(unsigned short, q0) | ((unsigned)__builtin_bit_cast(unsigned short, q1) << 16);
+                pk.y = (unsigned)__builtin_bit_cast(unsigned short, q2) | ((unsigned)__builtin_bit_cast(unsigned short, q3) << 16);
+                *(uint2*)((__bf16*)a.out + o) = pk;
+            }
+        }
+    }
+}
+
+constexpr int kwd_lds_bytes(int nkc) {
+    const int halo = ((nkc * 800 + 511) / 512) * 512 * kSlotBytes;
+    const int red = 8 * (4 / (8 / nkc)) * 4096;                // [wave][local phase][4 KiB]
+    return halo > red ? halo : red;
+}
+
 // the launches this kernel takes: a bf16 3x3 conv (pad = dilation 1 | 2, reading x or x[::2, ::2]) with 64 / 128 / 256 / 512 input
 // channels, no shortcut sum; 32-bit source offsets (as the Winograd kernels)
 bool conv_kwave_applies(const ConvArgs& a) {
     if (a.zeros == nullptr || a.wgt == nullptr) return false;
+    if (a.nphase == 4)                                         // ConvTranspose 4x4 s2: conv_kwave_deconv_bf16 (shortcut sum and activation in its epilogue)
+        return (a.nkc == 2 || a.nkc == 4 || a.nkc == 8) && a.ntaps == 4 && a.so == 2 && a.si == 1 && a.img_shift == nullptr &&
+               a.head_w == nullptr && a.in2 == nullptr && a.pk_L == nullptr && wino_offsets_fit(a.Hs, a.Ws, 1, a.nkc);
     const int d = a.dy[8];
     return (a.nkc == 1 || a.nkc == 2 || a.nkc == 4 || a.nkc == 8) && (d == 1 || d == 2) && (a.si == 1 || a.si == 2) && a.so == 1 &&
            a.nphase == 1 && a.ntaps == 9 && a.resid == nullptr && a.head_w == nullptr && a.in2 == nullptr && a.pk_L == nullptr &&
@@ -247,6 +433,16 @@ static hipError_t launch_kw_t(ConvArgs& a, int d, hipStream_t s) {
 hipError_t launch_conv_kwave(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     if (!conv_kwave_applies(a)) return hipErrorInvalidConfiguration;
+    if (a.nphase == 4) {
+        a.tiles_x = (a.Ws + 7) / 8;
+        a.tiles_y = (a.Hs + 7) / 8;
+        const long long blocks = (long long)a.tiles_x * a.tiles_y * a.N * (a.ncg * 4);
+        if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+        if (a.nkc == 8) hipLaunchKernelGGL((conv_kwave_deconv_bf16<8>), dim3((unsigned)blocks), dim3(512), kwd_lds_bytes(8), s, a);
+        else if (a.nkc == 4) hipLaunchKernelGGL((conv_kwave_deconv_bf16<4>), dim3((unsigned)blocks), dim3(512), kwd_lds_bytes(4), s, a);
+        else hipLaunchKernelGGL((conv_kwave_deconv_bf16<2>), dim3((unsigned)blocks), dim3(512), kwd_lds_bytes(2), s, a);
+        return hipGetLastError();
+    }
     const int d = a.dy[8];
     if (a.nkc == 8) return launch_kw_t<8, 1, 8>(a, d, s);
     if (a.nkc == 4) return launch_kw_t<4, 2, 8>(a, d, s);
@@ -255,7 +451,13 @@ hipError_t launch_conv_kwave(const ConvArgs& a0, hipStream_t s) {
 }
 
 hipError_t init_kernels_kw() {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_kwave_bf16<8, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kw_lds_bytes(8, 1, 8));
+    hipError_t e = hipFuncSetAttribute((const void*)conv_kwave_deconv_bf16<8>, hipFuncAttributeMaxDynamicSharedMemorySize, kwd_lds_bytes(8));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)conv_kwave_deconv_bf16<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kwd_lds_bytes(4));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)conv_kwave_deconv_bf16<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kwd_lds_bytes(2));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)conv_kwave_bf16<8, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kw_lds_bytes(8, 1, 8));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)conv_kwave_bf16<4, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kw_lds_bytes(4, 2, 8));
     if (e != hipSuccess) return e;

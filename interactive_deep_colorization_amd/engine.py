@@ -86,7 +86,7 @@ def set_option(name, value):
     address arithmetic in the K loop, conv_igemm_v2p, default on), 'ds_mfma16' 0/1 (deconv + shortcut launches as conv_ds_fused_m),
     'conv1_lw' 0/2/3 (model1: 32x32 tile / 32x8 / 32x12 tiles with an LDS weight ring; default 3), 'code_warm' 0/1 (own-code
     warm-up at kernel entry), 'kwave' 0/1 (bf16 batch-1 click path: the 3x3 stride-1 layers as conv_kwave_bf16 -- K split over the waves
-    of a workgroup, default on -- instead of the Winograd form conv_wino_bf16)."""
+    of a workgroup, default on -- instead of the Winograd form conv_wino_bf16), 'kwave_deconv' 0/1 (likewise its deconvs as conv_kwave_deconv_bf16)."""
     N.check(N.load().idc_set_option(name.encode(), int(value)))
 
 

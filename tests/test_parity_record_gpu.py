@@ -107,7 +107,7 @@ def test_config5_512_global_hints_against_the_oracle(precision, style):
 ])
 def test_config2_click_path_against_the_oracle(make_sd, precision, style, bound):
     """BASELINE configs[1] -- ONE 256x256 image, 5 hints: the click path's kernels (fp32: Winograd F(2x2,3x3) for the 3x3 stride-1
-    layers; bf16, round 4: conv_kwave_bf16 for them, Winograd F(2x2,2x2) for model8up / model9up), measured error recorded."""
+    layers; bf16, round 4: conv_kwave_bf16 for them, conv_kwave_deconv_bf16 for model8up / model9up), measured error recorded."""
     sd = make_sd(0, style)
     L = workloads.random_batch(1, 256, seed=7)[0].astype(np.float32)
     hab, hm = workloads.hints_config2(256, 5, 3, 0)
@@ -116,8 +116,8 @@ def test_config2_click_path_against_the_oracle(make_sd, precision, style, bound)
     e.load_state_dict(sd)
     out = e.forward(L, ab, m, 0.0)
     table = [r["kernel"] for r in e.layer_table()]
-    if precision == "bf16":                                     # round 4: conv_kwave_bf16 on the 3x3 layers, Winograd F(2x2,2x2) on model8up / model9up
-        assert sum(k == "conv_kwave_bf16" for k in table) == 22 and sum(k == "conv_wino_deconv_bf16" for k in table) == 2, table
+    if precision == "bf16":                                     # round 4: conv_kwave_bf16 on the 3x3 layers, conv_kwave_deconv_bf16 on model8up / model9up
+        assert sum(k == "conv_kwave_bf16" for k in table) == 22 and sum(k == "conv_kwave_deconv_bf16" for k in table) == 2, table
     else:
         assert sum(k.startswith("conv_wino") for k in table) >= 17, table
     e.close()
@@ -153,7 +153,7 @@ def test_click_path_bf16_at_512_winograd_margin(make_sd, style, wino, bound):
     finally:
         engine.set_option("winograd_bf16", 1)
         engine.set_option("kwave", 1)
-    assert (n_kw >= 8 and n_wino <= 3) if wino == 2 else ((n_wino >= 8 and n_kw == 0) if wino else (n_wino == 0 and n_kw == 0)), (n_wino, n_kw)
+    assert (n_kw >= 8 and n_wino == 0) if wino == 2 else ((n_wino >= 8 and n_kw == 0) if wino else (n_wino == 0 and n_kw == 0)), (n_wino, n_kw)
     ref = siggraph_torch.forward(sd, L, ab, m, 0.0)
     row = record("configs[4] geometry N=1 512x512 (click path, %s)" % ("conv_kwave_bf16" if wino == 2 else "Winograd" if wino else "direct"), "bf16", style, (0,), out, ref)
     assert row["max_abs"] <= bound[0] and row["mean_abs"] <= bound[1] and row["q999"] <= bound[2], row

@@ -26,6 +26,7 @@ def _reset_options():
     engine.set_option("winograd", 1)
     engine.set_option("winograd_bf16", 1)
     engine.set_option("kwave", 1)
+    engine.set_option("kwave_deconv", 1)
     engine.set_option("winograd_deconv", 1)
     engine.set_option("winograd_form", 0)
     engine.set_option("mfma16", 1)
@@ -162,6 +163,7 @@ def test_winograd_deconv_bf16_layer_by_layer(golden, make_sd, name):
     _, _, acts = siggraph_torch.forward(make_sd(seed, style), g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]),
                                         return_acts=True, dtype=torch.float64)
     engine.set_option("winograd_deconv", 2)
+    engine.set_option("kwave_deconv", 0)                        # (round 4: conv_kwave_deconv_bf16 is the default on these launches)
     e = engine.HipColorizer(H, W, max_batch=n, precision="bf16")
     e.load_state_dict(make_sd(seed, style))
     out = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))

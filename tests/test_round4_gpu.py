@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _reset_options():
     yield
-    for k, v in (("mfma16", 1), ("ds_mfma16", 1), ("v2p", 1), ("fuse_conv1", 1), ("conv1_lw", 3), ("kwave", 1), ("winograd_bf16", 1)):
+    for k, v in (("mfma16", 1), ("ds_mfma16", 1), ("v2p", 1), ("fuse_conv1", 1), ("conv1_lw", 3), ("kwave", 1), ("kwave_deconv", 1), ("winograd_bf16", 1)):
         try:
             engine.set_option(k, v)
         except Exception:
@@ -148,6 +148,9 @@ KW_LAYERS = ["conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3", "conv4_1", "
              "conv6_3", "conv7_1", "conv7_2", "conv7_3", "conv3_3_short", "conv8_2", "conv8_3", "conv2_2_short", "conv9_2"]
 
 
+KW_DECONVS = ["conv8_1", "conv9_1", "conv10_1"]
+
+
 @pytest.mark.parametrize("name", ["net64_he_s0_mc05", "net32x48_he_s2", "net64_torch_s1_mc0"])
 def test_kwave_click_path_layer_by_layer(golden, make_sd, name):
     """bf16, small launches (the batch-1 click path's kernel choice): every 3x3 stride-1 layer with 64 / 128 / 256 / 512 input channels
@@ -170,8 +173,10 @@ def test_kwave_click_path_layer_by_layer(golden, make_sd, name):
         want = "conv_kwave_bf16" if kw else "conv_wino_bf16"
         assert [k for k in KW_LAYERS if table[k] != want] == [], table
         assert not any("splitK" in table[k] for k in KW_LAYERS)
+        if kw:                                                 # model8up / model9up / model10up + their shortcut sums (model.py:156,170,172)
+            assert [table[k] for k in KW_DECONVS] == ["conv_kwave_deconv_bf16"] * 3, table
         err[kw] = {k: float(np.abs(e.activation(k, n) - acts[k]).mean()) for k in KW_LAYERS}
-        for k in KW_LAYERS:
+        for k in KW_LAYERS + (KW_DECONVS if kw else []):
             mx = np.abs(e.activation(k, n) - acts[k]).max()
             assert mx <= 0.04 * (1 + np.abs(acts[k]).max()), "layer %s (kwave=%d): max-abs err %.3e" % (k, kw, mx)
         d = np.abs(out - g["out_ab"])
@@ -187,14 +192,15 @@ def test_kwave_click_path_layer_by_layer(golden, make_sd, name):
 
 
 def test_kwave_click_config(golden, make_sd):
-    """BASELINE configs[1] in bf16: 22 of the <= 28 launches of a click forward are conv_kwave_bf16, none a reduction, the reference golden
-    inside the torch-init bf16 bound; the N = 32 throughput path never selects the form."""
+    """BASELINE configs[1] in bf16: 22 of the <= 28 launches of a click forward are conv_kwave_bf16, two conv_kwave_deconv_bf16 (model8up,
+    model9up), none a reduction, the reference golden inside the torch-init bf16 bound; the N = 32 throughput path never selects the form."""
     g = golden("config2_mortar_5hints_torchinit")
     e = engine.HipColorizer(256, 256, max_batch=1, precision="bf16")
     e.load_state_dict(make_sd(int(g["weight_seed"]), str(g["weight_style"])))
     out = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
     rows = [r for r in e.layer_table() if r["launches"] > 0]
     launches = sum(r["launches"] + (1 if "splitK" in r["kernel"] else 0) for r in rows)
+    assert sum(r["kernel"] == "conv_kwave_deconv_bf16" for r in rows) == 2
     assert sum(r["kernel"] == "conv_kwave_bf16" for r in rows) == 22 and launches <= 28 and not any("splitK" in r["kernel"] for r in rows), (launches, [r["kernel"] for r in rows])
     d = np.abs(out - g["out_ab"])
     assert d.max() <= 0.6 and d.mean() <= 0.06, (d.max(), d.mean())
@@ -244,4 +250,38 @@ def test_kwave_single_conv(case):
         errv = np.abs(got[kw] - ref).max()
         assert np.isfinite(got[kw]).all() and errv <= 2.5e-2 * (1 + np.abs(ref).max()), (case, kw, errv)
     assert not np.array_equal(got[1], got[0])
+    assert np.abs(got[1] - ref).mean() <= 1.1 * np.abs(got[0] - ref).mean()
+
+
+KW_DECONV_OPS = [
+    # n, cin, cout, h, w, act, resid
+    (1, 512, 256, 8, 8, 1, True),        # model8up + shortcut sum + ReLU: a wave per chunk, all four phases
+    (2, 256, 128, 12, 20, 1, True),      # model9up: two waves per chunk (phases r = 0 | 1); ragged 8x8 site tiles, batch 2
+    (1, 128, 128, 9, 5, 2, True),        # model10up: four waves per chunk (one phase each); odd sizes, LeakyReLU(0.2) (model.py:99)
+    (1, 256, 64, 3, 3, 0, False),        # no shortcut, no activation, 64 couts, one partial tile
+]
+
+
+@pytest.mark.parametrize("case", KW_DECONV_OPS)
+def test_kwave_single_deconv(case):
+    """conv_kwave_deconv_bf16 as a single operator against torch float64 conv_transpose2d (4x4, stride 2, pad 1) + shortcut sum + activation,
+    at the bf16 operator tolerance; `kwave_deconv` = 0 gives the round-3 launch (Winograd F(2x2,2x2) or conv_click): different bits."""
+    n, cin, cout, h, w, act, use_res = case
+    rs = np.random.RandomState(abs(hash(case)) % (2 ** 31))
+    x = rs.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = (rs.standard_normal((cin, cout, 4, 4)) / np.sqrt(cin * 4)).astype(np.float32)
+    b = rs.uniform(-0.5, 0.5, cout).astype(np.float32)
+    resid = rs.standard_normal((n, cout, 2 * h, 2 * w)).astype(np.float32) if use_res else None
+    y = F.conv_transpose2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), torch.from_numpy(b).double(), stride=2, padding=1)
+    if use_res:
+        y = y + torch.from_numpy(resid).double()
+    ref = (F.relu(y) if act == 1 else (F.leaky_relu(y, 0.2) if act == 2 else y)).numpy()
+    got = {}
+    for kw in (1, 0):
+        engine.set_option("kwave_deconv", kw)
+        got[kw] = engine.op_deconv4x4s2(x, wt, b, act=act, resid=resid, precision="bf16")
+        errv = np.abs(got[kw] - ref).max()
+        assert np.isfinite(got[kw]).all() and errv <= 2.5e-2 * (1 + np.abs(ref).max()), (case, kw, errv)
+    if cin >= 256:                                             # (two chunks: conv_click's sums differ from this kernel's only below the bf16 rounding of the output)
+        assert not np.array_equal(got[1], got[0])
     assert np.abs(got[1] - ref).mean() <= 1.1 * np.abs(got[0] - ref).mean()

@@ -34,7 +34,7 @@ for kw in (0, 1):
     table = [(r["name"], r["kernel"]) for r in e.layer_table() if r["launches"] > 0]
     errs = {}
     for name, kern in table:
-        if name in acts and (kern.startswith("conv_kwave") or kern.startswith("conv_wino_bf16")):
+        if name in acts and (kern.startswith("conv_kwave") or kern.startswith("conv_wino_")):
             got = e.activation(name, 1)
             errs[name] = (kern, float(np.abs(got - acts[name]).max()), float(np.abs(got - acts[name]).mean()), float(np.abs(acts[name]).max()))
     d = np.abs(out - ref)
@@ -43,10 +43,10 @@ for kw in (0, 1):
     handles[kw] = e
 for kw in (0, 1):
     print("kwave=%d  launches on the form: %d   ab map vs float64 oracle: max %.4f mean %.5f" % (kw, res[kw]["n_kw"], res[kw]["ab_max"], res[kw]["ab_mean"]))
-print("%-14s %-18s %10s %10s | %-18s %10s %10s | %8s" % ("layer", "kernel", "max", "mean", "kernel", "max", "mean", "|ref|max"))
+print("%-14s %-22s %10s %10s | %-22s %10s %10s | %8s" % ("layer", "kernel", "max", "mean", "kernel", "max", "mean", "|ref|max"))
 for name in res[1]["layers"]:
     a0 = res[0]["layers"].get(name, ("-", 0, 0, 0)); a1 = res[1]["layers"][name]
-    print("%-14s %-18s %10.4f %10.5f | %-18s %10.4f %10.5f | %8.2f" % (name, a0[0][:18], a0[1], a0[2], a1[0][:18], a1[1], a1[2], a1[3]))
+    print("%-14s %-22s %10.4f %10.5f | %-22s %10.4f %10.5f | %8.2f" % (name, a0[0][:22], a0[1], a0[2], a1[0][:22], a1[1], a1[2], a1[3]))
 ts = {0: [], 1: []}
 for rep in range(4):
     for kw in (0, 1):

@@ -1,36 +1,80 @@
 #!/usr/bin/env python3
-"""Probe: does running the batch as two half-batches on two engine streams (kernels of both interleave on the
-chip) beat one batch-32 stream?  (tails / launch gaps / burst spreading).  Tuning experiment, not the product path."""
-import os, sys, time
+"""One batch of 32 images per step as ONE N=32 forward against TWO concurrent N=16 forwards on two handles (two streams):
+does space-sharing the chip hide launch floors and tile tails?  bf16, 256x256, device-resident, K steps per timed region."""
+import os
+import sys
+import time
+
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from interactive_deep_colorization_amd import engine, workloads
 
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from interactive_deep_colorization_amd import engine, workloads  # noqa: E402
+
+K = 20
 sd = workloads.random_state_dict(0, "he")
 dev = torch.device("cuda", 0)
-def mk(nb, seed):
-    e = engine.HipColorizer(256, 256, max_batch=nb, precision="bf16")
+L, ab, m = workloads.random_batch(32, 256, seed=0)
+dL, dab, dm = (torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev) for x in (L, ab, m))
+dout = torch.empty((32, 2, 256, 256), dtype=torch.float32, device=dev)
+
+
+def make(nb):
+    e = engine.HipColorizer(256, 256, max_batch=nb, precision="bf16", throughput_blob=True)
     e.load_state_dict(sd)
-    L, ab, m = workloads.random_batch(nb, 256, seed=seed)
-    t = [torch.from_numpy(x).to(dev) for x in (L, ab, m)]
-    out = torch.empty((nb, 2, 256, 256), dtype=torch.float32, device=dev)
-    return e, t, out
-def run(engs, steps=20):
-    for e, t, o in engs:
-        for _ in range(3): e.forward_device(t[0].shape[0], t[0], t[1], t[2], o, 0.0, sync=False)
-    for e, _, _ in engs: e.sync()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        for e, t, o in engs: e.forward_device(t[0].shape[0], t[0], t[1], t[2], o, 0.0, sync=False)
-    for e, _, _ in engs: e.sync()
-    dt = time.perf_counter() - t0
-    n = sum(t[0].shape[0] for _, t, _ in engs)
-    return n * steps / dt
-one = [mk(32, 0)]
-print("1 x 32      : %.0f img/s" % run(one))
-two = [mk(16, 0), mk(16, 1)]
-print("2 x 16 (2 streams): %.0f img/s" % run(two))
-four = [mk(8, i) for i in range(4)]
-print("4 x 8  (4 streams): %.0f img/s" % run(four))
-print("1 x 32 again: %.0f img/s" % run(one))
+    return e
+
+
+def region(fn):
+    for _ in range(10):
+        fn()
+    torch.cuda.synchronize()
+    best = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(K):
+            fn()
+        torch.cuda.synchronize()
+        best.append((time.perf_counter() - t0) / K)
+    return best
+
+
+e32 = make(32)
+parts = {}
+for split in (2, 4):
+    hs = [make(32 // split) for _ in range(split)]
+    parts[split] = hs
+
+
+def one():
+    e32.forward_device(32, dL, dab, dm, dout, 0.0, sync=False)
+    e32.sync()
+
+
+def multi(split):
+    hs = parts[split]
+    nb = 32 // split
+
+    def f():
+        for i, h in enumerate(hs):
+            s = slice(i * nb, (i + 1) * nb)
+            h.forward_device(nb, dL[s], dab[s], dm[s], dout[s], 0.0, sync=False)
+        for h in hs:
+            h.sync()
+    return f
+
+
+for rep in range(2):
+    r = region(one)
+    print("one N=32 forward per step      : %s ms  -> %.0f img/s" % (" ".join("%.4f" % (x * 1e3) for x in r), 32 / min(r)))
+    for split in (2, 4):
+        r = region(multi(split))
+        print("%d concurrent N=%d forwards      : %s ms  -> %.0f img/s" % (split, 32 // split, " ".join("%.4f" % (x * 1e3) for x in r), 32 / min(r)))
+ref = dout.clone()
+one()
+torch.cuda.synchronize()
+a = dout.clone()
+multi(2)()
+torch.cuda.synchronize()
+print("max |one - two-stream| over the batch: %.3e" % float((a - dout).abs().max()))
