@@ -42,7 +42,13 @@ constexpr int kw_lds_bytes(int nkc, int twb, int nw) {
     const int nt = nw * 64;
     const int halo = ((kw_halo_items(nkc, twb) + nt - 1) / nt) * nt * kSlotBytes;
     const int red = nw * 8192;                                 // one round of partial sums: [wave][64 pixels][32 couts] fp32
-    return halo > red ? halo : red;
+    return (halo > red ? halo : red) + 256;                    // + the scratch line of idc_warm_own_code
+}
+
+constexpr int kwd_lds_bytes(int nkc) {
+    const int halo = ((nkc * 800 + 511) / 512) * 512 * kSlotBytes;
+    const int red = 8 * (4 / (8 / nkc)) * 4096;                // [wave][local phase][4 KiB]
+    return (halo > red ? halo : red) + 256;                    // + the scratch line of idc_warm_own_code
 }
 
 template <int NKC, int TWB, int NW>
@@ -63,6 +69,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_kwave_bf16(const ConvArgs a) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = lane & 15, g = lane >> 4;
 
+    // first launch of this kernel after others (eight kernel changes per click forward): its code comes in as data, all lines at once
+    // (idc_kernels.h; 7.5-10.3 KB per instantiation, the <1,2,4> form is the last kernel of its code object: stay inside)
+    if (a.warm && wave == NW - 1) idc_warm_own_code(smem + kw_lds_bytes(NKC, TWB, NW) - 256, lane, NKC == 8 ? 64 : NKC == 4 ? 68 : NKC == 2 ? 76 : 48);
     int b = xcd_remap_k(blockIdx.x, gridDim.x);               // tile blocks fastest, the cout group slowest: an XCD's L2 sees few weight slices
     const int d = a.dy[8];
     const int bx = b % a.tiles_x; b /= a.tiles_x;
@@ -250,6 +259,7 @@ __global__ __launch_bounds__(512, NKC == 8 ? 2 : 4) void conv_kwave_deconv_bf16(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = lane & 15, g = lane >> 4;
 
+    if (a.warm && wave == NW - 1) idc_warm_own_code(smem + kwd_lds_bytes(NKC) - 256, lane, NKC == 8 ? 70 : NKC == 4 ? 46 : 32);   // 9.5 / 6.3 / 4.5 KB
     int b = xcd_remap_k(blockIdx.x, gridDim.x);
     const int bx = b % a.tiles_x; b /= a.tiles_x;
     const int by = b % a.tiles_y; b /= a.tiles_y;
@@ -401,11 +411,6 @@ __global__ __launch_bounds__(512, NKC == 8 ? 2 : 4) void conv_kwave_deconv_bf16(
     }
 }
 
-constexpr int kwd_lds_bytes(int nkc) {
-    const int halo = ((nkc * 800 + 511) / 512) * 512 * kSlotBytes;
-    const int red = 8 * (4 / (8 / nkc)) * 4096;                // [wave][local phase][4 KiB]
-    return halo > red ? halo : red;
-}
 
 // the launches this kernel takes: a bf16 3x3 conv (pad = dilation 1 | 2, reading x or x[::2, ::2]) with 64 / 128 / 256 / 512 input
 // channels, no shortcut sum; 32-bit source offsets (as the Winograd kernels)
