@@ -22,6 +22,7 @@ def _reset():
     yield
     engine.set_option("click", -1)
     engine.set_option("winograd", 1)
+    engine.set_option("kwave", 1)
     engine.set_option("fuse_conv1", 1)
     engine.set_tile_policy("auto")
     engine.set_splitk_policy("auto")
@@ -35,6 +36,7 @@ def test_click_kernel_whole_network(golden, make_sd, precision):
     g = golden("config2_mortar_5hints_torchinit")
     style, seed = str(g["weight_style"]), int(g["weight_seed"])
     engine.set_option("winograd", 0)          # (the fp32 default runs the 3x3 stride-1 layers as Winograd: tests/test_round3_gpu.py)
+    engine.set_option("kwave", 0)             # (... and the bf16 default, round 4, as conv_kwave_bf16: tests/test_round4_gpu.py)
     e = engine.HipColorizer(256, 256, max_batch=1, precision=precision)
     e.load_state_dict(make_sd(seed, style))
     out = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
@@ -65,6 +67,7 @@ def test_click_kernel_layer_by_layer(golden, make_sd, name, precision):
     _, _, acts = siggraph_torch.forward(make_sd(seed, style), g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]),
                                         return_acts=True, dtype=torch.float64)
     engine.set_option("winograd", 0)          # conv_click is what this test is about (fp32 default: Winograd, test_round3_gpu.py)
+    engine.set_option("kwave", 0)             # (bf16 default since round 4: conv_kwave_bf16 / conv_kwave_deconv_bf16, test_round4_gpu.py)
     e = engine.HipColorizer(H, W, max_batch=n, precision=precision)
     e.load_state_dict(make_sd(seed, style))
     for sk in ("auto", "always", "never"):
