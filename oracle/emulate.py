@@ -126,7 +126,34 @@ def _wino_deconv(x, w, round_ops):
     return out
 
 
+def split_bf16(x, terms):
+    """x (fp32) as a sum of `terms` bf16 values, largest first: x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1).  Three terms carry
+    all 24 mantissa bits of an fp32 value (8 + 8 + 8), two carry 16."""
+    parts, r = [], x
+    for _ in range(terms):
+        p = q(r)
+        parts.append(p)
+        r = r - p
+    return parts
+
+
+def _split_products(xs, ws, op):
+    """sum over the operand-term pairs (i, j) with i + j < terms of op(x_i, w_j), every product exact in fp32 (bf16 x bf16), accumulated in fp32
+    smallest terms first: terms = 3 -> six bf16 products per fp32 product (hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi), terms = 2 -> three."""
+    terms = len(xs)
+    pairs = sorted(((i, j) for i in range(terms) for j in range(terms) if i + j < terms), key=lambda ij: -(ij[0] + ij[1]))
+    y = None
+    for i, j in pairs:
+        t = op(xs[i], ws[j])
+        y = t if y is None else y + t
+    return y
+
+
 def _conv3(x, w, b, dilation, mode):
+    if mode.startswith("split"):                         # 'split3_fp32' / 'split2_fp32': an fp32 conv from bf16 MFMAs on split operands (study, DESIGN.md 8 #3)
+        terms = int(mode[5])
+        y = _split_products(split_bf16(x, terms), split_bf16(w, terms), lambda a, c: F.conv2d(a, c, None, padding=dilation, dilation=dilation))
+        return y + b[None, :, None, None]
     if mode in ("fp32", "bf16"):
         ww = q(w) if mode == "bf16" else w
         return F.conv2d(x, ww, b, padding=dilation, dilation=dilation)
@@ -143,7 +170,7 @@ def _conv3(x, w, b, dilation, mode):
 
 
 def forward(sd, L_mc, ab, mask, maskcent=0.0, modes=None, default="bf16", l_div=100., ab_div=110., out_mul=110., return_acts=False):
-    """modes: {layer name: 'fp32' | 'bf16' | 'wino2d' | 'wino1d' | 'wino2d_fp32' | 'wino1d_fp32'} (missing = ``default``).
+    """modes: {layer name: 'fp32' | 'bf16' | 'wino2d' | 'wino1d' | 'wino2d_fp32' | 'wino1d_fp32' | 'split3_fp32' | 'split2_fp32'} (missing = ``default``).
     A layer in any mode but 'fp32' / '*_fp32' rounds its operands (input activation, weights) and its stored output to
     bf16; an 'fp32' layer rounds nothing.  Returns the ab map (N,2,H,W) float32 numpy."""
     modes = dict(modes or {})
@@ -171,7 +198,11 @@ def forward(sd, L_mc, ab, mask, maskcent=0.0, modes=None, default="bf16", l_div=
         def up(name, key, x, skip):
             w, b = _w(sd, key)
             ws, bs = _w(sd, SHORT_OF[name])
-            if md(name).startswith("wino"):                     # deconv as F(2x2,2x2), shortcut conv as F(2x2,3x3)
+            if md(name).startswith("split"):
+                terms = int(md(name)[5])
+                y = _split_products(split_bf16(x, terms), split_bf16(w, terms), lambda a, c: F.conv_transpose2d(a, c, None, stride=2, padding=1)) + b[None, :, None, None]
+                y = y + _split_products(split_bf16(skip, terms), split_bf16(ws, terms), lambda a, c: F.conv2d(a, c, None, padding=1)) + bs[None, :, None, None]
+            elif md(name).startswith("wino"):                   # deconv as F(2x2,2x2), shortcut conv as F(2x2,3x3)
                 ro = not md(name).endswith("_fp32")
                 xin, sk = (q(x), q(skip)) if ro else (x, skip)
                 sc = _wino2d_d1(sk, ws, ro) + bs[None, :, None, None]
