@@ -144,3 +144,24 @@ def test_throughput_blob_is_about_half_and_host_packable():
     thr32 = int(lib.idc_weights_blob_bytes(0, _native.IDC_FLAG_THROUGHPUT_BLOB))
     assert thr32 < 0.5 * full32
     assert lib.idc_version() == 2
+
+
+def test_emulated_split_operand_arithmetic():
+    import numpy as np
+    """oracle/emulate.py 'split3_fp32' / 'split2_fp32' (the fp32-from-bf16-MFMAs study, profiles/r04_split_study.txt): three bf16 terms carry an
+    fp32 value exactly (8 + 8 + 8 mantissa bits), two carry 16 bits; on a small net the six-product form is at plain fp32's distance from the
+    float64 oracle, the three-product form clearly above it and far below bf16's."""
+    import torch
+    from interactive_deep_colorization_amd import workloads
+    from oracle import emulate, siggraph_torch, weights
+    x = torch.from_numpy(np.random.RandomState(0).standard_normal(4096).astype(np.float32) * 37.0)
+    p3, p2 = emulate.split_bf16(x, 3), emulate.split_bf16(x, 2)
+    assert torch.equal(p3[0] + p3[1] + p3[2], x)
+    rel2 = ((p2[0] + p2[1] - x).abs() / x.abs()).max().item()
+    assert 0 < rel2 <= 2.0 ** -16
+    sd = weights.make_state_dict(3, "he")
+    L, ab, m = workloads.random_batch(1, 32, seed=5, max_points=3, max_p=2)
+    ref = siggraph_torch.forward(sd, L, ab, m, 0.0, dtype=torch.float64)
+    err = {mode: emulate.error_stats(emulate.forward(sd, L, ab, m, 0.0, default=mode), ref)["mean_abs"] for mode in ("fp32", "split3_fp32", "split2_fp32", "bf16")}
+    assert err["split3_fp32"] <= 2.0 * err["fp32"], err
+    assert err["fp32"] < err["split2_fp32"] < 0.05 * err["bf16"], err
