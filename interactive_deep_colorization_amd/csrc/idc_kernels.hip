@@ -2368,7 +2368,8 @@ hipError_t launch_conv1_block(const ConvArgs& a, hipStream_t s) {
     static const int force8 = getenv("IDC_C1_TILE8") && atoi(getenv("IDC_C1_TILE8")) != 0;
     // round 4: weight tiles through an LDS ring, two workgroups per CU (g_c1_lw = 2: 32x8 tile, 3: 32x12 tile; 0: the 32x32 tile above)
     const bool big = !(force8 || a.tiles_y == 8);           // a.tiles_y = the engine's request: 8 on the batch-1 click path (too few 32x32 tiles)
-    const int lw = big ? g_c1_lw : 0;
+    // (the click path's 32x8 tile takes the ring too unless conv1_lw = 0: 16.4 -> 15.2 us at batch 1, bit-identical; profiles/r04_kwave.txt)
+    const int lw = big ? g_c1_lw : (g_c1_lw ? 2 : 0);
     const int th = lw == 3 ? 12 : (lw == 2 || !big) ? 8 : 32;
     const long long blocks = (long long)((a.Ws + 31) / 32) * ((a.Hs + th - 1) / th) * a.N;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;

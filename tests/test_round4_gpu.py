@@ -114,12 +114,13 @@ def test_throughput_3x3_tile_without_address_arithmetic(golden, make_sd, name):
     assert d.max() <= bound[0] and d.mean() <= bound[1], (d.max(), d.mean())
 
 
-@pytest.mark.parametrize("shape", [(2, 256, 256), (3, 208, 240)])
+@pytest.mark.parametrize("shape", [(2, 256, 256), (3, 208, 240), (1, 256, 256), (1, 200, 232)])
 def test_model1_block_with_lds_weight_ring(make_sd, shape):
     """conv1_block_fused_t<4,2,true> / <4,3,true> (`conv1_lw` = 2 / 3: 32x8 / 32x12 tiles, conv1_2's weight tiles through an LDS ring,
     two workgroups per CU) against the 32x32-tile form (itself checked per layer against the oracle in test_net_gpu / test_parity_record):
     conv1_2's output (model.py:13-17) and the ab map bit-identical -- the same MFMAs in the same order per accumulator -- ragged
-    tile edges included (208 = 17 x 12 + 4 rows, 240 = 7.5 x 32 columns)."""
+    tile edges included (208 = 17 x 12 + 4 rows, 240 = 7.5 x 32 columns).  Batch 1 = the click path's 32x8 tile, with the ring unless
+    `conv1_lw` = 0 (conv1_block_fused_t<4,2,true> against <4,2,false>; 200 x 232: ragged columns)."""
     n, H, W = shape
     sd = make_sd(0, "he")
     L, ab, m = workloads.random_batch(n, max(H, W), seed=3)

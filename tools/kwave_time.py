@@ -37,7 +37,7 @@ for _ in range(30):
 lo, med, hi = e.layer_times_stats()
 rows = [r for r in e.layer_table() if r["launches"] > 0]
 tag = "%s %d kwave=%d side_stream=%s" % (prec, size, kw, os.environ.get("IDC_SIDE_STREAM", "1"))
-pick = ["conv2_2", "conv3_2", "conv5_2", "conv7_3", "conv8_1", "conv8_2", "conv9_1", "conv9_2", "conv10_1", "conv10_2"]
+pick = ["conv1_1", "conv2_2", "conv3_2", "conv5_2", "conv7_3", "conv8_1", "conv8_2", "conv9_1", "conv9_2", "conv10_1", "conv10_2"]
 print(tag, " ".join("%s:%.1f" % (r["name"], med[r["index"]] * 1e3) for r in rows if r["name"] in pick),
       "| sum of launches %.1f us | forward p50 %.4f ms" % (sum(med[r["index"]] for r in rows) * 1e3, p50))
 e.close()
