@@ -1,11 +1,12 @@
 // idc_kw.hip -- conv_kwave_bf16: the 3x3 stride-1 convolutions of the bf16 BATCH-1 CLICK PATH (BASELINE configs[1]; ui/gui_draw.py:272-286
 // fires the forward on every drag pixel; model.py:13-102), K split over the WAVES of a workgroup (gfx950).
 //
-// What bounds a batch-1 layer (profiles/r04d_click_bf16_trace.txt): 256 workgroups, one per CU, each pulling
-// its operands L2 -> CU at the ~29-32 B/clk a CU gets.  The Winograd kernel this replaces (conv_wino_bf16) streams 16 positions x Cin x
-// 32 couts x 2 B of U per workgroup (512 KiB at Cin = 512) + the patch; touching U early (L2 residency) made it slower, so the stream
-// itself is the bound, not its latency.  The direct form needs 9/16 of the weight bytes; what it lacked at batch 1 was parallelism
-// without a split-K reduction LAUNCH.  Here the K split lives inside the workgroup:
+// What a batch-1 layer costs (profiles/r04_kwave.txt; DESIGN.md section 4, "Round 4: the click path"): 256 workgroups, one per CU.  An empty
+// kernel of that grid takes 6.1 us under per-launch events; a 512 -> 512 layer at 32 x 32 took 16.9 us as Winograd (conv_wino_bf16: 16 positions
+// x Cin x 32 couts x 2 B = 512 KiB of U per workgroup + the patch, eight chunks x (barrier, transform, U one chunk ahead) = a chain of eight
+// memory round trips; touching U early for L2 residency made it slower) and takes 11.7 us here: 6.1 launch floor + 2.4 MFMAs / reduction /
+// epilogue + ~1.5 weight stream + ~1.5 halo stream.  The direct form needs 9/16 of the weight bytes; what it lacked at batch 1 was
+// parallelism without a split-K reduction LAUNCH.  Here the K split lives inside the workgroup:
 //   * workgroup = 8 x (8*TWB) pixels of one dilation sub-grid (d = 2: four independent d = 1 problems on the parity grids, as in the
 //     Winograd kernels) x 32 couts x the WHOLE K; NW waves, wave w = (cin chunk w % NKC, tap range w / NKC): NKC = 8 -> a wave owns
 //     one 64-channel chunk and all nine taps; NKC = 4 -> two waves per chunk split the taps 4 : 5; ...
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_kwave_bf16(const ConvArgs a) 
 // T(0) = {(1,0),(3,-1)}, T(1) = {(0,+1),(2,0)}: four phases (r,s) x four taps (i,j), ky = (1-r) + 2i, dy = r - i.
 // Workgroup = 8 x 8 input sites (16 x 16 output pixels) x 16 couts (one MFMA row block of the layout-1 weight block: couts g*16 + q*4 + reg)
 // x the whole K; 8 waves, wave w = (cin chunk w % NKC, phases [(w / NKC) * PHW, +PHW)): every (phase, tap) weight tile (16 rows x 128 B)
-// is read by exactly one wave, two taps... four items ahead; the halo tile is the 3x3 kernel's (10 x 10 sites x NKC chunks, one barrier).
+// is read by exactly one wave, global -> registers four items ahead; the halo tile is the 3x3 kernel's (10 x 10 sites x NKC chunks, one barrier).
 // The NKC partial sums of a (phase, site, cout) meet in LDS in chunk order; + bias + the shortcut sum (model.py:156,170), activation,
 // store at (2m+r, 2n+s).  The Winograd F(2x2,2x2) form it replaces on model8up / model9up streams 36/16 of these weight bytes.
 template <int NKC>
