@@ -38,6 +38,14 @@ __device__ __forceinline__ int xcd_remap_k(int b, int nb) {
     return base + (b >> 3);
 }
 
+// weight fragments global -> registers by inline asm with counted waits: as plain loads hipcc sinks the look-ahead loads down to their first use
+// (a tap's weights then arrive one memory latency after they are asked for, tap after tap) and joins the first use with a vmcnt(0).  Loads return in
+// order; kw_wait*<N> = "these registers have landed once at most N younger loads are in flight", the operands tie the MFMAs that read them behind it.
+__device__ __forceinline__ void kw_gload(u32x4_k& dst, const char* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p)); }
+template <int N> __device__ __forceinline__ void kw_wait4(u32x4_k& a, u32x4_k& b, u32x4_k& c, u32x4_k& d) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+
 constexpr int kw_halo_items(int nkc, int twb) { return nkc * 10 * (8 * twb + 2) * 8; }
 constexpr int kw_lds_bytes(int nkc, int twb, int nw) {
     const int nt = nw * 64;
@@ -120,9 +128,13 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_kwave_bf16(const ConvArgs a) 
         const char* const src = wl + (size_t)(t < 8 ? t : 8) * w_tap_stride;         // past the range: a harmless re-read (same count on every wave)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-            areg[S][cb][0] = *(const u32x4_k*)(src + wo[cb][0]);
-            areg[S][cb][1] = *(const u32x4_k*)(src + wo[cb][1]);
+            kw_gload(areg[S][cb][0], src + wo[cb][0]);
+            kw_gload(areg[S][cb][1], src + wo[cb][1]);
         }
+    };
+    auto wait_A = [&](auto slotc, auto nc) {
+        constexpr int S = decltype(slotc)::value, N = decltype(nc)::value;
+        kw_wait4<N>(areg[S][0][0], areg[S][0][1], areg[S][1][0], areg[S][1][1]);
     };
     if constexpr (PD > 0) load_A(std::integral_constant<int, 0>{}, t0);
     if constexpr (PD > 1) load_A(std::integral_constant<int, 1>{}, t0 + 1);
@@ -149,6 +161,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_kwave_bf16(const ConvArgs a) 
     auto tap = [&](auto ic) {
         constexpr int I = decltype(ic)::value;
         const int t = t0 + I;
+        constexpr int YOUNGER = (PD - 1 < MAXT - 1 - I ? PD - 1 : MAXT - 1 - I) * 4;
+        wait_A(std::integral_constant<int, I % PD>{}, std::integral_constant<int, YOUNGER>{});
         if (t < t1) {                                          // wave-uniform
             const int ty = t / 3, tx = t - ty * 3;
             const int toff = (ty - 1) * PWD + (tx - 1);
@@ -298,8 +312,8 @@ __global__ __launch_bounds__(512, NKC == 8 ? 2 : 4) void conv_kwave_deconv_bf16(
     auto load_A = [&](auto slotc, int I) {
         constexpr int S = decltype(slotc)::value;
         const char* const src = wl + (size_t)item_tw(I) * w_tap_stride;
-        areg[S][0] = *(const u32x4_k*)(src + wo0);
-        areg[S][1] = *(const u32x4_k*)(src + wo1);
+        areg[S][0] = *(const u32x4_k*)(src + wo0);              // (plain loads here: with two loads per item hipcc's own schedule measured 0.3 us
+        areg[S][1] = *(const u32x4_k*)(src + wo1);              //  per launch better than the counted-wait form of conv_kwave_bf16)
     };
     if constexpr (PD > 0) load_A(std::integral_constant<int, 0>{}, 0);
     if constexpr (PD > 1) load_A(std::integral_constant<int, 1>{}, 1);
