@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- 256x256 images/sec of the Local-Hints forward pass on MI355X (+ p50 click latency).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: bench.py starts its own N ranks, see self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -63,6 +63,15 @@ def parse_args():
     ap.add_argument("--transport", default="torch", choices=["torch", "c_abi"],
                     help="weight broadcast at N>1: torch.distributed.broadcast (RCCL) or the library's own "
                          "idc_broadcast_weights (ncclBroadcast through the C ABI; experimental, see include/ideepcolor.h)")
+    ap.add_argument("--control-flow-only", action="store_true",
+                    help="no GPU, no engine, no number: every rank runs the launcher / process-group / weight-broadcast / barrier / "
+                         "MAX-reduce / per-rank gather control flow of the N>1 job over gloo with a stand-in that launches nothing "
+                         "(the real packed blob still travels).  Prints a line with value null and control_flow_only true.  For "
+                         "tests/test_round5_cpu.py on boxes without a GPU; never a measurement.")
+    ap.add_argument("--weights", default="torch", choices=["torch", "he"],
+                    help="weights `value` is quoted on: 'torch' = torch-default init + randomised BN buffers, the weights SURVEY.md "
+                         "8(d) config 3 names; 'he' = full-range he-style weights (harder data for a power-capped chip).  The "
+                         "other style is timed too and reported beside it (N=1).")
     ap.add_argument("--dryrun-single-gpu", action="store_true",
                     help="N>1 control flow on ONE GPU: every rank uses device 0, the process group is gloo (host "
                          "broadcast of the packed blob -> idc_set_weights_host); for exercising barriers, the MAX-reduce "
@@ -71,11 +80,12 @@ def parse_args():
     return ap.parse_args()
 
 
-def seeded_weights():
-    """Random-init weights of the reference architecture (no checkpoint ships / no network):
-    numpy-seeded, reference state_dict key set."""
+def seeded_weights(style="torch"):
+    """Random-init weights of the reference architecture (no checkpoint ships / no network): numpy-seeded, reference
+    state_dict key set.  'torch' = torch-default init + randomised BN buffers, the weights SURVEY.md
+    8(d) config 3 specifies for the headline; 'he' = he-style full-range weights (the secondary figure)."""
     from interactive_deep_colorization_amd import workloads
-    return workloads.random_state_dict(0, "he")
+    return workloads.random_state_dict(0, style)
 
 
 def cpu_baseline(sd, budget_s=12.0):
@@ -167,21 +177,127 @@ def measure_latency(sd, device):
     return out
 
 
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start the N ranks ourselves, exactly the way
+    the contract's launcher would -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port <free port> bench.py <the same arguments>` -- and hand its exit status back.  Rank 0 of the child job prints
+    the JSON line on the stdout this process inherited."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC only on these hosts (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(n_ranks, 1))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without a launcher -- starting %d ranks: %s" % (n_ranks, n_ranks, " ".join(cmd[1:9])), file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
+class _NoLaunchEngine(object):
+    """--control-flow-only: the surface ShardedColorizer and the timed loop touch, launching nothing and computing nothing
+    (no GPU, no oracle).  The blob size and the RCCL probe are the real library's (host code of libideepcolor_hip.so)."""
+
+    def __init__(self, precision, throughput_blob):
+        from interactive_deep_colorization_amd import engine as _e
+        self._e = _e
+        self.precision = precision
+        self.flags = _e._flags(throughput_blob=throughput_blob)
+        self.blob = None
+        self.device = 0
+
+    def blob_bytes(self):
+        return int(self._e.N.load().idc_weights_blob_bytes(1 if self.precision == "bf16" else 0, self.flags))
+
+    def comm_unique_id(self):                       # the library's own dlopen of librccl + ncclGetUniqueId: no handle needed
+        import ctypes
+        N = self._e.N
+        buf = (ctypes.c_char * N.IDC_UNIQUE_ID_BYTES)()
+        N.check(N.load().idc_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)))
+        return bytes(buf)
+
+    def broadcast_weights(self, unique_id, rank, world, root=0):
+        raise RuntimeError("control-flow-only run: no device handle exists for ncclBroadcast (reached after the librccl dlopen)")
+
+    def set_weights_blob(self, blob):
+        self.blob = (int(blob.size), int(blob[:4096].astype(np.uint64).sum()))
+
+    def set_weights_device(self, ptr, nbytes, copy=False, keepalive=None):
+        raise AssertionError("gloo groups move host bytes")
+
+    def forward_device(self, *a, **kw):
+        pass
+
+    def sync(self):
+        pass
+
+
+def control_flow_only(args, rank, world, dist, sharded, engine):
+    """The N>1 job's control flow without a GPU (see --control-flow-only)."""
+    import torch
+    tblob = args.precision == "bf16" and args.batch >= 8
+    e = _NoLaunchEngine(args.precision, tblob)
+    sc = sharded.ShardedColorizer(e, rank=rank, world_size=world)
+    blob = None
+    if rank == 0:
+        from interactive_deep_colorization_amd import workloads
+        blob = engine.pack_weights(workloads.random_state_dict(0, args.weights), args.precision, throughput_blob=tblob)
+    sc.broadcast_weights(blob, transport=args.transport)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        e.forward_device()
+    e.sync()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    per_rank, blobs = [elapsed], [e.blob]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        mine = t.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        per_rank = [float(q[0].item()) for q in parts]
+        blobs = [None] * world
+        dist.all_gather_object(blobs, e.blob)
+        assert float(t[0].item()) >= max(per_rank) - 1e-12
+    if rank == 0:
+        print(json.dumps({"metric": "256x256 images/sec", "value": None, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "control_flow_only": True, "ranks_reporting": len(per_rank),
+                          "launched_by": os.environ.get("IDC_BENCH_LAUNCHED_BY", "external launcher"),
+                          "process_group_backend": dist.get_backend() if world > 1 else None,
+                          "transport_requested": args.transport, "transport_used": sc.transport_used or args.transport,
+                          "transport_fallback_reason": sc.transport_fallback_reason,
+                          "weights_blob_bytes": e.blob_bytes(), "every_rank_holds_rank0_blob": len(set(blobs)) == 1 and blobs[0] is not None,
+                          "note": "no GPU work ran: launcher, rendezvous, weight broadcast, barriers and the rank reductions only"}))
+        sys.stdout.flush()
+    if world > 1:
+        dist.barrier()
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        os.environ["IDC_BENCH_LAUNCHED_BY"] = "bench.py self_launch"
+        sys.exit(self_launch(args.gpus))
     import torch
     import torch.distributed as dist
     from interactive_deep_colorization_amd import engine, sharded, workloads
 
-    rank, local_rank, world = sharded.init_process_group(backend="gloo" if args.dryrun_single_gpu else None)
+    rank, local_rank, world = sharded.init_process_group(
+        backend="gloo" if (args.dryrun_single_gpu or args.control_flow_only) else None)
     if args.dryrun_single_gpu:
         local_rank = 0
-    if world != args.gpus:
-        if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run for N>1"
-                  % (args.gpus, world), file=sys.stderr)
-        if world == 1 and args.gpus != 1:
-            sys.exit(2)
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; reporting n_gpus=%d"
+              % (args.gpus, world, world), file=sys.stderr)
+    if args.control_flow_only:
+        return control_flow_only(args, rank, world, dist, sharded, engine)
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible -- the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
@@ -195,7 +311,7 @@ def main():
     tblob = args.precision == "bf16" and nb >= 8
     e = engine.HipColorizer(H, W, max_batch=nb, precision=args.precision, device=local_rank, throughput_blob=tblob)
     sc = sharded.ShardedColorizer(e, rank=rank, world_size=world)
-    sd = seeded_weights() if rank == 0 else None
+    sd = seeded_weights(args.weights) if rank == 0 else None
     blob = engine.pack_weights(sd, args.precision, throughput_blob=tblob) if rank == 0 else None
     sc.broadcast_weights(blob, transport=args.transport)
 
@@ -285,7 +401,10 @@ def main():
         "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[2]: batch %d random 256x256 L-channels + random sparse ab "
                                "hint masks per GPU, %s MFMA conv path, Local-Hints SIGGRAPHGenerator forward "
-                               "(dist=False), seeded random-init weights" % (nb, args.precision),
+                               "(dist=False), seeded random-init weights (%s)" % (
+                                   nb, args.precision, "torch-default init + randomised BN buffers: SURVEY.md 8(d) config 3" if args.weights == "torch"
+                                   else "he-style full-range"),
+                   "weights": args.weights,
                    "global_batch": world * nb, "per_gpu_batch": nb, "height": H, "width": W,
                    "parallelism": "independent images sharded over %d GPU(s); one RCCL weight broadcast (transport: %s%s)" % (
                        world, sc.transport_used or args.transport, ", c_abi fell back: " + sc.transport_fallback_reason if sc.transport_fallback_reason else ""),
@@ -308,6 +427,9 @@ def main():
                      "whole_forward_frac": round(FLOP_PER_IMAGE_256 * nb / (ms_per_step * 1e-3) / 1e12 / peak, 4)},
         "repeats": _spread([world * nb * args.steps / t_ for t_ in [elapsed] + extra], args.steps),
         "per_rank_images_per_sec": [round(nb * args.steps / t_, 2) for t_ in per_rank],
+        "process_group": {"backend": (dist.get_backend() if world > 1 else None), "ranks": world,
+                          "rccl_ranks": world if (world > 1 and dist.get_backend() == "nccl") else (1 if world == 1 else 0),
+                          "launched_by": os.environ.get("IDC_BENCH_LAUNCHED_BY", "external launcher" if world > 1 else "single process")},
         "scaling_note": "no hardware scaling curve exists from the builder (1-GPU boxes only): per-N values are whatever the "
                         "driver's 8-GPU run of this command measures; the path has no data-path collective",
         "layers_ms": {r["name"]: round(float(layer_ms[r["index"]]), 4) for r in table},
@@ -325,10 +447,12 @@ def main():
     if world == 1 and not args.no_end_to_end:
         result["end_to_end"] = measure_end_to_end(e, nb, args.steps, args.warmup, value)
     if world == 1:
-        # SURVEY.md 8d config 3 names torch-default-init weights (+ randomised BN buffers); `value` above is on he-style
-        # full-range weights, the harder data for a power-capped chip.  Same engine, same inputs, same launches.
+        # the other weight style on the same engine, inputs and launches: `value` is on SURVEY.md 8d config 3's torch-default
+        # init (+ randomised BN buffers); he-style full-range weights are the harder data for a power-capped chip
+        other = "he" if args.weights == "torch" else "torch"
+        key = "he_style_weights" if other == "he" else "torch_init_weights"
         try:
-            e.load_state_dict(workloads.random_state_dict(0, "torch"))
+            e.load_state_dict(workloads.random_state_dict(0, other))
             for _ in range(args.warmup):
                 e.forward_device(nb, dL, dab, dm, dout, 0.0, sync=False)
             e.sync()
@@ -337,14 +461,14 @@ def main():
                 e.forward_device(nb, dL, dab, dm, dout, 0.0, sync=False)
             e.sync()
             tms = (time.perf_counter() - tt) / args.steps * 1e3
-            result["torch_init_weights"] = {
+            result[key] = {
                 "value": round(nb / (tms * 1e-3), 2), "unit": "images/sec", "ms_per_step": round(tms, 4),
                 "whole_forward_frac": round(FLOP_PER_IMAGE_256 * nb / (tms * 1e-3) / 1e12 / peak, 4),
-                "how": "the same %d steps with workloads.random_state_dict(0, 'torch') (torch-default init, randomised BN "
-                       "buffers = SURVEY.md 8d config 3's weights) instead of the he-style weights `value` is quoted on" % args.steps}
+                "how": "the same %d steps with workloads.random_state_dict(0, '%s') instead of the '%s' weights `value` is quoted on"
+                       % (args.steps, other, args.weights)}
             e.load_state_dict(sd)
         except Exception as ex:
-            result["torch_init_weights"] = {"error": str(ex)[:200]}
+            result[key] = {"error": str(ex)[:200]}
     if world == 1 and not args.no_peak_probe and args.precision == "bf16":
         # the SAME launches on all-zero operands (weights and inputs): no kernel branches on data, so the instruction
         # streams are identical and the time difference is the clock the power management grants -- separates the code's

@@ -96,15 +96,23 @@ class ShardedColorizer(object):
                 if packed_blob is None or int(packed_blob.size) != nbytes:
                     raise ValueError("rank %d must provide a %d-byte packed blob" % (src, nbytes))
                 self.engine.set_weights_blob(packed_blob)
-            box = [None, None]
-            if self.rank == src:
-                try:
-                    box[0] = self.engine.comm_unique_id()
-                except Exception as ex:
-                    box[1] = "idc_comm_unique_id failed on rank %d: %s" % (src, str(ex)[:200])
-            dist.broadcast_object_list(box, src=src)
-            why = box[1]
+            # pre-flight: EVERY rank probes its own librccl (dlopen + ncclGetUniqueId, result discarded) and the
+            # answers are gathered BEFORE anyone enters a collective of the new communicator -- a rank whose librccl cannot be
+            # opened (different LD_LIBRARY_PATH, heterogeneous nodes) would otherwise raise while the healthy ranks sit inside
+            # ncclCommInitRank waiting for it.
+            mine = None
+            uid = None
+            try:
+                uid = self.engine.comm_unique_id()
+            except Exception as ex:
+                mine = "idc_comm_unique_id failed on rank %d: %s" % (self.rank, str(ex)[:200])
+            probes = [None] * self.world_size
+            dist.all_gather_object(probes, mine)
+            bad = [r for r in probes if r]
+            why = bad[0] if bad else None
             if why is None:
+                box = [uid if self.rank == src else None]
+                dist.broadcast_object_list(box, src=src)
                 dist.barrier()
                 t0 = time.perf_counter()
                 mine = None
@@ -121,7 +129,7 @@ class ShardedColorizer(object):
                 why = bad[0]
             self.transport_used = "torch"
             self.transport_fallback_reason = why
-            if self.rank == 0:
+            if self.rank == src:
                 import sys
                 print("sharded.broadcast_weights: transport 'c_abi' unavailable (%s) -- falling back to torch.distributed.broadcast"
                       % why, file=sys.stderr)
