@@ -12,6 +12,8 @@ import torch
 from interactive_deep_colorization_amd import api, engine, workloads
 from oracle import siggraph_torch, weights
 
+from bounds import FP32_TOL, bf16_bound, check_bf16_ab  # noqa: F401
+
 pytestmark = pytest.mark.gpu
 
 
@@ -43,7 +45,7 @@ def test_global_hints_fusion(golden, precision, tiles):
     else:
         assert np.abs(c43 - g["conv4_3"]).max() <= 0.04 * (1 + np.abs(g["conv4_3"]).max())
         d = np.abs(out - g["out_ab"])
-        assert d.max() <= 20.0 and d.mean() <= 2.0, (d.max(), d.mean())
+        check_bf16_ab(d, "he")
     # the hints matter, and clearing them reproduces the zero-input branch (reference: glob_dist == -1)
     e.clear_global_hints()
     out0 = e.forward(g["L_mc"], g["ab"], g["mask"], 0.0)
@@ -75,7 +77,7 @@ def test_config5_512_global_hints_bf16():
     d = np.abs(out[3:4] - ref)
     # bf16 through 30 layers with he-style weights: the bulk stays within the usual bound, while the tail of the
     # max over 4x more pixels than the 256x256 cases grows (steep tanh region) -- stated as quantile + max
-    assert d.mean() <= 2.0 and np.quantile(d, 0.999) <= 20.0 and d.max() <= 45.0, (d.mean(), np.quantile(d, 0.999), d.max())
+    check_bf16_ab(d, "he", size=512)               # measured 23.7 / 0.86 / 12.2 (profiles/parity_r04_gpu.json)
     e.close()
 
 

@@ -1,5 +1,10 @@
-"""Host colour maths (skimage restatement, PARITY UNPINNED -- textbook known answers only)."""
+"""Host colour maths (skimage restatement: PARITY UNPINNED against the library -- skimage is not installable here -- pinned
+against an independent 50-digit evaluation of the published formulas with skimage's constants, tests/golden/colorspace_pairs.npz,
+written by oracle/make_golden_colorspace.py; plus the textbook known answers)."""
+import os
+
 import numpy as np
+import pytest
 
 from interactive_deep_colorization_amd import colorspace as prod
 from oracle import colorspace as ora
@@ -20,6 +25,26 @@ def test_known_answers():
         for impl in (prod, ora):
             got = impl.rgb2lab(px)[0, 0]
             np.testing.assert_allclose(got, lab, atol=0.02, err_msg="%s %s" % (impl.__name__, rgb))
+
+
+@pytest.mark.parametrize("impl", [prod, ora], ids=["product", "oracle"])
+def test_against_the_independent_50_digit_evaluation(impl):
+    """1200 sRGB -> Lab and 1200 Lab -> sRGB pairs (uint8 and float inputs, both sides of every branch knee,
+    out-of-gamut and negative-z Lab, the grey axis), each restatement at 1e-9 -- the tolerance the device kernel
+    (`lab_post_kernel`, tests/test_net_gpu.py) is then held to against oracle/colorspace.py."""
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "colorspace_pairs.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    assert len(g["rgb_u8"]) + len(g["rgb_f64"]) >= 1000 and len(g["lab_in"]) >= 1000
+    np.testing.assert_allclose(impl.rgb2lab(g["rgb_u8"].reshape(-1, 1, 3))[:, 0], g["lab_of_rgb_u8"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(impl.rgb2lab(g["rgb_f64"].reshape(-1, 1, 3))[:, 0], g["lab_of_rgb_f64"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(impl.lab2rgb(g["lab_in"].reshape(-1, 1, 3))[:, 0], g["rgb_of_lab"], rtol=0, atol=1e-9)
+    # and the uint8 rendering of data/colorize_image.py:27 (truncating cast): identical wherever the exact value is not within
+    # 1e-9 of an integer step
+    lab = g["lab_in"].T.reshape(3, 1, -1)
+    u8 = impl.lab2rgb_transpose(lab[[0]], lab[1:])[0]
+    exact = g["rgb_of_lab"] * 255
+    safe = np.abs(exact - np.round(exact)) > 1e-6
+    assert np.array_equal(u8[safe], np.floor(exact).astype(np.uint8)[safe]) and safe.mean() > 0.7     # (clipped channels sit exactly on 0 / 255)
 
 
 def test_product_matches_oracle_and_roundtrips():

@@ -13,6 +13,8 @@ from interactive_deep_colorization_amd import _native as N
 from interactive_deep_colorization_amd import api, engine, workloads
 from oracle import siggraph_torch
 
+from bounds import FP32_TOL, bf16_bound, check_bf16_ab  # noqa: F401
+
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 WINO_LAYERS = ["conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3", "conv4_1", "conv4_2", "conv4_3", "conv5_1", "conv5_2", "conv5_3", "conv6_1", "conv6_2",
@@ -94,13 +96,13 @@ def test_winograd_bf16_click_path_layer_by_layer(golden, make_sd, name, form):
         err = np.abs(e.activation(k, n) - ref).max()
         assert err <= 0.04 * (1 + np.abs(ref).max()), "layer %s (form %d): max-abs err %.3e" % (k, form, err)
     d = np.abs(out - g["out_ab"])
-    assert d.max() <= (20.0 if style == "he" else 0.6) and d.mean() <= (2.0 if style == "he" else 0.06), (d.max(), d.mean())
+    check_bf16_ab(d, style)
     np.testing.assert_array_equal(e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"])), out)       # deterministic
     engine.set_option("winograd_bf16", 0)
     base = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
     assert not any(r["kernel"] == "conv_wino_bf16" for r in e.layer_table())
     db = np.abs(base - g["out_ab"])
-    assert db.max() <= (20.0 if style == "he" else 0.6)
+    check_bf16_ab(db, style)
     e.close()
 
 
@@ -116,7 +118,7 @@ def test_winograd_bf16_click_config(golden, make_sd):
     launches = sum(r["launches"] + (1 if "splitK" in r["kernel"] else 0) for r in rows)
     assert sum(r["kernel"] == "conv_wino_bf16" for r in rows) >= 20 and launches <= 28 and not any("splitK" in r["kernel"] for r in rows), (launches, [r["kernel"] for r in rows])
     d = np.abs(out - g["out_ab"])
-    assert d.max() <= 0.6 and d.mean() <= 0.06, (d.max(), d.mean())
+    check_bf16_ab(d, "torch")
     e.close()
     e = engine.HipColorizer(256, 256, max_batch=32, precision="bf16")
     e.load_state_dict(make_sd(0, "he"))
@@ -175,7 +177,7 @@ def test_winograd_deconv_bf16_layer_by_layer(golden, make_sd, name):
         assert err <= 0.04 * (1 + np.abs(ref).max()), "layer %s: max-abs err %.3e" % (k, err)
     assert not any("splitK" in v for v in table.values()), table
     d = np.abs(out - g["out_ab"])
-    assert d.max() <= (20.0 if style == "he" else 0.6) and d.mean() <= (2.0 if style == "he" else 0.06), (d.max(), d.mean())
+    check_bf16_ab(d, style)
     e.close()
 
 
@@ -310,7 +312,7 @@ def test_winograd_odd_trunk_geometry(make_sd, precision):
     if precision == "bf16":                                     # round 4: the 3x3 layers of the bf16 click path are conv_kwave_bf16, the deconvs stay Winograd
         assert sum(r["kernel"].startswith("conv_kwave") for r in e.layer_table()) >= 19
     d = np.abs(out - ref)
-    assert d.max() <= (1e-3 if precision == "fp32" else 0.6), d.max()
+    assert d.max() <= (1e-3 if precision == "fp32" else bf16_bound("torch")[0]), d.max()
     for i in range(3):
         np.testing.assert_array_equal(e.forward(L[i:i + 1], ab[i:i + 1], m[i:i + 1], 0.5)[0], out[i])
     e.close()
@@ -377,9 +379,8 @@ def test_throughput_tile_in_both_mfma_shapes(golden, make_sd, name, mfma16):
             assert all("+m16" in k or "+shortcut" in k for k in kernels), kernels
         e.close()
     ref = g["out_ab"]
-    bound = (20.0, 2.0) if style == "he" else (0.6, 0.06)
+    bound = bf16_bound(style)
     for shape, out in outs.items():
-        d = np.abs(out - ref)
-        assert d.max() <= bound[0] and d.mean() <= bound[1], (shape, d.max(), d.mean())
+        check_bf16_ab(out - ref, style, tag="mfma16=%d" % shape)
     d = np.abs(outs[1] - outs[0])
     assert d.mean() <= bound[1] / 2, (d.max(), d.mean())

@@ -9,6 +9,8 @@ import torch.nn.functional as F
 from interactive_deep_colorization_amd import engine, workloads
 from oracle import siggraph_torch
 
+from bounds import FP32_TOL, bf16_bound, check_bf16_ab  # noqa: F401
+
 pytestmark = pytest.mark.gpu
 
 
@@ -50,17 +52,15 @@ def test_deconv_shortcut_launch_in_both_mfma_shapes(golden, make_sd, name):
         layers[shape] = {k: e.activation(k, n) for k in DS_LAYERS}
         np.testing.assert_array_equal(e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"])), outs[shape])   # deterministic
         e.close()
-    bound = (20.0, 2.0) if style == "he" else (0.6, 0.06)
     for shape in (1, 0):
         for k in DS_LAYERS:
             err = np.abs(layers[shape][k] - acts[k]).max()
             assert err <= 0.04 * (1 + np.abs(acts[k]).max()), "layer %s (ds_mfma16=%d): max-abs err %.3e" % (k, shape, err)
-        d = np.abs(outs[shape] - g["out_ab"])
-        assert d.max() <= bound[0] and d.mean() <= bound[1], (shape, d.max(), d.mean())
+        check_bf16_ab(outs[shape] - g["out_ab"], style, tag="ds_mfma16=%d" % shape)
     for k in DS_LAYERS:                                       # same sums in a different order: a bf16 ulp here and there
         a, b = layers[1][k], layers[0][k]
         assert np.abs(a - b).max() <= 2.0 ** -6 * (1 + np.abs(b).max()), k
-    assert np.abs(outs[1] - outs[0]).mean() <= bound[1] / 2
+    assert np.abs(outs[1] - outs[0]).mean() <= bf16_bound(style)[1] / 2
 
 
 def test_deconv_shortcut_m16_batch_is_per_image(make_sd):
@@ -109,9 +109,7 @@ def test_throughput_3x3_tile_without_address_arithmetic(golden, make_sd, name):
     for k in V2_LAYERS:
         np.testing.assert_array_equal(layers[1][k], layers[0][k], err_msg=k)
     np.testing.assert_array_equal(outs[1], outs[0])
-    bound = (20.0, 2.0) if style == "he" else (0.6, 0.06)
-    d = np.abs(outs[1] - g["out_ab"])
-    assert d.max() <= bound[0] and d.mean() <= bound[1], (d.max(), d.mean())
+    check_bf16_ab(outs[1] - g["out_ab"], style)
 
 
 @pytest.mark.parametrize("shape", [(2, 256, 256), (3, 208, 240), (1, 256, 256), (1, 200, 232)])
@@ -181,7 +179,7 @@ def test_kwave_click_path_layer_by_layer(golden, make_sd, name):
             mx = np.abs(e.activation(k, n) - acts[k]).max()
             assert mx <= 0.04 * (1 + np.abs(acts[k]).max()), "layer %s (kwave=%d): max-abs err %.3e" % (k, kw, mx)
         d = np.abs(out - g["out_ab"])
-        assert d.max() <= (20.0 if style == "he" else 0.6) and d.mean() <= (2.0 if style == "he" else 0.06), (kw, d.max(), d.mean())
+        check_bf16_ab(d, style, tag="kwave=%d" % kw)
         np.testing.assert_array_equal(e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"])), out)       # deterministic
         if kw:
             for i in range(n):
@@ -204,7 +202,7 @@ def test_kwave_click_config(golden, make_sd):
     assert sum(r["kernel"] == "conv_kwave_deconv_bf16" for r in rows) == 2
     assert sum(r["kernel"] == "conv_kwave_bf16" for r in rows) == 22 and launches <= 28 and not any("splitK" in r["kernel"] for r in rows), (launches, [r["kernel"] for r in rows])
     d = np.abs(out - g["out_ab"])
-    assert d.max() <= 0.6 and d.mean() <= 0.06, (d.max(), d.mean())
+    check_bf16_ab(d, "torch")
     e.close()
     e = engine.HipColorizer(256, 256, max_batch=32, precision="bf16")
     e.load_state_dict(make_sd(0, "he"))
