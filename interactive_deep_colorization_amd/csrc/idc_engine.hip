@@ -2089,6 +2089,9 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     HIPCHK(nullctx, hipSetDevice(device_id));
     HIPCHK(nullctx, init_kernels());
     Layer L;
+    // the shortcut sum arrives through the `resid` pointer; every eligibility gate of set_geometry reads spec.resid (a 3x3 op with
+    // a residual must not be handed to conv_kwave_bf16 / the Winograd forms, which do not take one -- ADVICE r4)
+    spec.resid = resid ? "resid" : nullptr;
     L.spec = &spec;
     L.blob.nkc = spec.cin / kc; L.blob.ncg = cout_pad(spec.cout) / kCoutGroup;
     L.blob.w_bytes = (size_t)weight_taps(spec.kind) * L.blob.nkc * L.blob.ncg * kWBlockBytes;

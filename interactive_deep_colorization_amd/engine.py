@@ -153,7 +153,9 @@ class _PinnedPool(object):
         self.free = {}                      # nbytes -> [ptr]
         self.retained = 0                   # bytes on the free lists
         self.live = 0                       # pinned bytes currently viewed by arrays handed out
-        self._lock = threading.Lock()
+        # re-entrant: give() runs from __del__, and a cyclic-GC pass triggered by an allocation INSIDE a locked region can finalise
+        # another pooled buffer on the same thread (a plain Lock would deadlock there); the counters tolerate the nesting
+        self._lock = threading.RLock()
 
     def take(self, shape, dtype):
         shape = tuple(int(x) for x in shape)

@@ -93,6 +93,27 @@ def test_conv3x3(case, precision):
     _check(got, ref, precision, "conv3x3 %s" % (case,))
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[9]] + [(1, 128, 128, 16, 16, 1, 1, 1, False, True), (2, 256, 128, 8, 8, 1, 1, 0, True, True)])
+def test_conv3x3_with_residual_under_the_default_policies(case, precision):
+    """with the AUTO tile policy a small bf16 3x3 op with 1 / 2 / 4 / 8 cin chunks is a conv_kwave_bf16 candidate; that
+    kernel takes no shortcut sum, and the single-op path used to decide before it knew about the residual (IDC_ERR_INTERNAL)."""
+    engine.set_tile_policy("auto")
+    engine.set_splitk_policy("auto")
+    n, cin, cout, h, w, dil, stride, act, bn, _ = case
+    rs = np.random.RandomState(7 + cin + cout + h)
+    x = rs.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = (rs.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    b = rs.uniform(-0.5, 0.5, cout).astype(np.float32)
+    bn_s = rs.uniform(0.5, 2.0, cout).astype(np.float32) if bn else None
+    bn_t = rs.uniform(-1, 1, cout).astype(np.float32) if bn else None
+    resid = rs.standard_normal((n, cout, h // stride, w // stride)).astype(np.float32)
+    got = engine.op_conv2d(x, wt, b, dilation=dil, in_stride=stride, act=act, bn_scale=bn_s, bn_shift=bn_t, resid=resid, precision=precision)
+    _check(got, _ref_conv(x, wt, b, dil, stride, act, bn_s, bn_t, resid), precision, "conv3x3 + resid, auto policy %s" % (case,))
+    got0 = engine.op_conv2d(x, wt, b, dilation=dil, in_stride=stride, act=act, bn_scale=bn_s, bn_shift=bn_t, resid=None, precision=precision)
+    _check(got0, _ref_conv(x, wt, b, dil, stride, act, bn_s, bn_t, None), precision, "conv3x3, auto policy %s" % (case,))
+
+
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_conv_is_transpose_detecting(precision):
     """Asymmetric single-tap weights: an (ky,kx) or (cin,cout) transpose cannot pass."""

@@ -60,3 +60,14 @@ def test_bench_headline_weights_are_config3s():
     sd = bench.seeded_weights("torch")
     ref = workloads.random_state_dict(0, "torch")
     assert all(np.array_equal(sd[k], ref[k]) for k in ref)
+
+
+def test_own_code_warmup_stays_inside_the_code_object():
+    """idc_warm_own_code reads a constant number of 128-byte lines from the kernel's own PC; tools/check_code_warm.py
+    holds every instance of the built objects against the end of its code object's .text (also run by __graft_entry__.build())."""
+    csrc = os.path.join(REPO, "interactive_deep_colorization_amd", "csrc")
+    if not os.path.exists(os.path.join(csrc, "idc_v2m.o")) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("objects not built in-tree (run __graft_entry__.build())")
+    p = subprocess.run([sys.executable, os.path.join(REPO, "tools", "check_code_warm.py")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert "0 problems" in p.stdout and int(p.stdout.split()[1]) >= 10, p.stdout
