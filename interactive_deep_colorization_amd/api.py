@@ -66,6 +66,24 @@ def read_state_dict(path):
     return sd
 
 
+def read_caffe_weights(path, state_dict=None):
+    """What the Caffe classes' ``prep_net(gpu_id, prototxt_path, caffemodel_path)`` loads -> ``(state_dict, out_mul)``.
+    A ``.caffemodel`` (the reference's default invocation, ``ideepcolor.py:60-66`` / ``data/colorize_image.py:392-403``) is read
+    straight from its protobuf wire format by :mod:`caffe_io` -- Caffe layer names mapped to the engine's keys, ``bw_conv1_1`` +
+    ``ab_conv1_1`` merged, Caffe BatchNorm statistics un-scaled -- and ``out_mul`` is the net's final ``Scale`` blob (100);
+    a ``.pth`` / ``.npz`` with the torch key names (e.g. the reference's converted ``caffemodel.pth``) or an explicit
+    ``state_dict`` is taken as is, with the prototxt's 100."""
+    if state_dict is not None:
+        return state_dict, 100.
+    from . import caffe_io
+    if str(path).endswith(".caffemodel") or (not str(path).endswith((".pth", ".npz")) and caffe_io.is_caffemodel(path)):
+        sd, info = caffe_io.read_caffemodel_state_dict(path)
+        if info["ignored"]:
+            print('caffemodel layers not used (injected at load time or outside the path): %s' % ', '.join(info["ignored"]))
+        return sd, (100. if info["out_mul"] is None else info["out_mul"])
+    return read_state_dict(path), 100.
+
+
 def _lazy(name, refresh):
     """Attribute that is materialised from device memory on first read after a forward (the reference fills these
     eagerly on the host in every ``net_forward``; here a click does not pay for copies nobody reads)."""
@@ -467,8 +485,10 @@ class ColorizeImageCaffe(ColorizeImageBase):
     input normalisation folded into its trained weights: it is fed raw ``L-50``, raw ab and
     ``mask*110`` (``:379-383,425``) and ends in ``TanH -> Scale 100`` (prototxt ``:812-821``).
     Caffe cannot be installed here, so ``prep_net`` takes the weights as a ``state_dict`` under
-    the torch key names (e.g. the reference's converted ``caffemodel.pth``),
-    passed as ``caffemodel_path`` or ``state_dict``; ``prototxt_path`` is accepted and ignored."""
+    the torch key names (e.g. the reference's converted ``caffemodel.pth``) or -- the
+    reference's default invocation -- a real ``.caffemodel`` (read from its protobuf wire format by :mod:`caffe_io`,
+    no Caffe needed), passed as ``caffemodel_path``, or an explicit ``state_dict``; ``prototxt_path`` is accepted
+    and not read (the three graphs of the reference's prototxts are built in, selected by the class)."""
 
     def __init__(self, Xd=256, precision='fp32', color_bins_dir=None):
         """``color_bins_dir`` (not in the reference): a directory holding ``pts_in_hull.npy`` / ``pts_grid.npy`` /
@@ -491,11 +511,12 @@ class ColorizeImageCaffe(ColorizeImageBase):
         print('gpu_id = %d, net_path = %s, model_path = %s' % (gpu_id, prototxt_path, caffemodel_path))
         if gpu_id == -1:
             raise RuntimeError('cpu mode is not available: this backend runs on gfx950 only')
-        sd = read_state_dict(caffemodel_path) if state_dict is None else state_dict
+        sd, out_mul = read_caffe_weights(caffemodel_path, state_dict)
+        out_mul = self.__dict__.pop('_file_out_mul', out_mul)      # (a subclass that already read the file passes what it found)
         self.gpu_id = gpu_id
         net = HipColorizer(H=self.Xd, W=self.Xd, max_batch=1, precision=self.precision, device=int(gpu_id),
                            global_hints=self._global_hints, dist313=self._dist313)
-        net.set_io_scales(l_div=1., ab_div=1., mask_mul=1., out_mul=100.)
+        net.set_io_scales(l_div=1., ab_div=1., mask_mul=1., out_mul=out_mul)
         net.load_state_dict(sd)
         self._new_engine(net)
 
@@ -522,7 +543,8 @@ class ColorizeImageCaffeGlobDist(ColorizeImageCaffe):
         self.glob_layer = 'glob_ab_313_mask'
 
     def prep_net(self, gpu_id, prototxt_path='', caffemodel_path='', state_dict=None):
-        sd = dict(read_state_dict(caffemodel_path) if state_dict is None else state_dict)
+        sd, self._file_out_mul = read_caffe_weights(caffemodel_path, state_dict)
+        sd = dict(sd)
         w = np.asarray(sd['model1.0.weight'])
         if w.shape[1] == 1:                                   # bw_conv1_1 only: ab / mask never reach the net
             w4 = np.zeros((w.shape[0], 4) + tuple(w.shape[2:]), np.float32)
@@ -602,7 +624,8 @@ class ColorizeImageCaffeDist(ColorizeImageCaffe):
         self.dist_entropy = np.zeros((self.Xd, self.Xd))
 
     def prep_net(self, gpu_id, prototxt_path='', caffemodel_path='', S=.2, state_dict=None):
-        sd = dict(read_state_dict(caffemodel_path) if state_dict is None else state_dict)
+        sd, self._file_out_mul = read_caffe_weights(caffemodel_path, state_dict)
+        sd = dict(sd)
         if 'pred.pred_ab.weight' not in sd:
             print('Setting ab cluster centers in layer: %s' % self.pred_ab_layer)
             sd['pred.pred_ab.weight'] = np.ascontiguousarray(np.asarray(self.pts_in_hull, np.float32).T)[:, :, None, None]
