@@ -393,6 +393,8 @@ struct Layer {
     bool click = false;                  // batch-1 click-path kernel (conv_click: whole K slice by LDS-DMA)
     bool wino = false;                   // fp32 Winograd F(2x2,3x3) kernel (conv_wino_f32, idc_wino.hip)
     bool kw = false;                     // bf16 click path: conv_kwave_bf16 (idc_kw.hip: K split over the waves of a workgroup, layout-1 weights)
+    int chain_len = 0;                   // > 0: this layer and the chain_len - 1 after it ran as ONE conv_kwave_chain_bf16 launch (last forward)
+    int chained_into = -1;               // >= 0: ran inside the chain launch headed by that layer (last forward)
     bool fused_head = false;             // conv10_2 only: model_out + tanh run in this layer's epilogue
     int fused_short = -1;                // deconv layers: index of the shortcut conv layer riding in this launch's K loop
     bool skip = false;                   // layer fused into another launch: not launched itself
@@ -423,6 +425,14 @@ struct idc_context {
     float* d_scratch = nullptr; size_t scratch_bytes = 0;
     float* d_partial = nullptr; size_t partial_bytes = 0;    // split-K slice sums (grown on demand)
     void* d_zeros = nullptr;             // 256 zero bytes: LDS-DMA source of out-of-image halo rows (conv_click)
+    unsigned long long* d_kw_bar = nullptr;   // conv_kwave_chain_bf16's grid-barrier counter (monotone) ...
+    unsigned long long kw_bar_count = 0;      // ... grid barriers done by every launch so far (each adds its arrivals to its counter)
+    int kw_bar_blocks = 0;                    // ... workgroups per launch those counts are for (a different grid resets the counters)
+    long long* d_kw_stamps = nullptr;         // IDC_KW_STAMPS=1: per-phase cycle stamps of the last chain launch, printed when the handle is destroyed
+    int kw_stamp_layers = 0, kw_stamp_blocks = 0;
+    int* h_kw_abort = nullptr;                // pinned, device-visible: a chain workgroup that gave up waiting sets it
+    bool kw_chain_off = false;                // set after a refused / aborted chain launch: the handle falls back to one launch per layer
+    int kw_chain_fits = -1;                   // workgroups of the chain kernel this device holds at once (-1: not asked yet)
     float *d_glob_in = nullptr, *d_glob_vec = nullptr;   // global hints: [max_batch][316] inputs, [max_batch][512] branch output
     int t_conv4_3 = -1, t_pred313 = -1;
     float *d_pred_ab = nullptr, *d_dist313 = nullptr, *h_pred_ab = nullptr, *h_dist313 = nullptr;   // 313 head outputs
@@ -503,6 +513,10 @@ static int g_code_warm = getenv("IDC_CODE_WARM") ? atoi(getenv("IDC_CODE_WARM"))
 // bf16 click path: the 3x3 stride-1 layers as conv_kwave_bf16 instead of conv_wino_bf16 ("kwave" / IDC_KWAVE)
 static int g_kwave = getenv("IDC_KWAVE") ? atoi(getenv("IDC_KWAVE")) : 1;
 static int g_kwave_deconv = getenv("IDC_KWAVE_DECONV") ? atoi(getenv("IDC_KWAVE_DECONV")) : 1;      // ... and the deconvs ("kwave_deconv")
+// ... and runs of consecutive same-shape 8-chunk conv_kwave_bf16 layers (the 512 -> 512 trunk at batch 1) as ONE persistent launch with a
+// grid barrier between layers ("kwave_chain" / IDC_KWAVE_CHAIN): 0 = off, 1 = hipLaunchCooperativeKernel (+24 us per launch on this runtime),
+// 2 = plain launch after an occupancy check (default; a workgroup that never sees the others gives up after ~0.3 s and the handle falls back)
+static int g_kwave_chain = getenv("IDC_KWAVE_CHAIN") ? atoi(getenv("IDC_KWAVE_CHAIN")) : 2;
 static int g_click = -1;                 // conv_click for small launches: -1 = environment default (on), 0 off, 1 on (idc_set_option "click")
 // Shortcut fusion (conv_igemm_v2<.,.,1,true>) is correct (parity-tested under tile policy 2) but measured slower
 // than two launches on MI355X (4x re-reads of the skip tensor by the four phase workgroups, VGPR spills around
@@ -802,6 +816,12 @@ static int alloc_graph(idc_context* c) {
     c->l_set.assign(nb, 0);
     HIPCHK(c, hipMalloc(&c->d_zeros, 256));
     HIPCHK(c, hipMemset(c->d_zeros, 0, 256));
+    if (c->precision == IDC_BF16) {              // conv_kwave_chain_bf16's grid-barrier counter and its host-visible abort flag
+        HIPCHK(c, hipMalloc((void**)&c->d_kw_bar, 1024));
+        HIPCHK(c, hipMemset(c->d_kw_bar, 0, 1024));
+        HIPCHK(c, hipHostMalloc((void**)&c->h_kw_abort, 64, hipHostMallocMapped));
+        *c->h_kw_abort = 0;
+    }
     // the memsets above run on the NULL stream, the kernels on the handle's non-blocking stream: every conv launch reads the
     // zero page (out-of-image halo rows), so make the fills complete before the handle can launch anything
     HIPCHK(c, hipStreamSynchronize(nullptr));
@@ -831,6 +851,12 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
                      float* dout, float* ddist) {
     hipStream_t s = c->stream;
     int step = 0;
+    if (c->h_kw_abort && *c->h_kw_abort) {       // a workgroup of an earlier conv_kwave_chain_bf16 launch gave up waiting at its grid barrier
+        *c->h_kw_abort = 0;
+        c->kw_chain_off = true;
+        return fail(&c->err, IDC_ERR_INTERNAL, "an earlier forward's persistent trunk launch (conv_kwave_chain_bf16) did not get all its workgroups "
+                    "co-resident and timed out: that forward's result is invalid; the handle now runs one launch per layer");
+    }
     const size_t ring = (size_t)(c->prof_count % kProfRing) * c->n_timed * 2;
     auto tic = [&]() { if (c->profiling == 1) (void)hipEventRecord(c->ev[ring + step * 2], s); };
     auto toc = [&]() { if (c->profiling == 1) (void)hipEventRecord(c->ev[ring + step * 2 + 1], s); ++step; };
@@ -884,10 +910,14 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
         }
     }
     bool head_done = false;
+    int chain_until = -1;                      // layers up to this index ran inside the conv_kwave_chain_bf16 launch of an earlier layer
     for (auto& L : c->layers) {
         const Tensor& ti = c->tensors[L.src];
         const Tensor& to = c->tensors[L.dst];
-        if (L.skip) { tic(); toc(); continue; }
+        const int li_ = (int)(&L - &c->layers[0]);
+        L.chain_len = 0;
+        if (li_ > chain_until) L.chained_into = -1;
+        if (L.skip || li_ <= chain_until) { tic(); toc(); continue; }
         ConvArgs& a = L.args;
         a.in = ti.ptr; a.out = to.ptr;
         a.zeros = c->d_zeros;
@@ -974,7 +1004,58 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             if (L.kw) {
                 if (!conv_kwave_applies(a))
                     return fail(&c->err, IDC_ERR_INTERNAL, "layer %s: conv_kwave_bf16 selected for a launch it does not cover", L.spec->name);
-                le = launch_conv_kwave(a, s);
+                le = hipErrorInvalidConfiguration;
+                // the run of same-shape 8-chunk layers that starts here (conv4_2 .. conv7_3 at batch 1) as ONE persistent launch
+                if (g_kwave_chain && !c->kw_chain_off && c->profiling != 1 && !double_launch && c->d_kw_bar && L.spec->kind == kConv3x3 && a.nkc == 8 &&
+                    a.si == 1 && a.img_shift == nullptr && !a.out_f32) {
+                    const int blocks = conv_kwave_chain_blocks(a.Hs, a.Ws, a.N, a.ncg, a.dy[8]);
+                    KwChainArgs ch{};
+                    ch.H = a.Hs; ch.W = a.Ws; ch.N = a.N; ch.ncg = a.ncg;
+                    ch.spin_limit = 200000u;                   // x ~1.5 us per poll: a third of a second, then the workgroup gives up
+                    int last = li_, prev_dst = L.src;
+                    for (int j = li_; j < (int)c->layers.size() && ch.nlayers < kKwChainMax; ++j) {
+                        Layer& Q = c->layers[j];
+                        const bool shifted = (c->flags & IDC_FLAG_GLOBAL_HINTS) && Q.dst == c->t_conv4_3;
+                        if (Q.skip || !Q.kw || Q.spec->kind != kConv3x3 || Q.blob.nkc != 8 || Q.spec->in_stride != 1 || Q.resid >= 0 || shifted ||
+                            c->tensors[Q.dst].is_f32 || Q.src != prev_dst || Q.args.Hs != a.Hs || Q.args.Ws != a.Ws || Q.args.ncg != a.ncg ||
+                            conv_kwave_chain_blocks(a.Hs, a.Ws, a.N, a.ncg, Q.args.dy[8]) != blocks)
+                            break;
+                        KwChainLayer& y = ch.layer[ch.nlayers++];
+                        y.in = c->tensors[Q.src].ptr; y.out = c->tensors[Q.dst].ptr;
+                        y.wgt = c->d_blob + Q.blob.w_off;
+                        y.bias = (const float*)(c->d_blob + Q.blob.bias_off);
+                        y.bn_scale = Q.blob.bn_scale_off != (size_t)-1 ? (const float*)(c->d_blob + Q.blob.bn_scale_off) : nullptr;
+                        y.bn_shift = Q.blob.bn_shift_off != (size_t)-1 ? (const float*)(c->d_blob + Q.blob.bn_shift_off) : nullptr;
+                        y.act = Q.spec->act; y.d = Q.args.dy[8];
+                        prev_dst = Q.dst; last = j;
+                    }
+                    if (ch.nlayers >= 2 && blocks > 0) {
+                        if (c->kw_chain_fits < 0) c->kw_chain_fits = conv_kwave_chain_capacity(c->device);
+                        if (c->kw_chain_fits >= blocks) {
+                            if (blocks != c->kw_bar_blocks) {      // counters hold (barriers so far) x (arrivals per barrier of THIS grid)
+                                HIPCHK(c, hipMemsetAsync(c->d_kw_bar, 0, 1024, s));
+                                c->kw_bar_count = 0; c->kw_bar_blocks = blocks;
+                            }
+                            ch.bar = c->d_kw_bar; ch.bar_base = c->kw_bar_count; ch.abort_flag = c->h_kw_abort;
+                            static const bool want_stamps = getenv("IDC_KW_STAMPS") && atoi(getenv("IDC_KW_STAMPS")) != 0;
+                            if (want_stamps && !c->d_kw_stamps) HIPCHK(c, hipMalloc((void**)&c->d_kw_stamps, (size_t)4096 * kKwChainMax * 8 * 8));
+                            ch.stamps = (want_stamps && blocks <= 4096) ? c->d_kw_stamps : nullptr;
+                            c->kw_stamp_layers = ch.nlayers; c->kw_stamp_blocks = blocks;
+                            const hipError_t ce = launch_conv_kwave_chain(ch, blocks, g_kwave_chain, s);
+                            if (ce == hipSuccess) {
+                                c->kw_bar_count += (unsigned long long)(ch.nlayers - 1);
+                                L.chain_len = ch.nlayers;
+                                for (int j = li_ + 1; j <= last; ++j) c->layers[j].chained_into = li_;
+                                chain_until = last;
+                                le = hipSuccess;
+                            } else {
+                                (void)hipGetLastError();          // refused (e.g. hipErrorCooperativeLaunchTooLarge): one launch per layer from now on
+                                c->kw_chain_off = true;
+                            }
+                        }                                          // (else: more workgroups than the chip holds at once -- this launch goes layer by layer)
+                    }
+                }
+                if (le != hipSuccess) le = launch_conv_kwave(a, s);
                 HIPCHK(c, le);
             }
             if (le == hipErrorInvalidConfiguration)
@@ -1082,6 +1163,29 @@ static void destroy_ctx(idc_context* c) {
     if (c->s_out) (void)hipStreamDestroy(c->s_out);
     if (c->ev_sync) (void)hipEventDestroy(c->ev_sync);
     if (c->d_zeros) (void)hipFree(c->d_zeros);
+    if (c->d_kw_stamps && c->kw_stamp_blocks > 0) {      // diagnostic: where a layer of the last chain launch spent its cycles (mean over workgroups)
+        std::vector<long long> st((size_t)c->kw_stamp_blocks * kKwChainMax * 8);
+        if (hipMemcpy(st.data(), c->d_kw_stamps, st.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            static const char* names[] = {"prefetch+barrier wait", "halo issue", "halo landed", "taps", "reduce+epilogue", "stores acked+wg barrier"};
+            static const int seq[] = {0, 1, 6, 2, 3, 4, 5};
+            for (int li = 0; li < c->kw_stamp_layers; ++li) {
+                double d[6] = {0, 0, 0, 0, 0, 0};
+                for (int b = 0; b < c->kw_stamp_blocks; ++b) {
+                    const long long* p = &st[((size_t)b * kKwChainMax + li) * 8];
+                    for (int k = 0; k < 6; ++k) {
+                        if (li + 1 == c->kw_stamp_layers && k == 5) continue;
+                        d[k] += (double)(p[seq[k + 1]] - p[seq[k]]);
+                    }
+                }
+                fprintf(stderr, "kw_chain stamps layer %2d:", li);
+                for (int k = 0; k < 6; ++k) fprintf(stderr, " %s %.0f |", names[k], d[k] / c->kw_stamp_blocks);
+                fprintf(stderr, "\n");
+            }
+        }
+        (void)hipFree(c->d_kw_stamps);
+    }
+    if (c->d_kw_bar) (void)hipFree(c->d_kw_bar);
+    if (c->h_kw_abort) (void)hipHostFree(c->h_kw_abort);
     if (c->d_up_rgb) (void)hipFree(c->d_up_rgb);
     if (c->d_up_L) (void)hipFree(c->d_up_L);
     if (c->h_up_rgb) (void)hipHostFree(c->h_up_rgb);
@@ -1134,6 +1238,7 @@ int idc_set_option(const char* name, int value) {
     if (strcmp(name, "code_warm") == 0) { g_code_warm = value != 0; return IDC_OK; }
     if (strcmp(name, "kwave") == 0) { g_kwave = value != 0; return IDC_OK; }
     if (strcmp(name, "kwave_deconv") == 0) { g_kwave_deconv = value != 0; return IDC_OK; }
+    if (strcmp(name, "kwave_chain") == 0) { g_kwave_chain = value < 0 ? 0 : (value > 2 ? 2 : value); return IDC_OK; }
     if (strcmp(name, "conv1_lw") == 0) { set_conv1_lw(value); return IDC_OK; }
     if (strcmp(name, "ds_mfma16") == 0) { g_ds_m16 = value != 0; return IDC_OK; }
     if (strcmp(name, "winograd_bf16") == 0) { g_wino_bf16 = value; return IDC_OK; }
@@ -1943,6 +2048,12 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
             for (const Layer& C : h->layers)
                 if (C.fused_short == layer - 1 || C.fused_next == layer - 1) snprintf(out->kernel, sizeof(out->kernel), "fused into %s", C.spec->name);
             out->flops = 0; out->min_bytes = 0; out->launches = 0;
+        } else if (L.chained_into >= 0) {    // ran inside the persistent trunk launch headed by another layer (its own MACs stay its own)
+            snprintf(out->kernel, sizeof(out->kernel), "chained into %s", h->layers[L.chained_into].spec->name);
+            out->flops = L.flops; out->min_bytes = L.min_bytes; out->launches = 0;
+        } else if (L.chain_len > 0) {
+            snprintf(out->kernel, sizeof(out->kernel), "conv_kwave_chain_bf16 x%d", L.chain_len);
+            out->flops = L.flops; out->min_bytes = L.min_bytes; out->launches = 1;
         } else {
             snprintf(out->kernel, sizeof(out->kernel), L.kw ? (L.spec->kind == kDeconv4x4 ? "conv_kwave_deconv_bf16" : "conv_kwave_bf16") : L.wino ? (L.spec->kind == kDeconv4x4 ? (h->precision == IDC_BF16 ? "conv_wino_deconv_bf16" : "conv_wino_deconv_f32") : h->precision == IDC_BF16 ? "conv_wino_bf16" : "conv_wino_f32") : L.click ? (h->precision == IDC_BF16 ? "conv_click<bf16,%d,%d>" : "conv_click<f32,%d,%d>")
                      : L.v2 ? "conv_igemm_v2<%d,%d>" : (h->precision == IDC_BF16 ? "conv_igemm<bf16,%d,%d>" : "conv_igemm<f32,%d,%d>"),

@@ -137,6 +137,29 @@ bool conv_wino_applies(int precision, const ConvArgs& a, bool deconv);
 hipError_t launch_conv_kwave(const ConvArgs& a, hipStream_t s);
 bool conv_kwave_applies(const ConvArgs& a);
 hipError_t init_kernels_kw();
+// conv_kwave_chain_bf16 (idc_kw.hip, round 5): a run of consecutive same-shape 8-chunk conv_kwave_bf16 layers (the 512 -> 512 trunk of
+// the bf16 click path: conv4_2 .. conv7_3 at batch 1) as ONE persistent launch, a grid barrier between layers instead of a launch floor.
+struct KwChainLayer {
+    const void* in; void* out; const void* wgt; const float* bias; const float* bn_scale; const float* bn_shift;
+    int act;                // 0 none, 1 ReLU, 2 LeakyReLU(0.2)
+    int d;                  // dilation 1 | 2
+};
+constexpr int kKwChainMax = 12;
+struct KwChainArgs {
+    int nlayers, H, W, N, ncg;
+    unsigned spin_limit;            // polls of the barrier counters before a workgroup gives up (sets *abort_flag, leaves)
+    unsigned long long* bar;        // eight device counters 128 bytes apart (one per blockIdx & 7), monotone: + its arrivals per barrier
+    unsigned long long bar_base;    // barriers done by every earlier launch of the handle (counter c then holds bar_base x arrivals_of(c))
+    int* abort_flag;                // host-visible (pinned) int: set to 1 by a workgroup that gave up
+    long long* stamps;              // diagnostic (IDC_KW_STAMPS=1), else null: [workgroup][layer][8] cycle stamps of the phases of a layer
+    KwChainLayer layer[kKwChainMax];
+};
+// workgroups of one layer (the same for every layer of a chain: 8x8-pixel tiles x parities x images x 32-cout groups), 0 if the shape is not covered
+int conv_kwave_chain_blocks(int H, int W, int N, int ncg, int d);
+// workgroups of the chain kernel the device holds at once (one per CU: 104 KiB of LDS each); 0 on error
+int conv_kwave_chain_capacity(int device);
+// mode 1: hipLaunchCooperativeKernel (the runtime guarantees co-residency or fails cleanly); mode 2: plain launch (caller checked the capacity)
+hipError_t launch_conv_kwave_chain(const KwChainArgs& c, int blocks, int mode, hipStream_t s);
 bool wino_offsets_fit(int Hs, int Ws, int si, int nkc);
 hipError_t init_kernels_wino();
 void set_wino_form(int form);      // 0 = by grid size, 12 / 21 / 22 = force conv_wino_f32<TB,CB> (speed only)

@@ -46,6 +46,14 @@ template <int N> __device__ __forceinline__ void kw_wait4(u32x4_k& a, u32x4_k& b
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
 }
 
+// agent-coherent accesses of the persistent trunk launch (conv_kwave_chain_bf16): sc1 = coherent across the XCDs' L2s
+__device__ __forceinline__ unsigned long long kw_ld64_sc1(const unsigned long long* p) {
+    unsigned long long v;
+    asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void kw_st64_sc1(void* p, uint2 v) { asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+
 constexpr int kw_halo_items(int nkc, int twb) { return nkc * 10 * (8 * twb + 2) * 8; }
 constexpr int kw_lds_bytes(int nkc, int twb, int nw) {
     const int nt = nw * 64;
@@ -427,6 +435,266 @@ __global__ __launch_bounds__(512, NKC == 8 ? 2 : 4) void conv_kwave_deconv_bf16(
 }
 
 
+// ------------------------------------------------------------------------------------------------------------------
+// conv_kwave_chain_bf16 (round 5): a run of consecutive conv_kwave_bf16<8,1,8> layers -- the 512 -> 512 trunk of the
+// bf16 click forward at batch 1: conv4_2, conv4_3, conv5_1 .. conv7_3, eleven launches of 9-12 us each of which 4.5-6 are launch floor -- as
+// ONE persistent launch.  Every layer has the same grid (8x8-pixel tiles x dilation parities x 32-cout groups = 256 workgroups at 32 x 32,
+// one per CU: 104 KiB of LDS each), so workgroup b runs its tile of layer 0, then of layer 1, ...; between two layers a GRID BARRIER:
+//   arrive : every wave waits for its stores (vmcnt 0), workgroup barrier, thread 0: one agent-scope atomic add on the counter of blockIdx & 7
+//            (eight counters, 32 arrivals each: 256 arrivals on ONE address serialise at ~17 ns apiece);
+//   wait   : threads 0..7 poll one counter each (sc1 loads, s_sleep between polls), workgroup barrier.
+// Measured (tools/ubench/grid_barrier.hip, profiles/r05_grid_barrier.txt): the textbook form -- agent-scope release fence (buffer_wbl2 sc1:
+// the XCD's whole L2 written back), one counter, acquire fence (buffer_inv sc1) -- costs 12.0 us per barrier, TWICE a launch floor; one counter
+// without cache maintenance 4.5 us; per-XCD counters 1.9 us.  So there is no cache maintenance at the barrier: the activations are STORED
+// with sc1 (agent-coherent write-through: in memory once vmcnt says so) and LOADED with sc1 (every halo piece comes from the memory side).
+// Invalidating instead (buffer_inv sc1 after the barrier, or before arriving -- nobody reads the next input until all have arrived -- and
+// plain halo loads that share lines in the XCD's L2) was measured too: the halo lands 1.2 k cycles earlier, the barrier completes 3 k cycles
+// later (profiles/r05_kwave_chain.txt).  Weights, biases and BN vectors are read-only for the whole launch: plain loads.
+// What a layer boundary costs is then the barrier round trip instead of a kernel boundary, and the part of the next layer that does NOT
+// depend on the previous one -- its first four taps of weight fragments and its bias / BN vectors, global -> registers -- is requested BEFORE
+// the wait, so that latency runs under the barrier.  Against conv_kwave_bf16<8,1,8> the body also drops two workgroup barriers: wave w owns
+// cin chunk w for all nine taps, so it brings in ITS OWN halo chunk (buffer loads to LDS: 32-bit offsets, bounds check = zero padding) and
+// starts its taps when its own pieces have landed; and it parks its partial sums in its own chunk's LDS when its own taps are done.
+// Same arithmetic in the same order as the eleven launches (tests/test_round5_gpu.py: array_equal on the ab map and every trunk activation).
+// Co-residency: all workgroups must be on the chip at once.  launch mode 2 = a plain launch after an occupancy check (default); mode 1 =
+// hipLaunchCooperativeKernel (the runtime checks and fails cleanly; it costs ~24 us more per launch on this runtime: a separate queue and
+// cross-queue ordering).  Either way a workgroup that polls `spin_limit` times without seeing the others gives up: it sets *abort_flag
+// (host-visible) and leaves; the engine then reports the forward as failed and turns the chain off for the handle -- a partitioned or shared
+// device costs one forward, never a hang.
+__global__ __launch_bounds__(512, 2) void conv_kwave_chain_bf16(const KwChainArgs c) {
+    constexpr int NKC = 8, NW = 8;
+    constexpr int PWD = 10, HR = 100;                          // 10 x 10 halo pixels of one chunk (8 x 8 tile + 1)
+    constexpr int CHUNK = HR * kRowBytes;                      // 12800 bytes of LDS per cin chunk (= per wave)
+    constexpr int NHJ = (HR * 8 + 63) / 64;                    // 13 LDS-DMA instructions per wave (the last one: 32 lanes)
+    constexpr int PB = 4, PD = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_abort;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 15, g = lane >> 4;
+    const int H = c.H, W = c.W;
+    const int pix_bytes = NKC * kRowBytes;
+    const int bid = xcd_remap_k(blockIdx.x, gridDim.x);
+    const unsigned long long nwg = gridDim.x;
+    const size_t w_kc_stride = (size_t)c.ncg * kWBlockBytes;
+    const size_t w_tap_stride = w_kc_stride * NKC;
+    const int CoutPad = c.ncg * kCoutGroup;
+    if (tid == 0) s_abort = 0;
+
+    int wo[2][2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            wo[cb][ks] = (cb * 16 + px) * kRowBytes + (((ks * 4 + g) ^ (px & 7)) * kSlotBytes);
+    int hbase[PB];
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) hbase[pb] = (pb * 2 + (px >> 3) + 1) * PWD + (px & 7) + 1;
+    char* const hchunk = smem + wave * CHUNK;                   // wave w owns cin chunk w: halo, all nine taps, then its partial sums
+    // halo item of (lane, j): halo pixel hr = 8 j + (lane >> 3), LDS slot lane & 7 <- logical slot (lane & 7) ^ (hr & 7) = (lane & 7) ^ (lane >> 3)
+    const int l8 = lane >> 3;
+    const int hsrc_lane = wave * kRowBytes + (((lane & 7) ^ l8) * kSlotBytes);
+    // the reduction's (pixel, 4 couts) of this thread
+    const int r_p64 = tid >> 3, r_slot = tid & 7;
+    const int r_off = r_p64 * kRowBytes + ((r_slot ^ (r_p64 & 7)) * kSlotBytes);
+    const int r_row = (r_p64 >> 4) * 2 + ((r_p64 & 15) >> 3), r_col = r_p64 & 7;
+
+#define IDC_KW_STAMP(k) do { if (c.stamps && tid == 0) c.stamps[((size_t)blockIdx.x * kKwChainMax + li) * 8 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+    for (int li = 0; li < c.nlayers; ++li) {
+        const KwChainLayer& Ly = c.layer[li];
+        const int d = Ly.d;
+        IDC_KW_STAMP(0);
+        const int tiles_x = ((W + d - 1) / d + 7) / 8, tiles_y = ((H + d - 1) / d + 7) / 8;
+        int b = bid;
+        const int bx = b % tiles_x; b /= tiles_x;
+        const int by = b % tiles_y; b /= tiles_y;
+        const int par = b % (d * d); b /= d * d;
+        const int n = b % c.N;
+        const int cg = b / c.N;
+        const int Y0 = par / d + d * 8 * by, X0 = par % d + d * 8 * bx;
+        const char* const wl = (const char*)Ly.wgt + (size_t)wave * w_kc_stride + (size_t)(cg >> 1) * kWBlockBytes + (cg & 1) * 32 * kRowBytes;
+
+        // ---- weights, bias, BN do not depend on the previous layer: on their way before the grid barrier is waited for
+        u32x4_k areg[PD][2][2];
+        auto load_A = [&](auto slotc, int t) {
+            constexpr int S = decltype(slotc)::value;
+            const char* const src = wl + (size_t)(t < 8 ? t : 8) * w_tap_stride;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                kw_gload(areg[S][cb][0], src + wo[cb][0]);
+                kw_gload(areg[S][cb][1], src + wo[cb][1]);
+            }
+        };
+        auto wait_A = [&](auto slotc, auto nc) {
+            constexpr int S = decltype(slotc)::value, N = decltype(nc)::value;
+            kw_wait4<N>(areg[S][0][0], areg[S][0][1], areg[S][1][0], areg[S][1][1]);
+        };
+        load_A(std::integral_constant<int, 0>{}, 0);
+        load_A(std::integral_constant<int, 1>{}, 1);
+        load_A(std::integral_constant<int, 2>{}, 2);
+        load_A(std::integral_constant<int, 3>{}, 3);
+        const int co = (cg >> 1) * kCoutGroup + (r_slot >> 1) * 16 + (cg & 1) * 8 + (r_slot & 1) * 4;
+        const bool has_bn = Ly.bn_scale != nullptr;
+        const f32x4_k e_bias = *(const f32x4_k*)(Ly.bias + co);
+        f32x4_k e_sc = f32x4_k{1.f, 1.f, 1.f, 1.f}, e_sh = f32x4_k{0.f, 0.f, 0.f, 0.f};
+        if (has_bn) { e_sc = *(const f32x4_k*)(Ly.bn_scale + co); e_sh = *(const f32x4_k*)(Ly.bn_shift + co); }
+
+        if (li > 0) {
+            // ---- grid barrier, wait side: everybody's layer li-1 output is in memory
+            if (tid < 8) {
+                const unsigned long long target = (c.bar_base + (unsigned long long)li) * ((nwg + 7 - tid) >> 3);  // arrivals at counter `tid` so far
+                const unsigned long long* const ctr = c.bar + tid * 16;                                        // 128 bytes apart
+                unsigned spins = 0;
+                while (kw_ld64_sc1(ctr) < target) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > c.spin_limit) {
+                        s_abort = 1;
+                        __hip_atomic_store(c.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            if (s_abort) return;                               // (uniform: every thread reads the same LDS word after the barrier)
+        }
+        IDC_KW_STAMP(1);
+
+        // ---- this wave's halo chunk of this layer: global -> LDS, sc1 (agent-coherent), out-of-image pixels = the buffer's bounds check
+        {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)Ly.in + (size_t)n * H * W * pix_bytes), 0,
+                                                                                 H * W * pix_bytes, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < NHJ; ++j) {
+                const int hr = 8 * j + l8;
+                const int hy = (hr * 205) >> 11, hx = hr - hy * PWD;       // hr / 10, hr % 10 for hr < 1029
+                const int Y = Y0 + d * (hy - 1), X = X0 + d * (hx - 1);
+                const bool inside = (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W;
+                const int off = inside ? (Y * W + X) * pix_bytes + hsrc_lane : (int)0x80000000;
+                if (j < NHJ - 1 || lane < 32)                               // 100 pixels x 8 slots = 12.5 instructions of 64 lanes
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(hchunk + j * 1024), 16, off, 0, 0, 16);
+            }
+        }
+        IDC_KW_STAMP(6);
+        f32x4_k acc[2][PB];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < PB; ++j) acc[i][j] = f32x4_k{0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // MY halo chunk has landed (the youngest loads; the weight taps and vectors were asked for first)
+        IDC_KW_STAMP(2);
+
+        auto tap = [&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            constexpr int YOUNGER = (PD - 1 < 8 - I ? PD - 1 : 8 - I) * 4;
+            wait_A(std::integral_constant<int, I % PD>{}, std::integral_constant<int, YOUNGER>{});
+            {
+                constexpr int ty = I / 3, tx = I - ty * 3;
+                constexpr int toff = (ty - 1) * PWD + (tx - 1);
+                u32x4_k bf[PB][2];
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) {
+                    const int hr = hbase[pb] + toff;
+                    const int o0 = hr * kRowBytes + ((g ^ (hr & 7)) * kSlotBytes);
+                    bf[pb][0] = *(const u32x4_k*)(hchunk + o0);
+                    bf[pb][1] = *(const u32x4_k*)(hchunk + (o0 ^ (4 * kSlotBytes)));
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                        for (int pb = 0; pb < PB; ++pb)
+                            acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_k, areg[I % PD][cb][ks]),
+                                                                                  __builtin_bit_cast(bf16x8_k, bf[pb][ks]), acc[cb][pb], 0, 0, 0);
+            }
+            if constexpr (I + PD < 9) load_A(std::integral_constant<int, I % PD>{}, I + PD);
+        };
+        tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{}); tap(std::integral_constant<int, 2>{});
+        tap(std::integral_constant<int, 3>{}); tap(std::integral_constant<int, 4>{}); tap(std::integral_constant<int, 5>{});
+        tap(std::integral_constant<int, 6>{}); tap(std::integral_constant<int, 7>{}); tap(std::integral_constant<int, 8>{});
+        IDC_KW_STAMP(3);
+
+        // ---- the eight partial sums of a (pixel, cout) meet in LDS in wave order: each wave parks its 8 KiB in its OWN halo chunk (its taps
+        //      are done, nobody else reads that chunk), one workgroup barrier, then bias, activation, eval-BN, bf16 store
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const int p64 = q * 16 + px;
+                *(f32x4_k*)(hchunk + p64 * kRowBytes + (((g * 2 + cb) ^ (p64 & 7)) * kSlotBytes)) = acc[cb][q];
+            }
+        __syncthreads();
+        {
+            f32x4_k s = *(const f32x4_k*)(smem + r_off);
+#pragma unroll
+            for (int w = 1; w < NW; ++w) s += *(const f32x4_k*)(smem + w * CHUNK + r_off);
+            const int yy = Y0 + d * r_row, xx = X0 + d * r_col;
+            f32x4_k v = s + e_bias;
+            if (Ly.act == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            else if (Ly.act == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.2f * v[r];
+            }
+            if (has_bn) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaf(v[r], e_sc[r], e_sh[r]);
+            }
+            if (yy < H && xx < W) {
+                const size_t o = (((size_t)n * H + yy) * W + xx) * CoutPad + co;
+                const __bf16 q0 = (__bf16)v[0], q1 = (__bf16)v[1], q2 = (__bf16)v[2], q3 = (__bf16)v[3];
+                uint2 pk;
+                pk.x = (unsigned)__builtin_bit_cast(unsigned short, q0) | ((unsigned)__builtin_bit_cast(unsigned short, q1) << 16);
+                pk.y = (unsigned)__builtin_bit_cast(unsigned short, q2) | ((unsigned)__builtin_bit_cast(unsigned short, q3) << 16);
+                kw_st64_sc1((__bf16*)Ly.out + o, pk);           // agent-coherent: in memory when vmcnt says it is done
+            }
+        }
+        IDC_KW_STAMP(4);
+        if (li + 1 < c.nlayers) {
+            // ---- grid barrier, arrive side: this workgroup's tile of layer li is written
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my stores are acknowledged
+            __syncthreads();                                   // ... everybody's (and every wave has read the partial sums: the chunks are free)
+            IDC_KW_STAMP(5);
+            if (tid == 0) __hip_atomic_fetch_add(c.bar + (blockIdx.x & 7) * 16, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+#undef IDC_KW_STAMP
+
+int conv_kwave_chain_blocks(int H, int W, int N, int ncg, int d) {
+    if (H <= 0 || W <= 0 || N <= 0 || ncg <= 0 || (d != 1 && d != 2) || !wino_offsets_fit(H, W, 1, 8)) return 0;
+    const long long tx = ((W + d - 1) / d + 7) / 8, ty = ((H + d - 1) / d + 7) / 8;
+    const long long blocks = tx * ty * d * d * N * (ncg * 2);
+    return blocks > 0 && blocks <= 0x7fffffffLL ? (int)blocks : 0;
+}
+
+int conv_kwave_chain_capacity(int device) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_kwave_chain_bf16, 512, kw_lds_bytes(8, 1, 8)) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    const long long cap = (long long)per_cu * prop.multiProcessorCount;
+    return cap > 0x7fffffffLL ? 0x7fffffff : (int)cap;
+}
+
+hipError_t launch_conv_kwave_chain(const KwChainArgs& c, int blocks, int mode, hipStream_t s) {
+    if (c.nlayers < 2 || c.nlayers > kKwChainMax || blocks <= 0 || c.bar == nullptr || c.abort_flag == nullptr)
+        return hipErrorInvalidValue;
+    if (mode == 1) {
+        KwChainArgs args = c;
+        void* params[] = {(void*)&args};
+        return hipLaunchCooperativeKernel((const void*)conv_kwave_chain_bf16, dim3((unsigned)blocks), dim3(512), params,
+                                          (unsigned)kw_lds_bytes(8, 1, 8), s);
+    }
+    hipLaunchKernelGGL(conv_kwave_chain_bf16, dim3((unsigned)blocks), dim3(512), kw_lds_bytes(8, 1, 8), s, c);
+    return hipGetLastError();
+}
+
 // the launches this kernel takes: a bf16 3x3 conv (pad = dilation 1 | 2, reading x or x[::2, ::2]) with 64 / 128 / 256 / 512 input
 // channels, no shortcut sum; 32-bit source offsets (as the Winograd kernels)
 bool conv_kwave_applies(const ConvArgs& a) {
@@ -478,6 +746,8 @@ hipError_t init_kernels_kw() {
     e = hipFuncSetAttribute((const void*)conv_kwave_deconv_bf16<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kwd_lds_bytes(2));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)conv_kwave_bf16<8, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kw_lds_bytes(8, 1, 8));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)conv_kwave_chain_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, kw_lds_bytes(8, 1, 8));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)conv_kwave_bf16<4, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kw_lds_bytes(4, 2, 8));
     if (e != hipSuccess) return e;

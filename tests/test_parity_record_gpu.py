@@ -122,7 +122,9 @@ def test_config2_click_path_against_the_oracle(make_sd, precision, style, bound)
     out = e.forward(L, ab, m, 0.0)
     table = [r["kernel"] for r in e.layer_table()]
     if precision == "bf16":                                     # round 4: conv_kwave_bf16 on the 3x3 layers, conv_kwave_deconv_bf16 on model8up / model9up
-        assert sum(k == "conv_kwave_bf16" for k in table) == 22 and sum(k == "conv_kwave_deconv_bf16" for k in table) == 2, table
+        # round 5: eleven of the 22 conv_kwave_bf16 layers (conv4_2 .. conv7_3) run inside ONE persistent launch, conv_kwave_chain_bf16
+        assert sum(k == "conv_kwave_bf16" for k in table) == 11 and sum(k.startswith("conv_kwave_chain_bf16") for k in table) == 1 and \
+            sum(k.startswith("chained into") for k in table) == 10 and sum(k == "conv_kwave_deconv_bf16" for k in table) == 2, table
     else:
         assert sum(k.startswith("conv_wino") for k in table) >= 17, table
     e.close()

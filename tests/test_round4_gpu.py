@@ -163,6 +163,7 @@ def test_kwave_click_path_layer_by_layer(golden, make_sd, name):
     sd = make_sd(seed, style)
     _, _, acts = siggraph_torch.forward(sd, g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]), return_acts=True, dtype=torch.float64)
     err = {}
+    engine.set_option("kwave_chain", 0)                       # one launch per layer here (the persistent trunk launch: tests/test_round5_gpu.py)
     for kw in (1, 0):
         engine.set_option("kwave", kw)
         e = engine.HipColorizer(H, W, max_batch=n, precision="bf16")
@@ -186,6 +187,7 @@ def test_kwave_click_path_layer_by_layer(golden, make_sd, name):
                 one = e.forward(g["L_mc"][i:i + 1], g["ab"][i:i + 1], g["mask"][i:i + 1], float(g["maskcent"]))
                 np.testing.assert_array_equal(one[0], out[i])
         e.close()
+    engine.set_option("kwave_chain", 2)
     # plain bf16 products against transformed ones: the mean error over the layers does not exceed the Winograd form's
     assert np.mean([err[1][k] for k in KW_LAYERS]) <= 1.05 * np.mean([err[0][k] for k in KW_LAYERS]), (err[1], err[0])
 
@@ -194,9 +196,11 @@ def test_kwave_click_config(golden, make_sd):
     """BASELINE configs[1] in bf16: 22 of the <= 28 launches of a click forward are conv_kwave_bf16, two conv_kwave_deconv_bf16 (model8up,
     model9up), none a reduction, the reference golden inside the torch-init bf16 bound; the N = 32 throughput path never selects the form."""
     g = golden("config2_mortar_5hints_torchinit")
+    engine.set_option("kwave_chain", 0)                       # round 4's launch list: one launch per layer (round 5 chains eleven of them)
     e = engine.HipColorizer(256, 256, max_batch=1, precision="bf16")
     e.load_state_dict(make_sd(int(g["weight_seed"]), str(g["weight_style"])))
     out = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
+    engine.set_option("kwave_chain", 2)
     rows = [r for r in e.layer_table() if r["launches"] > 0]
     launches = sum(r["launches"] + (1 if "splitK" in r["kernel"] else 0) for r in rows)
     assert sum(r["kernel"] == "conv_kwave_deconv_bf16" for r in rows) == 2

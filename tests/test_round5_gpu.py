@@ -12,6 +12,7 @@ from oracle import siggraph_torch
 from bounds import FP32_TOL, bf16_bound, check_bf16_ab  # noqa: F401
 
 pytestmark = pytest.mark.gpu
+CHAIN_DEFAULT = 2               # the library's default for "kwave_chain" (csrc/idc_engine.hip)
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -58,3 +59,98 @@ def test_caffe_class_loads_a_caffemodel_with_the_reference_argument_order(tmp_pa
     ref = siggraph_torch.forward(sd, L_mc, hab[None].astype(np.float32), hm[None].astype(np.float32) * 110.0, 0.0,
                                  l_div=1., ab_div=1., out_mul=100.)
     assert np.abs(outs["caffemodel"][0][None] - ref).max() <= 3e-3, np.abs(outs["caffemodel"][0][None] - ref).max()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("style", ["torch", "he"])
+def test_kwave_chain_equals_the_eleven_launches(make_sd, mode, style):
+    """the 512 -> 512 trunk of the bf16 click forward (conv4_2 .. conv7_3 at batch 1) as ONE persistent launch
+    (conv_kwave_chain_bf16: a grid barrier between layers instead of a launch floor; mode 1 = hipLaunchCooperativeKernel, 2 = plain launch
+    after an occupancy check, the default).  Same arithmetic in the same order as the eleven conv_kwave_bf16 launches: the ab map and every trunk
+    activation are IDENTICAL, call after call; 17 launches instead of 27."""
+    sd = make_sd(0, style)
+    L = workloads.random_batch(1, 256, seed=7)[0].astype(np.float32)
+    hab, hm = workloads.hints_config2(256, 5, 3, 0)
+    ab, m = hab[None].astype(np.float32), hm[None].astype(np.float32)
+    trunk = ["conv4_2", "conv4_3", "conv5_1", "conv5_2", "conv5_3", "conv6_1", "conv6_2", "conv6_3", "conv7_1", "conv7_2", "conv7_3"]
+    res = {}
+    try:
+        for chain in (0, mode):
+            engine.set_option("kwave_chain", chain)
+            e = engine.HipColorizer(256, 256, max_batch=1, precision="bf16")
+            e.load_state_dict(sd)
+            outs = [e.forward(L, ab, m, 0.0) for _ in range(4)]
+            rows = {r["name"]: r for r in e.layer_table()}
+            acts = {k: e.activation(k, 1) for k in trunk + ["conv8_1"]}
+            launches = sum(r["launches"] for r in rows.values())
+            res[chain] = (outs, rows, acts, launches)
+            e.close()
+    finally:
+        engine.set_option("kwave_chain", CHAIN_DEFAULT)
+    (o0, rows0, a0, n0), (o1, rows1, a1, n1) = res[0], res[mode]
+    assert [rows0[k]["kernel"] for k in trunk] == ["conv_kwave_bf16"] * 11
+    assert rows1["conv4_2"]["kernel"] == "conv_kwave_chain_bf16 x11" and rows1["conv4_2"]["launches"] == 1, rows1["conv4_2"]
+    assert [rows1[k]["kernel"] for k in trunk[1:]] == ["chained into conv4_2"] * 10 and all(rows1[k]["launches"] == 0 for k in trunk[1:])
+    assert n0 - n1 == 10 and n1 <= 18, (n0, n1)
+    for k in a0:
+        np.testing.assert_array_equal(a1[k], a0[k], err_msg=k)
+    for o in o1 + o0[1:]:
+        np.testing.assert_array_equal(o, o0[0])
+    ref = siggraph_torch.forward(sd, L, ab, m, 0.0)
+    check_bf16_ab(o1[0] - ref, style, tag="chain mode %d" % mode)
+
+
+@pytest.mark.parametrize("name", ["net64_he_s0_mc05", "net32x48_he_s2", "net64_torch_s1_mc0"])
+def test_kwave_chain_small_and_ragged_images(golden, make_sd, name):
+    """The chain on the reference-generated goldens (64 x 64 and 32 x 48, batch 2): the trunk is 8 x 8 / 4 x 6 pixels there, the dilated
+    layers need four times the workgroups of the others (one tile per parity), so a forward holds THREE chains (conv4_2-3, conv5_1-conv6_3,
+    conv7_1-3) with different grids -- the barrier counters are re-based between them.  Identical to one launch per layer, batch == singles."""
+    g = golden(name)
+    style, seed = str(g["weight_style"]), int(g["weight_seed"])
+    n, _, H, W = g["L_mc"].shape
+    sd = make_sd(seed, style)
+    res = {}
+    try:
+        for chain in (0, 2):
+            engine.set_option("kwave_chain", chain)
+            e = engine.HipColorizer(H, W, max_batch=n, precision="bf16")
+            e.load_state_dict(sd)
+            outs = [e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"])) for _ in range(3)]
+            kernels = {r["name"]: r["kernel"] for r in e.layer_table()}
+            acts = {k: e.activation(k, n) for k in ("conv4_3", "conv6_3", "conv7_3")}
+            ones = [e.forward(g["L_mc"][i:i + 1], g["ab"][i:i + 1], g["mask"][i:i + 1], float(g["maskcent"]))[0] for i in range(n)]
+            res[chain] = (outs, kernels, acts, ones)
+            e.close()
+    finally:
+        engine.set_option("kwave_chain", CHAIN_DEFAULT)
+    heads = [k for k, v in res[2][1].items() if v.startswith("conv_kwave_chain_bf16")]
+    assert heads == ["conv4_2", "conv5_1", "conv7_1"], res[2][1]
+    assert [res[2][1][k] for k in heads] == ["conv_kwave_chain_bf16 x2", "conv_kwave_chain_bf16 x6", "conv_kwave_chain_bf16 x3"]
+    for o in res[2][0]:
+        np.testing.assert_array_equal(o, res[0][0][0])
+    for k in res[0][2]:
+        np.testing.assert_array_equal(res[2][2][k], res[0][2][k], err_msg=k)
+    for i in range(n):
+        np.testing.assert_array_equal(res[2][3][i], res[2][0][0][i])
+    check_bf16_ab(res[2][0][0] - g["out_ab"], style, tag=name)
+
+
+def test_kwave_chain_is_not_taken_where_it_does_not_apply(make_sd):
+    """Per-launch profiling wants eleven event pairs (the chain is one launch): it falls back; so does a handle whose trunk carries the
+    Global-Hints shift in conv4_3's epilogue (the chain starts behind it), and a batch that needs more workgroups than the chip holds."""
+    sd = make_sd(0, "torch")
+    L, ab, m = workloads.random_batch(2, 256, seed=3)
+    e = engine.HipColorizer(256, 256, max_batch=1, precision="bf16")
+    e.load_state_dict(sd)
+    base = e.forward(L[:1], ab[:1], m[:1], 0.0)
+    assert any(r["kernel"].startswith("conv_kwave_chain_bf16") for r in e.layer_table())
+    e.set_profiling(True)
+    prof = e.forward(L[:1], ab[:1], m[:1], 0.0)
+    assert not any(r["kernel"].startswith("conv_kwave_chain_bf16") for r in e.layer_table())
+    idx = [r["index"] for r in e.layer_table() if r["name"] == "conv5_2"][0]
+    assert float(e.layer_times_ms()[idx]) > 0                   # its own event pair again
+    e.set_profiling(False)
+    np.testing.assert_array_equal(prof, base)
+    np.testing.assert_array_equal(e.forward(L[:1], ab[:1], m[:1], 0.0), base)
+    assert any(r["kernel"].startswith("conv_kwave_chain_bf16") for r in e.layer_table())
+    e.close()
