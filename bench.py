@@ -170,6 +170,15 @@ def measure_latency(sd, device):
                 model.net_forward(hab, hm)
                 ta.append(time.perf_counter() - t0)
             out[prec]["api_net_forward_p50_ms"] = round(statistics.median(ta) * 1e3, 4)
+            # ... and the call followed by a read of output_ab, as ui/gui_draw.py:280 does after every net_forward: since round 5 the
+            # ab map and the refreshed Lab stay on the device until an attribute read fetches them (2.0 of the 2.2 MB a click sent back)
+            tb = []
+            for _ in range(100):
+                t0 = time.perf_counter()
+                model.net_forward(hab, hm)
+                _ = model.output_ab
+                tb.append(time.perf_counter() - t0)
+            out[prec]["api_net_forward_then_output_ab_p50_ms"] = round(statistics.median(tb) * 1e3, 4)
             model.net.close()
         except Exception as ex:                      # the latency leg must never sink the bench line
             out[prec]["api_net_forward_p50_ms"] = None

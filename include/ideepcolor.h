@@ -192,6 +192,14 @@ int idc_set_dist_temperature(idc_handle h, float S);
 int idc_lab2rgb(idc_handle h, int n, const float* L, const float* ab, uint8_t* rgb, double* lab_q);
 int idc_forward_rgb(idc_handle h, int n, const float* L_mc, const float* ab, const float* mask, float maskcent,
                     float l_cent, float* out_ab, uint8_t* rgb, double* lab_q);
+/*      Round 5 (the reference-API call's host time): of the 2.2 MB idc_forward_rgb sends back per 256x256 click, the value
+ *      net_forward RETURNS is the 0.2 MB uint8 image (colorize_image.py:264-268); the ab map (:263) and the refreshed Lab
+ *      (_set_out_ab_, :196-198) are attributes a caller may or may not read.  idc_forward_rgb_lazy computes all three on the
+ *      device and copies only rgb; idc_fetch_outputs copies the resident ab map (out_ab [n,2,H,W] f32) and / or refreshed Lab
+ *      (lab_q [n,3,H,W] f64) of the LAST forward when asked (either may be NULL).  Same values as idc_forward_rgb. */
+int idc_forward_rgb_lazy(idc_handle h, int n, const float* L_mc, const float* ab, const float* mask, float maskcent,
+                         float l_cent, uint8_t* rgb);
+int idc_fetch_outputs(idc_handle h, int n, float* out_ab, double* lab_q);
 /* ---- Global statistics of a reference image: replaces the global_stats.prototxt net the
  *      notebook runs to obtain glob_dist (DemoGlobalHistogramTransfer.ipynb:176-186; models/global_model/
  *      global_stats.prototxt:10-31,101-111,214-244; caffe_traininglayers.py:53-119,161-196; color_quantization.py:7-33):

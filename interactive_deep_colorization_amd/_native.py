@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = [
     "idc_version", "idc_set_tile_policy", "idc_set_option", "idc_set_splitk_policy", "idc_device_count", "idc_last_error", "idc_create", "idc_destroy", "idc_set_io_scales",
     "idc_weights_blob_bytes", "idc_pack_weights", "idc_set_weights_host", "idc_set_weights_device",
     "idc_load_weights", "idc_weights_device_ptr", "idc_forward", "idc_forward_device", "idc_forward_dist",
-    "idc_lab2rgb", "idc_forward_rgb", "idc_global_histogram", "idc_forward_dist313", "idc_set_dist_temperature", "idc_set_global_hints", "idc_clear_global_hints", "idc_sync", "idc_stream", "idc_num_layers", "idc_layer_info_get", "idc_set_profiling",
+    "idc_lab2rgb", "idc_forward_rgb", "idc_forward_rgb_lazy", "idc_fetch_outputs", "idc_global_histogram", "idc_forward_dist313", "idc_set_dist_temperature", "idc_set_global_hints", "idc_clear_global_hints", "idc_sync", "idc_stream", "idc_num_layers", "idc_layer_info_get", "idc_set_profiling",
     "idc_layer_times_ms", "idc_layer_times_stats", "idc_get_activation", "idc_op_conv2d", "idc_op_deconv4x4s2",
     "idc_set_image_l", "idc_set_hints", "idc_get_hint_planes", "idc_forward_resident",
     "idc_dist_bins", "idc_keep_dist", "idc_dist_at", "idc_get_dist", "idc_suggest_colors",
@@ -101,6 +101,8 @@ def load():
     proto("idc_global_histogram", ci, [vp, ci, vp, c_float_p, c_float_p, c_float_p])
     proto("idc_lab2rgb", ci, [vp, ci, c_float_p, c_float_p, vp, vp])
     proto("idc_forward_rgb", ci, [vp, ci, c_float_p, c_float_p, c_float_p, cf, cf, c_float_p, vp, vp])
+    proto("idc_forward_rgb_lazy", ci, [vp, ci, c_float_p, c_float_p, c_float_p, cf, cf, vp])
+    proto("idc_fetch_outputs", ci, [vp, ci, c_float_p, vp])
     proto("idc_forward_dist313", ci, [vp, ci, c_float_p, c_float_p, c_float_p, cf, c_float_p, c_float_p, c_float_p])
     proto("idc_set_dist_temperature", ci, [vp, cf])
     proto("idc_set_global_hints", ci, [vp, ci, c_float_p, c_float_p])

@@ -1105,10 +1105,10 @@ static bool is_pinned(const void* p);
 // finish = false: everything is enqueued (the D2H of the ab map into h_out included) but the stream is NOT synchronised and
 // nothing is copied to out_ab -- idc_forward_rgb appends the colour step and synchronises once for both
 static int forward_host(idc_context* c, int n, const float* L_mc, const float* ab, const float* mask, float maskcent,
-                        float* out_ab, float* dist_q, bool keep_dist = false, bool finish = true) {
+                        float* out_ab, float* dist_q, bool keep_dist = false, bool finish = true, bool copy_out = true) {
     int rc = check_forward_args(c, n);
     if (rc) return rc;
-    if (!L_mc || !ab || !mask || !out_ab) return fail(&c->err, IDC_ERR_INVALID_ARG, "null tensor pointer");
+    if (!L_mc || !ab || !mask || (copy_out && !out_ab)) return fail(&c->err, IDC_ERR_INVALID_ARG, "null tensor pointer");
     if ((dist_q || keep_dist) && !(c->flags & IDC_FLAG_DIST_HEAD))
         return fail(&c->err, IDC_ERR_UNSUPPORTED, "handle was created without IDC_FLAG_DIST_HEAD");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1129,9 +1129,10 @@ static int forward_host(idc_context* c, int n, const float* L_mc, const float* a
     HIPCHK(c, hipMemcpyAsync(c->d_mask, sm, (size_t)n * hw * 4, hipMemcpyHostToDevice, c->stream));
     rc = run_graph(c, n, c->d_L, c->d_ab, c->d_mask, maskcent, c->d_out, (dist_q || keep_dist) ? c->d_dist : nullptr);
     if (rc) return rc;
-    const bool out_direct = out_ab != c->h_out && is_pinned(out_ab);
-    c->out_copy_pending = out_ab != c->h_out && !out_direct;
-    HIPCHK(c, hipMemcpyAsync(out_direct ? out_ab : c->h_out, c->d_out, (size_t)n * hw * 2 * 4, hipMemcpyDeviceToHost, c->stream));
+    const bool out_direct = copy_out && out_ab != c->h_out && is_pinned(out_ab);
+    c->out_copy_pending = copy_out && out_ab != c->h_out && !out_direct;
+    if (copy_out)          // (copy_out = false: the ab map stays in d_out -- idc_fetch_outputs brings it over when somebody asks)
+        HIPCHK(c, hipMemcpyAsync(out_direct ? out_ab : c->h_out, c->d_out, (size_t)n * hw * 2 * 4, hipMemcpyDeviceToHost, c->stream));
     const size_t dq = (size_t)n * 529 * (hw / 16) * 4;
     if (dist_q) HIPCHK(c, hipMemcpyAsync(c->h_dist, c->d_dist, dq, hipMemcpyDeviceToHost, c->stream));
     if (!finish) return IDC_OK;
@@ -1521,6 +1522,48 @@ int idc_forward_rgb(idc_handle h, int n, const float* L_mc, const float* ab, con
     h->out_copy_pending = false;
     h->labq_resident = rc == IDC_OK && lab_q != nullptr;
     return rc;
+}
+
+// The click as the reference API needs it on the critical path: the colourised image.  The ab map and the refreshed Lab (2.0 MB of
+// the 2.2 MB idc_forward_rgb sends back per 256x256 click) stay on the device until idc_fetch_outputs asks for them.
+int idc_forward_rgb_lazy(idc_handle h, int n, const float* L_mc, const float* ab, const float* mask, float maskcent, float l_cent, uint8_t* rgb) {
+    int rc = check_forward_args(h, n);
+    if (rc) return rc;
+    if (!rgb) return fail(&h->err, IDC_ERR_INVALID_ARG, "null rgb");
+    rc = ensure_post_buffers(h);
+    if (rc) return rc;
+    rc = forward_host(h, n, L_mc, ab, mask, maskcent, nullptr, nullptr, false, /*finish=*/false, /*copy_out=*/false);
+    if (rc) return rc;
+    const size_t hw = (size_t)h->H * h->W;
+    HIPCHK(h, launch_lab_post(h->d_L, l_cent, h->d_out, h->d_rgb, h->d_labq, n, h->H, h->W, h->stream));
+    const bool rgb_direct = is_pinned(rgb);
+    HIPCHK(h, hipMemcpyAsync(rgb_direct ? rgb : h->h_rgb, h->d_rgb, (size_t)n * hw * 3, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (!rgb_direct) memcpy(rgb, h->h_rgb, (size_t)n * hw * 3);
+    h->out_copy_pending = false;
+    h->labq_resident = true;
+    return IDC_OK;
+}
+
+int idc_fetch_outputs(idc_handle h, int n, float* out_ab, double* lab_q) {
+    if (!h) return fail(nullptr, IDC_ERR_INVALID_ARG, "null handle");
+    if (n <= 0 || n > h->max_batch) return fail(&h->err, IDC_ERR_BATCH, "batch %d outside 1..%d", n, h->max_batch);
+    if (n > h->last_n) return fail(&h->err, IDC_ERR_UNSUPPORTED, "only %d image(s) of the last forward are resident", h->last_n);
+    if (out_ab && !h->out_resident) return fail(&h->err, IDC_ERR_UNSUPPORTED, "no forward result is resident");
+    if (lab_q && !h->labq_resident) return fail(&h->err, IDC_ERR_UNSUPPORTED, "no refreshed Lab is resident (run idc_forward_rgb_lazy / idc_forward_rgb with lab_q first)");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t hw = (size_t)h->H * h->W;
+    const bool ab_direct = out_ab && is_pinned(out_ab), lab_direct = lab_q && is_pinned(lab_q);
+    if (out_ab) HIPCHK(h, hipMemcpyAsync(ab_direct ? out_ab : h->h_out, h->d_out, (size_t)n * hw * 2 * 4, hipMemcpyDeviceToHost, h->stream));
+    if (lab_q) {
+        int rc = ensure_post_buffers(h);
+        if (rc) return rc;
+        HIPCHK(h, hipMemcpyAsync(lab_direct ? (void*)lab_q : (void*)h->h_labq, h->d_labq, (size_t)n * hw * 3 * 8, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (out_ab && !ab_direct) memcpy(out_ab, h->h_out, (size_t)n * hw * 2 * 4);
+    if (lab_q && !lab_direct) memcpy(lab_q, h->h_labq, (size_t)n * hw * 3 * 8);
+    return IDC_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- click session

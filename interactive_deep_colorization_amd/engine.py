@@ -250,6 +250,7 @@ class HipColorizer(object):
                                     ctypes.byref(self._h)))
         self._blob_keepalive = None
         self._pool = _result_pool(self.lib)
+        self.forward_serial = 0             # bumped by every call that replaces the handle's resident results (api.py's lazy output attributes)
 
     # ---- lifetime -------------------------------------------------------------------------
     def close(self):
@@ -335,6 +336,7 @@ class HipColorizer(object):
         """(N,1,H,W),(N,2,H,W),(N,1,H,W) -> (N,2,H,W) float32 ab.  3-D inputs = one image."""
         n, L, A, M = self._prep(L_mc, ab, mask)
         out = self._pool.take((n, 2, self.H, self.W), np.float32)
+        self.forward_serial += 1
         self._chk(self.lib.idc_forward(self._h, n, _fptr(L), _fptr(A), _fptr(M), float(maskcent), _fptr(out)))
         return out
 
@@ -344,6 +346,7 @@ class HipColorizer(object):
         n, L, A, M = self._prep(L_mc, ab, mask)
         out = np.empty((n, 2, self.H, self.W), np.float32)
         dq = np.empty((n, 529, self.H // 4, self.W // 4), np.float32) if want_dist else None
+        self.forward_serial += 1
         self._chk(self.lib.idc_forward_dist(self._h, n, _fptr(L), _fptr(A), _fptr(M), float(maskcent),
                                             _fptr(out), _fptr(dq) if want_dist else None))
         return out, dq
@@ -378,6 +381,7 @@ class HipColorizer(object):
         out = np.empty((n, 2, self.H, self.W), np.float32) if want_ab else None
         rgb = np.empty((n, self.H, self.W, 3), np.uint8) if want_rgb else None
         labq = np.empty((n, 3, self.H, self.W), np.float64) if (want_rgb and want_lab) else None
+        self.forward_serial += 1
         self._chk(self.lib.idc_forward_resident(self._h, int(n), float(maskcent), float(l_cent), _fptr(out) if want_ab else None,
                                                 rgb.ctypes.data_as(ctypes.c_void_p) if want_rgb else None,
                                                 labq.ctypes.data_as(ctypes.c_void_p) if labq is not None else None))
@@ -441,6 +445,7 @@ class HipColorizer(object):
         Lc, Ac = _f32c(L, (n, 1, self.H, self.W)), _f32c(ab, (n, 2, self.H, self.W))
         rgb = np.empty((n, self.H, self.W, 3), np.uint8)
         labq = np.empty((n, 3, self.H, self.W), np.float64) if want_lab else None
+        self.forward_serial += 1
         self._chk(self.lib.idc_lab2rgb(self._h, n, _fptr(Lc), _fptr(Ac), rgb.ctypes.data_as(ctypes.c_void_p),
                                        labq.ctypes.data_as(ctypes.c_void_p) if want_lab else None))
         return rgb, labq
@@ -451,10 +456,29 @@ class HipColorizer(object):
         out = self._pool.take((n, 2, self.H, self.W), np.float32)       # pinned: the library copies device -> result in place
         rgb = self._pool.take((n, self.H, self.W, 3), np.uint8)
         labq = self._pool.take((n, 3, self.H, self.W), np.float64) if want_lab else None
+        self.forward_serial += 1
         self._chk(self.lib.idc_forward_rgb(self._h, n, _fptr(L), _fptr(A), _fptr(M), float(maskcent), float(l_cent), _fptr(out),
                                            rgb.ctypes.data_as(ctypes.c_void_p),
                                            labq.ctypes.data_as(ctypes.c_void_p) if want_lab else None))
         return out, rgb, labq
+
+    def forward_rgb_lazy(self, L_mc, ab, mask, maskcent=0.0, l_cent=50.0):
+        """forward + the colour step on the device, only the uint8 image copied back: rgb (n,H,W,3).  The ab map and the refreshed Lab
+        stay resident; ``fetch_outputs`` brings them over when somebody reads them (2.0 of the 2.2 MB a 256x256 click sends back)."""
+        n, L, A, M = self._prep(L_mc, ab, mask)
+        rgb = self._pool.take((n, self.H, self.W, 3), np.uint8)
+        self.forward_serial += 1
+        self._chk(self.lib.idc_forward_rgb_lazy(self._h, n, _fptr(L), _fptr(A), _fptr(M), float(maskcent), float(l_cent),
+                                                rgb.ctypes.data_as(ctypes.c_void_p)))
+        return rgb
+
+    def fetch_outputs(self, n=1, want_ab=True, want_lab=True):
+        """(out_ab (n,2,H,W) f32 | None, lab_q (n,3,H,W) f64 | None) of the last forward, from the device."""
+        out = self._pool.take((n, 2, self.H, self.W), np.float32) if want_ab else None
+        labq = self._pool.take((n, 3, self.H, self.W), np.float64) if want_lab else None
+        self._chk(self.lib.idc_fetch_outputs(self._h, int(n), _fptr(out) if want_ab else None,
+                                             labq.ctypes.data_as(ctypes.c_void_p) if want_lab else None))
+        return out, labq
 
     def forward_dist313(self, L_mc, ab, mask, maskcent=0.0, want_dist=True):
         """313-bin head of the Caffe distribution net: returns (out_ab regression, pred_ab soft-decode (N,2,H,W),
@@ -463,6 +487,7 @@ class HipColorizer(object):
         out = np.empty((n, 2, self.H, self.W), np.float32)
         pred = np.empty((n, 2, self.H, self.W), np.float32)
         dist = np.empty((n, 313, self.H, self.W), np.float32) if want_dist else None
+        self.forward_serial += 1
         self._chk(self.lib.idc_forward_dist313(self._h, n, _fptr(L), _fptr(A), _fptr(M), float(maskcent), _fptr(out),
                                                _fptr(pred), _fptr(dist) if want_dist else None))
         return out, pred, dist
@@ -479,6 +504,7 @@ class HipColorizer(object):
             if isinstance(x, np.ndarray):               # pinned host memory (pinned_empty): zero-copy, see idc_pipeline_times' note
                 return ctypes.c_void_p(int(x.ctypes.data))
             return ctypes.c_void_p(int(x))
+        self.forward_serial += 1
         self._chk(self.lib.idc_forward_device(self._h, int(n), p(d_L), p(d_ab), p(d_mask), float(maskcent),
                                               p(d_out), 1 if sync else 0))
 
@@ -512,6 +538,7 @@ class HipColorizer(object):
         for a, shp in ((L_mc, (n, 1, self.H, self.W)), (ab, (n, 2, self.H, self.W)), (mask, (n, 1, self.H, self.W)), (out, (n, 2, self.H, self.W))):
             if a.dtype != np.float32 or not a.flags.c_contiguous or tuple(a.shape) != shp:
                 raise ValueError("forward_async needs float32 C-contiguous arrays of shape %s" % (shp,))
+        self.forward_serial += 1
         self._chk(self.lib.idc_forward_async(self._h, int(slot), int(n), _fptr(L_mc), _fptr(ab), _fptr(mask), float(maskcent), _fptr(out)))
 
     def wait(self, slot):

@@ -81,7 +81,7 @@ def test_new_engine_resets_every_device_side_flag():
     m._new_engine(new)
     assert m.net is new and old.closed and m.net_set
     assert not m._l_resident and not m._hints_on_device and not m._dist_on_device and not m.dist_ab_set
-    assert m._dev_out_token is None
+    assert m._dev_out_valid is False and not m._out_pending       # (round 5: the token became a flag + the lazily fetched attributes)
 
 
 def test_read_state_dict_drops_metadata(tmp_path):

@@ -154,3 +154,44 @@ def test_kwave_chain_is_not_taken_where_it_does_not_apply(make_sd):
     np.testing.assert_array_equal(e.forward(L[:1], ab[:1], m[:1], 0.0), base)
     assert any(r["kernel"].startswith("conv_kwave_chain_bf16") for r in e.layer_table())
     e.close()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_reference_api_outputs_are_fetched_on_read(make_sd, precision):
+    """net_forward returns the uint8 image; output_ab_raw / output_lab / output_ab -- which the reference fills on the
+    host inside every call (colorize_image.py:263-267,196-198) -- are computed by the same device call and copied over when first READ.
+    Same values as the eager three-output call (engine.forward_rgb), plain numpy arrays afterwards, each net_forward's attributes its own;
+    assigning one makes it a plain attribute; using the engine directly in between is reported, not silently mixed up."""
+    sd = make_sd(0, "torch")
+    rgb = np.load(os.path.join(REPO, "tests", "golden", "mortar_pestle_256_rgb.npy"))
+    hab, hm = workloads.hints_config2(256, 5, 3, 0)
+    hab2 = hab.copy(); hab2[:, 40:47, 40:47] = 33.0
+    hm2 = hm.copy(); hm2[:, 40:47, 40:47] = 1.0
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = api.ColorizeImageTorch(Xd=256, precision=precision)
+        m.prep_net(gpu_id=0, state_dict=sd)
+        m.set_image(rgb)
+    img1 = m.net_forward(hab, hm)
+    assert m._out_pending == set(api._OUT_ATTRS)                     # nothing but the image has crossed PCIe
+    L = m.img_l_mc[None].astype(np.float32)
+    raw_e, rgb_e, lab_e = m.net.forward_rgb(L, hab[None].astype(np.float32), hm[None].astype(np.float32), m.mask_cent, l_cent=50.0)
+    with pytest.raises(RuntimeError):                                # the engine ran another forward: that call's maps are gone, and it says so
+        _ = m.output_ab
+    img1b = m.net_forward(hab, hm)
+    np.testing.assert_array_equal(img1b, img1)
+    np.testing.assert_array_equal(img1, rgb_e[0])
+    ab1, lab1, raw1 = m.output_ab, m.output_lab, m.output_ab_raw
+    assert not m._out_pending and isinstance(ab1, np.ndarray) and ab1.dtype == np.float64 and ab1.shape == (2, 256, 256)
+    np.testing.assert_array_equal(raw1, raw_e[0]); np.testing.assert_array_equal(lab1, lab_e[0]); np.testing.assert_array_equal(ab1, lab_e[0][1:])
+    assert m.output_ab is ab1                                        # cached: one fetch per forward
+    img2 = m.net_forward(hab2, hm2)
+    assert (img2 != img1).any()
+    ab2 = m.output_ab
+    assert (ab2 != ab1).any() and np.array_equal(ab1, lab_e[0][1:])  # the first call's array is the caller's to keep
+    win = m.get_result_window(np.full((300, 280), 60.0))             # the display step still runs on the resident map
+    assert win.shape == (300, 280, 3)
+    m.net_forward(hab, hm)
+    m.output_ab = np.zeros((2, 256, 256))                            # caller-supplied map (what _set_out_ab_ does): a plain attribute now
+    assert not m._out_on_device() and (m.output_ab == 0).all()
+    np.testing.assert_array_equal(m.output_ab_raw, raw_e[0])         # ... the other two are still fetched from the device
+    m.net.close()
