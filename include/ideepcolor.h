@@ -54,12 +54,10 @@ typedef enum idc_precision { IDC_FP32 = 0, IDC_BF16 = 1 } idc_precision;
                                       models/reference_model/deploy_nopred.prototxt:650-850 (needs the pred.* tensors, see idc_forward_dist313) */
 #define IDC_FLAG_GLOBAL_HINTS 0x4u /* also build the Global-Hints branch of models/global_model/deploy_nodist.prototxt:37-172,
                                       501-518 (needs the glob.* tensors, see idc_set_global_hints) */
-#define IDC_FLAG_THROUGHPUT_BLOB 0x10u /* weight blob WITHOUT the Winograd images (U = G g G^T of the 3x3 layers and the deconvs): those
-                                        * serve the batch-1 click path (bf16) and the fp32 path; a bf16 throughput handle (large batches)
-                                        * never reads them, and they are half of the blob -- 136 MB instead of 260 MB to pack, upload and
-                                        * broadcast (sharded.py / bench.py use it for the N = 32 bf16 job).  With the flag those kernel
-                                        * variants are simply not selected (direct kernels run instead: same results within tolerance, slower
-                                        * at batch 1 and in fp32). */
+#define IDC_FLAG_THROUGHPUT_BLOB 0x10u /* weight blob WITHOUT the Winograd images (U = G g G^T of the 3x3 layers and the deconvs).  Since
+                                        * round 5 only the fp32 blob carries them (384 MB -> 136 MB with the flag; the direct fp32 kernels then run:
+                                        * same results within tolerance, slower); a bf16 blob is 136 MB with or without the flag -- the bf16 click
+                                        * path's kernels (conv_kwave_*) read the same layout-1 images as the throughput kernels. */
 
 /* ---- library ------------------------------------------------------------------------------- */
 int idc_version(void);
@@ -68,21 +66,26 @@ int idc_version(void);
  * (conv_igemm_v2) wherever it applies.  Exists so that the parity tests can drive every kernel
  * variant at small sizes.  No reference counterpart. */
 int idc_set_tile_policy(int policy);
-/* Process-wide switches for the parity tests (speed only).  "fuse_conv1" (default 1): model1 = conv1_1 + conv1_2 as one
- * launch on the bf16 throughput path -- 0 keeps the two launches apart, so that conv1_1's own output exists and can be
- * read with idc_get_activation.  "click" (default -1 = on unless IDC_CLICK=0): small launches (the batch-1 click path) run
- * conv_click (weight tiles streamed by LDS-DMA, fragments prefetched across steps); 0 keeps them on conv_igemm.
- * "mfma16" (default 1): the bf16 throughput tile runs as conv_igemm_v2m (v_mfma_f32_16x16x32_bf16, fewer joules per FLOP at the
- * power cap) wherever it applies; 0 = conv_igemm_v2 (v_mfma_f32_32x32x16_bf16) everywhere.  "winograd" / "winograd_bf16" /
- * "winograd_deconv" / "winograd_form" / "fuse_conv1_small": kernel choice on the fp32 path and the batch-1 click path.
- * Round 4: "v2p" (default 1): the 3x3 convs among the conv_igemm_v2m launches run as conv_igemm_v2p (column-swizzled halo tile, unrolled
- * taps, immediates; bit-identical results); "ds_mfma16" (default 1): the deconv + shortcut launches run as conv_ds_fused_m (16x16x32 MFMA),
- * 0 = conv_ds_fused; "conv1_lw" (default 3): model1 on 32x12 tiles with conv1_2's weight tiles through an LDS ring, two workgroups per CU
- * (2: 32x8 tiles; 0: the 32x32 tile, weights global -> registers; bit-identical results); "code_warm" (default 1): the throughput kernels
- * pull their own code into L2 at entry (first-use cost of a kernel on some boxes); "kwave" (default 1): on the bf16
- * batch-1 click path the 3x3 stride-1 layers run as conv_kwave_bf16 (direct form, K split over the waves of a workgroup, layout-1 weights),
- * 0 = the Winograd form conv_wino_bf16 of round 3; "kwave_deconv" (default 1): likewise the ConvTranspose 4x4 s2 launches of that path as
- * conv_kwave_deconv_bf16 (0 = conv_wino_deconv_bf16 / conv_click).
+/* Process-wide switches for the parity tests and A/B measurements (speed / kernel choice only: every setting computes the same
+ * function).  EIGHT names since round 5 (round 4 had fourteen):
+ *   "fuse_conv1"  (1)  model1 = conv1_1 + conv1_2 as one launch on the bf16 path; 0 keeps the two launches apart, so that conv1_1's own
+ *                      output exists and can be read with idc_get_activation.
+ *   "click"       (-1 = on unless IDC_CLICK=0)  small launches (the batch-1 click path, fp32 and what "kwave" does not cover) run conv_click
+ *                      (weight tiles by LDS-DMA, fragments prefetched across steps); 0 keeps them on conv_igemm.
+ *   "winograd"    (1)  fp32 path: 3x3 stride-1 layers as Winograd F(2x2,3x3), small deconv launches as F(2x2,2x2).  0 = direct kernels,
+ *                      1 = automatic, 2 = every deconv too (tests), 12 / 21 / 22 = automatic with the 3x3 form <TB,CB> forced (tests).
+ *   "mfma16"      (1)  bf16 throughput tile as conv_igemm_v2m (v_mfma_f32_16x16x32_bf16: fewer joules per FLOP at the power cap);
+ *                      0 = conv_igemm_v2 (v_mfma_f32_32x32x16_bf16).
+ *   "v2p"         (1)  the 3x3 convs among them as conv_igemm_v2p (column-swizzled halo tile, unrolled taps; bit-identical results).
+ *   "ds_mfma16"   (1)  deconv + shortcut launches as conv_ds_fused_m (16x16x32 MFMA); 0 = conv_ds_fused.
+ *   "kwave"       (1)  bf16 batch-1 click path: 3x3 stride-1 layers and ConvTranspose launches as conv_kwave_bf16 / conv_kwave_deconv_bf16
+ *                      (direct form, K split over the waves of a workgroup); 0 = conv_click + split-K (round 2's kernels).
+ *   "kwave_chain" (2)  ... and runs of consecutive same-shape 512-channel layers of that path (conv4_2 .. conv7_3 at batch 1) as ONE
+ *                      persistent launch with a grid barrier between layers (conv_kwave_chain_bf16): 0 = one launch per layer,
+ *                      1 = through hipLaunchCooperativeKernel, 2 = plain launch after an occupancy check; a workgroup that never sees the
+ *                      others gives up after ~0.3 s, that forward fails with IDC_ERR_INTERNAL and the handle goes back to one launch per layer.
+ * Retired in round 5 together with their kernels, or folded into the above: "fuse_conv1_small", "winograd_bf16", "winograd_form",
+ * "winograd_deconv", "conv1_lw", "code_warm", "kwave_deconv" (IDC_ERR_INVALID_ARG now).
  * Take effect on the next forward; unknown names return IDC_ERR_INVALID_ARG. */
 int idc_set_option(const char* name, int value);
 /* Split-K policy of the small-tile kernels (speed only): 0 automatic (launches too small to fill the chip: the

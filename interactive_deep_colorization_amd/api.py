@@ -274,6 +274,10 @@ class ColorizeImageBase(object):
         eager three-output call (injected engines of the host-logic tests)."""
         lazy = getattr(self.net, 'forward_rgb_lazy', None)
         if lazy is not None and hasattr(self.net, 'fetch_outputs'):
+            # a new net_forward replaces the previous call's maps by definition: whatever of them was never read is dropped, not fetched
+            self._out_pending = set()
+            if getattr(self.net, 'before_overwrite', None) is not None:
+                self.net.before_overwrite = None
             rgb = lazy(self._l_plane(), self.input_ab_mc, self.input_mask_mult, maskcent, l_cent=self.l_mean)
             return self._finish_forward_lazy(rgb[0])
         raw, rgb, lab_q = self.net.forward_rgb(self._l_plane(), self.input_ab_mc, self.input_mask_mult, maskcent, l_cent=self.l_mean)
@@ -286,6 +290,9 @@ class ColorizeImageBase(object):
         self._out_pending = set(_OUT_ATTRS)
         self._out_serial = getattr(self.net, 'forward_serial', None)
         self._dev_out_valid = True
+        # anything else that is about to replace the engine's resident results (a direct engine call behind this object's back) first lets
+        # this object fetch what it has not read yet: the attributes keep the reference's meaning whatever happens in between
+        self.net.before_overwrite = self._refresh_outputs
         return self.output_rgb
 
     def _refresh_outputs(self):
@@ -294,6 +301,8 @@ class ColorizeImageBase(object):
             return
         names = set(pend)
         pend.clear()
+        if getattr(self.net, 'before_overwrite', None) is not None:
+            self.net.before_overwrite = None
         if getattr(self.net, 'forward_serial', None) != self.__dict__.get('_out_serial'):
             raise RuntimeError('the engine has run another forward since net_forward: the ab map of that call was never fetched '
                                '(read output_ab / output_lab / output_ab_raw before using the engine directly)')

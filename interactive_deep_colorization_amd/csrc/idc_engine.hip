@@ -31,7 +31,9 @@ BlobPlan make_blob_plan(int precision, unsigned flags) {
     BlobPlan p;
     p.precision = precision;
     p.flags = flags & (IDC_FLAG_DIST_HEAD | IDC_FLAG_GLOBAL_HINTS | IDC_FLAG_DIST313 | IDC_FLAG_THROUGHPUT_BLOB);
-    const bool wino_images = !(flags & IDC_FLAG_THROUGHPUT_BLOB);
+    // Winograd U images: the fp32 path only (round 5: the bf16 click path's Winograd kernels were retired -- conv_kwave_* read the layout-1
+    // images -- so a bf16 blob is 136 MB whatever the flag says; fp32: 384 MB, 136 MB with IDC_FLAG_THROUGHPUT_BLOB)
+    const bool wino_images = !(flags & IDC_FLAG_THROUGHPUT_BLOB) && precision == IDC_FP32;
     const auto& specs = layer_specs();
     size_t off = sizeof(BlobHeader);
     const int kc = kc_elems(precision);
@@ -496,23 +498,21 @@ static int g_fuse_conv1 = !(getenv("IDC_FUSE_CONV1") && atoi(getenv("IDC_FUSE_CO
 // Split-K policy of the small-tile kernels (speed only): 0 = automatic (launches that would leave most CUs idle,
 // i.e. the batch-1 click path), 1 = never, 2 = always split as far as the cin chunks allow (tests).
 static int g_splitk_policy = 0;
-static int g_wino = !(getenv("IDC_WINO") && atoi(getenv("IDC_WINO")) == 0);   // fp32 3x3 stride-1 layers in Winograd form (idc_set_option "winograd" / env IDC_WINO=0 for A/B)
-static int g_fuse_conv1_small = !(getenv("IDC_FUSE_CONV1_SMALL") && atoi(getenv("IDC_FUSE_CONV1_SMALL")) == 0);   // model1 as one 32x8-tile launch on the bf16 click path
-static int g_wino_deconv = !(getenv("IDC_WINO_DECONV") && atoi(getenv("IDC_WINO_DECONV")) == 0);   // fp32 deconvs as Winograd F(2x2,2x2) (idc_set_option "winograd_deconv")
-// bf16 batch-1 click path: Winograd instead of conv_click + split-K reduction (idc_set_option "winograd_bf16"); 2 = every eligible
-// bf16 layer at every batch size (measurement only: slower than the direct kernels at N = 32)
-static int g_wino_bf16 = getenv("IDC_WINO_BF16") ? atoi(getenv("IDC_WINO_BF16")) : 1;
+// fp32 path: 3x3 stride-1 layers as Winograd F(2x2,3x3), small deconv launches as F(2x2,2x2) (idc_set_option "winograd"): 0 = off (direct kernels),
+// 1 = automatic (default), 2 = wherever the forms are implemented (deconvs at every size: tests), 12 / 21 / 22 = automatic with the 3x3 form
+// <TB,CB> forced (tests, tuning).  The bf16 twins of round 3 were retired in round 5 (docs/experiments/conv_wino_bf16_round3.hip.txt).
+static int g_wino = 1;
+static int g_wino_deconv = 1;            // 1 = small launches with Cin >= 256 only; 2 = every deconv ("winograd" = 2)
 // conv_igemm_v2 launches that qualify run as conv_igemm_v2m (16x16x32 MFMA: fewer joules per FLOP at the power cap; idc_set_option "mfma16")
 static int g_mfma16 = getenv("IDC_MFMA16") ? atoi(getenv("IDC_MFMA16")) : 1;
 // ... and so do the three deconv + shortcut launches (conv_ds_fused_m, idc_dsm.hip; idc_set_option "ds_mfma16" / env IDC_DS_M16=0 for A/B)
 static int g_ds_m16 = getenv("IDC_DS_M16") ? atoi(getenv("IDC_DS_M16")) : 1;
 // ... and the 3x3 convs among them as conv_igemm_v2p (no address arithmetic in the K loop; idc_set_option "v2p" / env IDC_V2P=0 for A/B)
 static int g_v2p = getenv("IDC_V2P") ? atoi(getenv("IDC_V2P")) : 1;
-// throughput kernels touch their own code at entry (idc_warm_own_code, idc_kernels.h; idc_set_option "code_warm" / env IDC_CODE_WARM=0 for A/B)
+// throughput kernels touch their own code at entry (idc_warm_own_code, idc_kernels.h; env IDC_CODE_WARM=0 for the A/B of profiles/r04_firstuse.txt)
 static int g_code_warm = getenv("IDC_CODE_WARM") ? atoi(getenv("IDC_CODE_WARM")) : 1;
-// bf16 click path: the 3x3 stride-1 layers as conv_kwave_bf16 instead of conv_wino_bf16 ("kwave" / IDC_KWAVE)
-static int g_kwave = getenv("IDC_KWAVE") ? atoi(getenv("IDC_KWAVE")) : 1;
-static int g_kwave_deconv = getenv("IDC_KWAVE_DECONV") ? atoi(getenv("IDC_KWAVE_DECONV")) : 1;      // ... and the deconvs ("kwave_deconv")
+// bf16 click path: the 3x3 stride-1 layers and the deconvs as conv_kwave_bf16 / conv_kwave_deconv_bf16 ("kwave"; 0 = conv_click + split-K, round 2's kernels)
+static int g_kwave = 1;
 // ... and runs of consecutive same-shape 8-chunk conv_kwave_bf16 layers (the 512 -> 512 trunk at batch 1) as ONE persistent launch with a
 // grid barrier between layers ("kwave_chain" / IDC_KWAVE_CHAIN): 0 = off, 1 = hipLaunchCooperativeKernel (+24 us per launch on this runtime),
 // 2 = plain launch after an occupancy check (default; a workgroup that never sees the others gives up after ~0.3 s and the handle falls back)
@@ -625,9 +625,6 @@ static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, i
     // (deconvs: only the small launches of the click path with Cin >= 256 -- the form is transform-bound (one 16-cout block per
     //  workgroup at the 168-register budget of its 12 waves): model10up (4 chunks) 123 us vs 96 us direct at batch 1, and at N = 32
     //  model8up / model9up 1.30 / 1.54 ms vs 1.23 / 1.31 ms direct; "winograd_deconv" = 2 forces it everywhere for the tests)
-    if (precision == IDC_BF16 && g_wino && g_wino_bf16 == 2 && g_tile_policy != 1 && L.blob.w3_off != (size_t)-1 &&
-        L.spec->resid == nullptr && L.spec->kind == kConv3x3)
-        L.wino = true;                               // measurement switch: the click path's Winograd kernel at every batch size
     const bool wino_fits = wino_offsets_fit(Hs, Ws, L.spec->kind == kDeconv4x4 ? 1 : L.spec->in_stride, a.nkc);   // 32-bit patch offsets
     L.wino = L.wino && wino_fits;
     L.kw = false;
@@ -667,15 +664,9 @@ static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, i
     const int wm_big = a.ncg % 4 == 0 ? 4 : (a.ncg % 2 == 0 ? 2 : 1), rows_big = wm_big == 4 ? 8 : 16;
     const long long big_tiles = (long long)((Ws + 31) / 32) * ((Hs + rows_big - 1) / rows_big) * n_policy * (a.ncg / wm_big) * a.nphase;
     // bf16 click path, deconvs: the direct form with K split over the waves of a workgroup (conv_kwave_deconv_bf16, idc_kw.hip)
-    if (precision == IDC_BF16 && g_kwave && g_kwave_deconv && g_tile_policy != 1 && big_tiles < tuning().v2_min_blocks && wino_fits &&
+    if (precision == IDC_BF16 && g_kwave && g_tile_policy != 1 && big_tiles < tuning().v2_min_blocks && wino_fits &&
         L.spec->kind == kDeconv4x4 && (a.nkc == 2 || a.nkc == 4 || a.nkc == 8)) {
         L.kw = true; a.ksplit = 1; a.kc_per = a.nkc; a.tiles_x = a.tiles_y = 0;
-        return;
-    }
-    // bf16 click path, deconvs with Cin >= 256 (model8up / model9up): Winograd F(2x2,2x2) instead of conv_click + a reduction launch
-    if (precision == IDC_BF16 && g_wino && g_wino_bf16 && g_wino_deconv && g_tile_policy != 1 && big_tiles < tuning().v2_min_blocks && wino_fits &&
-        L.blob.w3_off != (size_t)-1 && L.spec->kind == kDeconv4x4 && (a.nkc >= 4 || g_wino_deconv == 2)) {
-        L.wino = true; a.ksplit = 1; a.kc_per = a.nkc; a.tiles_x = a.tiles_y = 0;
         return;
     }
     // bf16 click path, 3x3 stride-1 layers: the direct form with K split over the waves of a workgroup (idc_kw.hip) -- 9/16 of the Winograd
@@ -684,13 +675,6 @@ static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, i
     if (precision == IDC_BF16 && g_kwave && g_tile_policy != 1 && big_tiles < tuning().v2_min_blocks && wino_fits && L.spec->resid == nullptr &&
         L.spec->kind == kConv3x3 && (a.nkc == 1 || a.nkc == 2 || a.nkc == 4 || a.nkc == 8)) {
         L.kw = true; a.ksplit = 1; a.kc_per = a.nkc; a.tiles_x = a.tiles_y = 0;
-        return;
-    }
-    // bf16 click path: a 3x3 stride-1 layer that would run conv_click + a split-K reduction launch runs as Winograd instead
-    // (16 position-GEMMs fill the chip without split-K: no slabs, no second launch; idc_wino.hip)
-    if (precision == IDC_BF16 && g_wino && g_wino_bf16 && g_tile_policy != 1 && big_tiles < tuning().v2_min_blocks && wino_fits &&
-        L.blob.w3_off != (size_t)-1 && L.spec->resid == nullptr && L.spec->kind == kConv3x3) {
-        L.wino = true; a.ksplit = 1; a.kc_per = a.nkc; a.tiles_x = a.tiles_y = 0;
         return;
     }
     if ((g_click < 0 ? tuning().click : g_click) && g_tile_policy != 1 && big_tiles < tuning().v2_min_blocks &&
@@ -882,7 +866,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
         // workgroups -- the batch-1 click path: one launch instead of conv1_1 + conv1_2 and no 8 MB intermediate
         const long long t32 = (long long)((c->W + 31) / 32) * ((c->H + 31) / 32) * c->max_batch;
         const long long t8 = (long long)((c->W + 31) / 32) * ((c->H + 7) / 8) * c->max_batch;
-        if (t32 < 128 && (t8 < 128 || !g_fuse_conv1_small)) continue;
+        if (t32 < 128 && t8 < 128) continue;
         const int tile_req = t32 >= 128 ? 32 : 8;              // tile height request of launch_conv1_block
         for (size_t j = 0; j < c->layers.size(); ++j) {
             Layer& P = c->layers[j];
@@ -1231,20 +1215,20 @@ int idc_set_tile_policy(int policy) {
 int idc_set_option(const char* name, int value) {
     if (!name) return fail(nullptr, IDC_ERR_INVALID_ARG, "null option name");
     if (strcmp(name, "fuse_conv1") == 0) { g_fuse_conv1 = value != 0; return IDC_OK; }
-    if (strcmp(name, "fuse_conv1_small") == 0) { g_fuse_conv1_small = value != 0; return IDC_OK; }
     if (strcmp(name, "click") == 0) { g_click = value; return IDC_OK; }
-    if (strcmp(name, "winograd") == 0) { g_wino = value != 0; return IDC_OK; }
+    if (strcmp(name, "winograd") == 0) {         // 0 off | 1 automatic | 2 everywhere implemented | 12 / 21 / 22 automatic, 3x3 form <TB,CB> forced
+        if (value != 0 && value != 1 && value != 2 && value != 12 && value != 21 && value != 22)
+            return fail(nullptr, IDC_ERR_INVALID_ARG, "option 'winograd': %d not in {0, 1, 2, 12, 21, 22}", value);
+        g_wino = value != 0;
+        g_wino_deconv = value == 2 ? 2 : 1;
+        set_wino_form(value >= 12 ? value : 0);
+        return IDC_OK;
+    }
     if (strcmp(name, "mfma16") == 0) { g_mfma16 = value != 0; return IDC_OK; }
     if (strcmp(name, "v2p") == 0) { g_v2p = value != 0; return IDC_OK; }
-    if (strcmp(name, "code_warm") == 0) { g_code_warm = value != 0; return IDC_OK; }
-    if (strcmp(name, "kwave") == 0) { g_kwave = value != 0; return IDC_OK; }
-    if (strcmp(name, "kwave_deconv") == 0) { g_kwave_deconv = value != 0; return IDC_OK; }
-    if (strcmp(name, "kwave_chain") == 0) { g_kwave_chain = value < 0 ? 0 : (value > 2 ? 2 : value); return IDC_OK; }
-    if (strcmp(name, "conv1_lw") == 0) { set_conv1_lw(value); return IDC_OK; }
     if (strcmp(name, "ds_mfma16") == 0) { g_ds_m16 = value != 0; return IDC_OK; }
-    if (strcmp(name, "winograd_bf16") == 0) { g_wino_bf16 = value; return IDC_OK; }
-    if (strcmp(name, "winograd_deconv") == 0) { g_wino_deconv = value; return IDC_OK; }
-    if (strcmp(name, "winograd_form") == 0) { set_wino_form(value); return IDC_OK; }     // 0 automatic, 12 / 21 / 22 = <TB,CB> (tests, tuning)
+    if (strcmp(name, "kwave") == 0) { g_kwave = value != 0; return IDC_OK; }
+    if (strcmp(name, "kwave_chain") == 0) { g_kwave_chain = value < 0 ? 0 : (value > 2 ? 2 : value); return IDC_OK; }
     return fail(nullptr, IDC_ERR_INVALID_ARG, "unknown option '%s'", name);
 }
 

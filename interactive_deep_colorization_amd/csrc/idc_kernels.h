@@ -112,7 +112,6 @@ hipError_t init_kernels_dsm();
 // model1 = conv1_1 + conv1_2 of a 32x32 tile in one workgroup (conv1_block_fused): `a` = conv1_1's arguments with conv1_2's
 // riding in (wgt2 = its layout-1 weights, head_b = its bias, bn_scale/bn_shift, out = its output)
 hipError_t launch_conv1_block(const ConvArgs& a, hipStream_t s);
-void set_conv1_lw(int v);          // 0: 32x32 tile, weights global -> registers; 2 / 3: 32x8 / 32x12 tile, weight tiles through an LDS ring (two workgroups per CU)
 // conv1_1 (4 -> 64, input pack fused) as one 32x32 tile per workgroup, bf16; hipErrorInvalidConfiguration if the
 // launch does not qualify (the caller then uses launch_conv)
 hipError_t launch_conv1_1_bf16(const ConvArgs& a, hipStream_t s);

@@ -1510,8 +1510,6 @@ hipError_t init_kernels_v2() {
     // the two fused kernels use more than the default 64 KiB of dynamic LDS (set per device: this runs for every handle)
     e = hipFuncSetAttribute((const void*)conv_ds_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)conv1_block_fused_t<4, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, conv1_block_lds(4, 2, false));
-    if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)conv1_block_fused_t<4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv1_block_lds(4, 2, true));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)conv1_block_fused_t<4, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv1_block_lds(4, 3, true));
@@ -2355,27 +2353,21 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || LW) ? 2 : 3) void conv1_block_
 // model1 (conv1_1 + conv1_2) in one launch.  `a` = conv1_1's arguments (fused-pack planes, layout-1 weights, bias, act)
 // with conv1_2's riding in: wgt2 = its layout-1 weights (9 taps x 8 KiB), head_b = its bias, bn_scale/bn_shift = its
 // eval-BN affine, out = its output.  conv1_2 is ReLU + (optional) BN, 64 -> 64.
-// default 3: same-box A/B of the N = 32 forward, conv1 block 0.2315 -> 0.2121 ms (-8.4 %) and 0.2106 -> 0.2001 (-5 %) on two boxes; 2 (32x8): +7 %
-int g_c1_lw = getenv("IDC_C1_LW") ? atoi(getenv("IDC_C1_LW")) : 3;
-void set_conv1_lw(int v) { g_c1_lw = v == 2 || v == 3 ? v : 0; }
+// Tile (round 4, profiles/r04d_*): conv1_block_fused_t<4,3,true> -- 32x12 pixels, conv1_2's weight tiles through an LDS ring, two workgroups per CU --
+// at N = 32 (same-box conv1 block 0.2315 -> 0.2121 ms against the 32x32 tile); the click path's too-few-tiles case takes the 32x8 form
+// <4,2,true>.  IDC_C1_LW=0 keeps the round-2 32x32 tile (<8,4,false>: weights global -> registers per wave) as the A/B partner; the
+// ring-less 32x8 tile <4,2,false> and the "conv1_lw" option were retired in round 5 (bit-identical results in every form).
+static const int g_c1_lw = getenv("IDC_C1_LW") ? atoi(getenv("IDC_C1_LW")) : 3;
 
 hipError_t launch_conv1_block(const ConvArgs& a, hipStream_t s) {
     if (a.pk_L == nullptr || a.wgt2 == nullptr || a.head_b == nullptr || a.ncg != 1 || a.out_f32 || a.resid != nullptr)
         return hipErrorInvalidConfiguration;
-    // 32x8 tile / three workgroups per CU: measured -2 % on this kernel (0.229 vs 0.234 ms), nothing on the
-    // forward (profiles/r03_conv1_tile8.txt) -- the A fragments of conv1_2 come from global memory per wave and tap, so the smaller
-    // tile doubles an L2 -> CU stream that is already 5 TB/s.  Off by default; IDC_C1_TILE8=1 selects it (parity-tested).
-    static const int force8 = getenv("IDC_C1_TILE8") && atoi(getenv("IDC_C1_TILE8")) != 0;
-    // round 4: weight tiles through an LDS ring, two workgroups per CU (g_c1_lw = 2: 32x8 tile, 3: 32x12 tile; 0: the 32x32 tile above)
-    const bool big = !(force8 || a.tiles_y == 8);           // a.tiles_y = the engine's request: 8 on the batch-1 click path (too few 32x32 tiles)
-    // (the click path's 32x8 tile takes the ring too unless conv1_lw = 0: 16.4 -> 15.2 us at batch 1, bit-identical; profiles/r04_kwave.txt)
-    const int lw = big ? g_c1_lw : (g_c1_lw ? 2 : 0);
-    const int th = lw == 3 ? 12 : (lw == 2 || !big) ? 8 : 32;
+    const bool big = a.tiles_y != 8;                        // a.tiles_y = the engine's request: 8 on the batch-1 click path (too few 32x32 tiles)
+    const int th = !big ? 8 : g_c1_lw ? 12 : 32;
     const long long blocks = (long long)((a.Ws + 31) / 32) * ((a.Hs + th - 1) / th) * a.N;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (lw == 3) hipLaunchKernelGGL((conv1_block_fused_t<4, 3, true>), dim3((unsigned)blocks), dim3(256), conv1_block_lds(4, 3, true), s, a);
-    else if (lw == 2) hipLaunchKernelGGL((conv1_block_fused_t<4, 2, true>), dim3((unsigned)blocks), dim3(256), conv1_block_lds(4, 2, true), s, a);
-    else if (!big) hipLaunchKernelGGL((conv1_block_fused_t<4, 2, false>), dim3((unsigned)blocks), dim3(256), conv1_block_lds(4, 2, false), s, a);
+    if (!big) hipLaunchKernelGGL((conv1_block_fused_t<4, 2, true>), dim3((unsigned)blocks), dim3(256), conv1_block_lds(4, 2, true), s, a);
+    else if (g_c1_lw) hipLaunchKernelGGL((conv1_block_fused_t<4, 3, true>), dim3((unsigned)blocks), dim3(256), conv1_block_lds(4, 3, true), s, a);
     else hipLaunchKernelGGL((conv1_block_fused_t<8, 4, false>), dim3((unsigned)blocks), dim3(512), conv1_block_lds(8, 4, false), s, a);
     return hipGetLastError();
 }

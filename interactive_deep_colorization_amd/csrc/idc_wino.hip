@@ -502,223 +502,6 @@ __global__ __launch_bounds__(kWinoNT, 2) void conv_wino_f32(const ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// conv_wino_bf16<TB,CB>: the same F(2x2,3x3) decomposition with bf16 operands, for the BATCH-1 CLICK PATH only (the engine
-// selects it where a 3x3 stride-1 layer would otherwise run conv_click + a split-K reduction launch).  At batch 1 a bf16 layer
-// is bound by launch count and by the weight stream, not by the matrix pipes: 16 position-GEMMs fill 256 CUs without
-// split-K (no slabs, no reduction launch), for 16/9 of the weight bytes.  At N = 32 this form loses (Winograd
-// study: LDS / L2 operand traffic) and is never selected.  Arithmetic: input transform in fp32 from the bf16 activations,
-// rounded to bf16 (RNE); U = G g G^T in float64 from the fp32 master weights, rounded to bf16 once (packer); 16x16x32 bf16
-// MFMAs, fp32 accumulation; output transform and epilogue in fp32; bf16 (or fp32) store.  Error against float64 (CPU
-// emulation, profiles/parity_r03.json): 1.2-1.35x the direct bf16 kernels', inside the stated bf16 bounds.
-// Chunk = 64 channels (128-byte rows as in fp32); loop = the single-V scheme of the fp32 <2,*> forms for both TB.
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_w;
-
-__device__ __forceinline__ unsigned pack_bf16x2_w(float lo, float hi) {
-    const __bf16 x = (__bf16)lo, y = (__bf16)hi;                 // v_cvt_pk_bf16_f32, RNE
-    return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
-}
-
-template <int TB, int CB>
-__global__ __launch_bounds__(kWinoNT, 2) void conv_wino_bf16(const ConvArgs a) {
-    constexpr int NT = kWinoNT, TXL = 4 * TB, PW = 8 * TB + 2, NTILE = 16 * TB, VB = wino_v_bytes(TB), PI = wino_p_items(TB);
-    constexpr int PB = wino_p_bytes(TB);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NV = TB == 1 ? 2 : 1;                        // TB = 1: two V buffers, ONE barrier per chunk; TB = 2: one (LDS), two barriers
-    char* const Vb = smem;
-    char* const Pb = smem + NV * VB;                           // two patch buffers
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int b = xcd_remap_w(blockIdx.x, gridDim.x);
-    const int d = a.dy[8];
-    const int bx = b % a.tiles_x; b /= a.tiles_x;
-    const int by = b % a.tiles_y; b /= a.tiles_y;
-    const int par = b % (d * d); b /= d * d;
-    const int n = b % a.N;
-    const int cg = b / a.N;
-    const int Y0 = par / d + d * 8 * by, X0 = par % d + d * 8 * TB * bx;
-    const int H = a.Hs, W = a.Ws;
-    const int nkc = a.nkc;                                     // 64-channel chunks
-    const int pix_bytes = nkc * kRowBytes;
-    const int si = a.si;                                       // 2: the layer reads x[::2, ::2] (model.py:149-151) -- a stride-1 conv on a strided view
-    const char* const img = (const char*)a.in + (size_t)n * (H * si) * (W * si) * pix_bytes;
-
-    int poff[PI];
-#pragma unroll
-    for (int j = 0; j < PI; ++j) {
-        const int k = tid + j * NT;
-        const int p = k >> 3, s = k & 7;
-        const int py = p / PW, px = p - py * PW;
-        const int Y = Y0 + d * (py - 1), X = X0 + d * (px - 1);
-        const bool inside = k < 10 * PW * 8 && (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W;
-        poff[j] = inside ? ((Y * si) * (W * si) + X * si) * pix_bytes + s * kSlotBytes : -1;
-    }
-    u32x4 xr[PI];
-    auto load_patch = [&](int c) {
-#pragma unroll
-        for (int j = 0; j < PI; ++j)
-            xr[j] = *(const u32x4*)((poff[j] >= 0 && c < nkc) ? img + poff[j] + c * kRowBytes : (const char*)a.zeros);
-    };
-    auto store_patch = [&](int pbuf) {
-#pragma unroll
-        for (int j = 0; j < PI; ++j) *(u32x4*)(Pb + pbuf * PB + (tid + j * NT) * kSlotBytes) = xr[j];
-    };
-
-    // input transform on a 16-byte slot = 8 bf16 channels: even / odd elements as two fp32 vectors (dword << 16, dword & 0xffff0000)
-    const int ts = tid & 7, ti = (tid >> 3) & 3;
-    const int rA = ti == 0 ? 0 : (ti == 2 ? 2 : 1), rB = ti == 3 ? 3 : (ti == 2 ? 1 : 2);
-    const float sgn = ti == 1 ? 1.f : -1.f;
-    auto ev = [](const u32x4& v) { return f32x4{__uint_as_float(v.x << 16), __uint_as_float(v.y << 16), __uint_as_float(v.z << 16), __uint_as_float(v.w << 16)}; };
-    auto od = [](const u32x4& v) { return f32x4{__uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y & 0xffff0000u), __uint_as_float(v.z & 0xffff0000u), __uint_as_float(v.w & 0xffff0000u)}; };
-    auto pk = [](const f32x4& e, const f32x4& o) { return u32x4{pack_bf16x2_w(e[0], o[0]), pack_bf16x2_w(e[1], o[1]), pack_bf16x2_w(e[2], o[2]), pack_bf16x2_w(e[3], o[3])}; };
-    auto transform = [&](int vbuf, int pbuf, bool on) {
-#pragma unroll
-        for (int q = 0; q < TB; ++q) {
-            const int tt = (tid >> 5) + q * 16;
-            const int pbase = pbuf * PB + ((2 * (tt / TXL)) * PW + 2 * (tt % TXL)) * kRowBytes + ts * kSlotBytes;
-            f32x4 te[4], to[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const u32x4 u = *(const u32x4*)(Pb + pbase + (rA * PW + c) * kRowBytes);
-                const u32x4 v = *(const u32x4*)(Pb + pbase + (rB * PW + c) * kRowBytes);
-                te[c] = ev(u) + sgn * ev(v);
-                to[c] = od(u) + sgn * od(v);
-            }
-            char* const dst = Vb + vbuf * VB + ((ti * 4) * NTILE + tt) * kRowBytes + ((ts ^ (tt & 7)) * kSlotBytes);
-            if (on) {
-                *(u32x4*)(dst) = pk(te[0] - te[2], to[0] - to[2]);
-                *(u32x4*)(dst + NTILE * kRowBytes) = pk(te[1] + te[2], to[1] + to[2]);
-                *(u32x4*)(dst + 2 * NTILE * kRowBytes) = pk(te[2] - te[1], to[2] - to[1]);
-                *(u32x4*)(dst + 3 * NTILE * kRowBytes) = pk(te[1] - te[3], to[1] - to[3]);
-            }
-        }
-    };
-
-    const int p0 = wave * 2;
-    const int ncb = a.ncg * 4;
-    const char* const ubase = (const char*)a.wgt + ((size_t)(cg * CB) * 2 * 64 + lane) * kSlotBytes;
-    const size_t u_pos_stride = (size_t)ncb * 2 * 64 * kSlotBytes;
-    u32x4 areg[2][2][CB][2];
-    auto load_A = [&](int c, auto bufc) {
-        constexpr int B = decltype(bufc)::value;
-        const int cn = c < nkc ? c : nkc - 1;                  // past the end: a harmless re-read
-        const char* const src0 = ubase + ((size_t)cn * 16 + p0) * u_pos_stride;
-#pragma unroll
-        for (int pp = 0; pp < 2; ++pp)
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-                    areg[B][pp][cb][ks] = *(const u32x4*)(src0 + (size_t)pp * u_pos_stride + (cb * 2 + ks) * 64 * kSlotBytes);
-    };
-    const int fn = lane & 15, fg = lane >> 4;
-    f32x4 tot[2][CB][TB];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < CB; ++j)
-#pragma unroll
-            for (int k = 0; k < TB; ++k) tot[i][j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    load_patch(0);
-    load_A(0, std::integral_constant<int, 0>{});
-    store_patch(0);
-    load_patch(1);
-    __syncthreads();
-    transform(0, 0, true);
-    store_patch(1);
-    load_patch(2);
-    auto chunk = [&](int c, auto curc) {
-        constexpr int CUR = decltype(curc)::value;
-        const int vcur = NV == 2 ? (c & 1) : 0;
-        __syncthreads();                                       // A: V(c) and the patch of chunk c+1 are complete
-        u32x4 bf[2][TB][2];
-#pragma unroll
-        for (int pp = 0; pp < 2; ++pp)
-#pragma unroll
-            for (int tb = 0; tb < TB; ++tb)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-                    bf[pp][tb][ks] = *(const u32x4*)(Vb + vcur * VB + ((p0 + pp) * NTILE + tb * 16 + fn) * kRowBytes + (((ks * 4 + fg) ^ (fn & 7)) * kSlotBytes));
-        if constexpr (NV == 1) __syncthreads();                // B: every wave holds its fragments, the one V buffer may be overwritten
-        load_A(c + 1, std::integral_constant<int, CUR ^ 1>{});
-        store_patch(c & 1);                                    // patch c+2
-        load_patch(c + 3);
-        transform(NV == 2 ? ((c + 1) & 1) : 0, (c + 1) & 1, c + 1 < nkc);      // patch c+1 -> V(c+1)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int pp = 0; pp < 2; ++pp)
-#pragma unroll
-                for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-                    for (int tb = 0; tb < TB; ++tb)
-                        tot[pp][cb][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_w, areg[CUR][pp][cb][ks]),
-                                                                                  __builtin_bit_cast(bf16x8_w, bf[pp][tb][ks]), tot[pp][cb][tb], 0, 0, 0);
-    };
-    int c = 0;
-    for (; c + 1 < nkc; c += 2) {
-        chunk(c, std::integral_constant<int, 0>{});
-        chunk(c + 1, std::integral_constant<int, 1>{});
-    }
-    if (c < nkc) chunk(c, std::integral_constant<int, 0>{});
-    __syncthreads();
-
-    // ---- output transform (fp32) + epilogue: as the fp32 kernel; the store is bf16 unless the tensor is kept fp32 ---------
-    char* const Mx = smem;
-#pragma unroll
-    for (int pp = 0; pp < 2; ++pp)
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-            for (int tb = 0; tb < TB; ++tb)
-                *(f32x4*)(Mx + ((p0 + pp) * NTILE + tb * 16 + fn) * kRowBytes + (((cb * 4 + fg) ^ (fn & 7)) * kSlotBytes)) = tot[pp][cb][tb];
-    __syncthreads();
-    const int CoutPad = a.ncg * kCoutGroup;
-    const bool has_bn = a.bn_scale != nullptr;
-    constexpr int NC = 16 * CB;
-#pragma unroll
-    for (int q = 0; q < (NTILE * NC) / NT; ++q) {
-        const int idx = tid + q * NT;
-        const int oc = idx % NC, ot = idx / NC;
-        float m[16];
-#pragma unroll
-        for (int p = 0; p < 16; ++p)
-            m[p] = *(const float*)(Mx + (p * NTILE + ot) * kRowBytes + (((oc >> 2) ^ (ot & 7)) * kSlotBytes) + (oc & 3) * 4);
-        float s0[4], s1[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s0[j] = m[0 * 4 + j] + m[1 * 4 + j] + m[2 * 4 + j];
-            s1[j] = m[1 * 4 + j] - m[2 * 4 + j] - m[3 * 4 + j];
-        }
-        const float y[2][2] = {{s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3]}, {s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]}};
-        const int co = cg * NC + oc;
-        const float bias = a.bias[co];
-        const float bsc = has_bn ? a.bn_scale[co] : 1.f, bsh = has_bn ? a.bn_shift[co] : 0.f;
-        const float ish = a.img_shift ? a.img_shift[(size_t)n * CoutPad + co] : 0.f;
-        const size_t obase = (size_t)n * H * W * CoutPad + co;
-        const int oy = Y0 + d * 2 * (ot / TXL), ox = X0 + d * 2 * (ot % TXL);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int yy = oy + d * i, xx = ox + d * j;
-                float v = y[i][j] + bias;
-                if (a.act == 1) v = fmaxf(v, 0.f);
-                else if (a.act == 2) v = v > 0.f ? v : 0.2f * v;
-                if (has_bn) v = fmaf(v, bsc, bsh);
-                v += ish;
-                if (yy < H && xx < W) {
-                    const size_t o = obase + ((size_t)yy * W + xx) * CoutPad;
-                    if (a.out_f32) ((float*)a.out)[o] = v;
-                    else ((__bf16*)a.out)[o] = (__bf16)v;
-                }
-            }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
 // conv_wino_deconv_f32<CB>: ConvTranspose2d 4x4 stride 2 pad 1 (model8up / 9up / 10up, model.py:75,87,97) on the fp32 path as
 // Winograd F(2x2,2x2).  Each of the four output phases (r,s) of the deconv is a 2x2-tap correlation over the input grid
 // (out[2m+r,2n+s] uses taps (ky,dy) in T(r) = {(3,-1),(1,0)} | {(2,0),(0,+1)}); for a tile of 2x2 sites:
@@ -918,172 +701,6 @@ __global__ __launch_bounds__(kWinoDNT, 3) void conv_wino_deconv_f32(const ConvAr
             }
     }
 }
-
-// bf16 twin of conv_wino_deconv_f32 for the batch-1 click path (the last two layers that needed a split-K reduction launch there):
-// 64-channel chunks, transform in fp32 from the bf16 patch and rounded to bf16, 16x16x32 bf16 MFMAs, fp32 accumulation and output
-// transform, bf16 shortcut sum read in the epilogue, bf16 store.  One 16-cout block per workgroup.
-__global__ __launch_bounds__(kWinoDNT, 3) void conv_wino_deconv_bf16(const ConvArgs a) {
-    constexpr int NT = kWinoDNT, PW = 10, NTILE = 16, PBY = kWinoDPBytes;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const Vb = smem;
-    char* const Pb = smem + kWinoDVBytes;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int b = xcd_remap_w(blockIdx.x, gridDim.x);
-    const int bx = b % a.tiles_x; b /= a.tiles_x;
-    const int by = b % a.tiles_y; b /= a.tiles_y;
-    const int n = b % a.N;
-    const int cg = b / a.N;
-    const int Y0 = 8 * by, X0 = 8 * bx;
-    const int H = a.Hs, W = a.Ws;
-    const int nkc = a.nkc;
-    const int pix_bytes = nkc * kRowBytes;
-    const char* const img = (const char*)a.in + (size_t)n * H * W * pix_bytes;
-    int poff[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int k = tid + j * NT;
-        const int p = k >> 3, s = k & 7;
-        const int py = p / PW, px = p - py * PW;
-        const int Y = Y0 - 1 + py, X = X0 - 1 + px;
-        const bool inside = k < PW * PW * 8 && (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W;
-        poff[j] = inside ? (Y * W + X) * pix_bytes + s * kSlotBytes : -1;
-    }
-    u32x4 xr[2];
-    auto load_patch = [&](int c) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            xr[j] = *(const u32x4*)((poff[j] >= 0 && c < nkc) ? img + poff[j] + c * kRowBytes : (const char*)a.zeros);
-    };
-    auto store_patch = [&](int pbuf) {
-        *(u32x4*)(Pb + pbuf * PBY + tid * kSlotBytes) = xr[0];
-        if (tid < PW * PW * 8 - NT) *(u32x4*)(Pb + pbuf * PBY + (tid + NT) * kSlotBytes) = xr[1];
-    };
-    auto ev = [](const u32x4& v) { return f32x4{__uint_as_float(v.x << 16), __uint_as_float(v.y << 16), __uint_as_float(v.z << 16), __uint_as_float(v.w << 16)}; };
-    auto od = [](const u32x4& v) { return f32x4{__uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y & 0xffff0000u), __uint_as_float(v.z & 0xffff0000u), __uint_as_float(v.w & 0xffff0000u)}; };
-    auto pk = [](const f32x4& e, const f32x4& o) { return u32x4{pack_bf16x2_w(e[0], o[0]), pack_bf16x2_w(e[1], o[1]), pack_bf16x2_w(e[2], o[2]), pack_bf16x2_w(e[3], o[3])}; };
-    const int ts = tid & 7, tq = tid >> 3;
-    const int tt = tq / 6, tri = tq - tt * 6, tr = tri / 3, ti = tri - tr * 3;
-    const int rowA = tr + (ti == 2 ? 2 : (ti == 1 ? 1 : 0)), rowB = tr + 1;
-    const float wB = ti == 1 ? 0.f : -1.f;
-    const int pbase = ((2 * (tt >> 2)) * PW + 2 * (tt & 3)) * kRowBytes + ts * kSlotBytes;
-    auto transform = [&](int pbuf, bool on) {
-        f32x4 te[4], to[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const u32x4 u = *(const u32x4*)(Pb + pbuf * PBY + pbase + (rowA * PW + c) * kRowBytes);
-            const u32x4 v = *(const u32x4*)(Pb + pbuf * PBY + pbase + (rowB * PW + c) * kRowBytes);
-            te[c] = ev(u) + wB * ev(v);
-            to[c] = od(u) + wB * od(v);
-        }
-        if (on) {
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                char* const dst = Vb + ((((tr * 2 + s2) * 3 + ti) * 3) * NTILE + tt) * kRowBytes + ((ts ^ (tt & 7)) * kSlotBytes);
-                *(u32x4*)(dst) = pk(te[s2] - te[s2 + 1], to[s2] - to[s2 + 1]);
-                *(u32x4*)(dst + NTILE * kRowBytes) = pk(te[s2 + 1], to[s2 + 1]);
-                *(u32x4*)(dst + 2 * NTILE * kRowBytes) = pk(te[s2 + 2] - te[s2 + 1], to[s2 + 2] - to[s2 + 1]);
-            }
-        }
-    };
-    const int p0 = wave * 3;
-    const int ncb = a.ncg * 4;
-    const char* const ubase = (const char*)a.wgt + ((size_t)cg * 2 * 64 + lane) * kSlotBytes;
-    const size_t u_pos_stride = (size_t)ncb * 2 * 64 * kSlotBytes;
-    u32x4 areg[2][3][2];
-    auto load_A = [&](int c, auto bufc) {
-        constexpr int B = decltype(bufc)::value;
-        const int cn = c < nkc ? c : nkc - 1;
-        const char* const src0 = ubase + ((size_t)cn * 36 + p0) * u_pos_stride;
-#pragma unroll
-        for (int pp = 0; pp < 3; ++pp)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                areg[B][pp][ks] = *(const u32x4*)(src0 + (size_t)pp * u_pos_stride + ks * 64 * kSlotBytes);
-    };
-    const int fn = lane & 15, fg = lane >> 4;
-    f32x4 tot[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) tot[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    load_patch(0);
-    load_A(0, std::integral_constant<int, 0>{});
-    store_patch(0);
-    load_patch(1);
-    __syncthreads();
-    transform(0, true);
-    store_patch(1);
-    load_patch(2);
-    auto chunk = [&](int c, auto curc) {
-        constexpr int CUR = decltype(curc)::value;
-        __syncthreads();
-        u32x4 bf[3][2];
-#pragma unroll
-        for (int pp = 0; pp < 3; ++pp)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                bf[pp][ks] = *(const u32x4*)(Vb + ((p0 + pp) * NTILE + fn) * kRowBytes + (((ks * 4 + fg) ^ (fn & 7)) * kSlotBytes));
-        __syncthreads();
-        load_A(c + 1, std::integral_constant<int, CUR ^ 1>{});
-        store_patch(c & 1);
-        load_patch(c + 3);
-        transform((c + 1) & 1, c + 1 < nkc);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int pp = 0; pp < 3; ++pp)
-                tot[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_w, areg[CUR][pp][ks]),
-                                                                  __builtin_bit_cast(bf16x8_w, bf[pp][ks]), tot[pp], 0, 0, 0);
-    };
-    int c = 0;
-    for (; c + 1 < nkc; c += 2) {
-        chunk(c, std::integral_constant<int, 0>{});
-        chunk(c + 1, std::integral_constant<int, 1>{});
-    }
-    if (c < nkc) chunk(c, std::integral_constant<int, 0>{});
-    __syncthreads();
-    char* const Mx = smem;
-#pragma unroll
-    for (int pp = 0; pp < 3; ++pp)
-        *(f32x4*)(Mx + ((p0 + pp) * NTILE + fn) * kRowBytes + ((fg ^ (fn & 7)) * kSlotBytes)) = tot[pp];
-    __syncthreads();
-    const int CoutPad = a.ncg * kCoutGroup;
-    const bool has_bn = a.bn_scale != nullptr;
-    constexpr int NC = 16, NITEM = NTILE * 4 * NC;
-    const int Ho = 2 * H, Wo = 2 * W;
-    for (int idx = tid; idx < NITEM; idx += NT) {
-        const int oc = idx % NC, rem = idx / NC, ph = rem & 3, ot = rem >> 2;
-        float m[9];
-#pragma unroll
-        for (int p = 0; p < 9; ++p)
-            m[p] = *(const float*)(Mx + ((ph * 9 + p) * NTILE + ot) * kRowBytes + (((oc >> 2) ^ (ot & 7)) * kSlotBytes) + (oc & 3) * 4);
-        float sa[2][3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { sa[0][j] = m[0 * 3 + j] + m[1 * 3 + j]; sa[1][j] = m[1 * 3 + j] + m[2 * 3 + j]; }
-        const int co = cg * NC + oc;
-        const float bias = a.bias[co];
-        const float bsc = has_bn ? a.bn_scale[co] : 1.f, bsh = has_bn ? a.bn_shift[co] : 0.f;
-        const int r = ph >> 1, s2 = ph & 1;
-        const int sy = Y0 + 2 * (ot >> 2), sx = X0 + 2 * (ot & 3);
-#pragma unroll
-        for (int ya = 0; ya < 2; ++ya)
-#pragma unroll
-            for (int xb = 0; xb < 2; ++xb) {
-                const int my = sy + ya, mx = sx + xb;
-                if (my < H && mx < W) {
-                    const size_t o = (((size_t)n * Ho + (2 * my + r)) * Wo + (2 * mx + s2)) * CoutPad + co;
-                    float v = sa[ya][xb] + sa[ya][xb + 1] + bias;
-                    if (a.resid != nullptr) v += a.resid_bf16 ? (float)((const __bf16*)a.resid)[o] : ((const float*)a.resid)[o];
-                    if (a.act == 1) v = fmaxf(v, 0.f);
-                    else if (a.act == 2) v = v > 0.f ? v : 0.2f * v;
-                    if (has_bn) v = fmaf(v, bsc, bsh);
-                    if (a.out_f32) ((float*)a.out)[o] = v;
-                    else ((__bf16*)a.out)[o] = (__bf16)v;
-                }
-            }
-    }
-}
-
 // ConvTranspose 4x4 s2 p1, fp32, Winograd F(2x2,2x2).  a.wgt = the layer's 36-position U image, a.Hs / a.Ws = INPUT size,
 // a.resid = optional fp32 shortcut sum at the output resolution.
 // The kernels of this file address a source image with 32-bit byte offsets (poff[] = ((Y*si)*(W*si) + X*si) * pix_bytes + ..., -1 =
@@ -1096,7 +713,7 @@ bool wino_offsets_fit(int Hs, int Ws, int si, int nkc) {
 // ONE predicate for "this launch can run as Winograd" -- the engine's variant choice (set_geometry), the single-operator entry points and
 // the two launchers below all ask it (the launch guards used to be wider than the eligibility tests).
 bool conv_wino_applies(int precision, const ConvArgs& a, bool deconv) {
-    if (a.zeros == nullptr || a.nkc < 1 || a.wgt == nullptr) return false;
+    if (precision != 0 || a.zeros == nullptr || a.nkc < 1 || a.wgt == nullptr) return false;       // the Winograd forms are the fp32 path's
     if (deconv)
         return a.nphase == 4 && a.so == 2 && a.si == 1 && a.img_shift == nullptr && wino_offsets_fit(a.Hs, a.Ws, 1, a.nkc) &&
                !(precision == 0 && (!a.out_f32 || (a.resid != nullptr && a.resid_bf16)));
@@ -1115,8 +732,8 @@ hipError_t launch_deconv_wino(int precision, const ConvArgs& a0, hipStream_t s) 
     (void)tb;
     const long long blocks = tb * (a.ncg * 4 / cb);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (precision == 1) hipLaunchKernelGGL(conv_wino_deconv_bf16, dim3((unsigned)blocks), dim3(kWinoDNT), kWinoDLds, s, a);
-    else hipLaunchKernelGGL((conv_wino_deconv_f32<1>), dim3((unsigned)blocks), dim3(kWinoDNT), kWinoDLds, s, a);
+    if (precision != 0) return hipErrorInvalidConfiguration;      // fp32 only (the bf16 twin was retired in round 5: conv_kwave_deconv_bf16)
+    hipLaunchKernelGGL((conv_wino_deconv_f32<1>), dim3((unsigned)blocks), dim3(kWinoDNT), kWinoDLds, s, a);
     return hipGetLastError();
 }
 
@@ -1124,16 +741,14 @@ int g_wino_form = getenv("IDC_WINO_FORM") ? atoi(getenv("IDC_WINO_FORM")) : 0;  
 
 void set_wino_form(int form) { g_wino_form = form; }
 
-constexpr int wino_lds_bf16(int tb) { return (tb == 1 ? 2 : 1) * wino_v_bytes(tb) + 2 * wino_p_bytes(tb); }
-
 template <int TB, int CB>
 static hipError_t launch_wino_t(ConvArgs& a, int d, int precision, hipStream_t s) {
     a.tiles_x = ((a.Ws + d - 1) / d + 8 * TB - 1) / (8 * TB);
     a.tiles_y = ((a.Hs + d - 1) / d + 7) / 8;
     const long long blocks = (long long)a.tiles_x * a.tiles_y * d * d * a.N * (a.ncg * 4 / CB);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (precision == 1) hipLaunchKernelGGL((conv_wino_bf16<TB, CB>), dim3((unsigned)blocks), dim3(kWinoNT), wino_lds_bf16(TB), s, a);
-    else hipLaunchKernelGGL((conv_wino_f32<TB, CB>), dim3((unsigned)blocks), dim3(kWinoNT), wino_lds(TB), s, a);
+    if (precision != 0) return hipErrorInvalidConfiguration;      // fp32 only (the bf16 twin was retired in round 5: conv_kwave_bf16)
+    hipLaunchKernelGGL((conv_wino_f32<TB, CB>), dim3((unsigned)blocks), dim3(kWinoNT), wino_lds(TB), s, a);
     return hipGetLastError();
 }
 
@@ -1162,15 +777,7 @@ hipError_t init_kernels_wino() {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)conv_wino_f32<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_lds(2));
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)conv_wino_deconv_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, kWinoDLds);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)conv_wino_deconv_f32<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kWinoDLds);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)conv_wino_bf16<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_lds_bf16(1));
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)conv_wino_bf16<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_lds_bf16(2));
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)conv_wino_bf16<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_lds_bf16(2));
+    return hipFuncSetAttribute((const void*)conv_wino_deconv_f32<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kWinoDLds);
 }
 
 }  // namespace idc

@@ -78,15 +78,15 @@ SPLITK_POLICIES = {"auto": 0, "never": 1, "always": 2}
 
 
 def set_option(name, value):
-    """Process-wide switches (``idc_set_option``; speed / kernel choice only): 'fuse_conv1' 0/1, 'fuse_conv1_small' 0/1
-    (model1 as one 32x8-tile launch on the bf16 click path), 'click' -1/0/1, 'winograd_deconv' 0/1/2,
-    'winograd' 0/1 (3x3 stride-1 layers as Winograd F(2x2,3x3): fp32 at every batch size, bf16 on the batch-1 click path;
-    default on; 0 switches both off), 'winograd_bf16' 0/1 (the bf16 half alone), 'winograd_form' 0/12/21/22, 'mfma16' 0/1 (the bf16
-    throughput tile from the 16x16x32 MFMA -- conv_igemm_v2m, default -- or from the 32x32x16 one), 'v2p' 0/1 (its 3x3 form without
-    address arithmetic in the K loop, conv_igemm_v2p, default on), 'ds_mfma16' 0/1 (deconv + shortcut launches as conv_ds_fused_m),
-    'conv1_lw' 0/2/3 (model1: 32x32 tile / 32x8 / 32x12 tiles with an LDS weight ring; default 3), 'code_warm' 0/1 (own-code
-    warm-up at kernel entry), 'kwave' 0/1 (bf16 batch-1 click path: the 3x3 stride-1 layers as conv_kwave_bf16 -- K split over the waves
-    of a workgroup, default on -- instead of the Winograd form conv_wino_bf16), 'kwave_deconv' 0/1 (likewise its deconvs as conv_kwave_deconv_bf16)."""
+    """Process-wide switches (``idc_set_option``; speed / kernel choice only -- every setting computes the same function).  Eight names:
+    'fuse_conv1' 0/1 (model1 = conv1_1 + conv1_2 as one launch; 0 keeps conv1_1's output readable), 'click' -1/0/1 (small launches on
+    conv_click), 'winograd' 0 / 1 / 2 / 12 / 21 / 22 (fp32 path: off / automatic / every deconv too / automatic with the 3x3 form <TB,CB>
+    forced), 'mfma16' 0/1 (bf16 throughput tile from the 16x16x32 MFMA -- conv_igemm_v2m -- or the 32x32x16 one), 'v2p' 0/1 (its 3x3 form
+    without address arithmetic in the K loop), 'ds_mfma16' 0/1 (deconv + shortcut launches as conv_ds_fused_m / conv_ds_fused), 'kwave' 0/1
+    (bf16 batch-1 click path: conv_kwave_bf16 / conv_kwave_deconv_bf16, or round 2's conv_click + split-K), 'kwave_chain' 0/1/2 (its 512 -> 512
+    trunk as one persistent launch: off / hipLaunchCooperativeKernel / plain launch after an occupancy check, the default).
+    Retired in round 5 with their kernels or folded into the above: fuse_conv1_small, winograd_bf16, winograd_form, winograd_deconv,
+    conv1_lw, code_warm, kwave_deconv."""
     N.check(N.load().idc_set_option(name.encode(), int(value)))
 
 
@@ -251,6 +251,7 @@ class HipColorizer(object):
         self._blob_keepalive = None
         self._pool = _result_pool(self.lib)
         self.forward_serial = 0             # bumped by every call that replaces the handle's resident results (api.py's lazy output attributes)
+        self.before_overwrite = None        # callable run ONCE right before the next such call: whoever still wants the resident results fetches them
 
     # ---- lifetime -------------------------------------------------------------------------
     def close(self):
@@ -310,6 +311,12 @@ class HipColorizer(object):
         self._chk(self.lib.idc_clear_global_hints(self._h))
 
     # ---- forward --------------------------------------------------------------------------
+    def _results_will_be_replaced(self):
+        cb, self.before_overwrite = self.before_overwrite, None
+        if cb is not None:
+            cb()
+        self.forward_serial += 1
+
     def _prep(self, L_mc, ab, mask):
         L_mc = np.asarray(L_mc)
         if L_mc.ndim == 3:                      # reference call shape: (1,X,X),(2,X,X),(1,X,X)
@@ -336,7 +343,7 @@ class HipColorizer(object):
         """(N,1,H,W),(N,2,H,W),(N,1,H,W) -> (N,2,H,W) float32 ab.  3-D inputs = one image."""
         n, L, A, M = self._prep(L_mc, ab, mask)
         out = self._pool.take((n, 2, self.H, self.W), np.float32)
-        self.forward_serial += 1
+        self._results_will_be_replaced()
         self._chk(self.lib.idc_forward(self._h, n, _fptr(L), _fptr(A), _fptr(M), float(maskcent), _fptr(out)))
         return out
 
@@ -346,7 +353,7 @@ class HipColorizer(object):
         n, L, A, M = self._prep(L_mc, ab, mask)
         out = np.empty((n, 2, self.H, self.W), np.float32)
         dq = np.empty((n, 529, self.H // 4, self.W // 4), np.float32) if want_dist else None
-        self.forward_serial += 1
+        self._results_will_be_replaced()
         self._chk(self.lib.idc_forward_dist(self._h, n, _fptr(L), _fptr(A), _fptr(M), float(maskcent),
                                             _fptr(out), _fptr(dq) if want_dist else None))
         return out, dq
@@ -381,7 +388,7 @@ class HipColorizer(object):
         out = np.empty((n, 2, self.H, self.W), np.float32) if want_ab else None
         rgb = np.empty((n, self.H, self.W, 3), np.uint8) if want_rgb else None
         labq = np.empty((n, 3, self.H, self.W), np.float64) if (want_rgb and want_lab) else None
-        self.forward_serial += 1
+        self._results_will_be_replaced()
         self._chk(self.lib.idc_forward_resident(self._h, int(n), float(maskcent), float(l_cent), _fptr(out) if want_ab else None,
                                                 rgb.ctypes.data_as(ctypes.c_void_p) if want_rgb else None,
                                                 labq.ctypes.data_as(ctypes.c_void_p) if labq is not None else None))
@@ -445,7 +452,7 @@ class HipColorizer(object):
         Lc, Ac = _f32c(L, (n, 1, self.H, self.W)), _f32c(ab, (n, 2, self.H, self.W))
         rgb = np.empty((n, self.H, self.W, 3), np.uint8)
         labq = np.empty((n, 3, self.H, self.W), np.float64) if want_lab else None
-        self.forward_serial += 1
+        self._results_will_be_replaced()
         self._chk(self.lib.idc_lab2rgb(self._h, n, _fptr(Lc), _fptr(Ac), rgb.ctypes.data_as(ctypes.c_void_p),
                                        labq.ctypes.data_as(ctypes.c_void_p) if want_lab else None))
         return rgb, labq
@@ -456,7 +463,7 @@ class HipColorizer(object):
         out = self._pool.take((n, 2, self.H, self.W), np.float32)       # pinned: the library copies device -> result in place
         rgb = self._pool.take((n, self.H, self.W, 3), np.uint8)
         labq = self._pool.take((n, 3, self.H, self.W), np.float64) if want_lab else None
-        self.forward_serial += 1
+        self._results_will_be_replaced()
         self._chk(self.lib.idc_forward_rgb(self._h, n, _fptr(L), _fptr(A), _fptr(M), float(maskcent), float(l_cent), _fptr(out),
                                            rgb.ctypes.data_as(ctypes.c_void_p),
                                            labq.ctypes.data_as(ctypes.c_void_p) if want_lab else None))
@@ -467,7 +474,7 @@ class HipColorizer(object):
         stay resident; ``fetch_outputs`` brings them over when somebody reads them (2.0 of the 2.2 MB a 256x256 click sends back)."""
         n, L, A, M = self._prep(L_mc, ab, mask)
         rgb = self._pool.take((n, self.H, self.W, 3), np.uint8)
-        self.forward_serial += 1
+        self._results_will_be_replaced()
         self._chk(self.lib.idc_forward_rgb_lazy(self._h, n, _fptr(L), _fptr(A), _fptr(M), float(maskcent), float(l_cent),
                                                 rgb.ctypes.data_as(ctypes.c_void_p)))
         return rgb
@@ -487,7 +494,7 @@ class HipColorizer(object):
         out = np.empty((n, 2, self.H, self.W), np.float32)
         pred = np.empty((n, 2, self.H, self.W), np.float32)
         dist = np.empty((n, 313, self.H, self.W), np.float32) if want_dist else None
-        self.forward_serial += 1
+        self._results_will_be_replaced()
         self._chk(self.lib.idc_forward_dist313(self._h, n, _fptr(L), _fptr(A), _fptr(M), float(maskcent), _fptr(out),
                                                _fptr(pred), _fptr(dist) if want_dist else None))
         return out, pred, dist
@@ -504,7 +511,7 @@ class HipColorizer(object):
             if isinstance(x, np.ndarray):               # pinned host memory (pinned_empty): zero-copy, see idc_pipeline_times' note
                 return ctypes.c_void_p(int(x.ctypes.data))
             return ctypes.c_void_p(int(x))
-        self.forward_serial += 1
+        self._results_will_be_replaced()
         self._chk(self.lib.idc_forward_device(self._h, int(n), p(d_L), p(d_ab), p(d_mask), float(maskcent),
                                               p(d_out), 1 if sync else 0))
 
@@ -538,7 +545,7 @@ class HipColorizer(object):
         for a, shp in ((L_mc, (n, 1, self.H, self.W)), (ab, (n, 2, self.H, self.W)), (mask, (n, 1, self.H, self.W)), (out, (n, 2, self.H, self.W))):
             if a.dtype != np.float32 or not a.flags.c_contiguous or tuple(a.shape) != shp:
                 raise ValueError("forward_async needs float32 C-contiguous arrays of shape %s" % (shp,))
-        self.forward_serial += 1
+        self._results_will_be_replaced()
         self._chk(self.lib.idc_forward_async(self._h, int(slot), int(n), _fptr(L_mc), _fptr(ab), _fptr(mask), float(maskcent), _fptr(out)))
 
     def wait(self, slot):

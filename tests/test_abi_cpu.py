@@ -95,12 +95,12 @@ def _plan(precision, dist):
         off = _al(off); e["w_off"] = off; off += ntap * nkc * e["ncg"] * 8192
         if precision == "bf16" and kind != "im2col" and cpad >= 128:   # second image: layout 2 (conv_igemm_v2)
             off = _al(off); e["w2_off"] = off; off += ntap * nkc * e["ncg"] * 8192
-        if kind == "c3":
-            # third image: Winograd F(2x2,3x3) weights U = G g G^T of the 3x3 stride-1 layers (idc_wino.hip; fp32: every
-            # batch size, bf16: the batch-1 click path)
-            off = _al(off); e["w3_off"] = off; off += cin * cpad * 16 * (2 if precision == "bf16" else 4)
-        if kind == "dc":                             # deconvs: Winograd F(2x2,2x2) over the four phases, 36 values per (cin, cout)
-            off = _al(off); e["w3d_off"] = off; off += cin * cpad * 36 * (2 if precision == "bf16" else 4)
+        if kind == "c3" and precision == "fp32":
+            # third image, fp32 blob only (round 5: the bf16 click path's Winograd kernels were retired, a bf16 blob is 136 MB):
+            # Winograd F(2x2,3x3) weights U = G g G^T of the 3x3 stride-1 layers (idc_wino.hip)
+            off = _al(off); e["w3_off"] = off; off += cin * cpad * 16 * 4
+        if kind == "dc" and precision == "fp32":     # deconvs: Winograd F(2x2,2x2) over the four phases, 36 values per (cin, cout)
+            off = _al(off); e["w3d_off"] = off; off += cin * cpad * 36 * 4
         off = _al(off); e["b_off"] = off; off += cpad * 4
         if bnkey:
             off = _al(off); e["s_off"] = off; off += cpad * 4

@@ -25,12 +25,8 @@ WINO_LAYERS = ["conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3",
 @pytest.fixture(autouse=True)
 def _reset_options():
     yield
-    engine.set_option("winograd", 1)
-    engine.set_option("winograd_bf16", 1)
+    engine.set_option("winograd", 1)           # (round 5: one option -- 0 off, 1 automatic, 2 every deconv too, 12 / 21 / 22 a forced 3x3 form)
     engine.set_option("kwave", 1)
-    engine.set_option("kwave_deconv", 1)
-    engine.set_option("winograd_deconv", 1)
-    engine.set_option("winograd_form", 0)
     engine.set_option("mfma16", 1)
     engine.set_tile_policy("auto")
     engine.set_splitk_policy("auto")
@@ -48,7 +44,7 @@ def test_winograd_fp32_layer_by_layer(golden, make_sd, name, form):
     n, _, H, W = g["L_mc"].shape
     _, _, acts = siggraph_torch.forward(make_sd(seed, style), g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]),
                                         return_acts=True, dtype=torch.float64)
-    engine.set_option("winograd_form", form)
+    engine.set_option("winograd", form if form else 1)
     e = engine.HipColorizer(H, W, max_batch=n, precision="fp32")
     e.load_state_dict(make_sd(seed, style))
     out = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
@@ -70,62 +66,8 @@ def test_winograd_fp32_layer_by_layer(golden, make_sd, name, form):
     e.close()
 
 
-@pytest.mark.parametrize("form", [0, 12, 22])
-@pytest.mark.parametrize("name", ["net64_he_s0_mc05", "net32x48_he_s2", "net64_torch_s1_mc0"])
-def test_winograd_bf16_click_path_layer_by_layer(golden, make_sd, name, form):
-    """bf16, small launches (the batch-1 click path's kernel choice): every 3x3 stride-1 layer runs as conv_wino_bf16 instead of
-    conv_click + a split-K reduction launch.  Each layer against the float64 oracle at the bf16 per-layer tolerance (4 % of the
-    layer's range), the ab map inside the stated bf16 bounds, no split-K left on those layers; `winograd_bf16` = 0 restores
-    conv_click and lands within the same bounds."""
-    g = golden(name)
-    style, seed = str(g["weight_style"]), int(g["weight_seed"])
-    n, _, H, W = g["L_mc"].shape
-    _, _, acts = siggraph_torch.forward(make_sd(seed, style), g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]),
-                                        return_acts=True, dtype=torch.float64)
-    engine.set_option("winograd_form", form)
-    engine.set_option("kwave", 0)                               # (round 4: conv_kwave_bf16 is the default on these layers; this is the Winograd form's test)
-    e = engine.HipColorizer(H, W, max_batch=n, precision="bf16")
-    e.load_state_dict(make_sd(seed, style))
-    out = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
-    table = {r["name"]: r["kernel"] for r in e.layer_table()}
-    wino = [k for k in WINO_LAYERS if table[k] == "conv_wino_bf16"]
-    assert len(wino) >= 19, table                               # (conv1_2 / conv1_2_short / conv10_2 may ride in fused launches)
-    assert not any("splitK" in table[k] for k in wino)
-    for k in wino:
-        ref = acts[k]
-        err = np.abs(e.activation(k, n) - ref).max()
-        assert err <= 0.04 * (1 + np.abs(ref).max()), "layer %s (form %d): max-abs err %.3e" % (k, form, err)
-    d = np.abs(out - g["out_ab"])
-    check_bf16_ab(d, style)
-    np.testing.assert_array_equal(e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"])), out)       # deterministic
-    engine.set_option("winograd_bf16", 0)
-    base = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
-    assert not any(r["kernel"] == "conv_wino_bf16" for r in e.layer_table())
-    db = np.abs(base - g["out_ab"])
-    check_bf16_ab(db, style)
-    e.close()
-
-
-def test_winograd_bf16_click_config(golden, make_sd):
-    """BASELINE configs[1] in bf16: <= 28 launches per click forward, none of them a reduction (51 with conv_click + split-K), the reference golden inside
-    the torch-init bf16 bound; the N = 32 throughput path never selects the bf16 Winograd form."""
-    g = golden("config2_mortar_5hints_torchinit")
-    engine.set_option("kwave", 0)                               # (the round-4 default is tested in tests/test_round4_gpu.py::test_kwave_click_config)
-    e = engine.HipColorizer(256, 256, max_batch=1, precision="bf16")
-    e.load_state_dict(make_sd(int(g["weight_seed"]), str(g["weight_style"])))
-    out = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
-    rows = [r for r in e.layer_table() if r["launches"] > 0]
-    launches = sum(r["launches"] + (1 if "splitK" in r["kernel"] else 0) for r in rows)
-    assert sum(r["kernel"] == "conv_wino_bf16" for r in rows) >= 20 and launches <= 28 and not any("splitK" in r["kernel"] for r in rows), (launches, [r["kernel"] for r in rows])
-    d = np.abs(out - g["out_ab"])
-    check_bf16_ab(d, "torch")
-    e.close()
-    e = engine.HipColorizer(256, 256, max_batch=32, precision="bf16")
-    e.load_state_dict(make_sd(0, "he"))
-    L, ab, m = workloads.random_batch(1, 256, seed=3)
-    e.forward(L, ab, m, 0.0)
-    assert not any(r["kernel"].startswith("conv_wino") for r in e.layer_table())
-    e.close()
+# (round 5: conv_wino_bf16 / conv_wino_deconv_bf16 -- the bf16 Winograd kernels of the round-3 click path -- were retired to
+#  docs/experiments/conv_wino_bf16_round3.hip.txt together with their tests; conv_kwave_* are tested in test_round4_gpu.py / test_round5_gpu.py)
 
 
 @pytest.mark.parametrize("name", ["net64_he_s0_mc05", "net32x48_he_s2"])
@@ -137,7 +79,7 @@ def test_winograd_deconv_fp32_layer_by_layer(golden, make_sd, name):
     n, _, H, W = g["L_mc"].shape
     _, _, acts = siggraph_torch.forward(make_sd(seed, style), g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]),
                                         return_acts=True, dtype=torch.float64)
-    engine.set_option("winograd_deconv", 2)
+    engine.set_option("winograd", 2)
     e = engine.HipColorizer(H, W, max_batch=n, precision="fp32")
     e.load_state_dict(make_sd(seed, style))
     out = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
@@ -148,36 +90,10 @@ def test_winograd_deconv_fp32_layer_by_layer(golden, make_sd, name):
         err = np.abs(e.activation(k, n) - ref).max()
         assert err <= 2e-4 * (1 + np.abs(ref).max()), "layer %s: max-abs err %.3e" % (k, err)
     assert np.abs(out - g["out_ab"]).max() <= 3e-3
-    engine.set_option("winograd_deconv", 0)
+    engine.set_option("winograd", 0)
     base = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
-    assert not any(r["kernel"] == "conv_wino_deconv_f32" for r in e.layer_table())
+    assert not any(r["kernel"].startswith("conv_wino") for r in e.layer_table())
     assert np.abs(out - base).max() <= 3e-3
-    e.close()
-
-
-@pytest.mark.parametrize("name", ["net64_he_s0_mc05", "net32x48_he_s2", "net64_torch_s1_mc0"])
-def test_winograd_deconv_bf16_layer_by_layer(golden, make_sd, name):
-    """The bf16 twin (conv_wino_deconv_bf16, forced on every deconv; by default model8up / model9up on the click path): deconv + bf16
-    shortcut sum + ReLU against the float64 oracle at the bf16 per-layer tolerance, the ab map inside the bf16 bounds."""
-    g = golden(name)
-    style, seed = str(g["weight_style"]), int(g["weight_seed"])
-    n, _, H, W = g["L_mc"].shape
-    _, _, acts = siggraph_torch.forward(make_sd(seed, style), g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]),
-                                        return_acts=True, dtype=torch.float64)
-    engine.set_option("winograd_deconv", 2)
-    engine.set_option("kwave_deconv", 0)                        # (round 4: conv_kwave_deconv_bf16 is the default on these launches)
-    e = engine.HipColorizer(H, W, max_batch=n, precision="bf16")
-    e.load_state_dict(make_sd(seed, style))
-    out = e.forward(g["L_mc"], g["ab"], g["mask"], float(g["maskcent"]))
-    table = {r["name"]: r["kernel"] for r in e.layer_table()}
-    for k in ("conv8_1", "conv9_1", "conv10_1"):
-        assert table[k] == "conv_wino_deconv_bf16", table
-        ref = acts[k]
-        err = np.abs(e.activation(k, n) - ref).max()
-        assert err <= 0.04 * (1 + np.abs(ref).max()), "layer %s: max-abs err %.3e" % (k, err)
-    assert not any("splitK" in v for v in table.values()), table
-    d = np.abs(out - g["out_ab"])
-    check_bf16_ab(d, style)
     e.close()
 
 
@@ -198,7 +114,7 @@ def test_winograd_fp32_click_config(golden, make_sd):
     for i in range(3):
         np.testing.assert_array_equal(e.forward(L[i:i + 1], ab[i:i + 1], m[i:i + 1], 0.0)[0], whole[i])
     for form in (12, 21, 22):                 # the forms differ in tiling only: same sums in the same order, bit for bit
-        engine.set_option("winograd_form", form)
+        engine.set_option("winograd", form)
         np.testing.assert_array_equal(e.forward(L, ab, m, 0.0), whole)
     e.close()
 
@@ -304,7 +220,7 @@ def test_winograd_odd_trunk_geometry(make_sd, precision):
     L, ab, m = L[:, :, :40, :], ab[:, :, :40, :], m[:, :, :40, :]
     L, ab, m = (np.ascontiguousarray(x) for x in (L, ab, m))
     ref = siggraph_torch.forward(sd, L, ab, m, 0.5)
-    engine.set_option("winograd_deconv", 2)
+    engine.set_option("winograd", 2)
     e = engine.HipColorizer(40, 72, max_batch=3, precision=precision)
     e.load_state_dict(sd)
     out = e.forward(L, ab, m, 0.5)
