@@ -51,9 +51,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--setup-forwards", type=int, default=40,
-                    help="untimed forwards run as part of engine setup, BEFORE the W warm-up steps of the contract (first use of every kernel's "
-                         "code and of the activation arena, clock settling after the idle period of weight packing); reported in the line")
+    ap.add_argument("--setup-forwards", type=int, default=0,
+                    help="untimed forwards run BEFORE the W warm-up steps of the contract.  Default 0 since round 5: the state the timed region "
+                         "starts from is the one the contract's own warm-up leaves (same-box A/B 0 vs 40: 8612 / 8619 vs 8798 / 8477 img/s -- inside "
+                         "the run-to-run spread, profiles/r05_setup_forwards.txt); reported in the line")
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="images per GPU per step")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-pointer (PCIe-inclusive) pipeline leg")
     ap.add_argument("--no-peak-probe", action="store_true", help="skip the 3 s MFMA-peak probe (tools/ubench/mfma_peak)")
