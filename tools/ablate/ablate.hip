@@ -13,6 +13,7 @@
 #include "../../interactive_deep_colorization_amd/csrc/idc_wino.hip"
 #include "../../interactive_deep_colorization_amd/csrc/idc_v2m.hip"
 #include "../../interactive_deep_colorization_amd/csrc/idc_dsm.hip"
+#include "../../interactive_deep_colorization_amd/csrc/idc_kw.hip"
 
 __global__ void fill_bf16(unsigned short* p, size_t n, unsigned seed) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
