@@ -73,6 +73,9 @@ def parse_args():
                     help="weights `value` is quoted on: 'torch' = torch-default init + randomised BN buffers, the weights SURVEY.md "
                          "8(d) config 3 names; 'he' = full-range he-style weights (harder data for a power-capped chip).  The "
                          "other style is timed too and reported beside it (N=1).")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="idc_set_option(NAME, VALUE) before the engine is created (A/B runs: --option winograd=0, --option kwave_chain=0 ...); "
+                         "recorded in the line under config.options")
     ap.add_argument("--dryrun-single-gpu", action="store_true",
                     help="N>1 control flow on ONE GPU: every rank uses device 0, the process group is gloo (host "
                          "broadcast of the packed blob -> idc_set_weights_host); for exercising barriers, the MAX-reduce "
@@ -299,6 +302,9 @@ def main():
     import torch.distributed as dist
     from interactive_deep_colorization_amd import engine, sharded, workloads
 
+    for kv in args.option:
+        name, _, val = kv.partition("=")
+        engine.set_option(name.strip(), int(val))
     rank, local_rank, world = sharded.init_process_group(
         backend="gloo" if (args.dryrun_single_gpu or args.control_flow_only) else None)
     if args.dryrun_single_gpu:
@@ -414,7 +420,7 @@ def main():
                                "(dist=False), seeded random-init weights (%s)" % (
                                    nb, args.precision, "torch-default init + randomised BN buffers: SURVEY.md 8(d) config 3" if args.weights == "torch"
                                    else "he-style full-range"),
-                   "weights": args.weights,
+                   "weights": args.weights, "options": args.option,
                    "global_batch": world * nb, "per_gpu_batch": nb, "height": H, "width": W,
                    "parallelism": "independent images sharded over %d GPU(s); one RCCL weight broadcast (transport: %s%s)" % (
                        world, sc.transport_used or args.transport, ", c_abi fell back: " + sc.transport_fallback_reason if sc.transport_fallback_reason else ""),

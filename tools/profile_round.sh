@@ -32,9 +32,10 @@ for p in bf16 fp32; do
   [ -n "$f" ] && python $R/tools/click_trace.py --gaps $f > $OUT/click_${p}_trace.txt && python $R/tools/rocpd_summary.py $f --family conv > $OUT/click_${p}_stats.txt
 done
 cd $R
-# N>1 control flow on one GPU: 2 ranks over gloo, both on device 0 (NOT a scaling measurement)
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29571 \
-    bench.py --gpus 2 --steps 10 --warmup 2 --dryrun-single-gpu > $OUT/dryrun_2ranks.json 2> $OUT/dryrun_2ranks.err
+# N>1 control flow on one GPU: 2 ranks over gloo, both on device 0 (NOT a scaling measurement); round 5: WITHOUT a launcher -- bench.py
+# starts its own ranks, exactly what `python3 bench.py --gpus N` does on the driver's 8-GPU node
+timeout 600 python bench.py --gpus 2 --steps 10 --warmup 2 --dryrun-single-gpu > $OUT/dryrun_2ranks.json 2> $OUT/dryrun_2ranks.err
+timeout 600 python bench.py --gpus 2 --steps 10 --warmup 2 --dryrun-single-gpu --transport c_abi > $OUT/dryrun_2ranks_c_abi.json 2> $OUT/dryrun_2ranks_c_abi.err
 tail -1 $OUT/dryrun_2ranks.json | cut -c1-400
 python tools/extra_configs.py > $OUT/extra_configs.txt 2>&1
 python tools/gpu_diag.py 2>/dev/null | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" > $OUT/layer_table.txt
@@ -42,7 +43,7 @@ python tools/gpu_diag.py 2>/dev/null | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostnam
 python tools/power_probe.py 30 2>/dev/null | grep "^{" > $OUT/power_probe.txt
 # fp32 path (round 3: Winograd F(2x2,3x3) for the 3x3 stride-1 layers): bench line, kernel stats and SQ counters of the same command
 python bench.py --precision fp32 --no-cpu-baseline --no-end-to-end --no-peak-probe --no-latency > $OUT/bench_fp32.json 2>/dev/null
-IDC_WINO=0 python bench.py --precision fp32 --no-cpu-baseline --no-end-to-end --no-peak-probe --no-latency > $OUT/bench_fp32_direct.json 2>/dev/null
+python bench.py --precision fp32 --option winograd=0 --no-cpu-baseline --no-end-to-end --no-peak-probe --no-latency > $OUT/bench_fp32_direct.json 2>/dev/null
 cd /tmp
 CMD32="python $R/bench.py --precision fp32 --steps 3 --warmup 1 --no-latency --no-cpu-baseline --no-end-to-end --no-peak-probe"
 rocprofv3 --kernel-trace --stats -d $OUT/stats_fp32 -o x -- $CMD32 > $OUT/stats_fp32.log 2>&1
