@@ -128,9 +128,15 @@ def test_model1_block_with_lds_weight_ring(make_sd, shape):
     table = {r["name"]: r["kernel"] for r in e.layer_table()}
     assert table["conv1_1"] == "conv1_block_fused", table
     c12 = e.activation("conv1_2", n)
-    _, _, acts = siggraph_torch.forward(sd, L, ab, m, 0.0, return_acts=True, dtype=torch.float64)
-    err = np.abs(c12 - acts["conv1_2"]).max()
-    assert err <= 0.04 * (1 + np.abs(acts["conv1_2"]).max()), err
+    # model1 alone in float64 (model.py:13-17,139-148: pack, conv1_1 + ReLU, conv1_2 + ReLU, eval-BN) -- the whole-network oracle costs seconds here
+    t = lambda k: torch.from_numpy(np.asarray(sd[k])).double()
+    x = torch.cat((torch.from_numpy(L).double() / 100.0, torch.from_numpy(ab).double() / 110.0, torch.from_numpy(m).double()), dim=1)
+    x = F.relu(F.conv2d(x, t("model1.0.weight"), t("model1.0.bias"), padding=1))
+    x = F.relu(F.conv2d(x, t("model1.2.weight"), t("model1.2.bias"), padding=1))
+    x = F.batch_norm(x, t("model1.4.running_mean"), t("model1.4.running_var"), t("model1.4.weight"), t("model1.4.bias"), False, 0.0, 1e-5)
+    ref12 = x.numpy()
+    err = np.abs(c12 - ref12).max()
+    assert err <= 0.04 * (1 + np.abs(ref12).max()), err
     np.testing.assert_array_equal(e.forward(L, ab, m, 0.0), out)
     e.close()
     e1 = engine.HipColorizer(H, W, max_batch=1, precision="bf16")          # the click path's tile choice (32x8)
