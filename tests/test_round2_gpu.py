@@ -226,7 +226,7 @@ def test_upsample_lab2rgb_display_and_fullres(make_sd):
         d = np.abs(a.astype(np.int32) - b.astype(np.int32))
         assert d.max() <= 1 and (d > 0).mean() <= frac, (d.max(), (d > 0).mean())
 
-    for (wh, ww) in ((512, 512), (345, 410), (256, 256), (180, 200)):
+    for (wh, ww) in ((345, 410), (256, 256), (180, 200)):          # (512 x 512 dropped in round 5: 5 s of numpy cubic checker for a third up-scale case)
         l_win = rs.uniform(0, 100, (wh, ww))
         close(model.get_result_window(l_win), display.display_rgb(out_ab, l_win))
     for (fh, fw) in ((507, 600), (256, 256), (300, 280)):
