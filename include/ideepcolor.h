@@ -77,7 +77,8 @@ int idc_set_tile_policy(int policy);
  *   "mfma16"      (1)  bf16 throughput tile as conv_igemm_v2m (v_mfma_f32_16x16x32_bf16: fewer joules per FLOP at the power cap);
  *                      0 = conv_igemm_v2 (v_mfma_f32_32x32x16_bf16).
  *   "v2p"         (1)  the 3x3 convs among them as conv_igemm_v2p (column-swizzled halo tile, unrolled taps; bit-identical results).
- *   "ds_mfma16"   (1)  deconv + shortcut launches as conv_ds_fused_m (16x16x32 MFMA); 0 = conv_ds_fused.
+ *   "ds_mfma16"   (1)  deconv + shortcut launches as conv_ds_fused_m (16x16x32 MFMA), grids with fewer 128-cout workgroups than CUs (model10up of ONE
+ *                      256x256 image) in its 64-cout 4-wave form; 2 = 8-wave workgroups on every grid (A/B, tests); 0 = conv_ds_fused.
  *   "kwave"       (1)  bf16 batch-1 click path: 3x3 stride-1 layers and ConvTranspose launches as conv_kwave_bf16 / conv_kwave_deconv_bf16
  *                      (direct form, K split over the waves of a workgroup); 0 = conv_click + split-K (round 2's kernels).
  *   "kwave_chain" (2)  ... and runs of consecutive same-shape 512-channel layers of that path (conv4_2 .. conv7_3 at batch 1) as ONE

@@ -49,12 +49,20 @@ __device__ __forceinline__ unsigned pack_bf16x2_d(float lo, float hi) {
     return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
 }
 
-__global__ __launch_bounds__(512, 2) void conv_ds_fused_m(const ConvArgs a) {
-    constexpr int NT = 512;
+// NCW = cout waves per workgroup.  2: the tile of the N = 32 forward (128 couts, 8 waves).  1 (round 5, the batch-1 click path): 64 couts, four waves =
+// the four phases -- model10up + shortcut at 256x256 is 128 tiles of 64 x 8 output pixels, i.e. HALF the chip with 128-cout workgroups; with 64 couts per
+// workgroup it is 256 workgroups.  Same MFMAs in the same order per accumulator: bit-identical results.  Its 256 threads would need 21 halo registers each
+// for the skip tensor's chunk (84 KiB), so that chunk goes to LDS by LDS-DMA (buffer loads: bounds check = zero padding; de-interleave and swizzle in the
+// per-lane SOURCE address) -- once, in the prologue: the form is only launched for ONE shortcut chunk (64 skip channels: model1short10), which is the
+// only deconv + shortcut launch the click path hands to this kernel.
+template <int NCW>
+__global__ __launch_bounds__(NCW * 256, 2) void conv_ds_fused_m(const ConvArgs a) {
+    constexpr int NT = NCW * 256;
     constexpr int SW = 66, SROWS = 10 * SW, S_ITEMS = (SROWS * kSlots + NT - 1) / NT, S_HALO_BYTES = S_ITEMS * NT * kSlotBytes;
     constexpr int DW = 34, DROWS = 6 * DW, D_ITEMS = (DROWS * kSlots + NT - 1) / NT, D_HALO_BYTES = D_ITEMS * NT * kSlotBytes;
-    constexpr int S_WB = 2 * kWBlockBytes, D_WB = kWBlockBytes;
-    static_assert(S_HALO_BYTES + 3 * S_WB <= 160 * 1024 && D_HALO_BYTES + 16 * D_WB <= 160 * 1024, "LDS budget");
+    constexpr int S_WB = NCW * kWBlockBytes, D_WB = kWBlockBytes;
+    constexpr int H_ITEMS = NCW == 2 ? S_ITEMS : D_ITEMS;        // halo registers: the 4-wave form stages only deconv chunks through registers
+    static_assert(S_HALO_BYTES + 3 * S_WB <= 160 * 1024 && D_HALO_BYTES + NCW * 8 * D_WB <= 160 * 1024, "LDS budget");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const halo = smem;
@@ -62,11 +70,11 @@ __global__ __launch_bounds__(512, 2) void conv_ds_fused_m(const ConvArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wco = wave & 1, ph = wave >> 1;
+    const int wco = NCW == 2 ? (wave & 1) : 0, ph = NCW == 2 ? (wave >> 1) : wave;
     char* const ringD = smem + D_HALO_BYTES + wave * 2 * D_WB;
     const int r16 = lane & 15, g16 = lane >> 4;
     const int Hs = a.Hs, Ws = a.Ws;                            // deconv input (= site) resolution; output is 2x
-    const int ntx = (Ws + 31) >> 5, nty = (Hs + 3) >> 2, nct = a.ncg >> 1;
+    const int ntx = (Ws + 31) >> 5, nty = (Hs + 3) >> 2, nct = a.ncg / NCW;
     int b = xcd_remap_d(blockIdx.x, gridDim.x);
     const int ct = b % nct; b /= nct;
     const int txi = b % ntx; b /= ntx;
@@ -78,7 +86,7 @@ __global__ __launch_bounds__(512, 2) void conv_ds_fused_m(const ConvArgs a) {
     const int pixD = nkc * kRowBytes, pixS = nkc2 * kRowBytes;
     const char* const imgD = (const char*)a.in + (size_t)n * Hs * Ws * pixD;
     const char* const imgS = (const char*)a.in2 + (size_t)n * (4 * (size_t)Hs * Ws) * pixS;
-    const int cg0 = ct * 2;
+    const int cg0 = ct * NCW;
     // halo rows come through buffer loads: 32-bit offsets into one image, the bounds check returns zeros for out-of-image rows (offset 2^31)
     const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)imgS, 0, 4 * Hs * Ws * pixS, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)imgD, 0, Hs * Ws * pixD, 0x00020000);
@@ -97,8 +105,9 @@ __global__ __launch_bounds__(512, 2) void conv_ds_fused_m(const ConvArgs a) {
         }
     }
 
-    u32x4 hreg[S_ITEMS];
+    u32x4 hreg[H_ITEMS];
     auto load_halo_S = [&](int kc2) {
+      if constexpr (NCW == 2) {
         // (item -> address arithmetic recomputed per chunk on purpose, as in conv_ds_fused: hoisted, its 64-bit addresses spill)
         int tid_ = tid;
         asm volatile("" : "+v"(tid_));
@@ -113,6 +122,23 @@ __global__ __launch_bounds__(512, 2) void conv_ds_fused_m(const ConvArgs a) {
             const int off = (Y * (2 * Ws) + X) * pixS + ((sig ^ swz(hr)) + kc2 * kSlots) * kSlotBytes;
             hreg[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsS, inside ? off : (int)0x80000000, 0, 0));
         }
+      } else {
+        // 4-wave form: straight to LDS (the same item -> (LDS row, slot) map: thread tid's item j lands at (tid + j * NT) * 16)
+        int tid_ = tid;
+        asm volatile("" : "+v"(tid_));
+#pragma unroll
+        for (int j = 0; j < S_ITEMS; ++j) {
+            const int item = tid_ + j * NT;
+            const int hr = item >> 3, sig = item & 7;
+            const int hy = hr / SW, rem = hr - hy * SW;
+            const int par = rem >= 33 ? 1 : 0, hx = 2 * (rem - par * 33) + par;
+            const int Y = 2 * y0 - 1 + hy, X = 2 * x0 - 1 + hx;
+            const bool inside = (unsigned)Y < (unsigned)(2 * Hs) && (unsigned)X < (unsigned)(2 * Ws) && hr < SROWS;
+            const int off = (Y * (2 * Ws) + X) * pixS + ((sig ^ swz(hr)) + kc2 * kSlots) * kSlotBytes;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (__attribute__((address_space(3))) void*)(halo + (j * NT + wave * 64) * kSlotBytes), 16,
+                                                     inside ? off : (int)0x80000000, 0, 0, 0);
+        }
+      }
     };
     auto load_halo_D = [&](int kc) {
         int tid_ = tid;
@@ -128,16 +154,17 @@ __global__ __launch_bounds__(512, 2) void conv_ds_fused_m(const ConvArgs a) {
             hreg[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsD, inside ? off : (int)0x80000000, 0, 0));
         }
 #pragma unroll
-        for (int j = D_ITEMS; j < S_ITEMS; ++j) hreg[j] = u32x4{0u, 0u, 0u, 0u};   // (one definition per path for every halo register)
+        for (int j = D_ITEMS; j < H_ITEMS; ++j) hreg[j] = u32x4{0u, 0u, 0u, 0u};   // (one definition per path for every halo register)
     };
     auto dma_S = [&](int tap, int kc2, int buf) {              // 128 couts x 64 cin, shared: every wave brings 2 KiB
         const char* src = (const char*)a.wgt2 + (((size_t)tap * nkc2 + kc2) * ncg + cg0) * kWBlockBytes + (size_t)tid * kSlotBytes;
         char* dst = ringS + buf * S_WB + wave * 64 * kSlotBytes;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)                            // S_WB = 2 x NT x 16 bytes in both forms
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)j * NT * kSlotBytes),
                                              (__attribute__((address_space(3))) void*)(dst + j * NT * kSlotBytes), 16, 0, 0);
     };
+    static_assert(S_WB == 2 * NT * kSlotBytes, "a shortcut weight tile = two 16-byte pieces per thread");
     auto dma_D = [&](int tw, int kc, int buf) {                // this wave's 64 couts x 64 cin of its phase's tap
         int lane_ = lane;
         asm volatile("" : "+v"(lane_));
@@ -189,7 +216,7 @@ __global__ __launch_bounds__(512, 2) void conv_ds_fused_m(const ConvArgs a) {
     load_halo_S(0);
     dma_S(0, 0, 0);
     dma_S(1, 0, 1);
-    if (a.warm && wave == 0) idc_warm_own_code(halo + SROWS * kRowBytes, lane, 112);   // 14 of this kernel's 16.7 KB (the only kernel of its code object: stay inside); scratch: the halo area's unread tail
+    if (a.warm && wave == 0) idc_warm_own_code(halo + SROWS * kRowBytes, lane, NCW == 2 ? 100 : 96);   // 12.5 of this kernel's 13.8 KB (<2> is the last kernel of its code object: stay inside -- tools/check_code_warm.py holds the count against the build); scratch: the halo area's unread tail
     static_assert(S_HALO_BYTES - SROWS * kRowBytes >= 256, "scratch for the code warm-up");
     int rt = 2, rkc = 0;                                       // request cursor: (tap, chunk) of tile s+2
     auto dma_S_req = [&](int slot_off) {
@@ -214,12 +241,14 @@ __global__ __launch_bounds__(512, 2) void conv_ds_fused_m(const ConvArgs a) {
             xs[pj] = xr * kRowBytes + ((g16 ^ swz(xr)) * kSlotBytes);
         }
     };
-    const int wrowS = (wco * 64 + r16) * kRowBytes;
+    const int wrowS = (wco * 64 + r16) * kRowBytes;          // (4-wave form: wco = 0)
     int off_cur = 0, off_next = S_WB, off_free = 2 * S_WB;
+    if constexpr (NCW == 2) {
 #pragma unroll
-    for (int j = 0; j < S_ITEMS; ++j) *(u32x4*)(halo + (tid + j * NT) * kSlotBytes) = hreg[j];
+        for (int j = 0; j < S_ITEMS; ++j) *(u32x4*)(halo + (tid + j * NT) * kSlotBytes) = hreg[j];
+    }
     set_xs(0, 0, 4);
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");           // my pieces of tile 0 (tile 1 may still be in flight)
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");           // my pieces of tile 0 (tile 1 may still be in flight); 4-wave form: the halo pieces are older still
     __syncthreads();                                           // halo chunk 0 and tile 0 are visible
     IDC_DSTAMP(1);
 #pragma unroll
@@ -233,8 +262,8 @@ __global__ __launch_bounds__(512, 2) void conv_ds_fused_m(const ConvArgs a) {
             __syncthreads();                                    // ... everybody's: published; everybody left slot off_free
             dma_S_req(off_free);
             if constexpr (LAST) {
-                if (!last_kc) load_halo_S(kc2 + 1);
-                else load_halo_D(0);                            // the deconv input's first chunk: rows wait in registers
+                if (NCW == 2 && !last_kc) load_halo_S(kc2 + 1);
+                else load_halo_D(0);                            // the deconv input's first chunk: rows wait in registers (4-wave form: ONE shortcut chunk)
             }
             __builtin_amdgcn_sched_barrier(0);
             const char* const wcur = ringS + off_cur;
@@ -264,12 +293,14 @@ __global__ __launch_bounds__(512, 2) void conv_ds_fused_m(const ConvArgs a) {
             mma4(3, 1, xhi); read_a1(wnxt, wrowS, 0, 3);
             IDC_DSM_STAGE_B()
             if constexpr (LAST) {
-                if (!last_kc) {
-                    __syncthreads();                            // everybody is done with halo chunk kc2
+                if constexpr (NCW == 2) {
+                    if (!last_kc) {
+                        __syncthreads();                        // everybody is done with halo chunk kc2
 #pragma unroll
-                    for (int j = 0; j < S_ITEMS; ++j) *(u32x4*)(halo + (tid + j * NT) * kSlotBytes) = hreg[j];
-                    __syncthreads();
-                    read_b(xs, 0, 0, xlo);                      // the B half of the prefetch crossed the chunk change: read it again
+                        for (int j = 0; j < S_ITEMS; ++j) *(u32x4*)(halo + (tid + j * NT) * kSlotBytes) = hreg[j];
+                        __syncthreads();
+                        read_b(xs, 0, 0, xlo);                  // the B half of the prefetch crossed the chunk change: read it again
+                    }
                 }
             }
             const int o_ = off_cur; off_cur = off_next; off_next = off_free; off_free = o_;
@@ -413,6 +444,9 @@ __global__ __launch_bounds__(512, 2) void conv_ds_fused_m(const ConvArgs a) {
 // deconv 4x4 s2 + its 3x3 shortcut conv in one launch, 16x16x32 MFMA: bf16, Cout a multiple of 128, (ReLU | none), no BN.
 // a.wgt / a.wgt2 = the LAYOUT-1 images of the deconv / the shortcut conv.
 // buffer loads address ONE image with 32-bit offsets (out-of-image rows: offset 2^31)
+static int g_ds_half = 1;                 // 0 ("ds_mfma16" = 2): keep the 128-cout workgroups on small grids (A/B, tests)
+void set_ds_half(int v) { g_ds_half = v != 0; }
+
 bool conv_ds_m_fits(int Hs, int Ws, int nkc, int nkc2) {
     return (long long)4 * Hs * Ws * ((long long)(nkc2 > nkc ? nkc2 : nkc) * kRowBytes) < 0x7fffffffLL;
 }
@@ -424,12 +458,20 @@ hipError_t launch_conv_ds_m(const ConvArgs& a, hipStream_t s) {
         return hipErrorInvalidConfiguration;
     const long long blocks = (long long)((a.Ws + 31) / 32) * ((a.Hs + 3) / 4) * a.N * (a.ncg / 2);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(conv_ds_fused_m, dim3((unsigned)blocks), dim3(512), 160 * 1024, s, a);
+    // fewer 128-cout workgroups than CUs (model10up + shortcut of ONE 256x256 image: 128) and a single shortcut chunk: the 64-cout, 4-wave form
+    static int n_cu = 0;
+    if (n_cu == 0) { int dev = 0; hipDeviceProp_t pr; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : -1; }
+    if (g_ds_half && a.nkc2 == 1 && n_cu > 0 && blocks < n_cu)
+        hipLaunchKernelGGL(conv_ds_fused_m<1>, dim3((unsigned)(2 * blocks)), dim3(256), 160 * 1024, s, a);
+    else
+        hipLaunchKernelGGL(conv_ds_fused_m<2>, dim3((unsigned)blocks), dim3(512), 160 * 1024, s, a);
     return hipGetLastError();
 }
 
 hipError_t init_kernels_dsm() {
-    return hipFuncSetAttribute((const void*)conv_ds_fused_m, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_ds_fused_m<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)conv_ds_fused_m<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 }  // namespace idc

@@ -1226,7 +1226,7 @@ int idc_set_option(const char* name, int value) {
     }
     if (strcmp(name, "mfma16") == 0) { g_mfma16 = value != 0; return IDC_OK; }
     if (strcmp(name, "v2p") == 0) { g_v2p = value != 0; return IDC_OK; }
-    if (strcmp(name, "ds_mfma16") == 0) { g_ds_m16 = value != 0; return IDC_OK; }
+    if (strcmp(name, "ds_mfma16") == 0) { g_ds_m16 = value != 0; set_ds_half(value != 2); return IDC_OK; }     // 2: conv_ds_fused_m, 8-wave workgroups on every grid
     if (strcmp(name, "kwave") == 0) { g_kwave = value != 0; return IDC_OK; }
     if (strcmp(name, "kwave_chain") == 0) { g_kwave_chain = value < 0 ? 0 : (value > 2 ? 2 : value); return IDC_OK; }
     return fail(nullptr, IDC_ERR_INVALID_ARG, "unknown option '%s'", name);

@@ -109,6 +109,7 @@ hipError_t launch_conv_ds(const ConvArgs& a, hipStream_t s);
 hipError_t launch_conv_ds_m(const ConvArgs& a, hipStream_t s);
 bool conv_ds_m_fits(int Hs, int Ws, int nkc, int nkc2);   // (else conv_ds_fused, which addresses with 64-bit pointers)
 hipError_t init_kernels_dsm();
+void set_ds_half(int v);              // 1 (default): grids with fewer 128-cout workgroups than CUs run the 64-cout, 4-wave form of conv_ds_fused_m
 // model1 = conv1_1 + conv1_2 of a 32x32 tile in one workgroup (conv1_block_fused): `a` = conv1_1's arguments with conv1_2's
 // riding in (wgt2 = its layout-1 weights, head_b = its bias, bn_scale/bn_shift, out = its output)
 hipError_t launch_conv1_block(const ConvArgs& a, hipStream_t s);

@@ -197,3 +197,33 @@ def test_reference_api_outputs_are_fetched_on_read(make_sd, precision):
     assert not m._out_on_device() and (m.output_ab == 0).all()
     np.testing.assert_array_equal(m.output_ab_raw, raw_e[0])         # ... the other two are still fetched from the device
     m.net.close()
+
+
+@pytest.mark.parametrize("shape", [(1, 256, 256), (1, 200, 232), (2, 128, 160)])
+def test_deconv_shortcut_half_workgroups_on_small_grids(make_sd, shape):
+    """conv_ds_fused_m<1> (round 5): when model10up + shortcut would launch fewer 128-cout workgroups than the chip has CUs (ONE 256x256 image: 128) it
+    runs as 64-cout, 4-wave workgroups (256 of them) whose shortcut halo chunk goes to LDS by LDS-DMA.  Same MFMAs in the same order per accumulator:
+    conv10_1 and the ab map bit-identical to the 8-wave form (`ds_mfma16` = 2), ragged tiles included."""
+    n, H, W = shape
+    sd = make_sd(0, "he")
+    L, ab, m = workloads.random_batch(n, max(H, W), seed=6)
+    L, ab, m = L[:, :, :H, :W].copy(), ab[:, :, :H, :W].copy(), m[:, :, :H, :W].copy()
+    res = {}
+    try:
+        if (H, W) != (256, 256):
+            engine.set_tile_policy("large")                   # small images hand model10up to conv_kwave_deconv_bf16: force the throughput family
+        for mode in (2, 1):
+            engine.set_option("ds_mfma16", mode)
+            e = engine.HipColorizer(H, W, max_batch=n, precision="bf16")
+            e.load_state_dict(sd)
+            out = e.forward(L, ab, m, 0.0)
+            kern = {r["name"]: r["kernel"] for r in e.layer_table()}
+            res[mode] = (out, e.activation("conv10_1", n), kern["conv10_1"], e.forward(L, ab, m, 0.0))
+            e.close()
+    finally:
+        engine.set_option("ds_mfma16", 1)
+        engine.set_tile_policy("auto")
+    assert res[1][2].startswith("conv_ds_fused_m"), res[1][2]
+    np.testing.assert_array_equal(res[1][1], res[2][1])
+    np.testing.assert_array_equal(res[1][0], res[2][0])
+    np.testing.assert_array_equal(res[1][3], res[1][0])
