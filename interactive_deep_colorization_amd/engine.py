@@ -259,6 +259,12 @@ class HipColorizer(object):
         are NOT freed here: each is released when the last numpy view of it is garbage-collected, so an array that
         outlives the engine stays valid memory."""
         if getattr(self, "_h", None) is not None and self._h:
+            cb, self.before_overwrite = getattr(self, "before_overwrite", None), None
+            if cb is not None:                        # somebody still wants the resident results (api.py's lazy output attributes): last chance
+                try:
+                    cb()
+                except Exception:
+                    pass
             for slot in (0, 1):                       # batches still in flight own caller buffers: finish them first
                 try:
                     self.lib.idc_wait(self._h, slot)

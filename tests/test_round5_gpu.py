@@ -227,3 +227,48 @@ def test_deconv_shortcut_half_workgroups_on_small_grids(make_sd, shape):
     np.testing.assert_array_equal(res[1][1], res[2][1])
     np.testing.assert_array_equal(res[1][0], res[2][0])
     np.testing.assert_array_equal(res[1][3], res[1][0])
+
+
+def test_kwave_chain_gives_up_instead_of_hanging():
+    """The safety net of the plain-launch default: a workgroup that never sees the others at the grid barrier (a partitioned / shared device; played here by
+    IDC_KW_FORCE_ABORT=1 -- unreachable barrier, tiny poll budget) sets the host-visible flag and leaves; the blocking call that waited for that forward
+    returns IDC_ERR_INTERNAL, the handle falls back to one launch per layer, and the next call gives the right answer.  Own process: the hook is read once."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, sys
+sys.path.insert(0, %r)
+from interactive_deep_colorization_amd import engine, workloads, _native
+sd = workloads.random_state_dict(0, "torch")
+L, ab, m = workloads.random_batch(1, 256, seed=3)
+e = engine.HipColorizer(256, 256, max_batch=1, precision="bf16")
+e.load_state_dict(sd)
+try:
+    e.forward(L, ab, m, 0.0)
+    print("NO_ERROR")
+except _native.IdcError as ex:
+    print("ERROR:", str(ex)[:160].replace("\n", " "))
+out = e.forward(L, ab, m, 0.0)
+kern = [r["kernel"] for r in e.layer_table()]
+print("CHAIN_AFTER:", any(k.startswith("conv_kwave_chain") for k in kern), "KW:", sum(k == "conv_kwave_bf16" for k in kern))
+np.save(sys.argv[1], out)
+e.close()
+''' % REPO
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "out.npy")
+        env = dict(os.environ); env["IDC_KW_FORCE_ABORT"] = "1"
+        p = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, env=env, timeout=300)
+        assert p.returncode == 0, p.stderr[-1500:]
+        assert "ERROR:" in p.stdout and "timed" in p.stdout and "NO_ERROR" not in p.stdout, p.stdout
+        assert "CHAIN_AFTER: False KW: 22" in p.stdout, p.stdout
+        got = np.load(path)
+    engine.set_option("kwave_chain", 0)
+    try:
+        e = engine.HipColorizer(256, 256, max_batch=1, precision="bf16")
+        e.load_state_dict(workloads.random_state_dict(0, "torch"))
+        L, ab, m = workloads.random_batch(1, 256, seed=3)
+        np.testing.assert_array_equal(got, e.forward(L, ab, m, 0.0))
+        e.close()
+    finally:
+        engine.set_option("kwave_chain", CHAIN_DEFAULT)
