@@ -200,7 +200,9 @@ int idc_forward_rgb(idc_handle h, int n, const float* L_mc, const float* ab, con
  *      net_forward RETURNS is the 0.2 MB uint8 image (colorize_image.py:264-268); the ab map (:263) and the refreshed Lab
  *      (_set_out_ab_, :196-198) are attributes a caller may or may not read.  idc_forward_rgb_lazy computes all three on the
  *      device and copies only rgb; idc_fetch_outputs copies the resident ab map (out_ab [n,2,H,W] f32) and / or refreshed Lab
- *      (lab_q [n,3,H,W] f64) of the LAST forward when asked (either may be NULL).  Same values as idc_forward_rgb. */
+ *      (lab_q [n,3,H,W] f64) of the LAST forward when asked (either may be NULL).  Same values as idc_forward_rgb.
+ *      idc_forward_rgb_lazy accepts L_mc == NULL = "the L planes idc_set_image_l left in the handle": the image's L plane does not change
+ *      between the clicks on it (colorize_image.py:161-191 sets it in set_image), so the wrapper uploads it once per image. */
 int idc_forward_rgb_lazy(idc_handle h, int n, const float* L_mc, const float* ab, const float* mask, float maskcent,
                          float l_cent, uint8_t* rgb);
 int idc_fetch_outputs(idc_handle h, int n, float* out_ab, double* lab_q);

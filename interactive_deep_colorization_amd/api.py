@@ -248,9 +248,7 @@ class ColorizeImageBase(object):
                 return -1
         if self.ab_mean != 0 or self.ab_norm != 1:
             raise ValueError('device-side hints assume raw ab inputs (ab_mean 0, ab_norm 1)')
-        if not self._l_resident:
-            self.net.set_image_l(self.img_l_mc, 0)
-            self._l_resident = True
+        self._ensure_l_resident()
         self.net.set_hints(hints, mode=mode, img=0, mask_value=self.mask_mult)
         self._hints_on_device = True
         return 0
@@ -263,7 +261,17 @@ class ColorizeImageBase(object):
         if self._stage_hints(hints, mode) == -1:
             return -1
         raw, rgb, lab_q = self.net.forward_resident(1, getattr(self, 'mask_cent', 0), l_cent=self.l_mean)
+        self._l_serial = getattr(self.net, 'l_serial', None)
         return self._finish_forward(raw[0], rgb[0], lab_q[0])
+
+    def _ensure_l_resident(self):
+        """The image's L plane sits in the engine's slot 0: uploaded once per image (it is constant between the clicks,
+        ``colorize_image.py:161-191`` sets it in set_image), and again whenever something else has since used the engine behind this
+        object's back (``engine.l_serial`` moves with every call that may write the slot)."""
+        if not self._l_resident or self.__dict__.get('_l_serial') != getattr(self.net, 'l_serial', None):
+            self.net.set_image_l(self.img_l_mc, 0)
+            self._l_resident = True
+            self._l_serial = getattr(self.net, 'l_serial', None)
 
     output_ab_raw = _lazy_out('output_ab_raw')
     output_lab = _lazy_out('output_lab')
@@ -278,7 +286,12 @@ class ColorizeImageBase(object):
             self._out_pending = set()
             if getattr(self.net, 'before_overwrite', None) is not None:
                 self.net.before_overwrite = None
-            rgb = lazy(self._l_plane(), self.input_ab_mc, self.input_mask_mult, maskcent, l_cent=self.l_mean)
+            if hasattr(self.net, 'set_image_l') and hasattr(self.net, 'l_serial'):
+                self._ensure_l_resident()            # then L_mc=None = "the resident plane": one H2D copy less per click
+                rgb = lazy(None, self.input_ab_mc, self.input_mask_mult, maskcent, l_cent=self.l_mean)
+                self._l_serial = self.net.l_serial
+            else:
+                rgb = lazy(self._l_plane(), self.input_ab_mc, self.input_mask_mult, maskcent, l_cent=self.l_mean)
             return self._finish_forward_lazy(rgb[0])
         raw, rgb, lab_q = self.net.forward_rgb(self._l_plane(), self.input_ab_mc, self.input_mask_mult, maskcent, l_cent=self.l_mean)
         return self._finish_forward(raw[0], rgb[0], lab_q[0])

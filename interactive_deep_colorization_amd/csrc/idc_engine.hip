@@ -1108,23 +1108,28 @@ static int forward_host(idc_context* c, int n, const float* L_mc, const float* a
                         float* out_ab, float* dist_q, bool keep_dist = false, bool finish = true, bool copy_out = true) {
     int rc = check_forward_args(c, n);
     if (rc) return rc;
-    if (!L_mc || !ab || !mask || (copy_out && !out_ab)) return fail(&c->err, IDC_ERR_INVALID_ARG, "null tensor pointer");
+    if (!ab || !mask || (copy_out && !out_ab)) return fail(&c->err, IDC_ERR_INVALID_ARG, "null tensor pointer");
+    if (!L_mc) {                             // L_mc == NULL: the L planes idc_set_image_l left in the handle (constant between the clicks on one image)
+        if (copy_out) return fail(&c->err, IDC_ERR_INVALID_ARG, "null tensor pointer");      // (only idc_forward_rgb_lazy offers this form)
+        for (int i = 0; i < n; ++i)
+            if (!c->l_set[i]) return fail(&c->err, IDC_ERR_INVALID_ARG, "L_mc is NULL and image %d has no resident L plane (idc_set_image_l)", i);
+    }
     if ((dist_q || keep_dist) && !(c->flags & IDC_FLAG_DIST_HEAD))
         return fail(&c->err, IDC_ERR_UNSUPPORTED, "handle was created without IDC_FLAG_DIST_HEAD");
     HIPCHK(c, hipSetDevice(c->device));
     rc = drain_pipeline(c);
     if (rc) return rc;
     const size_t hw = (size_t)c->H * c->W;
-    for (int i = 0; i < n; ++i) c->l_set[i] = 1;
+    if (L_mc) for (int i = 0; i < n; ++i) c->l_set[i] = 1;
     c->out_resident = true; c->labq_resident = false;
     // Pinned caller buffers (idc_alloc_host / hipHostMalloc / hipHostRegister) are transferred in place; pageable ones go through
     // the handle's pinned staging with a host memcpy (2.2 MB per click through the reference API: most of its host-side time).
     const float *sL = L_mc, *sab = ab, *sm = mask;
     float* hL = c->h_in; float* hab = hL + (size_t)n * hw; float* hm = hab + (size_t)n * hw * 2;
-    if (!is_pinned(L_mc)) { memcpy(hL, L_mc, (size_t)n * hw * 4); sL = hL; }
+    if (L_mc && !is_pinned(L_mc)) { memcpy(hL, L_mc, (size_t)n * hw * 4); sL = hL; }
     if (!is_pinned(ab)) { memcpy(hab, ab, (size_t)n * hw * 2 * 4); sab = hab; }
     if (!is_pinned(mask)) { memcpy(hm, mask, (size_t)n * hw * 4); sm = hm; }
-    HIPCHK(c, hipMemcpyAsync(c->d_L, sL, (size_t)n * hw * 4, hipMemcpyHostToDevice, c->stream));
+    if (L_mc) HIPCHK(c, hipMemcpyAsync(c->d_L, sL, (size_t)n * hw * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_ab, sab, (size_t)n * hw * 2 * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_mask, sm, (size_t)n * hw * 4, hipMemcpyHostToDevice, c->stream));
     rc = run_graph(c, n, c->d_L, c->d_ab, c->d_mask, maskcent, c->d_out, (dist_q || keep_dist) ? c->d_dist : nullptr);

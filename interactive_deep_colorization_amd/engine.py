@@ -251,6 +251,7 @@ class HipColorizer(object):
         self._blob_keepalive = None
         self._pool = _result_pool(self.lib)
         self.forward_serial = 0             # bumped by every call that replaces the handle's resident results (api.py's lazy output attributes)
+        self.l_serial = 0                   # bumped by every call that may write image slot 0's L plane (set_image_l and every forward): api.py's resident L
         self.before_overwrite = None        # callable run ONCE right before the next such call: whoever still wants the resident results fetches them
 
     # ---- lifetime -------------------------------------------------------------------------
@@ -322,6 +323,7 @@ class HipColorizer(object):
         if cb is not None:
             cb()
         self.forward_serial += 1
+        self.l_serial += 1
 
     def _prep(self, L_mc, ab, mask):
         L_mc = np.asarray(L_mc)
@@ -368,6 +370,7 @@ class HipColorizer(object):
     def set_image_l(self, L_mc, img=0):
         """Upload L-50 of one image slot ((H,W) or (1,H,W)); stays resident for ``forward_resident``."""
         L = _f32c(np.asarray(L_mc).reshape(self.H, self.W))
+        self.l_serial += 1
         self._chk(self.lib.idc_set_image_l(self._h, int(img), _fptr(L)))
 
     def set_hints(self, hints, mode="ab", img=0, mask_value=1.0):
@@ -477,11 +480,20 @@ class HipColorizer(object):
 
     def forward_rgb_lazy(self, L_mc, ab, mask, maskcent=0.0, l_cent=50.0):
         """forward + the colour step on the device, only the uint8 image copied back: rgb (n,H,W,3).  The ab map and the refreshed Lab
-        stay resident; ``fetch_outputs`` brings them over when somebody reads them (2.0 of the 2.2 MB a 256x256 click sends back)."""
-        n, L, A, M = self._prep(L_mc, ab, mask)
+        stay resident; ``fetch_outputs`` brings them over when somebody reads them (2.0 of the 2.2 MB a 256x256 click sends back).
+        ``L_mc=None``: the L plane ``set_image_l`` left in the handle (one image; it is constant between the clicks on that image)."""
+        if L_mc is None:
+            A = np.asarray(ab)
+            A = self._f32in(A[None] if A.ndim == 3 else A, (1, 2, self.H, self.W))
+            M = np.asarray(mask)
+            M = self._f32in(M[None] if M.ndim == 3 else M, (1, 1, self.H, self.W))
+            n, Lp = 1, None
+        else:
+            n, L, A, M = self._prep(L_mc, ab, mask)
+            Lp = _fptr(L)
         rgb = self._pool.take((n, self.H, self.W, 3), np.uint8)
         self._results_will_be_replaced()
-        self._chk(self.lib.idc_forward_rgb_lazy(self._h, n, _fptr(L), _fptr(A), _fptr(M), float(maskcent), float(l_cent),
+        self._chk(self.lib.idc_forward_rgb_lazy(self._h, n, Lp, _fptr(A), _fptr(M), float(maskcent), float(l_cent),
                                                 rgb.ctypes.data_as(ctypes.c_void_p)))
         return rgb
 

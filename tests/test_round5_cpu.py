@@ -291,3 +291,45 @@ def test_output_attributes_are_fetched_on_read_host_logic():
     m2.set_image(np.full((16, 16, 3), 128, np.uint8))
     m2.net_forward(ab, mask)
     assert m2.net.calls == ["lazy"] and (m2.output_ab == 10.0).all()
+
+
+class _ResidentLStubNet(_LazyStubNet):
+    """+ the L-slot bookkeeping of engine.HipColorizer: l_serial moves with set_image_l and with every forward."""
+
+    def __init__(self, X):
+        _LazyStubNet.__init__(self, X)
+        self.l_serial, self.slot_L = 0, None
+
+    def _replace(self):
+        _LazyStubNet._replace(self)
+        self.l_serial += 1
+
+    def set_image_l(self, L_mc, img=0):
+        self.l_serial += 1; self.calls.append("set_l"); self.slot_L = np.array(L_mc, np.float32).reshape(self.X, self.X)
+
+    def forward_rgb_lazy(self, L, ab, mask, maskcent=0.0, l_cent=50.0):
+        if L is not None:
+            self.slot_L = np.array(L, np.float32).reshape(self.X, self.X)
+        self.used_L = self.slot_L.copy()
+        return _LazyStubNet.forward_rgb_lazy(self, L, ab, mask, maskcent, l_cent)
+
+
+def test_l_plane_is_uploaded_once_per_image_host_logic():
+    """The L plane is constant between the clicks on one image (colorize_image.py:161-191): api.py uploads it once and passes L_mc=None afterwards; a
+    new image, or anything else that used the engine in between (l_serial moved), uploads again -- a click never runs on somebody else's L."""
+    from interactive_deep_colorization_amd import api
+    m = api.ColorizeImageTorch(Xd=16)
+    m.net = _ResidentLStubNet(16); m.net_set = True; m._new_engine(m.net)
+    m.set_image(np.full((16, 16, 3), 128, np.uint8))
+    ab, mask = np.zeros((2, 16, 16)), np.zeros((1, 16, 16))
+    for _ in range(3):
+        m.net_forward(ab, mask)
+    assert m.net.calls == ["set_l", "lazy", "lazy", "lazy"]
+    np.testing.assert_array_equal(m.net.used_L, np.asarray(m.img_l_mc, np.float32).reshape(16, 16))
+    m.net.forward_rgb_lazy(np.full((1, 1, 16, 16), 7.0, np.float32), ab, mask)       # behind the object's back, with another L
+    m.net_forward(ab, mask)
+    assert m.net.calls[-3:] == ["lazy", "set_l", "lazy"]
+    np.testing.assert_array_equal(m.net.used_L, np.asarray(m.img_l_mc, np.float32).reshape(16, 16))
+    m.set_image(np.full((16, 16, 3), 30, np.uint8))
+    m.net_forward(ab, mask)
+    assert m.net.calls[-2:] == ["set_l", "lazy"] and abs(float(m.net.used_L.mean()) - float(np.mean(m.img_l_mc))) < 1e-4

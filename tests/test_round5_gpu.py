@@ -272,3 +272,31 @@ e.close()
         e.close()
     finally:
         engine.set_option("kwave_chain", CHAIN_DEFAULT)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_click_with_resident_l_plane_equals_click_with_l_passed(make_sd, precision):
+    """idc_forward_rgb_lazy(L_mc=NULL) = "the L plane idc_set_image_l left in the handle" (api.py uploads it once per image): same bits as passing L; NULL
+    without a resident plane is refused; the wrapper uploads again when the engine was used with another L in between (engine.l_serial)."""
+    sd = make_sd(0, "torch")
+    rgb = np.load(os.path.join(REPO, "tests", "golden", "mortar_pestle_256_rgb.npy"))
+    hab, hm = workloads.hints_config2(256, 5, 3, 0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = api.ColorizeImageTorch(Xd=256, precision=precision)
+        m.prep_net(gpu_id=0, state_dict=sd)
+        with pytest.raises(RuntimeError, match="resident L"):
+            m.net.forward_rgb_lazy(None, hab, hm, 0.5)                 # nothing uploaded yet
+        m.set_image(rgb)
+    e = m.net
+    L = m.img_l_mc[None].astype(np.float32)
+    want_rgb = e.forward_rgb_lazy(L, hab[None].astype(np.float32), hm[None].astype(np.float32), m.mask_cent, l_cent=50.0).copy()
+    want_ab, want_lab = [a.copy() for a in e.fetch_outputs(1)]
+    serial = e.l_serial
+    for _ in range(3):
+        np.testing.assert_array_equal(m.net_forward(hab, hm), want_rgb[0])
+    assert e.l_serial == serial + 1 + 3                                # ONE set_image_l for the three clicks
+    np.testing.assert_array_equal(m.output_ab_raw, want_ab[0]); np.testing.assert_array_equal(m.output_lab, want_lab[0])
+    e.forward_rgb_lazy(np.full((1, 1, 256, 256), 11.0, np.float32), hab[None].astype(np.float32), hm[None].astype(np.float32), 0.5)   # another L in the slot
+    np.testing.assert_array_equal(m.net_forward(hab, hm), want_rgb[0])
+    np.testing.assert_array_equal(m.output_ab_raw, want_ab[0])
+    e.close()
