@@ -1102,6 +1102,35 @@ static int check_forward_args(idc_context* c, int n) {
 static int drain_pipeline(idc_context* c);
 static bool is_pinned(const void* p);
 
+// The end of a click: hipStreamSynchronize parks the thread on an interrupt (tens of microseconds to come back, against a 0.3-1.1 ms forward); the calls
+// that serve ONE OR TWO images poll the stream instead (bounded: after ~4 ms of polling -- several forwards -- it blocks like everybody else).  Batches
+// keep the blocking wait: there the CPU is better spent elsewhere.  IDC_SPIN_SYNC=0 restores the blocking wait everywhere (A/B).
+static hipError_t wait_stream(idc_context* c, int n) {
+    static const bool spin = !(getenv("IDC_SPIN_SYNC") && atoi(getenv("IDC_SPIN_SYNC")) == 0);
+    if (spin && n <= 2) {
+        for (int i = 0; i < 4000; ++i) {
+            const hipError_t e = hipStreamQuery(c->stream);
+            if (e != hipErrorNotReady) return e;
+            for (int k = 0; k < 40; ++k) __builtin_ia32_pause();
+        }
+    }
+    return hipStreamSynchronize(c->stream);
+}
+
+// A click's transfers (<= 2 MiB between pinned host memory and HBM) run as a kernel on the forward's stream (pcie_copy_kernel, idc_kernels.hip) instead of
+// going to a copy engine: no cross-queue hand-over on either side of them.  `host` must be pinned (ours, or the caller's idc_alloc_host / hipHostMalloc /
+// mapped hipHostRegister memory); anything the device cannot address, bigger, or not 16-byte shaped takes hipMemcpyAsync.  IDC_PCIE_KERNEL=0: always (A/B).
+static hipError_t copy_h2d_or_d2h(idc_context* c, void* dev, void* host, size_t bytes, bool to_device) {
+    static const bool by_kernel = !(getenv("IDC_PCIE_KERNEL") && atoi(getenv("IDC_PCIE_KERNEL")) == 0);
+    if (by_kernel && bytes <= ((size_t)2 << 20) && bytes % 16 == 0 && (((uintptr_t)dev | (uintptr_t)host) & 15) == 0) {
+        void* hv = nullptr;
+        if (hipHostGetDevicePointer(&hv, host, 0) == hipSuccess && hv)
+            return to_device ? launch_pcie_copy(dev, hv, bytes, c->stream) : launch_pcie_copy(hv, dev, bytes, c->stream);
+        (void)hipGetLastError();
+    }
+    return to_device ? hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream) : hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream);
+}
+
 // finish = false: everything is enqueued (the D2H of the ab map into h_out included) but the stream is NOT synchronised and
 // nothing is copied to out_ab -- idc_forward_rgb appends the colour step and synchronises once for both
 static int forward_host(idc_context* c, int n, const float* L_mc, const float* ab, const float* mask, float maskcent,
@@ -1124,24 +1153,35 @@ static int forward_host(idc_context* c, int n, const float* L_mc, const float* a
     c->out_resident = true; c->labq_resident = false;
     // Pinned caller buffers (idc_alloc_host / hipHostMalloc / hipHostRegister) are transferred in place; pageable ones go through
     // the handle's pinned staging with a host memcpy (2.2 MB per click through the reference API: most of its host-side time).
-    const float *sL = L_mc, *sab = ab, *sm = mask;
+    // Staged in pieces (>= 256 KiB, at most four per tensor), each piece's DMA issued as soon as it is in the staging buffer: the copy engine moves piece k
+    // while the CPU copies piece k + 1, so a click pays the host memcpy plus ONE piece of DMA instead of memcpy + all of it.
     float* hL = c->h_in; float* hab = hL + (size_t)n * hw; float* hm = hab + (size_t)n * hw * 2;
-    if (L_mc && !is_pinned(L_mc)) { memcpy(hL, L_mc, (size_t)n * hw * 4); sL = hL; }
-    if (!is_pinned(ab)) { memcpy(hab, ab, (size_t)n * hw * 2 * 4); sab = hab; }
-    if (!is_pinned(mask)) { memcpy(hm, mask, (size_t)n * hw * 4); sm = hm; }
-    if (L_mc) HIPCHK(c, hipMemcpyAsync(c->d_L, sL, (size_t)n * hw * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_ab, sab, (size_t)n * hw * 2 * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_mask, sm, (size_t)n * hw * 4, hipMemcpyHostToDevice, c->stream));
+    auto upload = [&](void* dst, const float* src, float* staging, size_t bytes) -> hipError_t {
+        if (is_pinned(src)) return copy_h2d_or_d2h(c, dst, (void*)src, bytes, true);
+        size_t piece = (bytes + 3) / 4;
+        if (piece < (size_t)256 * 1024) piece = (size_t)256 * 1024;
+        piece = (piece + 4095) & ~(size_t)4095;
+        for (size_t o = 0; o < bytes; o += piece) {
+            const size_t m = bytes - o < piece ? bytes - o : piece;
+            memcpy((char*)staging + o, (const char*)src + o, m);
+            const hipError_t e = copy_h2d_or_d2h(c, (char*)dst + o, (char*)staging + o, m, true);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    };
+    if (L_mc) HIPCHK(c, upload(c->d_L, L_mc, hL, (size_t)n * hw * 4));
+    HIPCHK(c, upload(c->d_ab, ab, hab, (size_t)n * hw * 2 * 4));
+    HIPCHK(c, upload(c->d_mask, mask, hm, (size_t)n * hw * 4));
     rc = run_graph(c, n, c->d_L, c->d_ab, c->d_mask, maskcent, c->d_out, (dist_q || keep_dist) ? c->d_dist : nullptr);
     if (rc) return rc;
     const bool out_direct = copy_out && out_ab != c->h_out && is_pinned(out_ab);
     c->out_copy_pending = copy_out && out_ab != c->h_out && !out_direct;
     if (copy_out)          // (copy_out = false: the ab map stays in d_out -- idc_fetch_outputs brings it over when somebody asks)
-        HIPCHK(c, hipMemcpyAsync(out_direct ? out_ab : c->h_out, c->d_out, (size_t)n * hw * 2 * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, copy_h2d_or_d2h(c, c->d_out, out_direct ? out_ab : c->h_out, (size_t)n * hw * 2 * 4, false));
     const size_t dq = (size_t)n * 529 * (hw / 16) * 4;
     if (dist_q) HIPCHK(c, hipMemcpyAsync(c->h_dist, c->d_dist, dq, hipMemcpyDeviceToHost, c->stream));
     if (!finish) return IDC_OK;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, wait_stream(c, n));
     rc = check_chain_abort(c);
     if (rc) return rc;
     if (c->out_copy_pending) memcpy(out_ab, c->h_out, (size_t)n * hw * 2 * 4);
@@ -1412,7 +1452,7 @@ int idc_forward_device(idc_handle h, int n, const float* d_L_mc, const float* d_
     h->labq_resident = false;
     rc = run_graph(h, n, d_L_mc, d_ab, d_mask, maskcent, d_out_ab, (h->flags & IDC_FLAG_DIST_HEAD) ? h->d_dist : nullptr);
     if (rc) return rc;
-    if (sync) HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (sync) HIPCHK(h, wait_stream(h, n));
     return IDC_OK;
 }
 
@@ -1488,9 +1528,9 @@ static int run_lab_post(idc_context* h, int n, const float* d_Lp, float l_add, c
     if (rc) return rc;
     HIPCHK(h, launch_lab_post(d_Lp, l_add, d_abp, h->d_rgb, lab_q ? h->d_labq : nullptr, n, h->H, h->W, h->stream));
     const bool rgb_direct = is_pinned(rgb), lab_direct = lab_q && is_pinned(lab_q);      // pinned caller buffers: no staging copy
-    HIPCHK(h, hipMemcpyAsync(rgb_direct ? rgb : h->h_rgb, h->d_rgb, (size_t)n * hw * 3, hipMemcpyDeviceToHost, h->stream));
-    if (lab_q) HIPCHK(h, hipMemcpyAsync(lab_direct ? (void*)lab_q : (void*)h->h_labq, h->d_labq, (size_t)n * hw * 3 * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, copy_h2d_or_d2h(h, h->d_rgb, rgb_direct ? (void*)rgb : (void*)h->h_rgb, (size_t)n * hw * 3, false));
+    if (lab_q) HIPCHK(h, copy_h2d_or_d2h(h, h->d_labq, lab_direct ? (void*)lab_q : (void*)h->h_labq, (size_t)n * hw * 3 * 8, false));
+    HIPCHK(h, wait_stream(h, n));
     rc = check_chain_abort(h);
     if (rc) return rc;
     if (!rgb_direct) memcpy(rgb, h->h_rgb, (size_t)n * hw * 3);
@@ -1546,8 +1586,8 @@ int idc_forward_rgb_lazy(idc_handle h, int n, const float* L_mc, const float* ab
     const size_t hw = (size_t)h->H * h->W;
     HIPCHK(h, launch_lab_post(h->d_L, l_cent, h->d_out, h->d_rgb, h->d_labq, n, h->H, h->W, h->stream));
     const bool rgb_direct = is_pinned(rgb);
-    HIPCHK(h, hipMemcpyAsync(rgb_direct ? rgb : h->h_rgb, h->d_rgb, (size_t)n * hw * 3, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, copy_h2d_or_d2h(h, h->d_rgb, rgb_direct ? (void*)rgb : (void*)h->h_rgb, (size_t)n * hw * 3, false));
+    HIPCHK(h, wait_stream(h, n));
     rc = check_chain_abort(h);
     if (rc) return rc;
     if (!rgb_direct) memcpy(rgb, h->h_rgb, (size_t)n * hw * 3);
@@ -1565,13 +1605,13 @@ int idc_fetch_outputs(idc_handle h, int n, float* out_ab, double* lab_q) {
     HIPCHK(h, hipSetDevice(h->device));
     const size_t hw = (size_t)h->H * h->W;
     const bool ab_direct = out_ab && is_pinned(out_ab), lab_direct = lab_q && is_pinned(lab_q);
-    if (out_ab) HIPCHK(h, hipMemcpyAsync(ab_direct ? out_ab : h->h_out, h->d_out, (size_t)n * hw * 2 * 4, hipMemcpyDeviceToHost, h->stream));
+    if (out_ab) HIPCHK(h, copy_h2d_or_d2h(h, h->d_out, ab_direct ? out_ab : h->h_out, (size_t)n * hw * 2 * 4, false));
     if (lab_q) {
         int rc = ensure_post_buffers(h);
         if (rc) return rc;
-        HIPCHK(h, hipMemcpyAsync(lab_direct ? (void*)lab_q : (void*)h->h_labq, h->d_labq, (size_t)n * hw * 3 * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, copy_h2d_or_d2h(h, h->d_labq, lab_direct ? (void*)lab_q : (void*)h->h_labq, (size_t)n * hw * 3 * 8, false));
     }
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, wait_stream(h, n));
     if (out_ab && !ab_direct) memcpy(out_ab, h->h_out, (size_t)n * hw * 2 * 4);
     if (lab_q && !lab_direct) memcpy(lab_q, h->h_labq, (size_t)n * hw * 3 * 8);
     return IDC_OK;

@@ -193,6 +193,7 @@ constexpr size_t glob_param_floats() { return (size_t)kGlobIn * kGlobC + 3 * kGl
 
 // Lab -> sRGB uint8 (+ optional rgb -> Lab refresh), float64 like skimage (colorize_image.py:20-28,31-36):
 // L [N,1,H,W] fp32 (+ l_add), ab [N,2,H,W] fp32 -> rgb [N,H,W,3] u8, lab_q [N,3,H,W] f64 (or nullptr)
+hipError_t launch_pcie_copy(void* dst, const void* src, size_t bytes, hipStream_t s);   // small host <-> device copies as a kernel on the forward's stream
 hipError_t launch_lab_post(const float* L, float l_add, const float* ab, unsigned char* rgb, double* lab_q, int N,
                            int H, int W, hipStream_t s);
 

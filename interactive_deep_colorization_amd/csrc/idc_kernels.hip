@@ -2676,6 +2676,24 @@ hipError_t launch_lab_post(const float* L, float l_add, const float* ab, unsigne
 }
 
 // ------------------------------------------------------------------------------------------------
+// pcie_copy: a click's host <-> device transfers as a KERNEL on the forward's own stream (round 5).  One side of (dst, src) is pinned host
+// memory mapped into the device's address space, the other is HBM; 16 bytes per lane, one pass.  hipMemcpyAsync hands the same bytes to a copy
+// engine on another queue: two cross-queue hand-overs per copy, which at 0.2-0.8 MB weigh more than the bytes (tools/click_host_breakdown.py:
+// 768 KB in, 37 us through the copy engine).  Batches keep the copy engines: there the bytes dominate and the compute units have better things to do.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pcie_copy_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, unsigned n16) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) dst[i] = src[i];
+}
+
+hipError_t launch_pcie_copy(void* dst, const void* src, size_t bytes, hipStream_t s) {       // bytes % 16 == 0, both 16-byte aligned
+    const unsigned n16 = (unsigned)(bytes / 16);
+    if (n16 == 0) return hipSuccess;
+    const unsigned blocks = (n16 + 255) / 256 < 1024 ? (n16 + 255) / 256 : 1024;
+    hipLaunchKernelGGL(pcie_copy_kernel, dim3(blocks), dim3(256), 0, s, (uint4*)dst, (const uint4*)src, n16);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // upsample_lab2rgb: the display step that follows every net_forward in the GUI (ui/gui_draw.py:280-283):
 //     ab_win = cv2.resize(output_ab, (win_w, win_h), interpolation=cv2.INTER_CUBIC); lab2rgb(concat(l_win, ab_win)) -> uint8
 // and the full-resolution getters (data/colorize_image.py:123-158): scipy.ndimage.zoom(ab, order=1 | 0) + lab2rgb with

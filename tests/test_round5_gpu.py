@@ -300,3 +300,28 @@ def test_click_with_resident_l_plane_equals_click_with_l_passed(make_sd, precisi
     np.testing.assert_array_equal(m.net_forward(hab, hm), want_rgb[0])
     np.testing.assert_array_equal(m.output_ab_raw, want_ab[0])
     e.close()
+
+
+def test_blocking_wait_switch_gives_the_same_click():
+    """IDC_SPIN_SYNC=0 (read once at load: a fresh process) = the blocking hipStreamSynchronize of rounds 1-4 instead of the bounded poll the one-image
+    calls use since round 5; same bytes either way."""
+    import subprocess
+    import sys
+    code = """
+import sys, hashlib, numpy as np
+sys.path.insert(0, %r)
+from interactive_deep_colorization_amd import engine, workloads
+e = engine.HipColorizer(64, 64, max_batch=1, precision="fp32")
+e.load_state_dict(workloads.random_state_dict(0, "torch"))
+L, ab, m = workloads.random_batch(1, 64, seed=3)
+out = e.forward(L, ab, m, 0.0)
+rgb = e.forward_rgb_lazy(L, ab, m, 0.0)
+oab, lab = e.fetch_outputs(1)
+print("SUM", hashlib.sha1(out.tobytes() + rgb.tobytes() + oab.tobytes() + lab.tobytes()).hexdigest())
+""" % REPO
+    sums = []
+    for v in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, IDC_SPIN_SYNC=v), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        sums.append([l for l in r.stdout.splitlines() if l.startswith("SUM")][0])
+    assert sums[0] == sums[1]
