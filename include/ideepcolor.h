@@ -91,7 +91,9 @@ int idc_set_tile_policy(int policy);
 int idc_set_option(const char* name, int value);
 /* How a call waits for the device (no reference counterpart): calls that serve ONE OR TWO images (the click path) poll the stream instead of
  * blocking in hipStreamSynchronize -- the interrupt wake-up after the copy back costs 15-20 us of a 0.4 ms click -- for a bounded time (a few
- * milliseconds, then they block); batches always block.  IDC_SPIN_SYNC=0 in the environment (read once) restores the blocking wait. */
+ * milliseconds, then they block); batches always block.  IDC_SPIN_SYNC=0 in the environment (read once) restores the blocking wait.
+ * The same calls move their transfers of at most 2 MiB between PINNED host memory and the device with a copy kernel on the handle's stream
+ * instead of a copy engine (no cross-queue hand-over; IDC_PCIE_KERNEL=0 = hipMemcpyAsync everywhere). */
 /* Split-K policy of the small-tile kernels (speed only): 0 automatic (launches too small to fill the chip: the
  * batch-1 click path), 1 never, 2 always (tests).  The slice sums are added in a fixed order: results stay
  * deterministic and independent of how many images a call carries. */
