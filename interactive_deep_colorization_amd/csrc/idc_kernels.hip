@@ -2089,24 +2089,37 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || LW) ? 2 : 3) void conv1_block_
         dma_w2(0, 0);                                          // lands under phases 0 and 1
         if (a.warm && wave == 0) idc_warm_own_code(wring + kWBlockBytes, lane, 64);   // 8 of this kernel's 7.6-9.7 KB (other kernels follow in this code object); scratch: ring slot 1 (rewritten by tap 1's tile)
     }
+    IDC_STAMP(0);
     // ---- phase 0 -------------------------------------------------------------------------------
     {
         const size_t hw = (size_t)Hs * Ws;
         const float* const pL = a.pk_L + (size_t)n * hw;
         const float* const pA = a.pk_ab + (size_t)n * 2 * hw;
         const float* const pM = a.pk_mask + (size_t)n * hw;
-        for (int idx = tid; idx < PW * PH; idx += NT) {
+        // every lane's (up to P_ITEMS) pixels: all twelve plane reads in flight before the first is used (round 5: the loop form waited for
+        // each pixel's four loads in turn -- three HBM round trips per tile, 5.2 k of a tile's 33 k ticks -> 3.6 k; tools/ablate v2 = 7)
+        constexpr int P_ITEMS = (PW * PH + NT - 1) / NT;
+        float vl[P_ITEMS], va[P_ITEMS], vb[P_ITEMS], vm[P_ITEMS];
+        bool ok[P_ITEMS];
+#pragma unroll
+        for (int j = 0; j < P_ITEMS; ++j) {
+            const int idx = tid + j * NT;
             const int py = idx / PW, pxx = idx - py * PW;
             const int yy = ty0 - 2 + py, xx = tx0 - 2 + pxx;
+            ok[j] = idx < PW * PH && (unsigned)yy < (unsigned)Hs && (unsigned)xx < (unsigned)Ws;
+            const size_t p = ok[j] ? (size_t)yy * Ws + xx : 0;
+            vl[j] = pL[p]; va[j] = pA[p]; vb[j] = pA[hw + p]; vm[j] = pM[p];
+        }
+#pragma unroll
+        for (int j = 0; j < P_ITEMS; ++j) {
+            const int idx = tid + j * NT;
             uint2 c = uint2{0u, 0u};
-            if ((unsigned)yy < (unsigned)Hs && (unsigned)xx < (unsigned)Ws) {
-                const size_t p = (size_t)yy * Ws + xx;
-                c = uint2{pack_bf16x2(pL[p] / a.pk_ldiv, pA[p] / a.pk_abdiv),
-                          pack_bf16x2(pA[hw + p] / a.pk_abdiv, pM[p] * a.pk_mmul - a.pk_mcent)};
-            }
-            patch[idx] = c;
+            if (ok[j])
+                c = uint2{pack_bf16x2(vl[j] / a.pk_ldiv, va[j] / a.pk_abdiv), pack_bf16x2(vb[j] / a.pk_abdiv, vm[j] * a.pk_mmul - a.pk_mcent)};
+            if (idx < PW * PH) patch[idx] = c;
         }
     }
+    IDC_STAMP(1);
     // A-fragment row of this lane: MFMA row rho = px of block mi is cout hh*32 + mi*16 + r (see conv1_1_bf16_kernel)
     int lam[2];
 #pragma unroll
@@ -2130,6 +2143,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || LW) ? 2 : 3) void conv1_block_
             }
         }
         __syncthreads();                                       // patch complete
+        IDC_STAMP(5);
         typedef short s16x2 __attribute__((ext_vector_type(2)));
         for (int g = wave; g * 32 < NSITE; g += NW) {
             const int sidx = g * 32 + px;                      // halo site = halo row of the tile
@@ -2171,6 +2185,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || LW) ? 2 : 3) void conv1_block_
             }
         }
     }
+    IDC_STAMP(2);
     // ---- phase 2 -------------------------------------------------------------------------------
     f32x16 acc[2][RPW];
 #pragma unroll
@@ -2255,8 +2270,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || LW) ? 2 : 3) void conv1_block_
 #pragma unroll 1
     for (int t = 0; t < 9; ++t) {
         const char* const wcur_ = wring + (t & 1) * kWBlockBytes;
+        if (t == 4) IDC_STAMP(9);                               // (tools/ablate v2 = 7: where a tap's time goes)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // my pieces of this tap's tile
+        if (t == 4) IDC_STAMP(10);
         __syncthreads();                                        // everybody's (t = 0: also the conv1_1 tile); everybody left the other slot
+        if (t == 4) IDC_STAMP(11);
+        if (t == 5) IDC_STAMP(12);
         if (t + 1 < 9) dma_w2(t + 1, (t + 1) & 1);
         const int dy = t / 3 - 1, dx = t - (t / 3) * 3 - 1;
         int xaddr[RPW];
@@ -2304,7 +2323,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || LW) ? 2 : 3) void conv1_block_
     }
   }
     // ---- phase 3 -------------------------------------------------------------------------------
+    IDC_STAMP(3);
     __syncthreads();                                           // every wave left the halo tile
+    IDC_STAMP(6);
     char* const tb16 = smem + wave * 4096;
     const int rr = lane >> 3, cc = lane & 7;
     const int CoutPad = a.ncg * kCoutGroup;
@@ -2348,6 +2369,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || LW) ? 2 : 3) void conv1_block_
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    IDC_STAMP(4);
+#ifdef IDC_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    IDC_STAMP(7);
+    if (tid == 0) g_idc_dbg[(size_t)blockIdx.x * 16 + 8] = (long long)__builtin_amdgcn_s_getreg(6 | (0 << 6) | (31 << 11));   // HW_REG_LDS_ALLOC: which of its CU's two LDS slots the workgroup got
+#endif
 }
 
 // model1 (conv1_1 + conv1_2) in one launch.  `a` = conv1_1's arguments (fused-pack planes, layout-1 weights, bias, act)

@@ -82,6 +82,20 @@ int main(int argc, char** argv) {
         printf("small-tile mode %s: ksplit %d, kc_per %d, %d workgroups\n", v2 == 4 ? "conv_click" : "conv_igemm", a.ksplit, a.kc_per,
                a.tiles_x * a.tiles_y * N * (a.ncg / wm) * a.ksplit);
     }
+    if (v2 == 7) {      // model1 block (conv1_1 + conv1_2 fused, conv1_block_fused_t): N images of HW x HW, fp32 input planes; per-phase stamps with IDC_TIMING
+        float *pl, *pab, *pm, *hb; void *w1, *w2, *o2;
+        const size_t hw = (size_t)HW * HW;
+        CK(hipMalloc(&pl, N * hw * 4)); CK(hipMalloc(&pab, N * hw * 8)); CK(hipMalloc(&pm, N * hw * 4)); CK(hipMalloc(&hb, 64 * 4));
+        CK(hipMalloc(&w1, 8192)); CK(hipMalloc(&w2, 9 * 8192)); CK(hipMalloc(&o2, N * hw * 64 * 2));
+        hipLaunchKernelGGL(fill_bf16, dim3(2048), dim3(256), 0, 0, (unsigned short*)pl, N * hw * 2, 3u);      // (bit patterns: finite floats made of two bf16 halves)
+        hipLaunchKernelGGL(fill_bf16, dim3(2048), dim3(256), 0, 0, (unsigned short*)pab, N * hw * 4, 5u);
+        hipLaunchKernelGGL(fill_bf16, dim3(2048), dim3(256), 0, 0, (unsigned short*)pm, N * hw * 2, 9u);
+        hipLaunchKernelGGL(fill_bf16, dim3(64), dim3(256), 0, 0, (unsigned short*)w1, 4096, 11u);
+        hipLaunchKernelGGL(fill_bf16, dim3(64), dim3(256), 0, 0, (unsigned short*)w2, 9 * 4096, 13u);
+        CK(hipMemset(hb, 0, 256));
+        a.pk_L = pl; a.pk_ab = pab; a.pk_mask = pm; a.pk_ldiv = 1.f; a.pk_abdiv = 1.f; a.pk_mmul = 1.f; a.pk_mcent = 0.f;
+        a.wgt = w1; a.wgt2 = w2; a.head_b = hb; a.out = o2; a.ncg = 1; a.nkc = 1; a.tiles_y = 0; a.act = 1;
+    }
     if (v2 == 6) {      // fp32 Winograd F(2x2,3x3): U image = 16 floats per (cin, cout); timing only (random U)
         CK(hipFree(w)); CK(hipMalloc(&w, (size_t)C * C * 64));
         hipLaunchKernelGGL(fill_bf16, dim3(2048), dim3(256), 0, 0, (unsigned short*)w, (size_t)C * C * 64 / 2, 7u);
@@ -89,13 +103,13 @@ int main(int argc, char** argv) {
     }
     idc::ConvConfig cfg{wm, wp};
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-#define LAUNCH() (v2 == 6 ? idc::launch_conv_wino(prec, a, 0) : v2 == 4 ? idc::launch_conv_click(prec, wp, halo, a, 0) : v2 == 5 ? idc::launch_conv(prec, cfg, halo, a, 0) : v2 == 2 ? (dsm ? idc::launch_conv_ds_m(a, 0) : idc::launch_conv_ds(a, 0)) : v2 ? (ablv == 1 ? idc::launch_conv_v2p(cfg, halo, a, 0) : ablv == 2 ? idc::launch_conv_v2m(cfg, halo, a, 0) : idc::launch_conv_v2(cfg, halo, a, 0)) : idc::launch_conv(prec, cfg, halo, a, 0))
+#define LAUNCH() (v2 == 7 ? idc::launch_conv1_block(a, 0) : v2 == 6 ? idc::launch_conv_wino(prec, a, 0) : v2 == 4 ? idc::launch_conv_click(prec, wp, halo, a, 0) : v2 == 5 ? idc::launch_conv(prec, cfg, halo, a, 0) : v2 == 2 ? (dsm ? idc::launch_conv_ds_m(a, 0) : idc::launch_conv_ds(a, 0)) : v2 ? (ablv == 1 ? idc::launch_conv_v2p(cfg, halo, a, 0) : ablv == 2 ? idc::launch_conv_v2m(cfg, halo, a, 0) : idc::launch_conv_v2(cfg, halo, a, 0)) : idc::launch_conv(prec, cfg, halo, a, 0))
     a.warm = getenv("IDC_CODE_WARM") ? atoi(getenv("IDC_CODE_WARM")) : 1;
     const int dsm = getenv("IDC_DS_M16") ? atoi(getenv("IDC_DS_M16")) : 0;
     const int ablv = getenv("IDC_ABL_V2") ? atoi(getenv("IDC_ABL_V2")) : 0;      // 0: conv_igemm_v2 (32x32 MFMA), 1: conv_igemm_v2p, 2: conv_igemm_v2m
     if (v2 == 1 && ablv) { void* z; CK(hipMalloc(&z, 256)); CK(hipMemset(z, 0, 256)); a.zeros = z; }
 #ifdef IDC_TIMING
-    int nb = v2 == 6 ? (int)(((HW + halo - 1) / halo + 7) / 8) * (((HW + halo - 1) / halo + 7) / 8) * halo * halo * N * (C / 32) : v2 == 2 ? ((HW + 31) / 32) * ((HW + 3) / 4) * N * (a.ncg / 2) : a.tiles_x * a.tiles_y * N * (a.ncg / wm) * a.nphase * (a.ksplit > 1 ? a.ksplit : 1);
+    int nb = v2 == 7 ? ((HW + 31) / 32) * ((HW + (getenv("IDC_C1_LW") && atoi(getenv("IDC_C1_LW")) == 0 ? 31 : 11)) / (getenv("IDC_C1_LW") && atoi(getenv("IDC_C1_LW")) == 0 ? 32 : 12)) * N : v2 == 6 ? (int)(((HW + halo - 1) / halo + 7) / 8) * (((HW + halo - 1) / halo + 7) / 8) * halo * halo * N * (C / 32) : v2 == 2 ? ((HW + 31) / 32) * ((HW + 3) / 4) * N * (a.ncg / 2) : a.tiles_x * a.tiles_y * N * (a.ncg / wm) * a.nphase * (a.ksplit > 1 ? a.ksplit : 1);
     long long* dbg; CK(hipMalloc(&dbg, (size_t)nb * 128)); CK(hipMemset(dbg, 0, (size_t)nb * 128));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(idc::g_idc_dbg), &dbg, sizeof(dbg)));
 #endif
@@ -121,6 +135,15 @@ int main(int argc, char** argv) {
           if (cnt) printf("  one steady-state step of wave 0 (mean cycles over %d blocks): vmcnt+barrier %.0f | first reads + request issue %.0f | MFMA group 1 %.0f | group 2 %.0f | group 3 %.0f | tap-table update + group 4 %.0f | sum %.0f\n",
                           cnt, d[0] / cnt, d[1] / cnt, d[2] / cnt, d[3] / cnt, d[4] / cnt, d[5] / cnt, (d[0] + d[1] + d[2] + d[3] + d[4] + d[5]) / cnt); }
 #endif
+        if (v2 == 7) { double d[7] = {0, 0, 0, 0, 0, 0, 0}; for (int b = 0; b < nb; ++b) { const long long* q = &h[(size_t)b * 16];
+              d[0] += (double)(q[1] - q[0]); d[1] += (double)(q[5] - q[1]); d[2] += (double)(q[2] - q[5]); d[3] += (double)(q[3] - q[2]); d[4] += (double)(q[6] - q[3]); d[5] += (double)(q[4] - q[6]); d[6] += (double)(q[7] - q[4]); }
+            { double u[4] = {0, 0, 0, 0}; for (int b = 0; b < nb; ++b) { const long long* q = &h[(size_t)b * 16]; u[0] += (double)(q[10] - q[9]); u[1] += (double)(q[11] - q[10]); u[2] += (double)(q[12] - q[11]); }
+              printf("  tap 4 of phase 2 (mean ticks): wait for my LDS-DMA pieces %.0f | workgroup barrier %.0f | DMA issue + reads + 24 MFMAs + tap 5's wait and barrier %.0f\n", u[0] / nb, u[1] / nb, u[2] / nb); }
+            { int nz = 0, nz_first = 0; for (int b = 0; b < nb; ++b) { const unsigned r = (unsigned)h[(size_t)b * 16 + 8]; nz += (r & 0xfff) != 0; if (b < 512) nz_first += (r & 0xfff) != 0; }
+              printf("  HW_REG_LDS_ALLOC: block 0 %#x, block 1 %#x, block 256 %#x, block 300 %#x; LDS_BASE != 0 in %d of %d tiles, %d of the first 512\n",
+                     (unsigned)h[8], (unsigned)h[16 + 8], (unsigned)h[(size_t)256 * 16 + 8], (unsigned)h[(size_t)300 * 16 + 8], nz, nb, nz_first); }
+            printf("  conv1 block per tile (mean ticks over %d tiles): phase 0 patch issue+write %.0f | wait patch (barrier) %.0f | phase 1 conv1_1 %.0f | phase 2 conv1_2 %.0f | barrier %.0f | phase 3 epilogue %.0f | store drain %.0f | sum %.0f\n",
+                   nb, d[0] / nb, d[1] / nb, d[2] / nb, d[3] / nb, d[4] / nb, d[5] / nb, d[6] / nb, (d[0] + d[1] + d[2] + d[3] + d[4] + d[5] + d[6]) / nb); }
         printf("  timing (ticks, mean over %d blocks): start-offset %.0f | prologue %.0f | mainloop %.0f | epilogue-issue %.0f | store-drain %.0f | kernel span %lld\n",
                nb, s[0] / nb, s[1] / nb, s[2] / nb, s[3] / nb, s[4] / nb, tend - t0);
 #ifdef IDC_TIMING_FINE
