@@ -304,7 +304,7 @@ def test_click_with_resident_l_plane_equals_click_with_l_passed(make_sd, precisi
 
 def test_blocking_wait_switch_gives_the_same_click():
     """IDC_SPIN_SYNC=0 (read once at load: a fresh process) = the blocking hipStreamSynchronize of rounds 1-4 instead of the bounded poll the one-image
-    calls use since round 5; same bytes either way."""
+    calls use since round 5; IDC_PCIE_KERNEL=0 = the copy engines instead of pcie_copy_kernel for their transfers; same bytes in every combination."""
     import subprocess
     import sys
     code = """
@@ -320,8 +320,9 @@ oab, lab = e.fetch_outputs(1)
 print("SUM", hashlib.sha1(out.tobytes() + rgb.tobytes() + oab.tobytes() + lab.tobytes()).hexdigest())
 """ % REPO
     sums = []
-    for v in ("0", "1"):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, IDC_SPIN_SYNC=v), capture_output=True, text=True, timeout=300)
+    for spin, by_kernel in (("0", "0"), ("1", "1"), ("1", "0")):          # ... and IDC_PCIE_KERNEL=0: every transfer through hipMemcpyAsync, as before round 5
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, IDC_SPIN_SYNC=spin, IDC_PCIE_KERNEL=by_kernel), capture_output=True, text=True,
+                           timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         sums.append([l for l in r.stdout.splitlines() if l.startswith("SUM")][0])
-    assert sums[0] == sums[1]
+    assert sums[0] == sums[1] == sums[2]
