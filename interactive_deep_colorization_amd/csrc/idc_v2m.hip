@@ -30,6 +30,15 @@
 
 namespace idc {
 
+// in-kernel cycle stamps for the tuning harness (tools/ablate, -DIDC_TIMING): compiled out of the library
+#ifdef IDC_TIMING
+extern __device__ long long* g_idc_dbg;
+#define IDC_MSTAMP(i) do { if (tid == 0) g_idc_dbg[(size_t)blockIdx.x * 16 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define IDC_MSTAMP(i) do {} while (0)
+#endif
+
+
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_m;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -394,6 +403,7 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArg
     const char* const img = (const char*)a.in + (size_t)n * (size_t)(Hs * si) * Win * (size_t)pix_bytes;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)img, 0, (Hs * si) * Win * pix_bytes, 0x00020000);
 
+    IDC_MSTAMP(0);
     f32x4 acc[4][8];
     {
         const float* const bp = a.bias + (ct * WCO + wco) * kCoutGroup + g16 * 16;
@@ -454,6 +464,7 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArg
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);              // second-dispatched half of an 8-wave workgroup (as conv_igemm_v2)
     int buf_off = 0;                                           // byte offset of the ring slot holding the current tap's tile
 
+    IDC_MSTAMP(1);
     for (int kc = 0; kc < nkc; ++kc) {
         __syncthreads();                                       // previous chunk's halo reads are done
         store_halo();
@@ -464,8 +475,12 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArg
             constexpr int dy = (t / 3 - 1) * D;
             constexpr int tn = LAST ? 0 : t + 1;
             const char* const wcur = wbuf + buf_off;
+            if (t == 4 && kc == 0) IDC_MSTAMP(9);                   // (tools/ablate: where a tap's time goes)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // my pieces of this tap's weight tile landed
+            if (t == 4 && kc == 0) IDC_MSTAMP(10);
             __syncthreads();                                        // everybody's landed; everybody left the other buffer
+            if (t == 4 && kc == 0) IDC_MSTAMP(11);
+            if (t == 5 && kc == 0) IDC_MSTAMP(12);
             const char* const a0 = wcur + wa0;
             const char* const a1 = wcur + wa1;
             u32x4 wf[4], xlo[4], xhi[4];
@@ -540,6 +555,7 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArg
     }
 
     // ---- epilogue (conv_igemm_v2m's): lane (site r16, group g16) owns couts g16*16 + mi*4 + j of its wave's 64 ----------------------
+    IDC_MSTAMP(2);
     const int CoutPad = a.ncg * kCoutGroup;
     const bool has_bn = a.bn_scale != nullptr;
     const int cow = (ct * WCO + wco) * kCoutGroup;
@@ -639,6 +655,11 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArg
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    IDC_MSTAMP(3);
+#ifdef IDC_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    IDC_MSTAMP(4);
+#endif
 }
 
 
