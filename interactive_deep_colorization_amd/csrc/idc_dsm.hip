@@ -45,8 +45,12 @@ __device__ __forceinline__ int xcd_remap_d(int b, int nb) {
 }
 
 __device__ __forceinline__ unsigned pack_bf16x2_d(float lo, float hi) {
-    const __bf16 x = (__bf16)lo, y = (__bf16)hi;                 // v_cvt_pk_bf16_f32, RNE
-    return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+    // one v_cvt_pk_bf16_f32 (RNE) as a VECTOR conversion: from `(__bf16)lo | (__bf16)hi << 16` the vectoriser pairs the conversions of NEIGHBOURING packs
+    // and un-shuffles them with and / shift / two SDWA ors -- six instructions for two dwords instead of two (round 5: the epilogues are VALU-bound).
+    // (Not inline asm: the hazard recogniser does not see an asm's reads of MFMA results, and the scheduler may move it next to the MFMAs.)
+    typedef float f32x2_pk __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_pk __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_pk){lo, hi}, bf16x2_pk));
 }
 
 // NCW = cout waves per workgroup.  2: the tile of the N = 32 forward (128 couts, 8 waves).  1 (round 5, the batch-1 click path): 64 couts, four waves =
@@ -404,36 +408,42 @@ __global__ __launch_bounds__(NCW * 256, 2) void conv_ds_fused_m(const ConvArgs a
     const int CoutPad = ncg * kCoutGroup;
     const int co8 = (cg0 + wco) * kCoutGroup + cc * 8;
     const int Wout = 2 * Ws, Hout = 2 * Hs;
+    // (as conv_igemm_v2p's epilogue, round 5: one body per ReLU setting chosen once, the row's four transposed lines read BEFORE the first store's
+    //  bounds check -- the compiler sank each read under its store -- and one 64-bit base per lane with 32-bit strides)
+    unsigned short* const out00 = (unsigned short*)a.out + (((size_t)n * Hout + (2 * y0 + ro)) * Wout + (2 * (x0 + rr) + cof)) * CoutPad + co8;
+    auto rows = [&](auto relu_c) __attribute__((always_inline)) {
+        constexpr bool RELU = decltype(relu_c)::value;
 #pragma unroll
-    for (int pj = 0; pj < 4; ++pj) {
+        for (int pj = 0; pj < 4; ++pj) {
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            const int pt = pj * 2 + hf, site = hf * 16 + r16;
-            unsigned pk[8];
+            for (int hf = 0; hf < 2; ++hf) {
+                const int pt = pj * 2 + hf, site = hf * 16 + r16;
+                unsigned pk[8];
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+                for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    unsigned p = pack_bf16x2_d(acc[mi][pt][2 * e], acc[mi][pt][2 * e + 1]);
-                    if (a.act == 1) p = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), s16x2{0, 0}));
-                    pk[mi * 2 + e] = p;
-                }
-            const int s0 = g16 * 2;                             // the lane's 16 couts = slots 2g, 2g+1 of the site's 128-byte row
-            *(uint4*)(tb16 + site * 128 + ((s0 ^ (site & 7)) * 16)) = uint4{pk[0], pk[1], pk[2], pk[3]};
-            *(uint4*)(tb16 + site * 128 + (((s0 + 1) ^ (site & 7)) * 16)) = uint4{pk[4], pk[5], pk[6], pk[7]};
+                    for (int e = 0; e < 2; ++e) {
+                        unsigned p = pack_bf16x2_d(acc[mi][pt][2 * e], acc[mi][pt][2 * e + 1]);
+                        if constexpr (RELU) p = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), s16x2{0, 0}));
+                        pk[mi * 2 + e] = p;
+                    }
+                const int s0 = g16 * 2;                         // the lane's 16 couts = slots 2g, 2g+1 of the site's 128-byte row
+                *(uint4*)(tb16 + site * 128 + ((s0 ^ (site & 7)) * 16)) = uint4{pk[0], pk[1], pk[2], pk[3]};
+                *(uint4*)(tb16 + site * 128 + (((s0 + 1) ^ (site & 7)) * 16)) = uint4{pk[4], pk[5], pk[6], pk[7]};
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // same-wave LDS ops are in order: the row tile is complete
+            const int sy = y0 + pj;
+            auto line = [&](int i) { const int row = i * 8 + rr; return *(const uint4*)(tb16 + row * 128 + ((cc ^ (row & 7)) * 16)); };
+            const uint4 o0 = line(0), o1 = line(1), o2 = line(2), o3 = line(3);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // reads retired before the tile is rewritten (and before the first bounds check)
+            auto put = [&](int i, const uint4& o) {
+                const int sx = x0 + i * 8 + rr;
+                if (sy < Hs && sx < Ws) *(uint4*)(out00 + (2 * pj * Wout + 2 * i * 8) * CoutPad) = o;
+            };
+            put(0, o0); put(1, o1); put(2, o2); put(3, o3);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // same-wave LDS ops are in order: the row tile is complete
-        const int sy = y0 + pj;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = i * 8 + rr;
-            const uint4 o = *(const uint4*)(tb16 + row * 128 + ((cc ^ (row & 7)) * 16));
-            const int sx = x0 + row;
-            if (sy < Hs && sx < Ws)
-                *(uint4*)((unsigned short*)a.out + (((size_t)n * Hout + (2 * sy + ro)) * Wout + (2 * sx + cof)) * CoutPad + co8) = o;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads retired before the tile is rewritten
-    }
+    };
+    if (a.act == 1) rows(std::true_type{}); else rows(std::false_type{});
     IDC_DSTAMP(3);
 #ifdef IDC_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -62,9 +62,12 @@ template <> struct Mma<float> {
 };
 
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-    const __bf16 a = (__bf16)lo, b = (__bf16)hi;                 // v_cvt_pk_bf16_f32, RNE
-    return (unsigned)__builtin_bit_cast(unsigned short, a) |
-           ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+    // one v_cvt_pk_bf16_f32 (RNE) as a VECTOR conversion: from `(__bf16)lo | (__bf16)hi << 16` the vectoriser pairs the conversions of NEIGHBOURING packs
+    // and un-shuffles them with and / shift / two SDWA ors -- six instructions for two dwords instead of two (round 5: the epilogues are VALU-bound).
+    // (Not inline asm: the hazard recogniser does not see an asm's reads of MFMA results, and the scheduler may move it next to the MFMAs.)
+    typedef float f32x2_pk __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_pk __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_pk){lo, hi}, bf16x2_pk));
 }
 
 // XCD-aware, bijective block remap: hardware places block b on XCD b%8; give each XCD a
@@ -2342,33 +2345,39 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || LW) ? 2 : 3) void conv1_block_
                 bsh[mi][q * 4 + 0] = t4.x; bsh[mi][q * 4 + 1] = t4.y; bsh[mi][q * 4 + 2] = t4.z; bsh[mi][q * 4 + 3] = t4.w;
             }
     }
+    // (as conv_igemm_v2p's epilogue, round 5: one body per BN setting chosen once -- a run-time `if` per element was a uniform branch per packed pair --,
+    //  a row's four transposed lines read BEFORE the first store's bounds check, one 64-bit base per lane with 32-bit strides)
+    unsigned short* const out00 = (unsigned short*)a.out + (((size_t)n * Hs + ty0 + wave * RPW) * Ws + tx0 + rr) * CoutPad + cc * 8;
+    auto rows = [&](auto bn_c) __attribute__((always_inline)) {
+        constexpr bool BN = decltype(bn_c)::value;
 #pragma unroll
-    for (int pj = 0; pj < RPW; ++pj) {
+        for (int pj = 0; pj < RPW; ++pj) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            unsigned pk[8];
+            for (int mi = 0; mi < 2; ++mi) {
+                unsigned pk[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float v0 = fmaxf(acc[mi][pj][2 * e], 0.f), v1 = fmaxf(acc[mi][pj][2 * e + 1], 0.f);
-                if (has_bn) { v0 = fmaf(v0, bsc[mi][2 * e], bsh[mi][2 * e]); v1 = fmaf(v1, bsc[mi][2 * e + 1], bsh[mi][2 * e + 1]); }
-                pk[e] = pack_bf16x2(v0, v1);
+                for (int e = 0; e < 8; ++e) {
+                    float v0 = fmaxf(acc[mi][pj][2 * e], 0.f), v1 = fmaxf(acc[mi][pj][2 * e + 1], 0.f);
+                    if constexpr (BN) { v0 = fmaf(v0, bsc[mi][2 * e], bsh[mi][2 * e]); v1 = fmaf(v1, bsc[mi][2 * e + 1], bsh[mi][2 * e + 1]); }
+                    pk[e] = pack_bf16x2(v0, v1);
+                }
+                const int s0 = h * 4 + mi * 2;
+                *(uint4*)(tb16 + px * 128 + ((s0 ^ (px & 7)) * 16)) = uint4{pk[0], pk[1], pk[2], pk[3]};
+                *(uint4*)(tb16 + px * 128 + (((s0 + 1) ^ (px & 7)) * 16)) = uint4{pk[4], pk[5], pk[6], pk[7]};
             }
-            const int s0 = h * 4 + mi * 2;
-            *(uint4*)(tb16 + px * 128 + ((s0 ^ (px & 7)) * 16)) = uint4{pk[0], pk[1], pk[2], pk[3]};
-            *(uint4*)(tb16 + px * 128 + (((s0 + 1) ^ (px & 7)) * 16)) = uint4{pk[4], pk[5], pk[6], pk[7]};
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int sy = ty0 + wave * RPW + pj;
+            auto line = [&](int i) { const int row = i * 8 + rr; return *(const uint4*)(tb16 + row * 128 + ((cc ^ (row & 7)) * 16)); };
+            const uint4 o0 = line(0), o1 = line(1), o2 = line(2), o3 = line(3);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            auto put = [&](int i, const uint4& o) {
+                const int sx = tx0 + i * 8 + rr;
+                if (sy < Hs && sx < Ws) *(uint4*)(out00 + (pj * Ws + i * 8) * CoutPad) = o;
+            };
+            put(0, o0); put(1, o1); put(2, o2); put(3, o3);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int sy = ty0 + wave * RPW + pj;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = i * 8 + rr;
-            const uint4 o = *(const uint4*)(tb16 + row * 128 + ((cc ^ (row & 7)) * 16));
-            const int sx = tx0 + row;
-            if (sy < Hs && sx < Ws)
-                *(uint4*)((unsigned short*)a.out + (((size_t)n * Hs + sy) * Ws + sx) * CoutPad + cc * 8) = o;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
+    };
+    if (has_bn) rows(std::true_type{}); else rows(std::false_type{});
     IDC_STAMP(4);
 #ifdef IDC_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -50,8 +50,12 @@ __device__ __forceinline__ int xcd_remap_m(int b, int nb) {
 }
 
 __device__ __forceinline__ unsigned pack_bf16x2_m(float lo, float hi) {
-    const __bf16 x = (__bf16)lo, y = (__bf16)hi;                 // v_cvt_pk_bf16_f32, RNE
-    return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+    // one v_cvt_pk_bf16_f32 (RNE) as a VECTOR conversion: from `(__bf16)lo | (__bf16)hi << 16` the vectoriser pairs the conversions of NEIGHBOURING packs
+    // and un-shuffles them with and / shift / two SDWA ors -- six instructions for two dwords instead of two (round 5: the epilogues are VALU-bound).
+    // (Not inline asm: the hazard recogniser does not see an asm's reads of MFMA results, and the scheduler may move it next to the MFMAs.)
+    typedef float f32x2_pk __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_pk __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_pk){lo, hi}, bf16x2_pk));
 }
 
 template <int WCO, int WPX, int HALO>
@@ -261,21 +265,27 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2m(const ConvArg
             w1[mi] = f32x4{v.x, v.y, v.z, v.w};
         }
         float* const hp = (float*)smem;                        // [wave][pt 8][group 4][16 sites][2]
+        auto partial = [&](auto act_c) __attribute__((always_inline)) {        // (activation chosen once, as in conv_igemm_v2p)
+            constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
-        for (int pt = 0; pt < 8; ++pt) {
-            float s0 = 0.f, s1 = 0.f;
+            for (int pt = 0; pt < 8; ++pt) {
+                float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+                for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v = acc[mi][pt][j];
-                    if (a.act == 1) v = fmaxf(v, 0.f);
-                    else if (a.act == 2) v = fmaxf(v, 0.2f * v);
-                    s0 = fmaf(v, w0[mi][j], s0);
-                    s1 = fmaf(v, w1[mi][j], s1);
-                }
-            *(float2*)(hp + ((((wave * 8 + pt) * 4 + g16) * 16 + r16) * 2)) = float2{s0, s1};
-        }
+                    for (int j = 0; j < 4; ++j) {
+                        float v = acc[mi][pt][j];
+                        if constexpr (ACT == 1) v = fmaxf(v, 0.f);
+                        else if constexpr (ACT == 2) v = fmaxf(v, 0.2f * v);
+                        s0 = fmaf(v, w0[mi][j], s0);
+                        s1 = fmaf(v, w1[mi][j], s1);
+                    }
+                *(float2*)(hp + ((((wave * 8 + pt) * 4 + g16) * 16 + r16) * 2)) = float2{s0, s1};
+            }
+        };
+        if (a.act == 1) partial(std::integral_constant<int, 1>{});
+        else if (a.act == 2) partial(std::integral_constant<int, 2>{});
+        else partial(std::integral_constant<int, 0>{});
         __syncthreads();
         if (wco == 0) {                                        // waves wave, wave + 1 hold the two cout halves of these pixels
             const int px = lane & 31, ch = lane >> 5;
@@ -310,43 +320,52 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2m(const ConvArg
             bsh[mi] = f32x4{t4.x, t4.y, t4.z, t4.w};
         }
     }
+    // (one body per (BN, ReLU) combination chosen once, a row's four lines read before the first bounds check: conv_igemm_v2p's epilogue says why)
+    auto rows = [&](auto bn_c, auto relu_c) __attribute__((always_inline)) {
+        constexpr bool BN = decltype(bn_c)::value, RELU = decltype(relu_c)::value;
 #pragma unroll
-    for (int pj = 0; pj < 4; ++pj) {
+        for (int pj = 0; pj < 4; ++pj) {
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            const int pt = pj * 2 + hf, site = hf * 16 + r16;
-            unsigned pk[8];
+            for (int hf = 0; hf < 2; ++hf) {
+                const int pt = pj * 2 + hf, site = hf * 16 + r16;
+                unsigned pk[8];
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+                for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    float v0 = acc[mi][pt][2 * e], v1 = acc[mi][pt][2 * e + 1];
-                    if (has_bn) {
-                        if (a.act == 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-                        pk[mi * 2 + e] = pack_bf16x2_m(fmaf(v0, bsc[mi][2 * e], bsh[mi][2 * e]), fmaf(v1, bsc[mi][2 * e + 1], bsh[mi][2 * e + 1]));
-                    } else {
-                        unsigned p = pack_bf16x2_m(v0, v1);
-                        if (a.act == 1) p = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), s16x2{0, 0}));
-                        pk[mi * 2 + e] = p;
+                    for (int e = 0; e < 2; ++e) {
+                        float v0 = acc[mi][pt][2 * e], v1 = acc[mi][pt][2 * e + 1];
+                        if constexpr (BN) {
+                            if constexpr (RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                            pk[mi * 2 + e] = pack_bf16x2_m(fmaf(v0, bsc[mi][2 * e], bsh[mi][2 * e]), fmaf(v1, bsc[mi][2 * e + 1], bsh[mi][2 * e + 1]));
+                        } else {
+                            unsigned p = pack_bf16x2_m(v0, v1);
+                            if constexpr (RELU) p = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), s16x2{0, 0}));
+                            pk[mi * 2 + e] = p;
+                        }
                     }
-                }
-            const int s0 = g16 * 2;                             // the lane's 16 couts = slots 2g, 2g+1 of the site's 128-byte row
-            *(uint4*)(tb16 + site * 128 + ((s0 ^ (site & 7)) * 16)) = uint4{pk[0], pk[1], pk[2], pk[3]};
-            *(uint4*)(tb16 + site * 128 + (((s0 + 1) ^ (site & 7)) * 16)) = uint4{pk[4], pk[5], pk[6], pk[7]};
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // same-wave LDS ops are in order: the row tile is complete
-        const int sy = ty0 + wpx * 4 + pj;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = i * 8 + rr;
-            const uint4 o = *(const uint4*)(tb16 + row * 128 + ((cc ^ (row & 7)) * 16));
-            const int sx = tx0 + row;
-            if (sy < Hs && sx < Ws) {
-                const size_t oidx = (((size_t)n * Hout + (sy * so + ro)) * Wout + (sx * so + cof)) * CoutPad + co8;
-                *(uint4*)((unsigned short*)a.out + oidx) = o;
+                const int s0 = g16 * 2;                         // the lane's 16 couts = slots 2g, 2g+1 of the site's 128-byte row
+                *(uint4*)(tb16 + site * 128 + ((s0 ^ (site & 7)) * 16)) = uint4{pk[0], pk[1], pk[2], pk[3]};
+                *(uint4*)(tb16 + site * 128 + (((s0 + 1) ^ (site & 7)) * 16)) = uint4{pk[4], pk[5], pk[6], pk[7]};
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // same-wave LDS ops are in order: the row tile is complete
+            const int sy = ty0 + wpx * 4 + pj;
+            auto line = [&](int i) { const int row = i * 8 + rr; return *(const uint4*)(tb16 + row * 128 + ((cc ^ (row & 7)) * 16)); };
+            const uint4 o0 = line(0), o1 = line(1), o2 = line(2), o3 = line(3);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // reads retired before the tile is rewritten
+            auto put = [&](int i, const uint4& o) {
+                const int sx = tx0 + i * 8 + rr;
+                if (sy < Hs && sx < Ws) {
+                    const size_t oidx = (((size_t)n * Hout + (sy * so + ro)) * Wout + (sx * so + cof)) * CoutPad + co8;
+                    *(uint4*)((unsigned short*)a.out + oidx) = o;
+                }
+            };
+            put(0, o0); put(1, o1); put(2, o2); put(3, o3);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads retired before the tile is rewritten
+    };
+    if (has_bn) {
+        if (a.act == 1) rows(std::true_type{}, std::true_type{}); else rows(std::true_type{}, std::false_type{});
+    } else {
+        if (a.act == 1) rows(std::false_type{}, std::true_type{}); else rows(std::false_type{}, std::false_type{});
     }
 }
 
@@ -560,6 +579,7 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArg
     const bool has_bn = a.bn_scale != nullptr;
     const int cow = (ct * WCO + wco) * kCoutGroup;
     __syncthreads();                                           // every wave left the halo / weight tiles
+    IDC_MSTAMP(5);
     if (WCO == 2 && a.head_w != nullptr) {
         f32x4 w0[4], w1[4];
 #pragma unroll
@@ -570,21 +590,28 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArg
             w1[mi] = f32x4{v.x, v.y, v.z, v.w};
         }
         float* const hp = (float*)smem;                        // [wave][pt 8][group 4][16 sites][2]
+        // (the activation is chosen ONCE: as run-time `if`s per element it cost two uniform branches per accumulator register, 256 per wave)
+        auto partial = [&](auto act_c) __attribute__((always_inline)) {
+            constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
-        for (int pt = 0; pt < 8; ++pt) {
-            float s0 = 0.f, s1 = 0.f;
+            for (int pt = 0; pt < 8; ++pt) {
+                float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+                for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v = acc[mi][pt][j];
-                    if (a.act == 1) v = fmaxf(v, 0.f);
-                    else if (a.act == 2) v = fmaxf(v, 0.2f * v);
-                    s0 = fmaf(v, w0[mi][j], s0);
-                    s1 = fmaf(v, w1[mi][j], s1);
-                }
-            *(float2*)(hp + ((((wave * 8 + pt) * 4 + g16) * 16 + r16) * 2)) = float2{s0, s1};
-        }
+                    for (int j = 0; j < 4; ++j) {
+                        float v = acc[mi][pt][j];
+                        if constexpr (ACT == 1) v = fmaxf(v, 0.f);
+                        else if constexpr (ACT == 2) v = fmaxf(v, 0.2f * v);
+                        s0 = fmaf(v, w0[mi][j], s0);
+                        s1 = fmaf(v, w1[mi][j], s1);
+                    }
+                *(float2*)(hp + ((((wave * 8 + pt) * 4 + g16) * 16 + r16) * 2)) = float2{s0, s1};
+            }
+        };
+        if (a.act == 1) partial(std::integral_constant<int, 1>{});
+        else if (a.act == 2) partial(std::integral_constant<int, 2>{});
+        else partial(std::integral_constant<int, 0>{});
         __syncthreads();
         if (wco == 0) {
             const int px = lane & 31, ch = lane >> 5;
@@ -617,43 +644,54 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArg
             bsh[mi] = f32x4{t4.x, t4.y, t4.z, t4.w};
         }
     }
+    // One body per (BN, ReLU) combination, chosen ONCE: written as run-time `if`s inside the element loops the compiler kept a uniform branch per packed
+    // pair (32 taken branches per pixel row) and sank each transposed LDS read under its store's bounds check (read - wait - store, four times in a
+    // row): 2.6 k cycles per pixel row, 10.9 k per tile -- 17 % of a conv10_2-shaped tile (tools/ablate stamps, profiles/r05_v2p_tap_stamps.txt).
+    unsigned short* const out00 = (unsigned short*)a.out + (((size_t)n * Hs + ty0 + wpx * 4) * Ws + tx0 + rr) * CoutPad + co8;   // lane's line of the wave's first pixel row
+    auto rows = [&](auto bn_c, auto relu_c) __attribute__((always_inline)) {
+        constexpr bool BN = decltype(bn_c)::value, RELU = decltype(relu_c)::value;
 #pragma unroll
-    for (int pj = 0; pj < 4; ++pj) {
+        for (int pj = 0; pj < 4; ++pj) {
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            const int pt = pj * 2 + hf, site = hf * 16 + r16;
-            unsigned pk[8];
+            for (int hf = 0; hf < 2; ++hf) {
+                const int pt = pj * 2 + hf, site = hf * 16 + r16;
+                unsigned pk[8];
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+                for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    float v0 = acc[mi][pt][2 * e], v1 = acc[mi][pt][2 * e + 1];
-                    if (has_bn) {
-                        if (a.act == 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-                        pk[mi * 2 + e] = pack_bf16x2_m(fmaf(v0, bsc[mi][2 * e], bsh[mi][2 * e]), fmaf(v1, bsc[mi][2 * e + 1], bsh[mi][2 * e + 1]));
-                    } else {
-                        unsigned p = pack_bf16x2_m(v0, v1);
-                        if (a.act == 1) p = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), s16x2{0, 0}));
-                        pk[mi * 2 + e] = p;
+                    for (int e = 0; e < 2; ++e) {
+                        float v0 = acc[mi][pt][2 * e], v1 = acc[mi][pt][2 * e + 1];
+                        if constexpr (BN) {
+                            if constexpr (RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                            pk[mi * 2 + e] = pack_bf16x2_m(fmaf(v0, bsc[mi][2 * e], bsh[mi][2 * e]), fmaf(v1, bsc[mi][2 * e + 1], bsh[mi][2 * e + 1]));
+                        } else {
+                            unsigned p = pack_bf16x2_m(v0, v1);
+                            if constexpr (RELU) p = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), s16x2{0, 0}));
+                            pk[mi * 2 + e] = p;
+                        }
                     }
-                }
-            const int s0 = g16 * 2;
-            *(uint4*)(tb16 + site * 128 + ((s0 ^ (site & 7)) * 16)) = uint4{pk[0], pk[1], pk[2], pk[3]};
-            *(uint4*)(tb16 + site * 128 + (((s0 + 1) ^ (site & 7)) * 16)) = uint4{pk[4], pk[5], pk[6], pk[7]};
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int sy = ty0 + wpx * 4 + pj;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = i * 8 + rr;
-            const uint4 o = *(const uint4*)(tb16 + row * 128 + ((cc ^ (row & 7)) * 16));
-            const int sx = tx0 + row;
-            if (sy < Hs && sx < Ws) {
-                const size_t oidx = (((size_t)n * Hs + sy) * Ws + sx) * CoutPad + co8;
-                *(uint4*)((unsigned short*)a.out + oidx) = o;
+                const int s0 = g16 * 2;
+                *(uint4*)(tb16 + site * 128 + ((s0 ^ (site & 7)) * 16)) = uint4{pk[0], pk[1], pk[2], pk[3]};
+                *(uint4*)(tb16 + site * 128 + (((s0 + 1) ^ (site & 7)) * 16)) = uint4{pk[4], pk[5], pk[6], pk[7]};
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int sy = ty0 + wpx * 4 + pj;
+            auto line = [&](int i) { const int row = i * 8 + rr; return *(const uint4*)(tb16 + row * 128 + ((cc ^ (row & 7)) * 16)); };
+            const uint4 o0 = line(0), o1 = line(1), o2 = line(2), o3 = line(3);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // all four lines read (and the tile free for the next row) before the first store's bounds check
+            auto put = [&](int i, const uint4& o) {
+                const int sx = tx0 + i * 8 + rr;
+                if (sy < Hs && sx < Ws) *(uint4*)(out00 + (pj * Ws + i * 8) * CoutPad) = o;      // (one 64-bit base per lane, 32-bit strides)
+            };
+            put(0, o0); put(1, o1); put(2, o2); put(3, o3);
+            if (pj == 0) IDC_MSTAMP(6);
+            if (pj == 1) IDC_MSTAMP(7);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    if (has_bn) {
+        if (a.act == 1) rows(std::true_type{}, std::true_type{}); else rows(std::true_type{}, std::false_type{});
+    } else {
+        if (a.act == 1) rows(std::false_type{}, std::true_type{}); else rows(std::false_type{}, std::false_type{});
     }
     IDC_MSTAMP(3);
 #ifdef IDC_TIMING

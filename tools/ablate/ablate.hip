@@ -136,6 +136,8 @@ int main(int argc, char** argv) {
                           cnt, d[0] / cnt, d[1] / cnt, d[2] / cnt, d[3] / cnt, d[4] / cnt, d[5] / cnt, (d[0] + d[1] + d[2] + d[3] + d[4] + d[5]) / cnt); }
 #endif
         if (v2 == 1 && ablv == 1) { double u[3] = {0, 0, 0}; for (int b = 0; b < nb; ++b) { const long long* q = &h[(size_t)b * 16]; u[0] += (double)(q[10] - q[9]); u[1] += (double)(q[11] - q[10]); u[2] += (double)(q[12] - q[11]); }
+            { double e[4] = {0, 0, 0, 0}; for (int b = 0; b < nb; ++b) { const long long* q = &h[(size_t)b * 16]; e[0] += (double)(q[5] - q[2]); e[1] += (double)(q[6] - q[5]); e[2] += (double)(q[7] - q[6]); e[3] += (double)(q[3] - q[7]); }
+              printf("  conv_igemm_v2p epilogue (mean ticks): barrier after the K loop %.0f | pixel row 0 (pack, LDS transpose, stores issued) %.0f | row 1 %.0f | rows 2-3 %.0f\n", e[0] / nb, e[1] / nb, e[2] / nb, e[3] / nb); }
             printf("  conv_igemm_v2p tap 4 of chunk 0 (mean ticks): wait for my LDS-DMA pieces %.0f | workgroup barrier %.0f | reads + DMA issue + 64 MFMAs + tap 5's wait and barrier %.0f\n", u[0] / nb, u[1] / nb, u[2] / nb); }
         if (v2 == 7) { double d[7] = {0, 0, 0, 0, 0, 0, 0}; for (int b = 0; b < nb; ++b) { const long long* q = &h[(size_t)b * 16];
               d[0] += (double)(q[1] - q[0]); d[1] += (double)(q[5] - q[1]); d[2] += (double)(q[2] - q[5]); d[3] += (double)(q[3] - q[2]); d[4] += (double)(q[6] - q[3]); d[5] += (double)(q[4] - q[6]); d[6] += (double)(q[7] - q[4]); }
