@@ -612,7 +612,9 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArg
         if (a.act == 1) partial(std::integral_constant<int, 1>{});
         else if (a.act == 2) partial(std::integral_constant<int, 2>{});
         else partial(std::integral_constant<int, 0>{});
+        IDC_MSTAMP(6);
         __syncthreads();
+        IDC_MSTAMP(7);
         if (wco == 0) {
             const int px = lane & 31, ch = lane >> 5;
             const float hb = a.head_b[ch];
@@ -628,6 +630,11 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArg
                 if (sy < Hs && sx < Ws) a.head_out[(((size_t)n * 2 + ch) * Hs + sy) * Ws + sx] = tanhf(p) * a.head_mul;
             }
         }
+        IDC_MSTAMP(3);
+#ifdef IDC_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        IDC_MSTAMP(4);
+#endif
         return;
     }
     char* const tb16 = smem + wave * 4096;

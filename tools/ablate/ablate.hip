@@ -108,6 +108,12 @@ int main(int argc, char** argv) {
     const int dsm = getenv("IDC_DS_M16") ? atoi(getenv("IDC_DS_M16")) : 0;
     const int ablv = getenv("IDC_ABL_V2") ? atoi(getenv("IDC_ABL_V2")) : 0;      // 0: conv_igemm_v2 (32x32 MFMA), 1: conv_igemm_v2p, 2: conv_igemm_v2m
     if (v2 == 1 && ablv) { void* z; CK(hipMalloc(&z, 256)); CK(hipMemset(z, 0, 256)); a.zeros = z; }
+    if (v2 == 1 && getenv("IDC_ABL_HEAD") && atoi(getenv("IDC_ABL_HEAD"))) {      // conv10_2's real epilogue: LeakyReLU + the 128 -> 2 head + tanh (C must be 128, cfg <2,2>)
+        float *hw_, *hb_, *ho_; CK(hipMalloc(&hw_, 256 * 4)); CK(hipMalloc(&hb_, 8)); CK(hipMalloc(&ho_, (size_t)N * 2 * HW * HW * 4));
+        std::vector<float> hh(256); for (int i = 0; i < 256; ++i) hh[i] = 0.01f * (float)((i * 37) % 19 - 9);
+        CK(hipMemcpy(hw_, hh.data(), 1024, hipMemcpyHostToDevice)); CK(hipMemset(hb_, 0, 8));
+        a.head_w = hw_; a.head_b = hb_; a.head_out = ho_; a.head_mul = 110.f; a.act = 2;
+    }
 #ifdef IDC_TIMING
     int nb = v2 == 7 ? ((HW + 31) / 32) * ((HW + (getenv("IDC_C1_LW") && atoi(getenv("IDC_C1_LW")) == 0 ? 31 : 11)) / (getenv("IDC_C1_LW") && atoi(getenv("IDC_C1_LW")) == 0 ? 32 : 12)) * N : v2 == 6 ? (int)(((HW + halo - 1) / halo + 7) / 8) * (((HW + halo - 1) / halo + 7) / 8) * halo * halo * N * (C / 32) : v2 == 2 ? ((HW + 31) / 32) * ((HW + 3) / 4) * N * (a.ncg / 2) : a.tiles_x * a.tiles_y * N * (a.ncg / wm) * a.nphase * (a.ksplit > 1 ? a.ksplit : 1);
     long long* dbg; CK(hipMalloc(&dbg, (size_t)nb * 128)); CK(hipMemset(dbg, 0, (size_t)nb * 128));
