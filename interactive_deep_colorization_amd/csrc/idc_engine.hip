@@ -1111,7 +1111,11 @@ static hipError_t wait_stream(idc_context* c, int n) {
         for (int i = 0; i < 4000; ++i) {
             const hipError_t e = hipStreamQuery(c->stream);
             if (e != hipErrorNotReady) return e;
+#if defined(__x86_64__) || defined(__i386__)
             for (int k = 0; k < 40; ++k) __builtin_ia32_pause();
+#else
+            for (volatile int k = 0; k < 40; ++k) {}
+#endif
         }
     }
     return hipStreamSynchronize(c->stream);
