@@ -333,3 +333,20 @@ def test_l_plane_is_uploaded_once_per_image_host_logic():
     m.set_image(np.full((16, 16, 3), 30, np.uint8))
     m.net_forward(ab, mask)
     assert m.net.calls[-2:] == ["set_l", "lazy"] and abs(float(m.net.used_L.mean()) - float(np.mean(m.img_l_mc))) < 1e-4
+
+
+def test_throughput_kernels_keep_their_code_shape():
+    """The epilogue regression of rounds 1-5 (a uniform branch per packed pair, scratch for a four-element array: 2 % of the forward, same results) is held off
+    at build time: tools/check_kernel_shape.py passes on the built objects, and its rule fires on a kernel that looks like the old code."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import check_kernel_shape as chk
+    csrc = os.path.join(REPO, "interactive_deep_colorization_amd", "csrc")
+    if not all(os.path.exists(os.path.join(csrc, o)) for o in ("idc_v2m.o", "idc_dsm.o", "idc_kernels.o")):
+        pytest.skip("objects not built here")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "check_kernel_shape.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 findings" in r.stdout
+    old_shape = "0000 <void idc::conv_igemm_v2p<2, 2, 1>(idc::ConvArgs)>:\n" + "\tv_cvt_pk_bf16_f32 v0, v1, v2\n\ts_cbranch_vccnz 12\n" * 400 + "\tscratch_store_dwordx4 off, v[2:5], off\n"
+    stats = {"idc_v2m.o": chk.kernel_stats(old_shape), "idc_dsm.o": {}, "idc_kernels.o": {}}
+    findings, _ = chk.check(stats)
+    assert any("conditional branches" in f for f in findings) and any("scratch" in f for f in findings)
