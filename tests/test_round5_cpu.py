@@ -40,6 +40,16 @@ def test_bench_starts_its_own_ranks_without_torchrun(transport):
         assert line["transport_fallback_reason"]                   # a reason every rank agreed on, not a hang and not an exception
 
 
+def test_bench_control_flow_at_the_drivers_eight_ranks():
+    """... and at the rank count the driver's scaling run ends with: `python bench.py --gpus 8`, no launcher, eight gloo ranks on this box (7 s): every rank
+    reports, every rank holds rank 0's blob, one line, rc 0."""
+    p, line = _bench("--gpus", "8", "--steps", "3", "--warmup", "1", "--control-flow-only")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert line is not None and len([l for l in p.stdout.splitlines() if l.startswith("{")]) == 1
+    assert line["n_gpus"] == 8 and line["ranks_reporting"] == 8 and line["every_rank_holds_rank0_blob"] is True
+    assert line["launched_by"] == "bench.py self_launch" and line["value"] is None
+
+
 def test_bench_single_rank_needs_no_launcher():
     p, line = _bench("--gpus", "1", "--steps", "2", "--control-flow-only")
     assert p.returncode == 0 and line["n_gpus"] == 1 and line["launched_by"] == "external launcher"
