@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define IDC_VERSION 2   /* 2: blob header flags may carry IDC_FLAG_THROUGHPUT_BLOB; round-3 blobs (Winograd images added without a bump) were 1 */
+#define IDC_VERSION 2   /* (round 6 adds precisions 2 / 3 without a bump: older blobs stay valid) 2: blob header flags may carry IDC_FLAG_THROUGHPUT_BLOB; round-3 blobs (Winograd images added without a bump) were 1 */
 
 typedef struct idc_context* idc_handle;
 
@@ -44,7 +44,14 @@ typedef enum idc_status {
 
 /* Arithmetic type of the conv stack.  BF16: bf16 activations+weights, fp32 MFMA accumulation,
  * fp32 bias/BN/shortcut sums.  FP32: exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) end to end.      */
-typedef enum idc_precision { IDC_FP32 = 0, IDC_BF16 = 1 } idc_precision;
+typedef enum idc_precision { IDC_FP32 = 0, IDC_BF16 = 1, IDC_BF16X3 = 2, IDC_BF16X6 = 3 } idc_precision;
+/* BF16X3 / BF16X6 (round 6): the fp32 contract of colorize_image.py:263 carried on the bf16 matrix pipe.  Every fp32 operand travels as a sum of
+ * bf16 values -- x = hi + lo (X3) or hi + mid + lo (X6: all 24 mantissa bits) -- and a product x*w is the sum of the bf16 products that matter:
+ * hi.hi + lo.hi + hi.lo (three v_mfma_f32_16x16x32_bf16 per fragment pair, 2^-16 relative), or those + mid.hi + hi.mid + mid.mid (six, 2^-24:
+ * fp32-equivalent), all into ONE fp32 accumulator set.  Activations between layers are stored split (2 or 3 bf16 planes per pixel), bias / BN /
+ * shortcut sums / the tanh head stay fp32, model1 (4 -> 64 -> 64 channels, 3 % of the MACs) runs on the exact-fp32 kernels.  Throughput path:
+ * every layer runs the large-tile kernels whatever the batch (the batch-1 click path keeps IDC_FP32 / IDC_BF16).  Error against the float64
+ * oracle: X6 at or below IDC_FP32's, X3 <= 1e-3 on the +-110 ab map with torch-default-init weights (tests/bounds.py). */
 
 /* idc_create flags */
 #define IDC_FLAG_DIST_HEAD   0x1u  /* also build model_class (529-bin) head: SIGGRAPHGenerator(dist=True), model.py:105,159-160 */

@@ -36,26 +36,32 @@ BlobPlan make_blob_plan(int precision, unsigned flags) {
     const bool wino_images = !(flags & IDC_FLAG_THROUGHPUT_BLOB) && precision == IDC_FP32;
     const auto& specs = layer_specs();
     size_t off = sizeof(BlobHeader);
-    const int kc = kc_elems(precision);
     for (int i = 0; i < (int)specs.size(); ++i) {
         const LayerSpec& s = specs[i];
         if (s.dist_only == 1 && !(flags & IDC_FLAG_DIST_HEAD)) continue;
         if (s.dist_only == 2 && !(flags & IDC_FLAG_DIST313)) continue;
         LayerBlob lb;
+        // operand-split precisions: model1 is an fp32 island (fp32 images incl. conv1_2's Winograd image), every other layer carries
+        // split_parts() layout-1 bf16 images
+        lb.f32 = is_split(precision) && split_island(s);
+        lb.parts = (is_split(precision) && !lb.f32) ? split_parts(precision) : 1;
+        const int lprec = lb.f32 ? (int)IDC_FP32 : precision;
+        const int kc = kc_elems(lprec);
+        const bool wino_l = lb.f32 ? true : wino_images;
         const int kch = k_channels(s);
         lb.nkc = (s.kind == kConvIm2col) ? (64 / kc) : (kch + kc - 1) / kc;   // conv1_1 operand is 64 wide
         lb.ncg = cout_pad(s.cout) / kCoutGroup;
         lb.w_bytes = (size_t)weight_taps(s.kind) * lb.nkc * lb.ncg * kWBlockBytes;
-        off = align_up(off, 256); lb.w_off = off; off += lb.w_bytes;
+        off = align_up(off, 256); lb.w_off = off; off += lb.w_bytes * lb.parts;
         lb.w2_off = (size_t)-1;
         if (precision == IDC_BF16 && v2_eligible(s)) { off = align_up(off, 256); lb.w2_off = off; off += lb.w_bytes; }
         lb.w3_off = (size_t)-1; lb.w3_bytes = 0;
-        if (wino_images && wino_eligible(s) && s.cin % kc == 0) {                            // fp32: every batch size; bf16: the batch-1 click path
-            lb.w3_bytes = (size_t)s.cin * cout_pad(s.cout) * 16 * elem_bytes(precision);   // 16 transformed values per (cin, cout)
+        if (wino_l && wino_eligible(s) && s.cin % kc == 0) {                            // fp32: every batch size; bf16: the batch-1 click path
+            lb.w3_bytes = (size_t)s.cin * cout_pad(s.cout) * 16 * elem_bytes(lprec);   // 16 transformed values per (cin, cout)
             off = align_up(off, 256); lb.w3_off = off; off += lb.w3_bytes;
         }
-        if (wino_images && wino_deconv_eligible(s) && s.cin % kc == 0) {                      // deconvs: F(2x2,2x2) over the four phases (click path)
-            lb.w3_bytes = (size_t)s.cin * cout_pad(s.cout) * 36 * elem_bytes(precision);
+        if (wino_l && wino_deconv_eligible(s) && s.cin % kc == 0) {                      // deconvs: F(2x2,2x2) over the four phases (click path)
+            lb.w3_bytes = (size_t)s.cin * cout_pad(s.cout) * 36 * elem_bytes(lprec);
             off = align_up(off, 256); lb.w3_off = off; off += lb.w3_bytes;
         }
         off = align_up(off, 256); lb.bias_off = off; off += (size_t)cout_pad(s.cout) * 4;
@@ -100,6 +106,7 @@ static bool dims_are(const TensorView& t, std::initializer_list<int64_t> d) {
 }
 
 // Write one element of the packed weight image (layout 1: small-tile kernels, layout 2: conv_igemm_v2).
+static int g_pack_part = 0;      // operand-split precisions: which bf16 part of the weight put_w stores (0 = hi: rne(v); 1: rne(v - hi); 2: rne(v - hi - mid))
 static inline void put_w(uint8_t* wimg, int precision, int layout, int nkc, int ncg, int tw, int co, int k, float v) {
     const int kc_e = kc_elems(precision), eb = elem_bytes(precision), eps = kSlotBytes / eb;
     const int kc = k / kc_e, kin = k % kc_e;
@@ -117,8 +124,13 @@ static inline void put_w(uint8_t* wimg, int precision, int layout, int nkc, int 
     }
     const size_t off = ((size_t)(tw * nkc + kc) * ncg + cg) * kWBlockBytes + (size_t)lam * kRowBytes +
                        (size_t)sig * kSlotBytes + (size_t)e * eb;
-    if (precision == IDC_BF16) {
-        const uint16_t b = f32_to_bf16_rne(v);
+    if (precision != IDC_FP32) {
+        uint16_t b = f32_to_bf16_rne(v);
+        for (int q = 0; q < g_pack_part; ++q) {                    // (exact: the remainder of a round-to-nearest is representable)
+            uint32_t u = (uint32_t)b << 16; float hi; memcpy(&hi, &u, 4);
+            v -= hi;
+            b = f32_to_bf16_rne(v);
+        }
         memcpy(wimg + off, &b, 2);
     } else {
         memcpy(wimg + off, &v, 4);
@@ -229,7 +241,7 @@ static int fail(std::string* err, int code, const char* fmt, ...) {
 
 static int pack_weights_impl(int precision, unsigned flags, const idc_tensor_desc* tensors, int n_tensors,
                              void* blob, size_t blob_bytes, std::string* err) {
-    if (precision != IDC_FP32 && precision != IDC_BF16) return fail(err, IDC_ERR_INVALID_ARG, "bad precision %d", precision);
+    if (precision < IDC_FP32 || precision > IDC_BF16X6) return fail(err, IDC_ERR_INVALID_ARG, "bad precision %d", precision);
     if (!tensors || n_tensors <= 0 || !blob) return fail(err, IDC_ERR_INVALID_ARG, "null tensors/blob");
     const BlobPlan plan = make_blob_plan(precision, flags);
     if (blob_bytes < plan.total_bytes)
@@ -265,11 +277,16 @@ static int pack_weights_impl(int precision, unsigned flags, const idc_tensor_des
         else ok = dims_are(*w, {s.cout, s.cin, 3, 3});
         if (!ok) return fail(err, IDC_ERR_MISSING_KEY, "key '%s' has the wrong shape", wk.c_str());
         if (!dims_are(*b, {s.cout})) return fail(err, IDC_ERR_MISSING_KEY, "key '%s' has the wrong shape", bk.c_str());
-        pack_layer_weights(base + lb.w_off, precision, 1, s, lb, w->data);
-        if (lb.w2_off != (size_t)-1) pack_layer_weights(base + lb.w2_off, precision, 2, s, lb, w->data);
+        const int lprec = lb.f32 ? (int)IDC_FP32 : precision;        // (operand-split precisions: model1's fp32 island)
+        for (int part = 0; part < lb.parts; ++part) {
+            g_pack_part = part;
+            pack_layer_weights(base + lb.w_off + (size_t)part * lb.w_bytes, lprec, 1, s, lb, w->data);
+        }
+        g_pack_part = 0;
+        if (lb.w2_off != (size_t)-1) pack_layer_weights(base + lb.w2_off, lprec, 2, s, lb, w->data);
         if (lb.w3_off != (size_t)-1) {
-            if (s.kind == kDeconv4x4) pack_wino_deconv_weights(base + lb.w3_off, precision, s, lb, w->data);
-            else pack_wino_weights(base + lb.w3_off, precision, s, lb, w->data);
+            if (s.kind == kDeconv4x4) pack_wino_deconv_weights(base + lb.w3_off, lprec, s, lb, w->data);
+            else pack_wino_weights(base + lb.w3_off, lprec, s, lb, w->data);
         }
         float* bias = (float*)(base + lb.bias_off);
         for (int c = 0; c < s.cout; ++c) bias[c] = b->data[c];
@@ -380,6 +397,7 @@ struct Tensor {
     void* ptr = nullptr;
     int C = 0, Cpad = 0, H = 0, W = 0;
     int is_f32 = 0;                      // fp32 storage (else the context's element type)
+    int parts = 1;                       // operand-split precisions: bf16 planes per pixel ([part][Cpad]); 1 otherwise
     size_t bytes = 0;
 };
 
@@ -401,6 +419,9 @@ struct Layer {
     int fused_short = -1;                // deconv layers: index of the shortcut conv layer riding in this launch's K loop
     bool skip = false;                   // layer fused into another launch: not launched itself
     int fused_next = -1;                 // conv1_1 only: index of conv1_2 when model1 runs as one launch (conv1_block_fused)
+    int lprec = 0;                       // the precision this layer's kernels run in (the handle's; IDC_FP32 on the fp32 island of a split handle)
+    bool split = false;                  // operand-split launch (conv_igemm_v2s / conv_igemm_v2ps)
+    int split_dst = -1;                  // fp32-island layer whose result feeds the split stack: tensor that receives the split copy
     ConvArgs args{};                     // zero-initialised; pointers patched per forward where they depend on weights
     double flops = 0, min_bytes = 0;
 };
@@ -632,7 +653,8 @@ static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, i
     // large-tile bf16 kernel: 256 couts x (32x8 sites) when the cout groups divide by 4, else
     // 128 couts x (32x16 sites); used when its grid covers at least half of the 256 CUs
     L.v2 = false;
-    if (precision == IDC_BF16 && v2_eligible(*L.spec) && g_tile_policy != 1) {
+    const bool split = is_split(precision);      // operand-split precisions: a throughput path, the large tile on every layer whatever the grid
+    if ((precision == IDC_BF16 || split) && v2_eligible(*L.spec) && (split || g_tile_policy != 1)) {
         ConvConfig c2 = (a.ncg % 4 == 0) ? ConvConfig{4, 2} : ConvConfig{2, 4};
         int tx = (Ws + 31) / 32, ty = (Hs + 4 * c2.wp - 1) / (4 * c2.wp);
         long long blocks = (long long)tx * ty * n_policy * (a.ncg / c2.wm) * a.nphase;
@@ -650,7 +672,7 @@ static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, i
             ty = (Hs + 4 * c2.wp - 1) / (4 * c2.wp);
             blocks = (long long)tx * ty * n_policy * (a.ncg / c2.wm) * a.nphase;
         }
-        if (g_tile_policy == 2 || blocks >= tuning().v2_min_blocks) {
+        if (split || g_tile_policy == 2 || blocks >= tuning().v2_min_blocks) {
             L.v2 = true; L.cfg = c2; a.tiles_x = tx; a.tiles_y = ty;
             a.ksplit = 1; a.kc_per = a.nkc;
             return;
@@ -732,12 +754,23 @@ static double layer_flops(const LayerSpec& s, int H, int W) {       // per image
 static int build_graph(idc_context* c) {
     const auto& specs = layer_specs();
     const int eb = elem_bytes(c->precision);
+    const bool split = is_split(c->precision);
     auto add_tensor = [&](const char* name, int C, int Cpad, int level, int f32) -> int {
         Tensor t;
         t.name = name; t.C = C; t.Cpad = Cpad; t.H = c->H / level; t.W = c->W / level; t.is_f32 = f32;
-        t.bytes = (size_t)c->max_batch * t.H * t.W * Cpad * (f32 ? 4 : eb);
+        t.parts = (split && !f32) ? split_parts(c->precision) : 1;
+        t.bytes = (size_t)c->max_batch * t.H * t.W * Cpad * (f32 ? 4 : eb * t.parts);
         c->tensors.push_back(t);
         return (int)c->tensors.size() - 1;
+    };
+    // operand-split precisions: is tensor `name` read by a layer outside the fp32 island / summed into another layer as a shortcut?
+    auto read_by_split_layer = [&](const char* name) {
+        for (int ai : c->plan.active) { const LayerSpec& q = specs[ai]; if (!split_island(q) && strcmp(q.src, name) == 0) return true; }
+        return false;
+    };
+    auto used_as_shortcut = [&](const char* name) {
+        for (int ai : c->plan.active) { const LayerSpec& q = specs[ai]; if (q.resid && strcmp(q.resid, name) == 0) return true; }
+        return false;
     };
     c->t_input = add_tensor("data_l_ab_mask", 36, 64, 1, 0);      // never materialised: built inside conv1_1's operand staging
     c->tensors[c->t_input].bytes = 256;
@@ -753,13 +786,30 @@ static int build_graph(idc_context* c) {
         }
         // fp32 storage: everything on the fp32 path; on the bf16 path the class / 313 logits and the hyper-column
         // partial sums of the 313 head (LayerSpec.out_f32)
-        L.dst = add_tensor(s.name, s.cout, cout_pad(s.cout), s.level, c->precision == IDC_FP32 || s.out_f32);
+        L.lprec = c->precision;
+        if (split && split_island(s)) {
+            // fp32 island (model1): fp32 result; where the split stack reads it, the fp32 tensor gets the suffix ".f32" and the name goes to
+            // its split copy (launch_split_f32 after the layer's launch)
+            L.lprec = IDC_FP32;
+            if (read_by_split_layer(s.name)) {
+                const std::string fname = std::string(s.name) + ".f32";
+                L.dst = add_tensor(fname.c_str(), s.cout, cout_pad(s.cout), s.level, 1);
+                L.split_dst = add_tensor(s.name, s.cout, cout_pad(s.cout), s.level, 0);
+            } else {
+                L.dst = add_tensor(s.name, s.cout, cout_pad(s.cout), s.level, 1);
+            }
+        } else {
+            // fp32 storage: everything on the fp32 path; class / 313 logits and the hyper-column partial sums (LayerSpec.out_f32); on the
+            // operand-split path also every shortcut branch (summed in fp32 in its consumer's epilogue)
+            L.split = split;
+            L.dst = add_tensor(s.name, s.cout, cout_pad(s.cout), s.level, c->precision == IDC_FP32 || s.out_f32 || (split && used_as_shortcut(s.name)));
+        }
         fill_taps(L);
         L.flops = layer_flops(s, c->H, c->W);
         const Tensor& ti = c->tensors[L.src];
         const Tensor& to = c->tensors[L.dst];
         const double in_px = (double)(ti.H / s.in_stride) * (ti.W / s.in_stride);
-        L.min_bytes = in_px * ti.Cpad * (ti.is_f32 ? 4 : eb) + (double)to.H * to.W * to.Cpad * (to.is_f32 ? 4 : eb) +
+        L.min_bytes = in_px * ti.Cpad * (ti.is_f32 ? 4 : eb * ti.parts) + (double)to.H * to.W * to.Cpad * (to.is_f32 ? 4 : eb * to.parts) +
                       (L.resid >= 0 ? (double)to.H * to.W * to.Cpad * (c->tensors[L.resid].is_f32 ? 4 : eb) : 0.0);
         c->layers.push_back(L);
     }
@@ -855,7 +905,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
         const Tensor& to = c->tensors[L.dst];
         const int Hs = L.spec->kind == kDeconv4x4 ? ti.H : to.H;
         const int Ws = L.spec->kind == kDeconv4x4 ? ti.W : to.W;
-        set_geometry(L, c->precision, n, c->max_batch, Hs, Ws);
+        set_geometry(L, L.lprec, n, c->max_batch, Hs, Ws);
         L.fused_short = -1; L.skip = false; L.fused_next = -1;
     }
     // model1 in one launch: conv1_1 (input pack fused) followed by conv1_2 on the small-tile bf16 path, >= 128 big tiles
@@ -879,7 +929,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
         }
     }
     for (auto& L : c->layers) {
-        if (L.spec->kind != kDeconv4x4 || L.resid < 0 || !L.v2 || !fuse_shortcut_enabled()) continue;
+        if (L.spec->kind != kDeconv4x4 || L.resid < 0 || !L.v2 || !fuse_shortcut_enabled() || L.split) continue;   // (split: two launches, fp32 shortcut sum)
         if (L.spec->cout % 128 != 0 || L.spec->bnkey || L.spec->act == 2 || c->tensors[L.dst].is_f32) continue;   // conv_ds_fused's domain
         for (size_t j = 0; j < c->layers.size(); ++j) {
             Layer& P = c->layers[j];
@@ -956,7 +1006,17 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             }
             a.partial = c->d_partial;
         }
-        if (L.fused_short < 0) {
+        if (L.split) {
+            // operand-split launch: nseg passes of the K loop (input part x weight part) into one accumulator set; split in / out tensors
+            a.wgt = c->d_blob + L.blob.w_off;
+            a.in_parts = ti.parts; a.out_parts = (to.is_f32 || L.fused_head) ? 0 : to.parts;
+            a.nseg = split_segments(c->precision); a.seg_x = split_seg_x(c->precision); a.seg_w = split_seg_w(c->precision);
+            a.w_part_bytes = L.blob.w_bytes;
+            if (!L.v2 || !conv_v2s_applies(a))
+                return fail(&c->err, IDC_ERR_INTERNAL, "layer %s: no operand-split kernel covers this launch", L.spec->name);
+            L.m16 = true;
+            L.v2p = g_v2p && conv_v2ps_applies(L.cfg, L.halo, a);
+        } else if (L.fused_short < 0) {
             L.m16 = L.v2 && g_mfma16 && L.fused_next < 0 && !L.wino && !L.click && conv_v2m_applies(a);
             if (L.m16) a.wgt = c->d_blob + L.blob.w_off;            // the layout-1 image (the one conv_igemm / conv_click read)
             L.v2p = L.m16 && g_v2p && conv_v2p_applies(L.cfg, L.halo, a);
@@ -972,7 +1032,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             // Chosen by the handle's max_batch like every other kernel variant, so a result never depends on how many
             // images share the call.
             if (L.fused_next >= 0) le = launch_conv1_block(a, s);
-            else if (L.spec->kind == kConvIm2col && c->precision == IDC_BF16 && a.ksplit <= 1 &&
+            else if (L.spec->kind == kConvIm2col && L.lprec == IDC_BF16 && a.ksplit <= 1 &&
                 (long long)((a.Ws + 31) / 32) * ((a.Hs + 31) / 32) * c->max_batch >= 128)
                 le = launch_conv1_1_bf16(a, s);
             if (L.fused_short >= 0) le = L.m16 ? launch_conv_ds_m(a, s) : launch_conv_ds(a, s);
@@ -980,9 +1040,9 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             if (L.wino) {
                 // a.wgt points at the Winograd U image and L.cfg / tiles were never set for this layer: a refused launch must not fall
                 // through to the direct kernels below -- it is a variant-selection bug and says so
-                if (!conv_wino_applies(c->precision, a, L.spec->kind == kDeconv4x4))
+                if (!conv_wino_applies(L.lprec, a, L.spec->kind == kDeconv4x4))
                     return fail(&c->err, IDC_ERR_INTERNAL, "layer %s: Winograd variant selected for a launch it does not cover", L.spec->name);
-                le = L.spec->kind == kDeconv4x4 ? launch_deconv_wino(c->precision, a, s) : launch_conv_wino(c->precision, a, s);
+                le = L.spec->kind == kDeconv4x4 ? launch_deconv_wino(L.lprec, a, s) : launch_conv_wino(L.lprec, a, s);
                 HIPCHK(c, le);
             }
             if (L.kw) {
@@ -1047,16 +1107,23 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
                 HIPCHK(c, le);
             }
             if (le == hipErrorInvalidConfiguration)
-                le = L.click ? launch_conv_click(c->precision, L.cfg.wp, L.halo, a, s)
+                le = L.split ? (L.v2p ? launch_conv_v2ps(L.cfg, L.halo, a, s) : launch_conv_v2s(L.cfg, L.halo, a, s))
+                   : L.click ? launch_conv_click(L.lprec, L.cfg.wp, L.halo, a, s)
                    : L.v2 ? (L.v2p ? launch_conv_v2p(L.cfg, L.halo, a, s) : L.m16 ? launch_conv_v2m(L.cfg, L.halo, a, s) : launch_conv_v2(L.cfg, L.halo, a, s))
-                          : launch_conv(c->precision, L.cfg, L.halo, a, s);
+                          : launch_conv(L.lprec, L.cfg, L.halo, a, s);
             HIPCHK(c, le);
         }
-        if (a.ksplit > 1) HIPCHK(c, launch_splitk_epilogue(c->precision, a, s));
+        if (a.ksplit > 1) HIPCHK(c, launch_splitk_epilogue(L.lprec, a, s));
+        if (L.split_dst >= 0) {                  // the fp32 island's result enters the split stack
+            const Tensor& ts = c->tensors[L.split_dst];
+            HIPCHK(c, launch_split_f32((const float*)to.ptr, ts.ptr, (long long)n * to.H * to.W, to.Cpad, ts.parts, s));
+        }
         }
         toc();
     }
     tic();
+    if (!head_done && is_split(c->precision))
+        return fail(&c->err, IDC_ERR_INTERNAL, "operand-split forward: the regression head did not ride in conv10_2's launch");
     if (!head_done)
         HIPCHK(c, launch_head(c->precision, c->tensors[c->t_conv10_2].ptr, (const float*)(c->d_blob + c->plan.head_w_off),
                               (const float*)(c->d_blob + c->plan.head_b_off), dout, n, c->H, c->W, c->out_mul, s));
@@ -1313,7 +1380,7 @@ int idc_create(int device_id, int height, int width, int max_batch, int precisio
     if (height <= 0 || width <= 0 || height % 8 || width % 8)
         return fail(nullptr, IDC_ERR_INVALID_ARG, "H and W must be positive multiples of 8 (got %dx%d)", height, width);
     if (max_batch <= 0) return fail(nullptr, IDC_ERR_INVALID_ARG, "max_batch must be positive");
-    if (precision != IDC_FP32 && precision != IDC_BF16) return fail(nullptr, IDC_ERR_INVALID_ARG, "bad precision %d", precision);
+    if (precision < IDC_FP32 || precision > IDC_BF16X6) return fail(nullptr, IDC_ERR_INVALID_ARG, "bad precision %d", precision);
     int rc = check_device(device_id, nullptr);
     if (rc) return rc;
     if (hipSetDevice(device_id) != hipSuccess) return fail(nullptr, IDC_ERR_HIP, "hipSetDevice(%d) failed", device_id);
@@ -1348,7 +1415,7 @@ int idc_set_io_scales(idc_handle h, float l_div, float ab_div, float mask_mul, f
 }
 
 size_t idc_weights_blob_bytes(int precision, unsigned flags) {
-    if (precision != IDC_FP32 && precision != IDC_BF16) return 0;
+    if (precision < IDC_FP32 || precision > IDC_BF16X6) return 0;
     return make_blob_plan(precision, flags).total_bytes;
 }
 
@@ -2153,10 +2220,12 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
             snprintf(out->kernel, sizeof(out->kernel), "conv_kwave_chain_bf16 x%d", L.chain_len);
             out->flops = L.flops; out->min_bytes = L.min_bytes; out->launches = 1;
         } else {
-            snprintf(out->kernel, sizeof(out->kernel), L.kw ? (L.spec->kind == kDeconv4x4 ? "conv_kwave_deconv_bf16" : "conv_kwave_bf16") : L.wino ? (L.spec->kind == kDeconv4x4 ? (h->precision == IDC_BF16 ? "conv_wino_deconv_bf16" : "conv_wino_deconv_f32") : h->precision == IDC_BF16 ? "conv_wino_bf16" : "conv_wino_f32") : L.click ? (h->precision == IDC_BF16 ? "conv_click<bf16,%d,%d>" : "conv_click<f32,%d,%d>")
-                     : L.v2 ? "conv_igemm_v2<%d,%d>" : (h->precision == IDC_BF16 ? "conv_igemm<bf16,%d,%d>" : "conv_igemm<f32,%d,%d>"),
+            snprintf(out->kernel, sizeof(out->kernel), L.kw ? (L.spec->kind == kDeconv4x4 ? "conv_kwave_deconv_bf16" : "conv_kwave_bf16") : L.wino ? (L.spec->kind == kDeconv4x4 ? "conv_wino_deconv_f32" : "conv_wino_f32") : L.click ? (L.lprec == IDC_BF16 ? "conv_click<bf16,%d,%d>" : "conv_click<f32,%d,%d>")
+                     : L.v2 ? "conv_igemm_v2<%d,%d>" : (L.lprec == IDC_BF16 ? "conv_igemm<bf16,%d,%d>" : "conv_igemm<f32,%d,%d>"),
                      L.cfg.wm, L.cfg.wp);
-            if (L.m16) strncat(out->kernel, L.v2p ? "+m16p" : "+m16", sizeof(out->kernel) - strlen(out->kernel) - 1);
+            if (L.split) snprintf(out->kernel, sizeof(out->kernel), L.v2p ? "conv_igemm_v2ps<%d,%d>x%d" : "conv_igemm_v2s<%d,%d>x%d", L.cfg.wm, L.cfg.wp, split_segments(h->precision));
+            else if (L.m16) strncat(out->kernel, L.v2p ? "+m16p" : "+m16", sizeof(out->kernel) - strlen(out->kernel) - 1);
+            if (L.split_dst >= 0) strncat(out->kernel, "+split", sizeof(out->kernel) - strlen(out->kernel) - 1);
             if (L.fused_head) strncat(out->kernel, "+head", sizeof(out->kernel) - strlen(out->kernel) - 1);
             if (L.args.ksplit > 1) {
                 char sk[16]; snprintf(sk, sizeof(sk), " splitK%d", L.args.ksplit);
@@ -2256,7 +2325,7 @@ int idc_get_activation(idc_handle h, const char* name, int n, float* out, size_t
     for (size_t li = 0; li < h->layers.size(); ++li) {      // a tensor the last forward never wrote: say so, do not return stale data
         const Layer& L = h->layers[li];
         if (L.dst != ti) continue;
-        bool fused_away = L.fused_next >= 0;                 // conv1_1 inside conv1_block_fused
+        bool fused_away = L.fused_next >= 0 || L.fused_head; // conv1_1 inside conv1_block_fused; conv10_2 consumed by the head in its own epilogue
         for (const Layer& C : h->layers) fused_away = fused_away || C.fused_short == (int)li;   // shortcut conv inside conv_ds_fused
         if (fused_away)
             return fail(&h->err, IDC_ERR_UNSUPPORTED, "activation '%s' is not materialised: its layer runs fused inside another "
@@ -2271,8 +2340,9 @@ int idc_get_activation(idc_handle h, const char* name, int n, float* out, size_t
         HIPCHK(h, hipMalloc((void**)&h->d_scratch, need * 4));
         h->scratch_bytes = need * 4;
     }
-    const int src_bf16 = (!t.is_f32 && h->precision == IDC_BF16) ? 1 : 0;
-    HIPCHK(h, launch_nhwc_to_nchw(src_bf16, t.ptr, h->d_scratch, n, t.C, t.H, t.W, t.Cpad, h->stream));
+    const int src_bf16 = (!t.is_f32 && h->precision != IDC_FP32) ? 1 : 0;
+    if (t.parts > 1) HIPCHK(h, launch_split_to_nchw(t.ptr, h->d_scratch, n, t.C, t.H, t.W, t.Cpad, t.parts, h->stream));
+    else HIPCHK(h, launch_nhwc_to_nchw(src_bf16, t.ptr, h->d_scratch, n, t.C, t.H, t.W, t.Cpad, h->stream));
     HIPCHK(h, hipMemcpyAsync(out, h->d_scratch, need * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (C) *C = t.C;
@@ -2288,8 +2358,11 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
                          const float* resid, float* y) {
     int rc = check_device(device_id, nullptr);
     if (rc) return rc;
-    if (precision != IDC_FP32 && precision != IDC_BF16) return fail(nullptr, IDC_ERR_INVALID_ARG, "bad precision");
+    if (precision < IDC_FP32 || precision > IDC_BF16X6) return fail(nullptr, IDC_ERR_INVALID_ARG, "bad precision");
     if (!x || !weight || !bias || !y || n <= 0 || h <= 0 || w <= 0) return fail(nullptr, IDC_ERR_INVALID_ARG, "bad argument");
+    const bool split = is_split(precision);
+    const int parts = split_parts(precision);
+    if (split && !v2_eligible(spec)) return fail(nullptr, IDC_ERR_UNSUPPORTED, "operand-split precisions run the large tile only: cout >= 65");
     const int kc = kc_elems(precision), eb = elem_bytes(precision);
     if (spec.cin % kc) return fail(nullptr, IDC_ERR_UNSUPPORTED, "cin must be a multiple of %d in this precision", kc);
     if (spec.in_stride != 1 && spec.in_stride != 2) return fail(nullptr, IDC_ERR_INVALID_ARG, "in_stride must be 1 or 2");
@@ -2307,12 +2380,13 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     L.blob.w_off = 0; L.blob.w2_off = (size_t)-1; L.blob.bias_off = L.blob.bn_scale_off = L.blob.bn_shift_off = L.blob.fbias_off = (size_t)-1;
     const int cpad = cout_pad(spec.cout);
     // fp32 3x3 stride-1 ops without a shortcut sum take the Winograd kernel exactly as inside the network
-    const bool wino_dc = wino_deconv_eligible(spec) && spec.cin % kc == 0;
-    const bool wino_ok = (wino_eligible(spec) && spec.cin % kc == 0 && resid == nullptr) || wino_dc;
+    const bool wino_dc = !split && wino_deconv_eligible(spec) && spec.cin % kc == 0;
+    const bool wino_ok = !split && ((wino_eligible(spec) && spec.cin % kc == 0 && resid == nullptr) || wino_dc);
     L.blob.w3_off = wino_ok ? 0 : (size_t)-1;
     L.blob.w3_bytes = wino_ok ? (size_t)spec.cin * cpad * (wino_dc ? 36 : 16) * eb : 0;
     if (wino_ok && L.blob.w3_bytes > L.blob.w_bytes) L.blob.w_bytes = L.blob.w3_bytes;      // one staging buffer serves either image
-    std::vector<uint8_t> wimg(L.blob.w_bytes);
+    std::vector<uint8_t> wimg(L.blob.w_bytes * parts);
+    L.lprec = precision; L.split = split;
     const int Hs = h / spec.in_stride, Ws = w / spec.in_stride;
     const int so = spec.kind == kDeconv4x4 ? 2 : 1;
     const int Ho = Hs * so, Wo = Ws * so;
@@ -2322,8 +2396,12 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     else if (L.wino) pack_wino_weights(wimg.data(), precision, spec, L.blob, weight);
     else {
         if (wino_ok) L.blob.w_bytes = (size_t)weight_taps(spec.kind) * L.blob.nkc * L.blob.ncg * kWBlockBytes;
-        L.m16 = L.v2 && g_mfma16 && resid == nullptr && spec.act != 2;       // as in the network: conv_igemm_v2m where it applies
-        pack_layer_weights(wimg.data(), precision, (L.v2 && !L.m16) ? 2 : 1, spec, L.blob, weight);
+        L.m16 = split || (L.v2 && g_mfma16 && resid == nullptr && spec.act != 2);       // as in the network: conv_igemm_v2m where it applies
+        for (int part = 0; part < parts; ++part) {
+            g_pack_part = part;
+            pack_layer_weights(wimg.data() + (size_t)part * L.blob.w_bytes, precision, (L.v2 && !L.m16) ? 2 : 1, spec, L.blob, weight);
+        }
+        g_pack_part = 0;
     }
     std::vector<float> hb(cpad, 0.f), hs(cpad, 1.f), ht(cpad, 0.f);
     for (int c = 0; c < spec.cout; ++c) {
@@ -2333,18 +2411,19 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     DevBuf d_x, d_xn, d_w, d_b, d_s, d_t, d_r, d_rn, d_yn, d_y;
     const size_t xin = (size_t)n * spec.cin * h * w, yout = (size_t)n * spec.cout * Ho * Wo;
     HIPCHK(nullctx, d_x.alloc(xin * 4));
-    HIPCHK(nullctx, d_xn.alloc(xin * eb));
-    HIPCHK(nullctx, d_w.alloc(L.blob.w_bytes));
+    HIPCHK(nullctx, d_xn.alloc(xin * eb * parts));
+    HIPCHK(nullctx, d_w.alloc(L.blob.w_bytes * parts));
     HIPCHK(nullctx, d_b.alloc(cpad * 4)); HIPCHK(nullctx, d_s.alloc(cpad * 4)); HIPCHK(nullctx, d_t.alloc(cpad * 4));
-    HIPCHK(nullctx, d_yn.alloc((size_t)n * Ho * Wo * cpad * 4));
+    HIPCHK(nullctx, d_yn.alloc((size_t)n * Ho * Wo * cpad * (split ? 2 * parts : 4)));
     HIPCHK(nullctx, d_y.alloc(yout * 4));
     HIPCHK(nullctx, hipMemcpy(d_x.p, x, xin * 4, hipMemcpyHostToDevice));
-    HIPCHK(nullctx, hipMemcpy(d_w.p, wimg.data(), L.blob.w_bytes, hipMemcpyHostToDevice));
+    HIPCHK(nullctx, hipMemcpy(d_w.p, wimg.data(), L.blob.w_bytes * parts, hipMemcpyHostToDevice));
     HIPCHK(nullctx, hipMemcpy(d_b.p, hb.data(), cpad * 4, hipMemcpyHostToDevice));
     HIPCHK(nullctx, hipMemcpy(d_s.p, hs.data(), cpad * 4, hipMemcpyHostToDevice));
     HIPCHK(nullctx, hipMemcpy(d_t.p, ht.data(), cpad * 4, hipMemcpyHostToDevice));
-    HIPCHK(nullctx, launch_nchw_to_nhwc(precision, (const float*)d_x.p, d_xn.p, n, spec.cin, h, w, spec.cin, nullptr));
-    // bf16 precision: the residual arrives and the output leaves in bf16, as inside the network
+    if (split) HIPCHK(nullctx, launch_nchw_to_split((const float*)d_x.p, d_xn.p, n, spec.cin, h, w, spec.cin, parts, nullptr));
+    else HIPCHK(nullctx, launch_nchw_to_nhwc(precision, (const float*)d_x.p, d_xn.p, n, spec.cin, h, w, spec.cin, nullptr));
+    // bf16 precision: the residual arrives and the output leaves in bf16, as inside the network (operand-split: fp32 residual, split output)
     const int io_bf16 = precision == IDC_BF16 ? 1 : 0;
     if (resid) {
         HIPCHK(nullctx, d_r.alloc(yout * 4));
@@ -2361,7 +2440,11 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_mul = 0.f;
     a.in2 = nullptr; a.wgt2 = nullptr; a.nkc2 = 0;
     a.warm = g_code_warm;
-    a.out_f32 = io_bf16 ? 0 : 1;
+    a.out_f32 = (io_bf16 || split) ? 0 : 1;
+    if (split) {
+        a.in_parts = parts; a.out_parts = parts; a.nseg = split_segments(precision); a.seg_x = split_seg_x(precision); a.seg_w = split_seg_w(precision);
+        a.w_part_bytes = L.blob.w_bytes;
+    }
     DevBuf d_part, d_zero;
     if (a.ksplit > 1) {
         HIPCHK(nullctx, d_part.alloc((size_t)a.ksplit * n * Ho * Wo * cpad * 4));
@@ -2372,16 +2455,19 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     a.zeros = d_zero.p;
     if (L.wino && !conv_wino_applies(precision, a, wino_dc))
         return fail(nullptr, IDC_ERR_INTERNAL, "single op: Winograd variant selected for a launch it does not cover");
-    if (L.m16 && !conv_v2m_applies(a))
+    if (split && (!L.v2 || !conv_v2s_applies(a)))
+        return fail(nullptr, IDC_ERR_INTERNAL, "single op: no operand-split kernel covers this launch");
+    if (!split && L.m16 && !conv_v2m_applies(a))
         return fail(nullptr, IDC_ERR_INTERNAL, "single op: conv_igemm_v2m selected for a launch it does not cover");
-    L.v2p = L.m16 && g_v2p && conv_v2p_applies(L.cfg, L.halo, a);
+    L.v2p = split ? (g_v2p && conv_v2ps_applies(L.cfg, L.halo, a)) : (L.m16 && g_v2p && conv_v2p_applies(L.cfg, L.halo, a));
     if (L.kw && !conv_kwave_applies(a))
         return fail(nullptr, IDC_ERR_INTERNAL, "single op: conv_kwave_bf16 selected for a launch it does not cover");
-    HIPCHK(nullctx, L.kw ? launch_conv_kwave(a, nullptr) : L.wino ? (wino_dc ? launch_deconv_wino(precision, a, nullptr) : launch_conv_wino(precision, a, nullptr)) : L.click ? launch_conv_click(precision, L.cfg.wp, L.halo, a, nullptr)
+    HIPCHK(nullctx, split ? (L.v2p ? launch_conv_v2ps(L.cfg, L.halo, a, nullptr) : launch_conv_v2s(L.cfg, L.halo, a, nullptr)) : L.kw ? launch_conv_kwave(a, nullptr) : L.wino ? (wino_dc ? launch_deconv_wino(precision, a, nullptr) : launch_conv_wino(precision, a, nullptr)) : L.click ? launch_conv_click(precision, L.cfg.wp, L.halo, a, nullptr)
                     : L.v2 ? (L.v2p ? launch_conv_v2p(L.cfg, L.halo, a, nullptr) : L.m16 ? launch_conv_v2m(L.cfg, L.halo, a, nullptr) : launch_conv_v2(L.cfg, L.halo, a, nullptr))
                            : launch_conv(precision, L.cfg, L.halo, a, nullptr));
     if (a.ksplit > 1) HIPCHK(nullctx, launch_splitk_epilogue(precision, a, nullptr));
-    HIPCHK(nullctx, launch_nhwc_to_nchw(io_bf16, d_yn.p, (float*)d_y.p, n, spec.cout, Ho, Wo, cpad, nullptr));
+    if (split) HIPCHK(nullctx, launch_split_to_nchw(d_yn.p, (float*)d_y.p, n, spec.cout, Ho, Wo, cpad, parts, nullptr));
+    else HIPCHK(nullctx, launch_nhwc_to_nchw(io_bf16, d_yn.p, (float*)d_y.p, n, spec.cout, Ho, Wo, cpad, nullptr));
     HIPCHK(nullctx, hipMemcpy(y, d_y.p, yout * 4, hipMemcpyDeviceToHost));
     HIPCHK(nullctx, hipDeviceSynchronize());
     return IDC_OK;

@@ -60,6 +60,14 @@ struct ConvArgs {
     const float* head_b;    // [2]
     float* head_out;        // NCHW fp32 [N][2][Hs][Ws]
     float head_mul;
+    // operand-split precisions (IDC_BF16X3 / IDC_BF16X6, conv_igemm_v2s / conv_igemm_v2ps in idc_v2m.hip): an fp32 value x travels as
+    // `parts` bf16 values x = hi (+ mid) + lo; a pixel of a split tensor is [part][Cpad] bf16.  The K loop runs `nseg` segments of nkc
+    // chunks each; segment s multiplies input part (seg_x >> 4s & 15) with weight part (seg_w >> 4s & 15) -- 3 segments (hi.hi, lo.hi,
+    // hi.lo) or 6 (+ mid.hi, hi.mid, mid.mid), all into ONE fp32 accumulator set.  Weight part p starts w_part_bytes * p after a.wgt.
+    // out_parts: parts written (0 with out_f32 / a fused head).  The shortcut sum (a.resid) is fp32 in these launches.
+    int in_parts, out_parts, nseg;
+    unsigned seg_x, seg_w;
+    unsigned long long w_part_bytes;
     int warm;               // != 0: the throughput kernels pull their own code into L2 at entry (idc_warm_own_code below)
     const void* zeros;      // >= 16 zero bytes in device memory: LDS-DMA source of out-of-image halo rows (conv_click)
     int dy[36], dx[36], tw[36];   // [phase*9 + t]: tap offset in sites, packed-weight tap index
@@ -101,6 +109,15 @@ bool conv_v2m_applies(const ConvArgs& a);
 hipError_t launch_conv_v2p(ConvConfig cfg, int halo, const ConvArgs& a, hipStream_t s);
 bool conv_v2p_applies(ConvConfig cfg, int halo, const ConvArgs& a);
 hipError_t init_kernels_v2m();
+// Operand-split form of the same tiles (conv_igemm_v2s: every geometry conv_igemm_v2m covers; conv_igemm_v2ps: the 3x3 forms of
+// conv_igemm_v2p): a.in / a.out are split tensors (in_parts / out_parts), a.wgt the layout-1 images of the weight parts, shortcut sum
+// fp32, fp32 output / per-image shift / LeakyReLU / fused head supported.  hipErrorInvalidConfiguration if the launch does not qualify.
+hipError_t launch_conv_v2s(ConvConfig cfg, int halo, const ConvArgs& a, hipStream_t s);
+hipError_t launch_conv_v2ps(ConvConfig cfg, int halo, const ConvArgs& a, hipStream_t s);
+bool conv_v2s_applies(const ConvArgs& a);
+bool conv_v2ps_applies(ConvConfig cfg, int halo, const ConvArgs& a);
+// fp32 NHWC [npix][Cpad] -> split bf16 [npix][parts][Cpad] (model1's fp32 result on its way into the split stack)
+hipError_t launch_split_f32(const float* src, void* dst, long long npix, int Cpad, int parts, hipStream_t s);
 // ConvTranspose 4x4 s2 + the 3x3 shortcut conv it is summed with, one K loop (conv_ds_fused); a.in2 / wgt2 / nkc2 = the
 // shortcut's input, layout-2 weights and channel chunks, a.bias = the two biases added.  hipErrorInvalidConfiguration if
 // the launch does not qualify.
@@ -226,5 +243,9 @@ hipError_t launch_nchw_to_nhwc(int precision, const float* src, void* dst, int N
                                int Cpad, hipStream_t s);
 hipError_t launch_nhwc_to_nchw(int src_is_bf16, const void* src, float* dst, int N, int C, int H,
                                int W, int Cstride, hipStream_t s);
+// ... of a split tensor: dst = sum over the `parts` bf16 planes of a pixel (fp32 sum, hi first)
+hipError_t launch_split_to_nchw(const void* src, float* dst, int N, int C, int H, int W, int Cpad, int parts, hipStream_t s);
+// fp32 NCHW -> split NHWC (single-operator test entry points)
+hipError_t launch_nchw_to_split(const float* src, void* dst, int N, int C, int H, int W, int Cpad, int parts, hipStream_t s);
 
 }  // namespace idc

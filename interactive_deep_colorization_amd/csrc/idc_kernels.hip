@@ -2964,4 +2964,79 @@ hipError_t launch_nhwc_to_nchw(int src_is_bf16, const void* src, float* dst, int
     return hipGetLastError();
 }
 
+// ---- operand-split tensors (IDC_BF16X3 / IDC_BF16X6): a pixel is [parts][Cpad] bf16, x = part 0 + part 1 (+ part 2) ----------------
+__device__ __forceinline__ unsigned short bf16_rne_bits(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+
+// fp32 NHWC -> split: 8 channels per thread (two float4 in, one uint4 per part out); HBM-bound, on the hot path once per forward
+// (model1's fp32 result entering the split stack)
+__global__ __launch_bounds__(256) void split_f32_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long long n8, int c8, int parts) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const long long pix = i / c8;
+        const int cg = (int)(i - pix * c8);
+        const float4 a = *(const float4*)(src + i * 8), b = *(const float4*)(src + i * 8 + 4);
+        float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        for (int p = 0; p < parts; ++p) {
+            unsigned short h[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { h[e] = bf16_rne_bits(v[e]); v[e] -= __uint_as_float((unsigned)h[e] << 16); }
+            uint4 o;
+            o.x = h[0] | ((unsigned)h[1] << 16); o.y = h[2] | ((unsigned)h[3] << 16);
+            o.z = h[4] | ((unsigned)h[5] << 16); o.w = h[6] | ((unsigned)h[7] << 16);
+            *(uint4*)(dst + ((pix * parts + p) * c8 + cg) * 8) = o;
+        }
+    }
+}
+
+hipError_t launch_split_f32(const float* src, void* dst, long long npix, int Cpad, int parts, hipStream_t s) {
+    if (Cpad % 8 || parts < 1 || parts > 3) return hipErrorInvalidValue;
+    const long long n8 = npix * (Cpad / 8);
+    const int blocks = (int)((n8 + 255) / 256 < 262144 ? (n8 + 255) / 256 : 262144);
+    hipLaunchKernelGGL(split_f32_kernel, dim3(blocks), dim3(256), 0, s, src, (unsigned short*)dst, n8, Cpad / 8, parts);
+    return hipGetLastError();
+}
+
+// test entry points / activation dumps only
+__global__ void split_to_nchw_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, int N, int C, int H, int W, int Cpad, int parts) {
+    const long long total = (long long)N * C * H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long hw = (long long)H * W;
+        const long long r = i % hw;
+        const int c = (int)((i / hw) % C);
+        const long long n = i / (hw * C);
+        float v = 0.f;
+        for (int p = 0; p < parts; ++p) v += __uint_as_float((unsigned)src[((n * hw + r) * parts + p) * Cpad + c] << 16);
+        dst[i] = v;
+    }
+}
+
+hipError_t launch_split_to_nchw(const void* src, float* dst, int N, int C, int H, int W, int Cpad, int parts, hipStream_t s) {
+    const long long total = (long long)N * C * H * W;
+    const int blocks = (int)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
+    hipLaunchKernelGGL(split_to_nchw_kernel, dim3(blocks), dim3(256), 0, s, (const unsigned short*)src, dst, N, C, H, W, Cpad, parts);
+    return hipGetLastError();
+}
+
+__global__ void nchw_to_split_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int N, int C, int H, int W, int Cpad, int parts) {
+    const long long total = (long long)N * H * W * Cpad;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cpad);
+        const long long pix = i / Cpad;
+        const long long hw = (long long)H * W;
+        const long long n = pix / hw, r = pix - n * hw;
+        float v = c < C ? src[(n * C + c) * hw + r] : 0.f;
+        for (int p = 0; p < parts; ++p) {
+            const unsigned short h = bf16_rne_bits(v);
+            v -= __uint_as_float((unsigned)h << 16);
+            dst[(pix * parts + p) * Cpad + c] = h;
+        }
+    }
+}
+
+hipError_t launch_nchw_to_split(const float* src, void* dst, int N, int C, int H, int W, int Cpad, int parts, hipStream_t s) {
+    const long long total = (long long)N * H * W * Cpad;
+    const int blocks = (int)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
+    hipLaunchKernelGGL(nchw_to_split_kernel, dim3(blocks), dim3(256), 0, s, src, (unsigned short*)dst, N, C, H, W, Cpad, parts);
+    return hipGetLastError();
+}
+
 }  // namespace idc

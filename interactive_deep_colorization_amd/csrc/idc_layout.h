@@ -49,7 +49,15 @@ __host__ __device__ inline int cg_cout_to_row2(int col) {
     return mi * 32 + (r >> 2) * 8 + hh * 4 + (r & 3);
 }
 
-inline int elem_bytes(int precision) { return precision == 1 ? 2 : 4; }       // IDC_BF16 == 1
+inline int elem_bytes(int precision) { return precision == 0 ? 4 : 2; }       // IDC_FP32 == 0; IDC_BF16 and the operand-split precisions store bf16
+// operand-split precisions (IDC_BF16X3 = 2: x = hi + lo, three products; IDC_BF16X6 = 3: hi + mid + lo, six products)
+inline bool is_split(int precision) { return precision == 2 || precision == 3; }
+inline int split_parts(int precision) { return precision == 2 ? 2 : precision == 3 ? 3 : 1; }
+// K segments (input part, weight part), 4 bits each, segment 0 in the low nibble.  Small products first is not needed: every partial sum lands in the
+// same fp32 accumulator whose rounding unit is set by the hi.hi total.
+inline int split_segments(int precision) { return precision == 2 ? 3 : precision == 3 ? 6 : 1; }
+inline unsigned split_seg_x(int precision) { return precision == 2 ? 0x010u : precision == 3 ? 0x010210u : 0u; }   // X3: hi, lo, hi      X6: hi, mid, lo, hi, mid, hi
+inline unsigned split_seg_w(int precision) { return precision == 2 ? 0x100u : precision == 3 ? 0x211000u : 0u; }   // X3: hi, hi, lo      X6: hi, hi,  hi, mid, mid, lo
 inline int kc_elems(int precision) { return kRowBytes / elem_bytes(precision); }  // 64 or 32
 
 // fp32 -> bf16, round to nearest even (matches v_cvt_pk_bf16_f32 for finite values)

@@ -87,6 +87,9 @@ inline bool wino_eligible(const LayerSpec& s) { return s.kind == kConv3x3 && s.r
 inline bool wino_deconv_eligible(const LayerSpec& s) { return s.kind == kDeconv4x4 && s.cin % 32 == 0; }
 // layers the bf16 large-tile kernel (conv_igemm_v2, >= 128 couts per workgroup) can run
 inline bool v2_eligible(const LayerSpec& s) { return s.kind != kConvIm2col && cout_pad(s.cout) >= 128; }
+// operand-split precisions: layers the large tile cannot run (model1: conv1_1's K = 36 im2col and the 64-cout conv1_2, 3.4 % of the MACs) form an
+// exact-fp32 "island" -- fp32 weights, fp32 activations, the fp32 kernels -- whose last result is split once on its way into the stack
+inline bool split_island(const LayerSpec& s) { return !v2_eligible(s); }
 
 // Where one layer's parameters live inside the packed blob (byte offsets).
 struct LayerBlob {
@@ -98,6 +101,8 @@ struct LayerBlob {
     size_t bn_scale_off, bn_shift_off;   // fp32 [cout_pad] or (size_t)-1
     size_t fbias_off;             // layers with a shortcut sum: fp32 [cout_pad] = bias + the shortcut conv's bias, or (size_t)-1
     int nkc, ncg;
+    int parts = 1;                // operand-split precisions: weight parts (hi, [mid,] lo), each w_bytes long, contiguous from w_off
+    int f32 = 0;                  // operand-split precisions: this layer belongs to the fp32 island (fp32 images, fp32 chunk size)
 };
 
 struct BlobPlan {

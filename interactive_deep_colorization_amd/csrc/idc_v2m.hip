@@ -58,8 +58,112 @@ __device__ __forceinline__ unsigned pack_bf16x2_m(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_pk){lo, hi}, bf16x2_pk));
 }
 
-template <int WCO, int WPX, int HALO>
-__global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2m(const ConvArgs a) {
+// Epilogue of the operand-split kernels: lane (site r16, group g16) holds couts g16*16 + mi*4 + j of its wave's 64 at site (pixel row pt >> 1,
+// column (pt & 1)*16 + r16) in acc[mi][pt][j].  value = BN(act(acc + fp32 shortcut sum)) + per-image shift, all fp32; then either an fp32 NHWC store
+// straight from the MFMA layout (out_parts = 0) or out_parts bf16 planes hi = rne(v), next = rne(v - hi), ... (each remainder is exact in fp32), every
+// plane through the wave-private [32 sites][64 couts] bf16 transpose tile so that stores cover whole 128-byte lines.
+template <int WCO>
+__device__ __forceinline__ void split_epilogue(const ConvArgs& a, f32x4 (&acc)[4][8], char* smem, int n, int ty0, int tx0, int wpx, int cow, int ro, int cof) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g16 = lane >> 4;
+    const int Hs = a.Hs, Ws = a.Ws, so = a.so, Wout = Ws * so, Hout = Hs * so;
+    const int CoutPad = a.ncg * kCoutGroup;
+    const int np = a.out_parts;
+    const float* const resid = (const float*)a.resid;
+    const bool has_bn = a.bn_scale != nullptr, has_shift = a.img_shift != nullptr;
+    f32x4 bsc[4], bsh[4], ish[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        bsc[mi] = f32x4{1.f, 1.f, 1.f, 1.f}; bsh[mi] = f32x4{0.f, 0.f, 0.f, 0.f}; ish[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (has_bn) {
+            const float4 s4 = *(const float4*)(a.bn_scale + cow + g16 * 16 + mi * 4);
+            const float4 t4 = *(const float4*)(a.bn_shift + cow + g16 * 16 + mi * 4);
+            bsc[mi] = f32x4{s4.x, s4.y, s4.z, s4.w}; bsh[mi] = f32x4{t4.x, t4.y, t4.z, t4.w};
+        }
+        if (has_shift) {
+            const float4 u4 = *(const float4*)(a.img_shift + (size_t)n * CoutPad + cow + g16 * 16 + mi * 4);
+            ish[mi] = f32x4{u4.x, u4.y, u4.z, u4.w};
+        }
+    }
+    char* const tb16 = smem + wave * 4096;
+    const int rr = lane >> 3, cc = lane & 7;
+    const int co8 = cow + cc * 8;
+    auto rows = [&](auto act_c) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(act_c)::value;
+#pragma unroll
+        for (int pj = 0; pj < 4; ++pj) {
+            const int sy = ty0 + wpx * 4 + pj;
+            f32x4 v[2][4];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int pt = pj * 2 + hf, sx = tx0 + hf * 16 + r16;
+                const bool inb = sy < Hs && sx < Ws;
+                const size_t opix = ((size_t)n * Hout + (sy * so + ro)) * Wout + (sx * so + cof);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    f32x4 x = acc[mi][pt];
+                    if (resid != nullptr && inb) {
+                        const float4 q = *(const float4*)(resid + opix * CoutPad + cow + g16 * 16 + mi * 4);
+                        x += f32x4{q.x, q.y, q.z, q.w};
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float e = x[j];
+                        if constexpr (ACT == 1) e = fmaxf(e, 0.f);
+                        else if constexpr (ACT == 2) e = fmaxf(e, 0.2f * e);
+                        x[j] = fmaf(e, bsc[mi][j], bsh[mi][j]) + ish[mi][j];
+                    }
+                    v[hf][mi] = x;
+                }
+                if (np == 0 && inb) {
+                    float* const op = (float*)a.out + opix * CoutPad + cow + g16 * 16;
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) *(float4*)(op + mi * 4) = float4{v[hf][mi][0], v[hf][mi][1], v[hf][mi][2], v[hf][mi][3]};
+                }
+            }
+            for (int p = 0; p < np; ++p) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int site = hf * 16 + r16;
+                    unsigned pk[8];
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const unsigned q = pack_bf16x2_m(v[hf][mi][2 * e], v[hf][mi][2 * e + 1]);
+                            pk[mi * 2 + e] = q;
+                            v[hf][mi][2 * e] -= __uint_as_float(q << 16);              // exact: the remainder of a round-to-nearest fits fp32
+                            v[hf][mi][2 * e + 1] -= __uint_as_float(q & 0xffff0000u);
+                        }
+                    const int s0 = g16 * 2;
+                    *(uint4*)(tb16 + site * 128 + ((s0 ^ (site & 7)) * 16)) = uint4{pk[0], pk[1], pk[2], pk[3]};
+                    *(uint4*)(tb16 + site * 128 + (((s0 + 1) ^ (site & 7)) * 16)) = uint4{pk[4], pk[5], pk[6], pk[7]};
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                auto line = [&](int i) { const int row = i * 8 + rr; return *(const uint4*)(tb16 + row * 128 + ((cc ^ (row & 7)) * 16)); };
+                const uint4 o0 = line(0), o1 = line(1), o2 = line(2), o3 = line(3);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                auto put = [&](int i, const uint4& o) {
+                    const int sx = tx0 + i * 8 + rr;
+                    if (sy < Hs && sx < Ws) {
+                        const size_t oidx = ((((size_t)n * Hout + (sy * so + ro)) * Wout + (sx * so + cof)) * np + p) * CoutPad + co8;
+                        *(uint4*)((unsigned short*)a.out + oidx) = o;
+                    }
+                };
+                put(0, o0); put(1, o1); put(2, o2); put(3, o3);
+            }
+        }
+    };
+    if (a.act == 1) rows(std::integral_constant<int, 1>{});
+    else if (a.act == 2) rows(std::integral_constant<int, 2>{});
+    else rows(std::integral_constant<int, 0>{});
+}
+
+// SPLIT = false: conv_igemm_v2m as described above.  SPLIT = true: conv_igemm_v2s, the operand-split form (IDC_BF16X3 / IDC_BF16X6) -- the same
+// tile and K-loop body walked over a.nseg segments of nkc chunks (input part x weight part per segment, ConvArgs), and its own epilogue.
+template <int WCO, int WPX, int HALO, bool SPLIT>
+__device__ __forceinline__ void conv_v2m_body(const ConvArgs& a) {
     constexpr int NT = WCO * WPX * 64;
     constexpr int TW = 32, TH = 4 * WPX;
     constexpr int HWP = TW + 2 * HALO, HHP = TH + 2 * HALO, HROWS = HWP * HHP;
@@ -97,7 +201,8 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2m(const ConvArg
     const int nkc = a.nkc, ntaps = a.ntaps, si = a.si;
     const size_t w_kc_stride = (size_t)a.ncg * kWBlockBytes;
     const char* const wb = (const char*)a.wgt + (size_t)(ct * WCO) * kWBlockBytes + (size_t)tid * kSlotBytes;
-    const char* const img = (const char*)a.in + (size_t)n * (size_t)(Hs * si) * (Ws * si) * ((size_t)nkc * kRowBytes);
+    const int pix_chunks = SPLIT ? a.in_parts * nkc : nkc;     // 128-byte chunks per input pixel (split tensors: [part][chunk])
+    const char* const img = (const char*)a.in + (size_t)n * (size_t)(Hs * si) * (Ws * si) * ((size_t)pix_chunks * kRowBytes);
 
     // accumulators start at the bias: lane (site r16, group g16) register j of acc[mi][.] is cout g16*16 + mi*4 + j of the wave's 64
     f32x4 acc[4][8];
@@ -112,8 +217,9 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2m(const ConvArg
         }
     }
 
+    size_t wpart = 0;                          // SPLIT: byte offset of the current segment's weight part
     auto dma_w = [&](int tw, int kc, int buf) {
-        const char* src = wb + ((size_t)tw * nkc + kc) * w_kc_stride;
+        const char* src = wb + ((size_t)tw * nkc + kc) * w_kc_stride + (SPLIT ? wpart : (size_t)0);
         char* dst = wbuf + buf * W_BYTES + wave * 64 * kSlotBytes;
 #pragma unroll
         for (int j = 0; j < N_WITEMS; ++j)
@@ -122,7 +228,7 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2m(const ConvArg
     };
     u32x4 hreg[N_HITEMS];
     auto load_halo = [&](int kc) {
-        const int Win = Ws * si, pix_bytes = nkc * kRowBytes;
+        const int Win = Ws * si, pix_bytes = pix_chunks * kRowBytes;
         int tid_ = tid;
         if constexpr (NT == 256 && HALO == 2) asm volatile("" : "+v"(tid_));   // as conv_igemm_v2: recompute the 14 item addresses per chunk
 #pragma unroll
@@ -137,7 +243,10 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2m(const ConvArg
         }
     };
 
-    load_halo(0);
+    // SPLIT: the K loop below runs once per segment; xoff = first chunk of the segment's input part inside a pixel
+    int seg = 0, xoff = 0;
+    if constexpr (SPLIT) { xoff = (int)(a.seg_x & 15u) * nkc; wpart = (size_t)(a.seg_w & 15u) * (size_t)a.w_part_bytes; }
+    load_halo(xoff);
     dma_w(tap_tw[0], 0, 0);
 
     const int wrow16 = (wco * 64 + r16) * kRowBytes;           // + mi*16 rows; swz(row) = r16 & 7 for all of them
@@ -157,11 +266,23 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2m(const ConvArg
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);              // second-dispatched half of an 8-wave workgroup (as conv_igemm_v2)
     int tw_dma = ntaps > 1 ? tap_tw[1] : tap_tw[0];
 
+    const int nseg = SPLIT ? a.nseg : 1;
+    for (;;) {
     for (int kc = 0; kc < nkc; ++kc) {
         __syncthreads();                       // previous chunk's halo reads are done
 #pragma unroll
         for (int j = 0; j < N_HITEMS; ++j) *(u32x4*)(halo + (tid + j * NT) * kSlotBytes) = hreg[j];
-        const bool last_kc = kc + 1 == nkc;
+        bool last_kc = kc + 1 == nkc;
+        // SPLIT: the chunk after a segment's last one is the next segment's first (its input part, its weight part)
+        int kc_next = kc + 1, xoff_next = xoff;
+        size_t wpart_next = wpart;
+        if constexpr (SPLIT) {
+            if (last_kc && seg + 1 < nseg) {
+                last_kc = false; kc_next = 0;
+                xoff_next = (int)((a.seg_x >> (4 * (seg + 1))) & 15u) * nkc;
+                wpart_next = (size_t)((a.seg_w >> (4 * (seg + 1))) & 15u) * (size_t)a.w_part_bytes;
+            }
+        }
         auto tap_body = [&](int t, auto last_tag) {
             constexpr bool LAST = decltype(last_tag)::value;
             const char* const wcur = wbuf + buf * W_BYTES;
@@ -192,8 +313,9 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2m(const ConvArg
             if constexpr (!LAST) {
                 dma_w(tw_dma, kc, buf ^ 1);
             } else if (!last_kc) {
-                dma_w(tw_dma, kc + 1, buf ^ 1);
-                load_halo(kc + 1);
+                if constexpr (SPLIT) wpart = wpart_next;
+                dma_w(tw_dma, kc_next, buf ^ 1);
+                load_halo(xoff_next + kc_next);
             }
             __builtin_amdgcn_sched_barrier(0);
             // stage (k32 step 0, pixel rows 0-1): 16 MFMAs over the reads of rows 2-3
@@ -245,6 +367,9 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2m(const ConvArg
         };
         for (int t = 0; t + 1 < ntaps; ++t) tap_body(t, std::false_type{});
         tap_body(ntaps - 1, std::true_type{});
+        if constexpr (SPLIT) xoff = xoff_next;
+    }
+        if (!SPLIT || ++seg >= nseg) break;
     }
 
     // ---- epilogue: lane (site r16, group g16) owns couts g16*16 + mi*4 + j of its wave's 64 -------------------------------------
@@ -302,6 +427,10 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2m(const ConvArg
                 if (sy < Hs && sx < Ws) a.head_out[(((size_t)n * 2 + ch) * Hs + sy) * Ws + sx] = tanhf(p) * a.head_mul;
             }
         }
+        return;
+    }
+    if constexpr (SPLIT) {
+        split_epilogue<WCO>(a, acc, smem, n, ty0, tx0, wpx, cow, ro, cof);
         return;
     }
     // bf16 outputs, activation (+ eval-BN) and rounding in the MFMA layout, then a wave-private [32 sites][64 couts] bf16 tile
@@ -368,6 +497,11 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2m(const ConvArg
         if (a.act == 1) rows(std::false_type{}, std::true_type{}); else rows(std::false_type{}, std::false_type{});
     }
 }
+
+template <int WCO, int WPX, int HALO>
+__global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2m(const ConvArgs a) { conv_v2m_body<WCO, WPX, HALO, false>(a); }
+template <int WCO, int WPX, int HALO>
+__global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2s(const ConvArgs a) { conv_v2m_body<WCO, WPX, HALO, true>(a); }
 
 // ================================================================================================
 // conv_igemm_v2p<WCO, WPX, D> -- conv_igemm_v2m for the 3x3 convolutions (dilation D = 1 | 2) with NO address arithmetic in the K loop
@@ -773,8 +907,42 @@ hipError_t launch_conv_v2m(ConvConfig cfg, int halo, const ConvArgs& a, hipStrea
     return hipErrorInvalidConfiguration;
 }
 
+// operand-split launches (IDC_BF16X3 / IDC_BF16X6): everything conv_igemm_v2m's geometry covers, plus fp32 shortcut sums, fp32 outputs, per-image shifts
+bool conv_v2s_applies(const ConvArgs& a) {
+    if (a.in2 != nullptr || a.pk_L != nullptr || a.ksplit > 1 || a.zeros == nullptr || a.resid_bf16) return false;
+    if (a.in_parts < 1 || a.in_parts > 3 || a.nseg < 1 || a.nseg > 6 || a.w_part_bytes == 0) return false;
+    if (a.head_w != nullptr) return a.bn_scale == nullptr && a.resid == nullptr && a.img_shift == nullptr;
+    return a.out_f32 ? a.out_parts == 0 : (a.out_parts >= 1 && a.out_parts <= 3);
+}
+
+hipError_t launch_conv_v2s(ConvConfig cfg, int halo, const ConvArgs& a, hipStream_t s) {
+    if (!conv_v2s_applies(a)) return hipErrorInvalidConfiguration;
+    const int nct = a.ncg / cfg.wm;
+    const long long blocks = (long long)a.tiles_x * a.tiles_y * a.N * nct * a.nphase;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+#define X(WCO, WPX, HL)                                                                                                          \
+    if (cfg.wm == WCO && cfg.wp == WPX && halo == HL) {                                                                          \
+        hipLaunchKernelGGL((conv_igemm_v2s<WCO, WPX, HL>), dim3((unsigned)blocks), dim3(WCO * WPX * 64),                         \
+                           conv_v2m_lds_bytes_c(WCO, WPX, HL), s, a);                                                            \
+        return hipGetLastError();                                                                                                \
+    }
+    IDC_FOR_EACH_CONV_V2M(X)
+#undef X
+    return hipErrorInvalidConfiguration;
+}
+
+// (conv_igemm_v2ps: the conv_igemm_v2p form of the operand-split launches -- below)
+bool conv_v2ps_applies(ConvConfig, int, const ConvArgs&) { return false; }
+hipError_t launch_conv_v2ps(ConvConfig, int, const ConvArgs&, hipStream_t) { return hipErrorInvalidConfiguration; }
+
 hipError_t init_kernels_v2m() {
     hipError_t e;
+#define X(WCO, WPX, HL)                                                                                                          \
+    e = hipFuncSetAttribute((const void*)conv_igemm_v2s<WCO, WPX, HL>, hipFuncAttributeMaxDynamicSharedMemorySize,               \
+                            (int)conv_v2m_lds_bytes_c(WCO, WPX, HL));                                                            \
+    if (e != hipSuccess) return e;
+    IDC_FOR_EACH_CONV_V2M(X)
+#undef X
 #define X(WCO, WPX, DD)                                                                                                          \
     e = hipFuncSetAttribute((const void*)conv_igemm_v2p<WCO, WPX, DD>, hipFuncAttributeMaxDynamicSharedMemorySize,               \
                             (int)conv_v2p_lds_bytes_c(WCO, WPX, DD));                                                            \

@@ -1,0 +1,165 @@
+"""Round 6, GPU: the operand-split precisions (IDC_BF16X3 / IDC_BF16X6) -- the fp32 contract of
+/root/reference/data/colorize_image.py:263 (ab map within 1e-3 of the reference's) carried on the bf16 matrix pipe.
+
+An fp32 operand travels as hi + lo (bf16x3: three bf16 MFMA products per fp32 product) or hi + mid + lo (bf16x6: six products,
+all 24 mantissa bits); products are accumulated in fp32; bias / BN / shortcut sums / tanh head stay fp32.  Oracle: torch float64
+on the CPU (single ops) and oracle/siggraph_torch.py in float64 (whole network, models/pytorch/model.py:148-175).
+
+Tolerances (stated here, used below):
+  single ops    bf16x6: 2e-5 * (1 + max|ref|)   = the exact-fp32 kernels' bound (tests/test_ops_gpu.py)
+                bf16x3: 1e-4 * (1 + max|ref|)   (operands rounded to 16 mantissa bits: 2^-17 relative per operand)
+  whole network bf16x6: tests/bounds.py FP32_TOL (1e-3 torch-init, 3e-3 he-style) -- the fp32 path's bounds
+                bf16x3: 1e-3 on torch-init weights (the north_star figure); he-style weights are outside its contract (5e-2 asserted)
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from interactive_deep_colorization_amd import engine, workloads
+from tests import bounds
+
+pytestmark = pytest.mark.gpu
+OP_TOL = {"bf16x6": 2e-5, "bf16x3": 1e-4}
+
+
+def _ref_conv(x, w, b, dilation, in_stride, act, bn_s, bn_t, resid):
+    xt = torch.from_numpy(x).double()[:, :, ::in_stride, ::in_stride]
+    y = F.conv2d(xt, torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=dilation * (w.shape[2] // 2), dilation=dilation)
+    if resid is not None:
+        y = y + torch.from_numpy(resid).double()
+    if act == 1:
+        y = F.relu(y)
+    elif act == 2:
+        y = F.leaky_relu(y, 0.2)
+    if bn_s is not None:
+        y = y * torch.from_numpy(bn_s).double()[None, :, None, None] + torch.from_numpy(bn_t).double()[None, :, None, None]
+    return y.numpy()
+
+
+def _check(got, ref, precision, what):
+    err = np.abs(got - ref).max()
+    tol = OP_TOL[precision] * (1 + np.abs(ref).max())
+    assert np.isfinite(got).all(), what
+    assert err <= tol, "%s: max-abs err %.3e > tol %.3e (max|ref| %.2f)" % (what, err, tol, np.abs(ref).max())
+    return err
+
+
+CONV_CASES = [
+    # n, cin, cout, h,  w,  k, dil, stride, act, bn,   resid
+    (2, 64, 128, 32, 48, 3, 1, 2, 1, False, False),    # conv2_1: reads x[::2, ::2]; <2,*> tile
+    (1, 128, 128, 24, 40, 3, 1, 1, 0, False, False),   # shortcut conv: no activation; ragged tile edges
+    (1, 128, 256, 8, 8, 3, 2, 1, 1, True, False),      # dilated (model5/6) + BN after ReLU; <4,2> tile
+    (3, 64, 128, 20, 36, 3, 1, 1, 2, False, True),     # LeakyReLU + fp32 shortcut sum
+    (1, 256, 128, 4, 4, 3, 2, 1, 1, False, False),     # image smaller than the dilation halo
+    (1, 512, 512, 16, 16, 3, 1, 1, 1, True, False),    # trunk shape: 8 chunks x 3 / 6 segments
+    (2, 256, 640, 8, 8, 1, 1, 1, 0, False, False),     # 1x1 (class logits shape class: 529 -> 640 padded couts)
+]
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16x6"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_split_conv(case, precision):
+    n, cin, cout, h, w, k, dil, stride, act, bn, has_res = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32) * 0.1
+    bn_s = (0.5 + rng.random(cout)).astype(np.float32) if bn else None
+    bn_t = rng.standard_normal(cout).astype(np.float32) * 0.1 if bn else None
+    resid = rng.standard_normal((n, cout, h // stride, w // stride)).astype(np.float32) if has_res else None
+    got = engine.op_conv2d(x, wt, b, dilation=dil, in_stride=stride, act=act, bn_scale=bn_s, bn_shift=bn_t, resid=resid, precision=precision)
+    ref = _ref_conv(x, wt, b, dil, stride, act, bn_s, bn_t, resid)
+    _check(got, ref, precision, "conv %s %s" % (case, precision))
+
+
+DECONV_CASES = [(1, 512, 256, 8, 8, True), (2, 256, 128, 12, 20, True), (1, 128, 128, 16, 16, False), (1, 512, 384, 8, 8, True)]
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16x6"])
+@pytest.mark.parametrize("case", DECONV_CASES)
+def test_split_deconv(case, precision):
+    n, cin, cout, h, w, has_res = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((cin, cout, 4, 4)) / np.sqrt(cin * 4)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32) * 0.1
+    resid = rng.standard_normal((n, cout, 2 * h, 2 * w)).astype(np.float32) if has_res else None
+    got = engine.op_deconv4x4s2(x, wt, b, act=1, resid=resid, precision=precision)
+    y = F.conv_transpose2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), torch.from_numpy(b).double(), stride=2, padding=1)
+    if resid is not None:
+        y = y + torch.from_numpy(resid).double()
+    ref = F.relu(y).numpy()
+    _check(got, ref, precision, "deconv %s %s" % (case, precision))
+
+
+def _net_case(size, n, style, precision, maskcent=0.5, **kw):
+    from oracle import siggraph_torch
+    from tests.conftest import state_dict_for
+    sd = state_dict_for(0, style)
+    L, ab, m = workloads.random_batch(n, size, seed=3, max_points=6, max_p=3)
+    e = engine.HipColorizer(size, size, max_batch=n, precision=precision, **kw)
+    try:
+        e.load_state_dict(sd)
+        out = e.forward(L, ab, m, maskcent)
+        again = e.forward(L, ab, m, maskcent)
+    finally:
+        e.close()
+    ref = siggraph_torch.forward(sd, L, ab, m, maskcent, dtype=torch.float64)
+    return out, again, ref
+
+
+@pytest.mark.parametrize("style", ["torch", "he"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16x6"])
+def test_split_network_small(precision, style):
+    """64x64, batch 2 (ragged grids for every large tile), against the float64 oracle; run-to-run identical."""
+    out, again, ref = _net_case(64, 2, style, precision)
+    assert np.array_equal(out, again)
+    err = float(np.abs(out - ref).max())
+    tol = bounds.FP32_TOL[style] if precision == "bf16x6" else (1e-3 if style == "torch" else 5e-2)
+    assert err <= tol, "%s %s: max-abs %.3e > %.1e" % (precision, style, err, tol)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16x6"])
+def test_split_network_layer_by_layer(precision):
+    """Every materialised activation of a 64x64 forward against the float64 oracle's (he-style weights: full dynamic range)."""
+    from oracle import siggraph_torch
+    from tests.conftest import state_dict_for
+    sd = state_dict_for(0, "he")
+    L, ab, m = workloads.random_batch(2, 64, seed=5, max_points=6, max_p=3)
+    ref_out, _, acts = siggraph_torch.forward(sd, L, ab, m, 0.0, dtype=torch.float64, return_acts=True)
+    names = ["conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3", "conv4_1", "conv4_2", "conv4_3", "conv5_1", "conv5_2", "conv5_3",
+             "conv6_1", "conv6_2", "conv6_3", "conv7_1", "conv7_2", "conv7_3", "conv3_3_short", "conv8_1", "conv8_2", "conv8_3", "conv2_2_short", "conv9_1",
+             "conv9_2", "conv1_2_short", "conv10_1"]            # (conv10_2 is consumed by the tanh head inside its own launch: never stored)
+    e = engine.HipColorizer(64, 64, max_batch=2, precision=precision)
+    try:
+        e.load_state_dict(sd)
+        out = e.forward(L, ab, m, 0.0)
+        rel = 2e-4 if precision == "bf16x6" else 2e-3
+        for name in names:
+            got, ref = e.activation(name, 2), acts[name]
+            assert got.shape == ref.shape, name
+            err = float(np.abs(got - ref).max())
+            assert err <= rel * (1 + np.abs(ref).max()), "%s %s: %.3e (max|ref| %.2f)" % (precision, name, err, np.abs(ref).max())
+        with pytest.raises(Exception):
+            e.activation("conv10_2", 2)
+        assert np.abs(out - ref_out).max() <= (bounds.FP32_TOL["he"] if precision == "bf16x6" else 5e-2)
+    finally:
+        e.close()
+
+
+def test_split_dist_head_and_global_hints_build():
+    """The operand-split handle also runs the 529-bin head (fp32 logits from a split 1x1 launch) -- models/pytorch/model.py:159-160."""
+    from oracle import siggraph_torch
+    from tests.conftest import state_dict_for
+    sd = state_dict_for(0, "torch")
+    L, ab, m = workloads.random_batch(1, 64, seed=9, max_points=4, max_p=2)
+    e = engine.HipColorizer(64, 64, max_batch=1, precision="bf16x6", dist=True)
+    try:
+        e.load_state_dict(sd)
+        out, dist = e.forward_dist(L, ab, m, 0.0)
+    finally:
+        e.close()
+    ref_out, ref_dist = siggraph_torch.forward(sd, L, ab, m, 0.0, dist=True, dtype=torch.float64)
+    assert np.abs(out - ref_out).max() <= 1e-3
+    assert np.abs(dist - ref_dist[:, :, ::4, ::4]).max() <= 1e-5
