@@ -50,7 +50,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=10)      # 40 ms: the clock ramp from idle ends inside the warm-up, not inside the timed region
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3", "bf16x6"],
+                    help="bf16x3 / bf16x6 (round 6): the fp32 contract on the bf16 matrix pipe -- fp32 operands as 2 / 3 bf16 parts, 3 / 6 bf16 MFMA products "
+                         "per fp32 product, fp32 accumulation; `roofline.peak` is then the dense bf16 peak / products")
     ap.add_argument("--setup-forwards", type=int, default=0,
                     help="untimed forwards run BEFORE the W warm-up steps of the contract.  Default 0 since round 5: the state the timed region "
                          "starts from is the one the contract's own warm-up leaves (same-box A/B 0 vs 40: 8612 / 8619 vs 8798 / 8477 img/s -- inside "
@@ -223,7 +225,7 @@ class _NoLaunchEngine(object):
         self.device = 0
 
     def blob_bytes(self):
-        return int(self._e.N.load().idc_weights_blob_bytes(1 if self.precision == "bf16" else 0, self.flags))
+        return int(self._e.N.load().idc_weights_blob_bytes(int(self._e._PREC[self.precision]), self.flags))
 
     def comm_unique_id(self):                       # the library's own dlopen of librccl + ncclGetUniqueId: no handle needed
         import ctypes
@@ -397,7 +399,9 @@ def main():
     conv_ms = forward_ms - other_ms                                          # timed region: the conv launches incl. their boundaries
     conv_flops = sum(r["flops"] for r, _ in conv_rows) * nb                 # algorithmic, per launch-set
     achieved_tflops = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-    peak = PEAK_BF16_DENSE_TFLOPS if args.precision == "bf16" else PEAK_FP32_MFMA_TFLOPS
+    # operand-split precisions: every algorithmic FLOP costs 3 (6) bf16 MFMA FLOPs, so the bound is the bf16 peak / products
+    products = {"bf16x3": 3, "bf16x6": 6}.get(args.precision, 1)
+    peak = (PEAK_BF16_DENSE_TFLOPS / products) if args.precision != "fp32" else PEAK_FP32_MFMA_TFLOPS
     ms_per_step = elapsed / args.steps * 1e3
     value = world * nb * args.steps / elapsed
     worst = sorted(conv_rows, key=lambda x: -x[1])[:6]
@@ -426,7 +430,9 @@ def main():
                        world, sc.transport_used or args.transport, ", c_abi fell back: " + sc.transport_fallback_reason if sc.transport_fallback_reason else ""),
                    "weights_blob_bytes": int(e.blob_bytes()),
                    "weights_broadcast_ms": sc.weights_broadcast_ms},
-        "roofline": {"bound": "mfma", "achieved": round(achieved_tflops, 2), "peak": peak, "unit": "TFLOP/s",
+        "roofline": {"bound": "mfma", "achieved": round(achieved_tflops, 2), "peak": round(peak, 2), "unit": "TFLOP/s",
+                     "peak_is": ("dense bf16 MFMA peak %.0f TFLOP/s / %d bf16 products per fp32 product" % (PEAK_BF16_DENSE_TFLOPS, products)) if products > 1
+                                else ("dense bf16 MFMA peak" if args.precision == "bf16" else "exact-fp32 MFMA peak"),
                      "frac": round(achieved_tflops / peak, 4), "traffic": traffic.get("conv_family_bytes_per_forward"),
                      "traffic_source": "profiles/pmc_traffic.json: rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command run by "
                                        "the builder (%s), replayed here -- not measured in this process" % traffic.get("tag", "r01j"),

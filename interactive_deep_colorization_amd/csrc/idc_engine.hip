@@ -421,7 +421,6 @@ struct Layer {
     int fused_next = -1;                 // conv1_1 only: index of conv1_2 when model1 runs as one launch (conv1_block_fused)
     int lprec = 0;                       // the precision this layer's kernels run in (the handle's; IDC_FP32 on the fp32 island of a split handle)
     bool split = false;                  // operand-split launch (conv_igemm_v2s / conv_igemm_v2ps)
-    int split_dst = -1;                  // fp32-island layer whose result feeds the split stack: tensor that receives the split copy
     ConvArgs args{};                     // zero-initialised; pointers patched per forward where they depend on weights
     double flops = 0, min_bytes = 0;
 };
@@ -654,8 +653,8 @@ static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, i
     // 128 couts x (32x16 sites); used when its grid covers at least half of the 256 CUs
     L.v2 = false;
     const bool split = is_split(precision);      // operand-split precisions: a throughput path, the large tile on every layer whatever the grid
-    if ((precision == IDC_BF16 || split) && v2_eligible(*L.spec) && (split || g_tile_policy != 1)) {
-        ConvConfig c2 = (a.ncg % 4 == 0) ? ConvConfig{4, 2} : ConvConfig{2, 4};
+    if (split ? !split_island(*L.spec) : (precision == IDC_BF16 && v2_eligible(*L.spec) && g_tile_policy != 1)) {
+        ConvConfig c2 = (a.ncg % 4 == 0) ? ConvConfig{4, 2} : (a.ncg % 2 == 0) ? ConvConfig{2, 4} : ConvConfig{1, 4};   // ({1,*}: split precisions only, conv1_2)
         int tx = (Ws + 31) / 32, ty = (Hs + 4 * c2.wp - 1) / (4 * c2.wp);
         long long blocks = (long long)tx * ty * n_policy * (a.ncg / c2.wm) * a.nphase;
         // between one half and one full wave of workgroups (batch-1 conv10_2: 128 tiles on 256 CUs): the 4-wave tile
@@ -666,8 +665,9 @@ static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, i
         // r02_tile22_ab.txt): conv10_2 -9.5 %, conv2_1 -8..14 %, conv2_2 -6 %, conv9_2 -6..12 %, conv3_1 -22 %; the
         // 512->512 trunk (one tile per CU, long K) is 1-2 % (dilated: 15 %) slower with it and keeps the 8-wave tile.
         const int force22 = tuning().v2_force22;     // experiment switch: 0 = rule above, 1 = never, 2 = everywhere
-        const bool rule22 = force22 == 2 || (force22 == 0 && (c2.wm == 2 || a.nkc <= tuning().v2_22_nkc) && blocks >= 256);
-        if (a.nphase == 1 && ((blocks >= tuning().v2_min_blocks && blocks < 256 && tuning().v2_half_tiles) || rule22)) {
+        // (the 64-cout tile of the split precisions keeps 32 x 16 sites: conv1_2 0.84 ms as {1,4}, 1.01 ms as {1,2} at N = 32, bf16x3)
+        const bool rule22 = force22 == 2 || (force22 == 0 && (c2.wm == 2 || (c2.wm == 4 && a.nkc <= tuning().v2_22_nkc)) && blocks >= 256);
+        if (a.nphase == 1 && c2.wm != 1 && ((blocks >= tuning().v2_min_blocks && blocks < 256 && tuning().v2_half_tiles) || rule22)) {
             c2 = ConvConfig{2, 2};
             ty = (Hs + 4 * c2.wp - 1) / (4 * c2.wp);
             blocks = (long long)tx * ty * n_policy * (a.ncg / c2.wm) * a.nphase;
@@ -788,16 +788,9 @@ static int build_graph(idc_context* c) {
         // partial sums of the 313 head (LayerSpec.out_f32)
         L.lprec = c->precision;
         if (split && split_island(s)) {
-            // fp32 island (model1): fp32 result; where the split stack reads it, the fp32 tensor gets the suffix ".f32" and the name goes to
-            // its split copy (launch_split_f32 after the layer's launch)
+            // fp32 island (conv1_1): exact-fp32 kernel; its epilogue writes the result as split planes where the split stack reads it
             L.lprec = IDC_FP32;
-            if (read_by_split_layer(s.name)) {
-                const std::string fname = std::string(s.name) + ".f32";
-                L.dst = add_tensor(fname.c_str(), s.cout, cout_pad(s.cout), s.level, 1);
-                L.split_dst = add_tensor(s.name, s.cout, cout_pad(s.cout), s.level, 0);
-            } else {
-                L.dst = add_tensor(s.name, s.cout, cout_pad(s.cout), s.level, 1);
-            }
+            L.dst = add_tensor(s.name, s.cout, cout_pad(s.cout), s.level, read_by_split_layer(s.name) ? 0 : 1);
         } else {
             // fp32 storage: everything on the fp32 path; class / 313 logits and the hyper-column partial sums (LayerSpec.out_f32); on the
             // operand-split path also every shortcut branch (summed in fp32 in its consumer's epilogue)
@@ -1006,6 +999,11 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             }
             a.partial = c->d_partial;
         }
+        if (is_split(c->precision) && !L.split) {        // fp32 island: conv_igemm<f32> with a split store (no split-K: its epilogue kernel writes fp32)
+            a.out_parts = to.is_f32 ? 0 : to.parts;
+            a.out_f32 = 1; a.ksplit = 1; a.kc_per = a.nkc;
+            if (L.wino || L.click || L.v2 || L.kw) return fail(&c->err, IDC_ERR_INTERNAL, "layer %s: fp32 island outside conv_igemm", L.spec->name);
+        }
         if (L.split) {
             // operand-split launch: nseg passes of the K loop (input part x weight part) into one accumulator set; split in / out tensors
             a.wgt = c->d_blob + L.blob.w_off;
@@ -1114,10 +1112,6 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             HIPCHK(c, le);
         }
         if (a.ksplit > 1) HIPCHK(c, launch_splitk_epilogue(L.lprec, a, s));
-        if (L.split_dst >= 0) {                  // the fp32 island's result enters the split stack
-            const Tensor& ts = c->tensors[L.split_dst];
-            HIPCHK(c, launch_split_f32((const float*)to.ptr, ts.ptr, (long long)n * to.H * to.W, to.Cpad, ts.parts, s));
-        }
         }
         toc();
     }
@@ -2225,7 +2219,6 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
                      L.cfg.wm, L.cfg.wp);
             if (L.split) snprintf(out->kernel, sizeof(out->kernel), L.v2p ? "conv_igemm_v2ps<%d,%d>x%d" : "conv_igemm_v2s<%d,%d>x%d", L.cfg.wm, L.cfg.wp, split_segments(h->precision));
             else if (L.m16) strncat(out->kernel, L.v2p ? "+m16p" : "+m16", sizeof(out->kernel) - strlen(out->kernel) - 1);
-            if (L.split_dst >= 0) strncat(out->kernel, "+split", sizeof(out->kernel) - strlen(out->kernel) - 1);
             if (L.fused_head) strncat(out->kernel, "+head", sizeof(out->kernel) - strlen(out->kernel) - 1);
             if (L.args.ksplit > 1) {
                 char sk[16]; snprintf(sk, sizeof(sk), " splitK%d", L.args.ksplit);

@@ -116,8 +116,7 @@ hipError_t launch_conv_v2s(ConvConfig cfg, int halo, const ConvArgs& a, hipStrea
 hipError_t launch_conv_v2ps(ConvConfig cfg, int halo, const ConvArgs& a, hipStream_t s);
 bool conv_v2s_applies(const ConvArgs& a);
 bool conv_v2ps_applies(ConvConfig cfg, int halo, const ConvArgs& a);
-// fp32 NHWC [npix][Cpad] -> split bf16 [npix][parts][Cpad] (model1's fp32 result on its way into the split stack)
-hipError_t launch_split_f32(const float* src, void* dst, long long npix, int Cpad, int parts, hipStream_t s);
+
 // ConvTranspose 4x4 s2 + the 3x3 shortcut conv it is summed with, one K loop (conv_ds_fused); a.in2 / wgt2 / nkc2 = the
 // shortcut's input, layout-2 weights and channel chunks, a.bias = the two biases added.  hipErrorInvalidConfiguration if
 // the launch does not qualify.

@@ -138,7 +138,22 @@ __device__ __forceinline__ void epilogue16(const ConvArgs& a, float (&v)[16], si
                                            const float* bsc, const float* bsh, bool has_bn,
                                            const float* ishift = nullptr) {
     epilogue_values16(a, v, oidx, bias, bsc, bsh, has_bn, ishift);
-    if (!OUT_BF16 || a.out_f32) {
+    if (!OUT_BF16 && a.out_parts > 0) {
+        // fp32 island of an operand-split handle (conv1_1): the result enters the split stack as out_parts bf16 planes per pixel,
+        // hi = rne(v), next = rne(v - hi), ... (each remainder exact in fp32); a pixel of the split tensor is [part][CoutPad]
+        const int CoutPad = a.ncg * kCoutGroup, np = a.out_parts;
+        const size_t co0 = oidx % (size_t)CoutPad;
+        unsigned short* o = (unsigned short*)a.out + (oidx - co0) * np + co0;
+        for (int p = 0; p < np; ++p) {
+            uint4 p0, p1;
+            pack16_bf16(v, p0, p1);
+            *(uint4*)(o + (size_t)p * CoutPad) = p0;
+            *(uint4*)(o + (size_t)p * CoutPad + 8) = p1;
+            const unsigned w[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[2 * e] -= __uint_as_float(w[e] << 16); v[2 * e + 1] -= __uint_as_float(w[e] & 0xffff0000u); }
+        }
+    } else if (!OUT_BF16 || a.out_f32) {
         float* o = (float*)a.out + oidx;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -2966,34 +2981,6 @@ hipError_t launch_nhwc_to_nchw(int src_is_bf16, const void* src, float* dst, int
 
 // ---- operand-split tensors (IDC_BF16X3 / IDC_BF16X6): a pixel is [parts][Cpad] bf16, x = part 0 + part 1 (+ part 2) ----------------
 __device__ __forceinline__ unsigned short bf16_rne_bits(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
-
-// fp32 NHWC -> split: 8 channels per thread (two float4 in, one uint4 per part out); HBM-bound, on the hot path once per forward
-// (model1's fp32 result entering the split stack)
-__global__ __launch_bounds__(256) void split_f32_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long long n8, int c8, int parts) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
-        const long long pix = i / c8;
-        const int cg = (int)(i - pix * c8);
-        const float4 a = *(const float4*)(src + i * 8), b = *(const float4*)(src + i * 8 + 4);
-        float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        for (int p = 0; p < parts; ++p) {
-            unsigned short h[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { h[e] = bf16_rne_bits(v[e]); v[e] -= __uint_as_float((unsigned)h[e] << 16); }
-            uint4 o;
-            o.x = h[0] | ((unsigned)h[1] << 16); o.y = h[2] | ((unsigned)h[3] << 16);
-            o.z = h[4] | ((unsigned)h[5] << 16); o.w = h[6] | ((unsigned)h[7] << 16);
-            *(uint4*)(dst + ((pix * parts + p) * c8 + cg) * 8) = o;
-        }
-    }
-}
-
-hipError_t launch_split_f32(const float* src, void* dst, long long npix, int Cpad, int parts, hipStream_t s) {
-    if (Cpad % 8 || parts < 1 || parts > 3) return hipErrorInvalidValue;
-    const long long n8 = npix * (Cpad / 8);
-    const int blocks = (int)((n8 + 255) / 256 < 262144 ? (n8 + 255) / 256 : 262144);
-    hipLaunchKernelGGL(split_f32_kernel, dim3(blocks), dim3(256), 0, s, src, (unsigned short*)dst, n8, Cpad / 8, parts);
-    return hipGetLastError();
-}
 
 // test entry points / activation dumps only
 __global__ void split_to_nchw_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, int N, int C, int H, int W, int Cpad, int parts) {

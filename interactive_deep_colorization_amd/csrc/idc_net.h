@@ -87,9 +87,9 @@ inline bool wino_eligible(const LayerSpec& s) { return s.kind == kConv3x3 && s.r
 inline bool wino_deconv_eligible(const LayerSpec& s) { return s.kind == kDeconv4x4 && s.cin % 32 == 0; }
 // layers the bf16 large-tile kernel (conv_igemm_v2, >= 128 couts per workgroup) can run
 inline bool v2_eligible(const LayerSpec& s) { return s.kind != kConvIm2col && cout_pad(s.cout) >= 128; }
-// operand-split precisions: layers the large tile cannot run (model1: conv1_1's K = 36 im2col and the 64-cout conv1_2, 3.4 % of the MACs) form an
-// exact-fp32 "island" -- fp32 weights, fp32 activations, the fp32 kernels -- whose last result is split once on its way into the stack
-inline bool split_island(const LayerSpec& s) { return !v2_eligible(s); }
+// operand-split precisions: conv1_1 (K = 36 im2col of the four input planes, 0.2 % of the MACs) is an exact-fp32 "island" -- fp32 weights, the
+// fp32 small-tile kernel -- whose epilogue writes its result as split planes; every other layer runs the large tile (conv1_2: its 64-cout form)
+inline bool split_island(const LayerSpec& s) { return s.kind == kConvIm2col; }
 
 // Where one layer's parameters live inside the packed blob (byte offsets).
 struct LayerBlob {

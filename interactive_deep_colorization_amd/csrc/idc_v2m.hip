@@ -58,6 +58,16 @@ __device__ __forceinline__ unsigned pack_bf16x2_m(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_pk){lo, hi}, bf16x2_pk));
 }
 
+__device__ __forceinline__ void add_bias_after_k(const float* bp, f32x4 (&acc)[4][8]) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const float4 bq = *(const float4*)(bp + mi * 4);
+        const f32x4 b4 = f32x4{bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+        for (int pt = 0; pt < 8; ++pt) acc[mi][pt] += b4;
+    }
+}
+
 // Epilogue of the operand-split kernels: lane (site r16, group g16) holds couts g16*16 + mi*4 + j of its wave's 64 at site (pixel row pt >> 1,
 // column (pt & 1)*16 + r16) in acc[mi][pt][j].  value = BN(act(acc + fp32 shortcut sum)) + per-image shift, all fp32; then either an fp32 NHWC store
 // straight from the MFMA layout (out_parts = 0) or out_parts bf16 planes hi = rne(v), next = rne(v - hi), ... (each remainder is exact in fp32), every
@@ -211,7 +221,7 @@ __device__ __forceinline__ void conv_v2m_body(const ConvArgs& a) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             const float4 bq = *(const float4*)(bp + mi * 4);
-            const f32x4 b4 = f32x4{bq.x, bq.y, bq.z, bq.w};
+            const f32x4 b4 = SPLIT ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{bq.x, bq.y, bq.z, bq.w};     // (SPLIT: the bias joins after the K loop, see idc_layout.h)
 #pragma unroll
             for (int pt = 0; pt < 8; ++pt) acc[mi][pt] = b4;
         }
@@ -373,6 +383,7 @@ __device__ __forceinline__ void conv_v2m_body(const ConvArgs& a) {
     }
 
     // ---- epilogue: lane (site r16, group g16) owns couts g16*16 + mi*4 + j of its wave's 64 -------------------------------------
+    if constexpr (SPLIT) add_bias_after_k(a.bias + (ct * WCO + wco) * kCoutGroup + g16 * 16, acc);
     const int CoutPad = a.ncg * kCoutGroup;
     const bool has_bn = a.bn_scale != nullptr;
     const int so = a.so, Wout = Ws * so, Hout = Hs * so;
@@ -517,8 +528,9 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2s(const ConvArg
 // halo tile (<2,2>, D = 1: 79.8 KiB -- still two workgroups per CU).
 // ================================================================================================
 
-template <int WCO, int WPX, int D>
-__global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArgs a) {
+// SPLIT = true: conv_igemm_v2ps, the operand-split form (as conv_igemm_v2s is conv_igemm_v2m's): a.nseg passes over the nkc chunks, split epilogue.
+template <int WCO, int WPX, int D, bool SPLIT>
+__device__ __forceinline__ void conv_v2p_body(const ConvArgs& a) {
     constexpr int NT = WCO * WPX * 64;
     constexpr int TW = 32, TH = 4 * WPX, HALO = D;
     constexpr int HWP = TW + 2 * HALO, HHP = TH + 2 * HALO, HROWS = HWP * HHP, HP = kRowBytes;
@@ -552,7 +564,7 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArg
     const size_t w_kc_stride = (size_t)a.ncg * kWBlockBytes;
     const size_t w_tap_stride = (size_t)nkc * w_kc_stride;
     const char* const wb = (const char*)a.wgt + (size_t)(ct * WCO) * kWBlockBytes + (size_t)tid * kSlotBytes;
-    const int pix_bytes = nkc * kRowBytes, Win = Ws * si;
+    const int pix_bytes = (SPLIT ? a.in_parts * nkc : nkc) * kRowBytes, Win = Ws * si;    // split tensors: a pixel is [part][chunk] x 128 bytes
     const char* const img = (const char*)a.in + (size_t)n * (size_t)(Hs * si) * Win * (size_t)pix_bytes;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)img, 0, (Hs * si) * Win * pix_bytes, 0x00020000);
 
@@ -563,14 +575,15 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArg
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             const float4 bq = *(const float4*)(bp + mi * 4);
-            const f32x4 b4 = f32x4{bq.x, bq.y, bq.z, bq.w};
+            const f32x4 b4 = SPLIT ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{bq.x, bq.y, bq.z, bq.w};     // (SPLIT: the bias joins after the K loop, see idc_layout.h)
 #pragma unroll
             for (int pt = 0; pt < 8; ++pt) acc[mi][pt] = b4;
         }
     }
 
+    size_t wpart = 0;                                          // SPLIT: byte offset of the current segment's weight part
     auto dma_w = [&](int t, int kc, int slot_byte) {           // slot_byte: 0 | W_BYTES
-        const char* src = wb + (size_t)t * w_tap_stride + (size_t)kc * w_kc_stride;
+        const char* src = wb + (size_t)t * w_tap_stride + (size_t)kc * w_kc_stride + (SPLIT ? wpart : (size_t)0);
         char* dst = wbuf + slot_byte + wave * 64 * kSlotBytes;
 #pragma unroll
         for (int j = 0; j < N_WITEMS; ++j)
@@ -596,7 +609,9 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArg
         for (int j = 0; j < N_HITEMS; ++j) *(u32x4*)(halo + (tid + j * NT) * kSlotBytes) = hreg[j];
     };
 
-    load_halo(0);
+    int seg = 0, xoff = 0;                                     // SPLIT: current segment, first chunk of its input part inside a pixel
+    if constexpr (SPLIT) { xoff = (int)(a.seg_x & 15u) * nkc; wpart = (size_t)(a.seg_w & 15u) * (size_t)a.w_part_bytes; }
+    load_halo(xoff);
     dma_w(0, 0, 0);
     // own code -> L2 (idc_kernels.h): 23-37 KB; the scratch is the tail of the halo area that no fragment read reaches
     if (a.warm && wave == 0) idc_warm_own_code(halo + HROWS * HP, lane, (WCO == 2 ? 288 : 180));   // 36.9 / 23.1-23.4 KB; conv_igemm_v2m's kernels follow in this code object
@@ -618,10 +633,21 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArg
     int buf_off = 0;                                           // byte offset of the ring slot holding the current tap's tile
 
     IDC_MSTAMP(1);
+    const int nseg = SPLIT ? a.nseg : 1;
+    for (;;) {
     for (int kc = 0; kc < nkc; ++kc) {
         __syncthreads();                                       // previous chunk's halo reads are done
         store_halo();
-        const bool last_kc = kc + 1 == nkc;
+        bool last_kc = kc + 1 == nkc;
+        int kc_next = kc + 1, xoff_next = xoff;                // SPLIT: after a segment's last chunk comes the next segment's first
+        size_t wpart_next = wpart;
+        if constexpr (SPLIT) {
+            if (last_kc && seg + 1 < nseg) {
+                last_kc = false; kc_next = 0;
+                xoff_next = (int)((a.seg_x >> (4 * (seg + 1))) & 15u) * nkc;
+                wpart_next = (size_t)((a.seg_w >> (4 * (seg + 1))) & 15u) * (size_t)a.w_part_bytes;
+            }
+        }
         auto tap_body = [&](auto t_tag) {
             constexpr int t = decltype(t_tag)::value;
             constexpr bool LAST = t == 8;
@@ -657,8 +683,9 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArg
             if constexpr (!LAST) {
                 dma_w(tn, kc, buf_off ^ W_BYTES);
             } else {
-                if (!last_kc) dma_w(0, kc + 1, buf_off ^ W_BYTES);
-                load_halo(last_kc ? kc : kc + 1);              // (unconditional: every halo register has one definition per trip -- a value
+                if constexpr (SPLIT) wpart = wpart_next;
+                if (!last_kc) dma_w(0, kc_next, buf_off ^ W_BYTES);
+                load_halo(last_kc ? xoff + kc : xoff_next + kc_next);   // (unconditional: every halo register has one definition per trip -- a value
             }                                                  //  that might survive "in case" would stay live through all nine taps)
             __builtin_amdgcn_sched_barrier(0);
             // stage (k32 step 0, pixel rows 0-1): 16 MFMAs over the reads of rows 2-3
@@ -705,10 +732,14 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArg
         tap_body(std::integral_constant<int, 0>{}); tap_body(std::integral_constant<int, 1>{}); tap_body(std::integral_constant<int, 2>{});
         tap_body(std::integral_constant<int, 3>{}); tap_body(std::integral_constant<int, 4>{}); tap_body(std::integral_constant<int, 5>{});
         tap_body(std::integral_constant<int, 6>{}); tap_body(std::integral_constant<int, 7>{}); tap_body(std::integral_constant<int, 8>{});
+        if constexpr (SPLIT) xoff = xoff_next;
+    }
+        if (!SPLIT || ++seg >= nseg) break;
     }
 
     // ---- epilogue (conv_igemm_v2m's): lane (site r16, group g16) owns couts g16*16 + mi*4 + j of its wave's 64 ----------------------
     IDC_MSTAMP(2);
+    if constexpr (SPLIT) add_bias_after_k(a.bias + (ct * WCO + wco) * kCoutGroup + g16 * 16, acc);
     const int CoutPad = a.ncg * kCoutGroup;
     const bool has_bn = a.bn_scale != nullptr;
     const int cow = (ct * WCO + wco) * kCoutGroup;
@@ -769,6 +800,10 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArg
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         IDC_MSTAMP(4);
 #endif
+        return;
+    }
+    if constexpr (SPLIT) {
+        split_epilogue<WCO>(a, acc, smem, n, ty0, tx0, wpx, cow, 0, 0);
         return;
     }
     char* const tb16 = smem + wave * 4096;
@@ -842,6 +877,11 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArg
 }
 
 
+template <int WCO, int WPX, int D>
+__global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArgs a) { conv_v2p_body<WCO, WPX, D, false>(a); }
+template <int WCO, int WPX, int D>
+__global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2ps(const ConvArgs a) { conv_v2p_body<WCO, WPX, D, true>(a); }
+
 static constexpr size_t conv_v2p_lds_bytes_c(int wco, int wpx, int d) {            // = conv_igemm_v2m's
     const int nt = wco * wpx * 64;
     const int hrows = (32 + 2 * d) * (4 * wpx + 2 * d);
@@ -850,6 +890,7 @@ static constexpr size_t conv_v2p_lds_bytes_c(int wco, int wpx, int d) {         
 }
 
 #define IDC_FOR_EACH_CONV_V2P(X) X(4, 2, 1) X(4, 2, 2) X(2, 2, 1)
+#define IDC_FOR_EACH_CONV_V2PS(X) IDC_FOR_EACH_CONV_V2P(X) X(1, 4, 1) X(1, 2, 1)      // (+ the 64-cout tiles of conv1_2)
 
 // 3x3 convs (so = 1, one phase, nine taps in ky*3 + kx order with offsets (ky-1, kx-1) * D) that conv_igemm_v2m covers
 bool conv_v2p_applies(ConvConfig cfg, int halo, const ConvArgs& a) {
@@ -885,6 +926,7 @@ static constexpr size_t conv_v2m_lds_bytes_c(int wco, int wpx, int halo) {
 }
 
 #define IDC_FOR_EACH_CONV_V2M(X) X(4, 2, 0) X(4, 2, 1) X(4, 2, 2) X(2, 4, 0) X(2, 4, 1) X(2, 4, 2) X(2, 2, 0) X(2, 2, 1) X(2, 2, 2)
+#define IDC_FOR_EACH_CONV_V2S(X) IDC_FOR_EACH_CONV_V2M(X) X(1, 4, 1) X(1, 2, 1)
 
 bool conv_v2m_applies(const ConvArgs& a) {
     return a.resid == nullptr && a.in2 == nullptr && !a.out_f32 && a.img_shift == nullptr && a.pk_L == nullptr && a.ksplit <= 1 &&
@@ -926,22 +968,49 @@ hipError_t launch_conv_v2s(ConvConfig cfg, int halo, const ConvArgs& a, hipStrea
                            conv_v2m_lds_bytes_c(WCO, WPX, HL), s, a);                                                            \
         return hipGetLastError();                                                                                                \
     }
-    IDC_FOR_EACH_CONV_V2M(X)
+    IDC_FOR_EACH_CONV_V2S(X)
 #undef X
     return hipErrorInvalidConfiguration;
 }
 
-// (conv_igemm_v2ps: the conv_igemm_v2p form of the operand-split launches -- below)
-bool conv_v2ps_applies(ConvConfig, int, const ConvArgs&) { return false; }
-hipError_t launch_conv_v2ps(ConvConfig, int, const ConvArgs&, hipStream_t) { return hipErrorInvalidConfiguration; }
+// conv_igemm_v2ps: the 3x3 launches among them on conv_igemm_v2p's body (column-swizzled halo tile, unrolled taps, buffer loads)
+bool conv_v2ps_applies(ConvConfig cfg, int halo, const ConvArgs& a) {
+    if (!conv_v2s_applies(a) || a.nphase != 1 || a.ntaps != 9 || a.so != 1 || (halo != 1 && halo != 2)) return false;
+    if (!((cfg.wm == 4 && cfg.wp == 2) || (cfg.wm == 2 && cfg.wp == 2 && halo == 1) || (cfg.wm == 1 && (cfg.wp == 2 || cfg.wp == 4) && halo == 1))) return false;
+    for (int t = 0; t < 9; ++t)
+        if (a.dy[t] != (t / 3 - 1) * halo || a.dx[t] != (t % 3 - 1) * halo || a.tw[t] != t) return false;
+    return (long long)a.Hs * a.si * (long long)a.Ws * a.si * ((long long)a.nkc * a.in_parts * kRowBytes) < 0x7fffffffLL;
+}
+
+hipError_t launch_conv_v2ps(ConvConfig cfg, int halo, const ConvArgs& a, hipStream_t s) {
+    if (!conv_v2ps_applies(cfg, halo, a)) return hipErrorInvalidConfiguration;
+    const int nct = a.ncg / cfg.wm;
+    const long long blocks = (long long)a.tiles_x * a.tiles_y * a.N * nct;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+#define X(WCO, WPX, DD)                                                                                                          \
+    if (cfg.wm == WCO && cfg.wp == WPX && halo == DD) {                                                                          \
+        hipLaunchKernelGGL((conv_igemm_v2ps<WCO, WPX, DD>), dim3((unsigned)blocks), dim3(WCO * WPX * 64),                        \
+                           conv_v2p_lds_bytes_c(WCO, WPX, DD), s, a);                                                            \
+        return hipGetLastError();                                                                                                \
+    }
+    IDC_FOR_EACH_CONV_V2PS(X)
+#undef X
+    return hipErrorInvalidConfiguration;
+}
 
 hipError_t init_kernels_v2m() {
     hipError_t e;
+#define X(WCO, WPX, DD)                                                                                                          \
+    e = hipFuncSetAttribute((const void*)conv_igemm_v2ps<WCO, WPX, DD>, hipFuncAttributeMaxDynamicSharedMemorySize,              \
+                            (int)conv_v2p_lds_bytes_c(WCO, WPX, DD));                                                            \
+    if (e != hipSuccess) return e;
+    IDC_FOR_EACH_CONV_V2PS(X)
+#undef X
 #define X(WCO, WPX, HL)                                                                                                          \
     e = hipFuncSetAttribute((const void*)conv_igemm_v2s<WCO, WPX, HL>, hipFuncAttributeMaxDynamicSharedMemorySize,               \
                             (int)conv_v2m_lds_bytes_c(WCO, WPX, HL));                                                            \
     if (e != hipSuccess) return e;
-    IDC_FOR_EACH_CONV_V2M(X)
+    IDC_FOR_EACH_CONV_V2S(X)
 #undef X
 #define X(WCO, WPX, DD)                                                                                                          \
     e = hipFuncSetAttribute((const void*)conv_igemm_v2p<WCO, WPX, DD>, hipFuncAttributeMaxDynamicSharedMemorySize,               \

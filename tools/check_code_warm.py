@@ -74,6 +74,14 @@ def call_sites(src):
     text = open(src).read()
     kernels = [(m.start(), m.group(2), [p.split()[-1] for p in m.group(1).split(",")] if m.group(1) else [])
                for m in re.finditer(r"(?:template\s*<([^>]*)>\s*)?__global__\s+(?:void\s+)?(?:__launch_bounds__\s*\((?:[^()]|\([^()]*\))*\)\s*)?(?:void\s+)?(\w+)\s*\(", text)]
+    # (round 6) kernel bodies shared by several kernels: `template <...> __device__ __forceinline__ void X_body(...)` called by thin
+    # `__global__ void K(const ConvArgs a) { X_body<...>(a); }` wrappers -- a call site inside X_body belongs to every such K (same leading
+    # template parameters)
+    bodies = [(m.start(), m.group(2), [p.split()[-1] for p in m.group(1).split(",")])
+              for m in re.finditer(r"template\s*<([^>]*)>\s*__device__\s+__forceinline__\s+void\s+(\w+_body)\s*\(", text)]
+    wrappers = {}
+    for m in re.finditer(r"void\s+(\w+)\s*\(const ConvArgs a\)\s*\{\s*(\w+_body)\s*<", text):
+        wrappers.setdefault(m.group(2), []).append(m.group(1))
     out = []
     for m in re.finditer(r"idc_warm_own_code\(([^;]*)\);", text):
         if text.rfind("\n", 0, m.start()) >= 0 and "__device__" in text[text.rfind("\n", 0, m.start()):m.start()]:
@@ -81,10 +89,12 @@ def call_sites(src):
         parts = _top_level_split(m.group(1))
         if len(parts) < 3:
             continue
-        owner = [k for k in kernels if k[0] < m.start()]
+        owner = [k for k in kernels + bodies if k[0] < m.start()]
         if not owner:
             continue
-        out.append((owner[-1][1], owner[-1][2], _c_ternary_to_python(parts[2].strip())))
+        owner = max(owner, key=lambda k: k[0])
+        for name in wrappers.get(owner[1], [owner[1]]):
+            out.append((name, owner[2], _c_ternary_to_python(parts[2].strip())))
     return out
 
 
