@@ -57,7 +57,13 @@ def parse_args():
                     help="untimed forwards run BEFORE the W warm-up steps of the contract.  Default 0 since round 5: the state the timed region "
                          "starts from is the one the contract's own warm-up leaves (same-box A/B 0 vs 40: 8612 / 8619 vs 8798 / 8477 img/s -- inside "
                          "the run-to-run spread, profiles/r05_setup_forwards.txt); reported in the line")
-    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="images per GPU per step (weak scaling)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default, the contract's form): --batch images per GPU whatever N.  strong (SURVEY.md 8(d) config 4's second "
+                         "form): --global-batch images in total, global-batch / N per GPU")
+    ap.add_argument("--global-batch", type=int, default=256, help="total images per step under --scaling strong (BASELINE configs[3]: 256)")
+    ap.add_argument("--cpu-worker", nargs=4, metavar=("THREADS", "T_START", "SECONDS", "STYLE"), default=None,
+                    help=argparse.SUPPRESS)       # internal: one process of cpu_baseline's whole-host leg
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-pointer (PCIe-inclusive) pipeline leg")
     ap.add_argument("--no-peak-probe", action="store_true", help="skip the 3 s MFMA-peak probe (tools/ubench/mfma_peak)")
     ap.add_argument("--repeats", type=int, default=3,
@@ -94,22 +100,68 @@ def seeded_weights(style="torch"):
     return workloads.random_state_dict(0, style)
 
 
-def cpu_baseline(sd, budget_s=12.0):
-    """The reference path on the host cores: the torch-CPU oracle (the reference's own ATen/oneDNN kernels,
-    models/pytorch/model.py:148-175 restated batched), N=1 per call as the reference runs it, fp32.
-    A short probe picks the thread count (oneDNN thrashes when oversubscribed: 256 threads on one 256x256
-    image take 22 s), then a bounded sample of about `budget_s` seconds of forwards is timed at that count."""
+def _cpu_forward(sd):
+    """(callable(L, ab, mask) -> ab map, kind): the reference's own nn.Module (models/pytorch/model.py:134-175, imported untouched) when the
+    reference tree is present -- the authoring container; it never travels to the GPU box -- else the oracle's restatement of it (bit-identical
+    at N = 1: oracle/make_golden.py asserts it).  Checker / baseline only: nothing here is on the product path."""
+    import torch
+    from oracle import siggraph_torch
+    ref_root = "/root/reference"
+    if os.path.isdir(os.path.join(ref_root, "models", "pytorch")):
+        try:
+            sys.path.insert(0, ref_root)
+            from models.pytorch import model as ref_model                 # noqa: E402
+            net = siggraph_torch.load_into_reference_module(ref_model.SIGGRAPHGenerator(dist=False), sd)
+
+            def run(L, ab, m):
+                with torch.no_grad():
+                    return net(L[0].astype(np.float64), ab[0].astype(np.float64), m[0].astype(np.float64), 0.0)[0].numpy()
+            return run, "reference"
+        except Exception as ex:
+            print("bench.py: reference module not usable for the CPU baseline (%s): timing the port" % str(ex)[:120], file=sys.stderr)
+        finally:
+            if sys.path and sys.path[0] == ref_root:
+                sys.path.pop(0)
+    return (lambda L, ab, m: siggraph_torch.forward(sd, L, ab, m, 0.0)), "port"
+
+
+def cpu_worker(threads, t_start, seconds, style):
+    """One process of the whole-host leg: `threads` threads, N = 1 forwards of the bench workload from t_start (absolute) for `seconds`."""
     import torch
     from interactive_deep_colorization_amd import workloads
-    from oracle import siggraph_torch
+    torch.set_num_threads(threads)
+    sd = workloads.random_state_dict(0, style)
+    fwd, kind = _cpu_forward(sd)
+    L, ab, m = workloads.random_batch(1, H, seed=0)
+    fwd(L, ab, m)                                   # warm-up (oneDNN primitive creation)
+    late = max(0.0, time.time() - t_start)
+    while time.time() < t_start:
+        time.sleep(0.01)
+    t0, n = time.time(), 0
+    while time.time() < t_start + seconds:
+        fwd(L, ab, m)
+        n += 1
+    print(json.dumps({"images": n, "elapsed": time.time() - t0, "late_s": late, "kind": kind}))
+
+
+def cpu_baseline(sd, budget_s=12.0, style="torch"):
+    """The reference path on the host cores: the reference's nn.Module when its tree is present (kind "reference"), else the torch-CPU oracle
+    (the same ATen/oneDNN kernels, models/pytorch/model.py:148-175 restated; kind "port"), N=1 per call as the reference runs it, fp32.
+    Two figures: (1) ONE stream -- a short probe picks the thread count (oneDNN thrashes when oversubscribed: 256 threads on one 256x256
+    image take 22 s), then a bounded sample of about `budget_s` seconds of forwards at that count: `value`, the latency-style baseline;
+    (2) the WHOLE HOST -- P concurrent processes x T threads with P x T ~ os.cpu_count(), each pinned to its own T
+    cpus, all counting inside the same `budget_s`-second window: `whole_host`, the host's throughput."""
+    import torch
+    from interactive_deep_colorization_amd import workloads
     ncpu = os.cpu_count() or 1
+    fwd, kind = _cpu_forward(sd)
     L, ab, m = workloads.random_batch(1, H, seed=0)
     probe = {}
     for cores in sorted(set(c for c in (8, 16, 32, 64) if c <= ncpu) or {ncpu}):
         torch.set_num_threads(cores)
-        siggraph_torch.forward(sd, L, ab, m, 0.0)                   # warm-up
+        fwd(L, ab, m)                                               # warm-up
         t0 = time.perf_counter()
-        siggraph_torch.forward(sd, L, ab, m, 0.0)
+        fwd(L, ab, m)
         probe[cores] = time.perf_counter() - t0
     cores = min(probe, key=probe.get)
     torch.set_num_threads(cores)
@@ -118,13 +170,55 @@ def cpu_baseline(sd, budget_s=12.0):
     for i in range(n_img):
         Li, abi, mi = workloads.random_batch(1, H, seed=0, start=i)
         t0 = time.perf_counter()
-        siggraph_torch.forward(sd, Li, abi, mi, 0.0)
+        fwd(Li, abi, mi)
         ts.append(time.perf_counter() - t0)
     total = sum(ts)
-    return {"value": round(n_img / total, 3), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "%d distinct 256x256 images of the bench workload, one per call (N=1, fp32, torch CPU oracle = the "
-                      "reference's ATen kernels), %d threads (best of 8/16/32/64 probed) on a %d-cpu host: %.1f s, "
-                      "p50 %.3f s per image" % (n_img, cores, ncpu, total, statistics.median(ts))}
+    res = {"value": round(n_img / total, 3), "unit": "images/sec", "cores": cores, "kind": kind,
+           "sample": "%d distinct 256x256 images of the bench workload, one per call (N=1, fp32, %s), %d threads (best of 8/16/32/64 probed) "
+                     "on a %d-cpu host: %.1f s, p50 %.3f s per image" % (
+                         n_img, "the reference's SIGGRAPHGenerator.forward on torch CPU" if kind == "reference"
+                         else "torch CPU oracle = the reference's ATen kernels", cores, ncpu, total, statistics.median(ts))}
+    try:
+        res["whole_host"] = cpu_whole_host(ncpu, min(cores, 8), budget_s, style)
+    except Exception as ex:                                           # a diagnostic leg: never sinks the line
+        res["whole_host"] = {"value": None, "error": str(ex)[:200]}
+    return res
+
+
+def cpu_whole_host(ncpu, threads, seconds, style):
+    """P = ncpu // threads processes x `threads` threads, started together, counting N = 1 forwards inside one common window."""
+    import subprocess
+    procs_n = ncpu // max(threads, 1)
+    if procs_n < 2:
+        return {"value": None, "note": "%d cpus: one %d-thread stream already is the whole host" % (ncpu, threads)}
+    t_start = time.time() + 20.0 + 0.25 * procs_n                    # every worker imports torch, draws the weights, warms up before this
+    procs = []
+    for i in range(procs_n):
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(threads), repr(t_start), repr(float(seconds)), style]
+        cpus = set(range(i * threads, (i + 1) * threads))
+
+        def pin(c=cpus):
+            try:
+                os.sched_setaffinity(0, c)
+            except Exception:
+                pass
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, preexec_fn=pin))
+    rows = []
+    for p_ in procs:
+        try:
+            out, _ = p_.communicate(timeout=seconds + 180)
+            rows.append(json.loads(out.decode().strip().splitlines()[-1]))
+        except Exception:
+            p_.kill()
+    if not rows:
+        return {"value": None, "note": "no worker reported"}
+    imgs = sum(r["images"] for r in rows)
+    return {"value": round(imgs / seconds, 2), "unit": "images/sec", "processes": procs_n, "threads_per_process": threads,
+            "cores": procs_n * threads, "host_cpus": ncpu, "workers_reporting": len(rows), "workers_late": sum(1 for r in rows if r["late_s"] > 0),
+            "kind": rows[0]["kind"],
+            "sample": "%d processes x %d threads, each pinned to its own cpus, N=1 forwards of one 256x256 image counted inside a common "
+                      "%.0f s window: %d images" % (procs_n, threads, seconds, imgs)}
 
 
 def measure_latency(sd, device):
@@ -270,8 +364,14 @@ def control_flow_only(args, rank, world, dist, sharded, engine):
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    per_rank, blobs = [elapsed], [e.blob]
+    per_rank, blobs, bcast_ms = [elapsed], [e.blob], [sc.weights_broadcast_ms]
+    if args.scaling == "strong" and args.global_batch % world:
+        print("bench.py: --global-batch %d does not divide by %d ranks" % (args.global_batch, world), file=sys.stderr)
+        sys.exit(2)
+    nb_cf = args.global_batch // world if args.scaling == "strong" else args.batch
     if world > 1:
+        bcast_ms = [None] * world
+        dist.all_gather_object(bcast_ms, sc.weights_broadcast_ms)
         t = torch.tensor([elapsed], dtype=torch.float64)
         mine = t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -284,6 +384,8 @@ def control_flow_only(args, rank, world, dist, sharded, engine):
     if rank == 0:
         print(json.dumps({"metric": "256x256 images/sec", "value": None, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "control_flow_only": True, "ranks_reporting": len(per_rank),
+                          "scaling": args.scaling, "per_gpu_batch": nb_cf, "global_batch": nb_cf * world,
+                          "weights_broadcast_ms_per_rank": [None if x is None else round(float(x), 3) for x in bcast_ms],
                           "launched_by": os.environ.get("IDC_BENCH_LAUNCHED_BY", "external launcher"),
                           "process_group_backend": dist.get_backend() if world > 1 else None,
                           "transport_requested": args.transport, "transport_used": sc.transport_used or args.transport,
@@ -297,6 +399,8 @@ def control_flow_only(args, rank, world, dist, sharded, engine):
 
 def main():
     args = parse_args()
+    if args.cpu_worker:
+        return cpu_worker(int(args.cpu_worker[0]), float(args.cpu_worker[1]), float(args.cpu_worker[2]), args.cpu_worker[3])
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         os.environ["IDC_BENCH_LAUNCHED_BY"] = "bench.py self_launch"
         sys.exit(self_launch(args.gpus))
@@ -322,6 +426,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     nb = args.batch
+    if args.scaling == "strong":                      # fixed total work: --global-batch images split evenly
+        if args.global_batch % world:
+            print("bench.py: --global-batch %d does not divide by %d ranks" % (args.global_batch, world), file=sys.stderr)
+            sys.exit(2)
+        nb = args.global_batch // world
 
     # ---- engine + weights (rank 0 packs, RCCL broadcast of the packed blob) --------------------------
     # bf16 throughput job: the blob without the Winograd images of the batch-1 / fp32 kernels (IDC_FLAG_THROUGHPUT_BLOB) -- the
@@ -374,7 +483,10 @@ def main():
     e.set_profiling(False)
 
     per_rank = [my_elapsed]
+    bcast_ms = [sc.weights_broadcast_ms]
     if world > 1:
+        bcast_ms = [None] * world
+        dist.all_gather_object(bcast_ms, sc.weights_broadcast_ms)
         on_cpu = dist.get_backend() == "gloo"
         t = torch.tensor([elapsed] + extra, dtype=torch.float64, device="cpu" if on_cpu else dev)
         mine = t.clone()
@@ -415,7 +527,7 @@ def main():
         "setup_forwards": max(args.setup_forwards, 0),
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": args.precision,
         "data": "synthetic",
@@ -429,7 +541,8 @@ def main():
                    "parallelism": "independent images sharded over %d GPU(s); one RCCL weight broadcast (transport: %s%s)" % (
                        world, sc.transport_used or args.transport, ", c_abi fell back: " + sc.transport_fallback_reason if sc.transport_fallback_reason else ""),
                    "weights_blob_bytes": int(e.blob_bytes()),
-                   "weights_broadcast_ms": sc.weights_broadcast_ms},
+                   "weights_broadcast_ms": sc.weights_broadcast_ms,
+                   "weights_broadcast_ms_per_rank": [None if x is None else round(float(x), 3) for x in bcast_ms]},
         "roofline": {"bound": "mfma", "achieved": round(achieved_tflops, 2), "peak": round(peak, 2), "unit": "TFLOP/s",
                      "peak_is": ("dense bf16 MFMA peak %.0f TFLOP/s / %d bf16 products per fp32 product" % (PEAK_BF16_DENSE_TFLOPS, products)) if products > 1
                                 else ("dense bf16 MFMA peak" if args.precision == "bf16" else "exact-fp32 MFMA peak"),
@@ -491,6 +604,10 @@ def main():
             e.load_state_dict(sd)
         except Exception as ex:
             result[key] = {"error": str(ex)[:200]}
+        # both styles under FIXED keys whatever --weights says: cross-round comparisons use the same key, never `value`
+        result["he_style_weights" if args.weights == "he" else "torch_init_weights"] = {
+            "value": round(value, 2), "unit": "images/sec", "ms_per_step": round(ms_per_step, 4),
+            "whole_forward_frac": round(FLOP_PER_IMAGE_256 * nb / (ms_per_step * 1e-3) / 1e12 / peak, 4), "how": "= `value` (--weights %s)" % args.weights}
     if world == 1 and not args.no_peak_probe and args.precision == "bf16":
         # the SAME launches on all-zero operands (weights and inputs): no kernel branches on data, so the instruction
         # streams are identical and the time difference is the clock the power management grants -- separates the code's
@@ -528,7 +645,7 @@ def main():
     if world == 1 and not args.no_latency:
         result["latency"] = measure_latency(sd, local_rank)
     if world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(sd)
+        result["cpu_baseline"] = cpu_baseline(sd, style=args.weights)
     elif world == 1:
         result["cpu_baseline"] = None
     print(json.dumps(result))

@@ -66,7 +66,7 @@ def read_state_dict(path):
     return sd
 
 
-def read_caffe_weights(path, state_dict=None):
+def read_caffe_weights(path, state_dict=None, net=None):
     """What the Caffe classes' ``prep_net(gpu_id, prototxt_path, caffemodel_path)`` loads -> ``(state_dict, out_mul)``.
     A ``.caffemodel`` (the reference's default invocation, ``ideepcolor.py:60-66`` / ``data/colorize_image.py:392-403``) is read
     straight from its protobuf wire format by :mod:`caffe_io` -- Caffe layer names mapped to the engine's keys, ``bw_conv1_1`` +
@@ -77,7 +77,7 @@ def read_caffe_weights(path, state_dict=None):
         return state_dict, 100.
     from . import caffe_io
     if str(path).endswith(".caffemodel") or (not str(path).endswith((".pth", ".npz")) and caffe_io.is_caffemodel(path)):
-        sd, info = caffe_io.read_caffemodel_state_dict(path)
+        sd, info = caffe_io.read_caffemodel_state_dict(path, net=net)    # net: the prototxt of the calling class (layers it lacks are skipped, as Caffe does)
         if info["ignored"]:
             print('caffemodel layers not used (injected at load time or outside the path): %s' % ', '.join(info["ignored"]))
         return sd, (100. if info["out_mul"] is None else info["out_mul"])
@@ -313,7 +313,8 @@ class ColorizeImageBase(object):
         if not pend:
             return
         names = set(pend)
-        pend.clear()
+        #  the pending set is cleared only AFTER a successful fetch: if the serial check or the fetch raises, every later read of
+        # output_ab / output_lab / output_ab_raw comes back here and raises again instead of handing out the maps of an older forward
         if getattr(self.net, 'before_overwrite', None) is not None:
             self.net.before_overwrite = None
         if getattr(self.net, 'forward_serial', None) != self.__dict__.get('_out_serial'):
@@ -327,6 +328,7 @@ class ColorizeImageBase(object):
             self.__dict__['_lazy_output_lab'] = lab_q[0]
         if 'output_ab' in names:
             self.__dict__['_lazy_output_ab'] = lab_q[0][1:]
+        pend.clear()
 
     def _finish_forward(self, raw_ab, rgb=None, lab_q=None):
         """Lab->RGB of the prediction, then refresh ``output_ab`` from the uint8 result -- the
@@ -601,7 +603,7 @@ class ColorizeImageCaffe(ColorizeImageBase):
         print('gpu_id = %d, net_path = %s, model_path = %s' % (gpu_id, prototxt_path, caffemodel_path))
         if gpu_id == -1:
             raise RuntimeError('cpu mode is not available: this backend runs on gfx950 only')
-        sd, out_mul = read_caffe_weights(caffemodel_path, state_dict)
+        sd, out_mul = read_caffe_weights(caffemodel_path, state_dict, net="global" if self._global_hints else ("nopred" if self._dist313 else "nodist"))
         out_mul = self.__dict__.pop('_file_out_mul', out_mul)      # (a subclass that already read the file passes what it found)
         self.gpu_id = gpu_id
         net = HipColorizer(H=self.Xd, W=self.Xd, max_batch=1, precision=self.precision, device=int(gpu_id),
@@ -632,7 +634,7 @@ class ColorizeImageCaffeGlobDist(ColorizeImageCaffe):
         self.glob_layer = 'glob_ab_313_mask'
 
     def prep_net(self, gpu_id, prototxt_path='', caffemodel_path='', state_dict=None):
-        sd, self._file_out_mul = read_caffe_weights(caffemodel_path, state_dict)
+        sd, self._file_out_mul = read_caffe_weights(caffemodel_path, state_dict, net='global')
         sd = dict(sd)
         w = np.asarray(sd['model1.0.weight'])
         if w.shape[1] == 1:                                   # bw_conv1_1 only: ab / mask never reach the net
@@ -713,7 +715,7 @@ class ColorizeImageCaffeDist(ColorizeImageCaffe):
         self.dist_entropy = np.zeros((self.Xd, self.Xd))
 
     def prep_net(self, gpu_id, prototxt_path='', caffemodel_path='', S=.2, state_dict=None):
-        sd, self._file_out_mul = read_caffe_weights(caffemodel_path, state_dict)
+        sd, self._file_out_mul = read_caffe_weights(caffemodel_path, state_dict, net="nopred")
         sd = dict(sd)
         if 'pred.pred_ab.weight' not in sd:
             print('Setting ab cluster centers in layer: %s' % self.pred_ab_layer)

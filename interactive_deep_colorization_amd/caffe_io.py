@@ -253,10 +253,16 @@ _DECONV = ("model8up.0", "model9up.0", "model10up.0", "pred.conv4_pred", "pred.c
 BN_EPS = 1e-5
 
 
-def caffe_layers_to_state_dict(layers):
+def caffe_layers_to_state_dict(layers, net=None):
     """Layers of ``read_caffemodel`` -> ``(state_dict, info)``.  ``state_dict``: the engine's keys (float32 arrays);
     ``info``: {'out_mul': the regression net's final Scale (100) or None, 'net': 'nodist' | 'nopred' | 'global',
-    'ignored': names of blob-carrying layers not used (injected at load time by the reference, or unknown)}."""
+    'ignored': names of blob-carrying layers not used (injected at load time by the reference, or unknown)}.
+
+    ``net`` = the prototxt the caller's class stands for ('nodist' | 'nopred' | 'global'; None = judge by the layers the file
+    holds).  Caffe copies blobs BY LAYER NAME into the net the prototxt defines and ignores source layers the net does not have
+    (``caffe.Net(prototxt, caffemodel)``, ``data/colorize_image.py:392-403``): the Global-Hints prototxt comments ``ab_conv1_1``
+    out (``models/global_model/deploy_nodist.prototxt:28-32,189-202``), so a checkpoint that still carries that layer must NOT feed
+    local ab / mask planes into the global net."""
     by_name = {}
     for L in layers:
         if L["blobs"]:
@@ -282,7 +288,9 @@ def caffe_layers_to_state_dict(layers):
     w4 = np.zeros((wl.shape[0], 4, 3, 3), np.float32)
     w4[:, :1] = wl
     b4 = np.zeros(wl.shape[0], np.float32) if bl_ is None else bl_.copy()
-    if "ab_conv1_1" in by_name:
+    if "ab_conv1_1" in by_name and net == "global":
+        ignored.append("ab_conv1_1")                              # not a layer of the Global-Hints net: Caffe would skip it
+    elif "ab_conv1_1" in by_name:
         wa, ba = conv_blobs("ab_conv1_1")
         if wa.shape != (wl.shape[0], 3, 3, 3):
             raise CaffeModelError("ab_conv1_1 weight %s, expected (%d, 3, 3, 3)" % (wa.shape, wl.shape[0]))
@@ -336,8 +344,9 @@ def caffe_layers_to_state_dict(layers):
                 raise CaffeModelError("'%s' carries a bias (the reference's layer has bias_term: false)" % name)
             sd[key + ".weight"] = sd[key + ".weight"] * s[None, :, None, None]
     ignored += [n for n in _INJECTED if n in by_name]
-    net = "nopred" if "pred.pred_313.weight" in sd else ("global" if "glob.glob_conv1.weight" in sd else "nodist")
-    return sd, {"out_mul": out_mul, "net": net, "ignored": sorted(ignored)}
+    found = "nopred" if "pred.pred_313.weight" in sd else ("global" if "glob.glob_conv1.weight" in sd else "nodist")
+    # 'net': what the caller's class asked for (the shared model.caffemodel carries several heads); 'net_in_file': what the layers say
+    return sd, {"out_mul": out_mul, "net": net or found, "net_in_file": found, "ignored": sorted(ignored)}
 
 
 def state_dict_to_caffe_layers(sd, net="nodist", out_mul=100.0, scale_factor=999.98236):
@@ -389,6 +398,6 @@ def state_dict_to_caffe_layers(sd, net="nodist", out_mul=100.0, scale_factor=999
     return layers
 
 
-def read_caffemodel_state_dict(path):
+def read_caffemodel_state_dict(path, net=None):
     """``.caffemodel`` -> ``(state_dict, info)`` (see ``caffe_layers_to_state_dict``)."""
-    return caffe_layers_to_state_dict(read_caffemodel(path))
+    return caffe_layers_to_state_dict(read_caffemodel(path), net=net)

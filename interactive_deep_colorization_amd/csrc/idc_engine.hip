@@ -1517,7 +1517,10 @@ int idc_forward_device(idc_handle h, int n, const float* d_L_mc, const float* d_
     h->labq_resident = false;
     rc = run_graph(h, n, d_L_mc, d_ab, d_mask, maskcent, d_out_ab, (h->flags & IDC_FLAG_DIST_HEAD) ? h->d_dist : nullptr);
     if (rc) return rc;
-    if (sync) HIPCHK(h, wait_stream(h, n));
+    if (sync) {
+        HIPCHK(h, wait_stream(h, n));
+        return check_chain_abort(h);           // (every blocking wait that follows run_graph reports a timed-out chain launch itself)
+    }
     return IDC_OK;
 }
 
@@ -1770,6 +1773,8 @@ int idc_forward_resident(idc_handle h, int n, float maskcent, float l_cent, floa
     } else {
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
+    rc = check_chain_abort(h);
+    if (rc) return rc;
     if (out_ab) memcpy(out_ab, h->h_out, (size_t)n * hw * 2 * 4);
     return IDC_OK;
 }
@@ -1950,8 +1955,10 @@ static int wait_slot(idc_context* h, int slot) {
     auto& sl = h->pipe[slot];
     if (!sl.pending) return IDC_OK;
     HIPCHK(h, hipEventSynchronize(sl.ev_out));
-    if (sl.staged_out) memcpy(sl.user_out, sl.h_out, (size_t)sl.n * h->H * h->W * 2 * 4);
     sl.pending = false;
+    const int arc = check_chain_abort(h);      // the forward this slot carried ran a chain launch that gave up: its result is invalid
+    if (arc) return arc;
+    if (sl.staged_out) memcpy(sl.user_out, sl.h_out, (size_t)sl.n * h->H * h->W * 2 * 4);
     return IDC_OK;
 }
 

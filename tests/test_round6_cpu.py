@@ -1,0 +1,155 @@
+"""Round 6, CPU side (no GPU): the operand-split precisions' weight blob, and this round's host-logic changes.
+
+Blob of IDC_BF16X3 / IDC_BF16X6 (csrc/idc_engine.hip make_blob_plan, re-derived here independently): conv1_1 is an fp32 island (fp32
+layout-1 image, 32-channel chunks); every other layer carries 2 / 3 layout-1 bf16 images back to back -- part 0 = rne(w), part 1 =
+rne(w - part 0), part 2 = rne(w - part 0 - part 1) -- so that hi + lo reproduces w to 2^-16 relative and hi + mid + lo reproduces it exactly.
+Reference semantics of the weights: torch layouts of models/pytorch/model.py:13-109.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from interactive_deep_colorization_amd import _native as N
+from interactive_deep_colorization_amd import engine
+
+from test_abi_cpu import LAYERS, _al, _bf16_bits, _read_w
+
+
+def _split_plan(parts, dist=False):
+    off, plan = 64, []
+    for wkey, bnkey, kind, cin, cout in LAYERS:
+        if wkey == "model_class.0" and not dist:
+            continue
+        island = kind == "im2col"
+        kc = 32 if island else 64
+        cpad = 64 if cout <= 64 else _al(cout, 128)
+        nkc = (64 // kc) if kind == "im2col" else -(-cin // kc)
+        ntap = {"c3": 9, "dc": 16, "c1": 1, "im2col": 1}[kind]
+        e = dict(wkey=wkey, bnkey=bnkey, kind=kind, cin=cin, cout=cout, cpad=cpad, nkc=nkc, ncg=cpad // 64, ntap=ntap, island=island)
+        e["w_bytes"] = ntap * nkc * e["ncg"] * 8192
+        off = _al(off); e["w_off"] = off; off += e["w_bytes"] * (1 if island else parts)
+        off = _al(off); e["b_off"] = off; off += cpad * 4
+        if bnkey:
+            off = _al(off); off += cpad * 4
+            off = _al(off); off += cpad * 4
+        if kind == "dc":
+            off = _al(off); off += cpad * 4
+        plan.append(e)
+    off = _al(off); off += 1024
+    off = _al(off); off += 8
+    return plan, _al(off)
+
+
+def _bf16_to_f32(bits):
+    return (np.uint32(bits) << np.uint32(16)).view(np.float32) if isinstance(bits, np.ndarray) else \
+        np.array([int(bits) << 16], np.uint32).view(np.float32)[0]
+
+
+@pytest.mark.parametrize("precision,parts", [("bf16x3", 2), ("bf16x6", 3)])
+def test_split_blob_layout_and_parts(make_sd, precision, parts):
+    sd = make_sd(0, "he")
+    blob = engine.pack_weights(sd, precision)
+    plan, total = _split_plan(parts)
+    assert blob.size == total == N.load().idc_weights_blob_bytes(engine._PREC[precision], 0)
+    assert blob[:4].view(np.uint32)[0] == 0x43444931 and blob[8:12].view(np.uint32)[0] == engine._PREC[precision]
+    rs = np.random.RandomState(1)
+    for e in plan:
+        w = sd[e["wkey"] + ".weight"]
+        for _ in range(25):
+            co, ci = rs.randint(e["cout"]), rs.randint(e["cin"])
+            if e["kind"] == "c3":
+                ky, kx = rs.randint(3), rs.randint(3); tw, k, val = ky * 3 + kx, ci, w[co, ci, ky, kx]
+            elif e["kind"] == "im2col":
+                ky, kx = rs.randint(3), rs.randint(3); tw, k, val = 0, (ky * 3 + kx) * 4 + ci, w[co, ci, ky, kx]
+            elif e["kind"] == "c1":
+                tw, k, val = 0, ci, w[co, ci, 0, 0]
+            else:
+                ky, kx = rs.randint(4), rs.randint(4); tw, k, val = ky * 4 + kx, ci, w[ci, co, ky, kx]
+            val = np.float32(val)
+            if e["island"]:                                   # conv1_1: the fp32 image, bit for bit
+                assert _read_w(blob, e, "fp32", tw, co, k) == float(val), e["wkey"]
+                continue
+            rem, total_v = val, np.float32(0)
+            for p in range(parts):
+                ep = dict(e, w_off=e["w_off"] + p * e["w_bytes"])
+                got = _read_w(blob, ep, "bf16", tw, co, k)
+                assert got == int(_bf16_bits(np.float32(rem)).ravel()[0]), (e["wkey"], co, ci, "part %d" % p)
+                piece = _bf16_to_f32(got)
+                rem = np.float32(rem - piece)                 # exact: the remainder of a round-to-nearest is representable
+                total_v = np.float32(total_v + piece)
+            if parts == 3:
+                assert total_v == val, (e["wkey"], co, ci)    # hi + mid + lo = all 24 mantissa bits
+            else:
+                assert abs(float(total_v) - float(val)) <= 2.0 ** -16 * abs(float(val)) + 1e-30
+
+
+def test_split_precisions_are_refused_where_they_do_not_apply():
+    lib = N.load()
+    assert lib.idc_weights_blob_bytes(4, 0) == 0 and lib.idc_weights_blob_bytes(-1, 0) == 0
+    assert lib.idc_weights_blob_bytes(N.IDC_BF16X3, 0) < lib.idc_weights_blob_bytes(N.IDC_BF16X6, 0)
+    with pytest.raises(KeyError):
+        engine.pack_weights({}, "bf16x9")
+
+
+def test_global_net_skips_a_checkpoints_ab_conv1_1():
+    """the Global-Hints prototxt has no ab_conv1_1 (models/global_model/deploy_nodist.prototxt:28-32,189-202) and
+    Caffe skips source layers the net lacks; a checkpoint that still carries the layer must not feed local ab / mask planes into the
+    global net.  The class passes its net kind; judged by the layers alone (net=None) the merge still happens."""
+    from interactive_deep_colorization_amd import caffe_io
+    from test_round5_cpu import _caffe_style_sd
+    sd = _caffe_style_sd(include_glob=True)
+    layers = caffe_io.state_dict_to_caffe_layers(sd, net="global")
+    rs = np.random.RandomState(3)
+    wa, ba = rs.randn(64, 3, 3, 3).astype(np.float32), rs.randn(64).astype(np.float32)
+    layers.insert(0, {"name": "ab_conv1_1", "type": "Convolution", "blobs": [wa, ba]})
+    back = caffe_io.read_caffemodel(caffe_io.write_caffemodel(None, layers))
+    got, info = caffe_io.caffe_layers_to_state_dict(back, net="global")
+    assert info["net"] == "global" and "ab_conv1_1" in info["ignored"]
+    assert np.abs(got["model1.0.weight"][:, 1:]).max() == 0 and np.array_equal(got["model1.0.bias"], sd["model1.0.bias"])
+    merged, info2 = caffe_io.caffe_layers_to_state_dict(back)
+    assert np.array_equal(merged["model1.0.weight"][:, 1:], wa) and info2["net_in_file"] == "global"
+    # the shared model.caffemodel carries several heads: 'net' reports what the class asked for, not what the file happens to hold
+    assert caffe_io.caffe_layers_to_state_dict(back, net="nodist")[1]["net"] == "nodist"
+
+
+# ---- the first 8-GPU run, made boring ------------------------------------------------------------------------------
+def test_eight_ranks_through_the_c_abi_transport():
+    """Eight gloo ranks with --transport c_abi (round 5 ran eight ranks on the torch transport only): every rank's librccl pre-flight, the
+    agreed fallback, the real blob on every rank, one line, rc 0."""
+    from test_round5_cpu import _bench
+    p, line = _bench("--gpus", "8", "--steps", "2", "--warmup", "1", "--control-flow-only", "--transport", "c_abi")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert line["n_gpus"] == 8 and line["ranks_reporting"] == 8 and line["every_rank_holds_rank0_blob"] is True
+    assert line["transport_requested"] == "c_abi" and line["transport_used"] == "torch" and line["transport_fallback_reason"]
+    assert len(line["weights_broadcast_ms_per_rank"]) == 8 and all(x is not None for x in line["weights_broadcast_ms_per_rank"])
+
+
+def test_strong_scaling_splits_a_fixed_global_batch():
+    """SURVEY.md 8(d) config 4, second form: --scaling strong keeps 256 images in total (32 per rank at 8, 64 at 4); weak keeps 32 per rank."""
+    from test_round5_cpu import _bench
+    p, line = _bench("--gpus", "4", "--steps", "2", "--warmup", "1", "--control-flow-only", "--scaling", "strong")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert line["scaling"] == "strong" and line["per_gpu_batch"] == 64 and line["global_batch"] == 256 and line["n_gpus"] == 4
+    p, line = _bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--control-flow-only")
+    assert line["scaling"] == "weak" and line["per_gpu_batch"] == 32 and line["global_batch"] == 64
+    p, _ = _bench("--gpus", "3", "--steps", "1", "--control-flow-only", "--scaling", "strong")
+    assert p.returncode != 0                                   # 256 does not divide by 3: refused, not rounded
+
+
+def test_cpu_baseline_times_the_reference_module_where_it_exists():
+    """kind 'reference' (models/pytorch/model.py imported untouched) in the authoring container, 'port' (the oracle's
+    restatement: bit-identical at N = 1) where the reference tree does not exist -- the GPU box."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from interactive_deep_colorization_amd import workloads
+    from oracle import siggraph_torch
+    sd = workloads.random_state_dict(0, "torch")
+    fwd, kind = bench._cpu_forward(sd)
+    assert kind == ("reference" if os.path.isdir("/root/reference/models/pytorch") else "port")
+    L, ab, m = workloads.random_batch(1, 256, seed=0)
+    out = np.asarray(fwd(L, ab, m)).reshape(2, 256, 256)
+    assert np.array_equal(out, siggraph_torch.forward(sd, L, ab, m, 0.0)[0])
+    wh = bench.cpu_whole_host(2, 4, 1.0, "torch")              # fewer than two workers fit: says so instead of inventing a number
+    assert wh["value"] is None and "whole host" in wh["note"]

@@ -20,7 +20,25 @@ import tempfile
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(REPO, "interactive_deep_colorization_amd", "csrc")
-LLVM = "/opt/rocm/lib/llvm/bin"
+def _llvm_bin():
+    """llvm-objdump / llvm-readelf of the toolchain that built the objects: $IDC_LLVM_BIN, else beside $HIPCC, else under $ROCM_PATH,
+    else /opt/rocm (no hard-coded install layout)."""
+    import shutil as _sh
+    cands = [os.environ.get("IDC_LLVM_BIN")]
+    hipcc = os.environ.get("HIPCC") or _sh.which("hipcc")
+    if hipcc:
+        cands.append(os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))), "lib", "llvm", "bin"))
+    for var in ("ROCM_PATH", "ROCM_HOME"):
+        if os.environ.get(var):
+            cands.append(os.path.join(os.environ[var], "lib", "llvm", "bin"))
+    cands.append("/opt/rocm/lib/llvm/bin")
+    for c in cands:
+        if c and os.path.exists(os.path.join(c, "llvm-objdump")):
+            return c
+    return cands[-1]
+
+
+LLVM = _llvm_bin()
 
 
 def _top_level_split(text, sep=","):

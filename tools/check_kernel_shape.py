@@ -19,7 +19,25 @@ import tempfile
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(REPO, "interactive_deep_colorization_amd", "csrc")
-LLVM = "/opt/rocm/lib/llvm/bin"
+def _llvm_bin():
+    """llvm-objdump / llvm-readelf of the toolchain that built the objects: $IDC_LLVM_BIN, else beside $HIPCC, else under $ROCM_PATH,
+    else /opt/rocm (no hard-coded install layout)."""
+    import shutil as _sh
+    cands = [os.environ.get("IDC_LLVM_BIN")]
+    hipcc = os.environ.get("HIPCC") or _sh.which("hipcc")
+    if hipcc:
+        cands.append(os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))), "lib", "llvm", "bin"))
+    for var in ("ROCM_PATH", "ROCM_HOME"):
+        if os.environ.get(var):
+            cands.append(os.path.join(os.environ[var], "lib", "llvm", "bin"))
+    cands.append("/opt/rocm/lib/llvm/bin")
+    for c in cands:
+        if c and os.path.exists(os.path.join(c, "llvm-objdump")):
+            return c
+    return cands[-1]
+
+
+LLVM = _llvm_bin()
 # kernel name prefix -> (object, max conditional branches, max scratch instructions); measured at the round-5 HEAD: v2p 92-109, v2m 119-198, ds 63-66, conv1 block 36-47; scratch 0 (v2p<4,2,*>: 6 = three spilled epilogue constants)
 BUDGET = [("conv_igemm_v2p<2, 2,", "idc_v2m.o", 165, 0), ("conv_igemm_v2p<4, 2,", "idc_v2m.o", 140, 12), ("conv_igemm_v2m<", "idc_v2m.o", 300, 0),
           ("conv_ds_fused_m<", "idc_dsm.o", 100, 0), ("conv1_block_fused_t<4,", "idc_kernels.o", 70, 0)]
@@ -86,6 +104,10 @@ def main():
     for f in findings:
         print("check_kernel_shape: " + f, file=sys.stderr)
     print("check_kernel_shape: %d kernels held to their branch / scratch budgets, %d findings" % (seen, len(findings)))
+    if (findings or seen < 8) and os.environ.get("IDC_SHAPE_CHECK", "").lower() in ("warn", "0", "off"):
+        # a performance lint, not a correctness check: a new compiler may legitimately move the numbers -- the build goes on, loudly
+        print("check_kernel_shape: IDC_SHAPE_CHECK=%s -- findings reported above, NOT failing the build" % os.environ["IDC_SHAPE_CHECK"], file=sys.stderr)
+        return 0
     return 1 if findings or seen < 8 else 0
 
 

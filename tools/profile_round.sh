@@ -37,6 +37,11 @@ cd $R
 timeout 600 python bench.py --gpus 2 --steps 10 --warmup 2 --dryrun-single-gpu > $OUT/dryrun_2ranks.json 2> $OUT/dryrun_2ranks.err
 timeout 600 python bench.py --gpus 2 --steps 10 --warmup 2 --dryrun-single-gpu --transport c_abi > $OUT/dryrun_2ranks_c_abi.json 2> $OUT/dryrun_2ranks_c_abi.err
 tail -1 $OUT/dryrun_2ranks.json | cut -c1-400
+# round 6: the driver's 8-rank job shape on ONE device -- eight processes, two HIP runtimes each, one engine each (small batch: the point is
+# the control flow and the queue budget, not the number), and the strong-scaling form
+timeout 900 python bench.py --gpus 8 --steps 5 --warmup 2 --batch 4 --dryrun-single-gpu --no-latency --no-cpu-baseline > $OUT/dryrun_8ranks.json 2> $OUT/dryrun_8ranks.err
+timeout 600 python bench.py --gpus 2 --steps 5 --warmup 2 --scaling strong --global-batch 16 --dryrun-single-gpu --no-latency --no-cpu-baseline > $OUT/dryrun_2ranks_strong.json 2> $OUT/dryrun_2ranks_strong.err
+tail -1 $OUT/dryrun_8ranks.json | cut -c1-300
 python tools/extra_configs.py > $OUT/extra_configs.txt 2>&1
 python tools/gpu_diag.py 2>/dev/null | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" > $OUT/layer_table.txt
 # identical launches on bench / damped / all-zero operands: how much of the forward time is the DVFS response to switching activity
@@ -50,6 +55,19 @@ rocprofv3 --kernel-trace --stats -d $OUT/stats_fp32 -o x -- $CMD32 > $OUT/stats_
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc_sq_fp32 -o x -- $CMD32 > $OUT/pmc_sq_fp32.log 2>&1
 cd $R
 for p in stats_fp32 pmc_sq_fp32; do
+  f=$(find $OUT/$p -name "*.db" | head -1)
+  [ -n "$f" ] && python tools/rocpd_summary.py $f --family conv > $OUT/${p}_summary.txt
+done
+# operand-split precisions (round 6): bench lines, kernel stats and SQ counters of the bf16x3 command
+for p in bf16x3 bf16x6; do
+  python bench.py --precision $p --no-cpu-baseline --no-end-to-end --no-peak-probe --no-latency > $OUT/bench_$p.json 2>/dev/null
+done
+cd /tmp
+CMDX3="python $R/bench.py --precision bf16x3 --steps 3 --warmup 1 --no-latency --no-cpu-baseline --no-end-to-end --no-peak-probe"
+rocprofv3 --kernel-trace --stats -d $OUT/stats_bf16x3 -o x -- $CMDX3 > $OUT/stats_bf16x3.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc_sq_bf16x3 -o x -- $CMDX3 > $OUT/pmc_sq_bf16x3.log 2>&1
+cd $R
+for p in stats_bf16x3 pmc_sq_bf16x3; do
   f=$(find $OUT/$p -name "*.db" | head -1)
   [ -n "$f" ] && python tools/rocpd_summary.py $f --family conv > $OUT/${p}_summary.txt
 done
