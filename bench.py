@@ -153,7 +153,10 @@ def cpu_baseline(sd, budget_s=12.0, style="torch"):
     cpus, all counting inside the same `budget_s`-second window: `whole_host`, the host's throughput."""
     import torch
     from interactive_deep_colorization_amd import workloads
-    ncpu = os.cpu_count() or 1
+    try:
+        ncpu = len(os.sched_getaffinity(0))          # the cpus this process may run on (a container's mask can be much smaller than os.cpu_count())
+    except Exception:
+        ncpu = os.cpu_count() or 1
     fwd, kind = _cpu_forward(sd)
     L, ab, m = workloads.random_batch(1, H, seed=0)
     probe = {}
@@ -175,14 +178,35 @@ def cpu_baseline(sd, budget_s=12.0, style="torch"):
     total = sum(ts)
     res = {"value": round(n_img / total, 3), "unit": "images/sec", "cores": cores, "kind": kind,
            "sample": "%d distinct 256x256 images of the bench workload, one per call (N=1, fp32, %s), %d threads (best of 8/16/32/64 probed) "
-                     "on a %d-cpu host: %.1f s, p50 %.3f s per image" % (
+                     "on a %d-cpu host (%d usable by this process): %.1f s, p50 %.3f s per image" % (
                          n_img, "the reference's SIGGRAPHGenerator.forward on torch CPU" if kind == "reference"
-                         else "torch CPU oracle = the reference's ATen kernels", cores, ncpu, total, statistics.median(ts))}
+                         else "torch CPU oracle = the reference's ATen kernels", cores, os.cpu_count() or ncpu, ncpu, total, statistics.median(ts))}
     try:
         res["whole_host"] = cpu_whole_host(ncpu, min(cores, 8), budget_s, style)
     except Exception as ex:                                           # a diagnostic leg: never sinks the line
         res["whole_host"] = {"value": None, "error": str(ex)[:200]}
     return res
+
+
+def cpu_limits():
+    """What the container may actually use of the host's cpus: the affinity mask and the cgroup CPU-time quota (v2 cpu.max / v1 cfs_quota_us).
+    A box that shows 256 cpus under a 16-core quota runs P x T = 256 threads at the speed of 16 -- the whole-host figure then says so."""
+    out = {"affinity_cpus": None, "cgroup_quota_cores": None}
+    try:
+        out["affinity_cpus"] = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        out["cgroup_quota_cores"] = None if q == "max" else round(float(q) / float(per), 2)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            out["cgroup_quota_cores"] = None if q <= 0 else round(q / per, 2)
+        except Exception:
+            pass
+    return out
 
 
 def cpu_whole_host(ncpu, threads, seconds, style):
@@ -193,10 +217,14 @@ def cpu_whole_host(ncpu, threads, seconds, style):
         return {"value": None, "note": "%d cpus: one %d-thread stream already is the whole host" % (ncpu, threads)}
     t_start = time.time() + 20.0 + 0.25 * procs_n                    # every worker imports torch, draws the weights, warms up before this
     procs = []
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except Exception:
+        allowed = list(range(ncpu))
     for i in range(procs_n):
         env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
         cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(threads), repr(t_start), repr(float(seconds)), style]
-        cpus = set(range(i * threads, (i + 1) * threads))
+        cpus = set(allowed[i * threads:(i + 1) * threads]) or set(allowed)
 
         def pin(c=cpus):
             try:
@@ -215,7 +243,7 @@ def cpu_whole_host(ncpu, threads, seconds, style):
         return {"value": None, "note": "no worker reported"}
     imgs = sum(r["images"] for r in rows)
     return {"value": round(imgs / seconds, 2), "unit": "images/sec", "processes": procs_n, "threads_per_process": threads,
-            "cores": procs_n * threads, "host_cpus": ncpu, "workers_reporting": len(rows), "workers_late": sum(1 for r in rows if r["late_s"] > 0),
+            "cores": procs_n * threads, "host_cpus": os.cpu_count(), "usable_cpus": ncpu, "container_limits": cpu_limits(), "workers_reporting": len(rows), "workers_late": sum(1 for r in rows if r["late_s"] > 0),
             "kind": rows[0]["kind"],
             "sample": "%d processes x %d threads, each pinned to its own cpus, N=1 forwards of one 256x256 image counted inside a common "
                       "%.0f s window: %d images" % (procs_n, threads, seconds, imgs)}

@@ -514,7 +514,15 @@ static int find_tensor(idc_context* c, const char* name) {
 // Tile policy (speed only; every choice computes the same result): 0 = automatic, 1 = always the
 // small-tile kernels (conv_igemm), 2 = the large-tile bf16 kernel (conv_igemm_v2) wherever it applies.
 static int g_tile_policy = 0;
-static int g_fuse_conv1 = !(getenv("IDC_FUSE_CONV1") && atoi(getenv("IDC_FUSE_CONV1")) == 0);   // model1 (conv1_1 + conv1_2) as one launch on the bf16 throughput path (idc_set_option / env IDC_FUSE_CONV1=0 for A/B)
+// The 32x32x16-MFMA partners of the throughput kernels (conv_igemm_v2, conv_ds_fused, conv1_1_bf16_kernel: idc_v2.hip, idc_conv1.hip) exist only in the
+// -DIDC_AB_PARTNERS build (round 6).  The default library plans every launch on conv_igemm_v2p / conv_igemm_v2m / conv_ds_fused_m / conv1_block_fused_t or
+// the small-tile kernels, and refuses the option values that ask for a partner.
+#ifdef IDC_AB_PARTNERS
+static constexpr bool kAbPartners = true;
+#else
+static constexpr bool kAbPartners = false;
+#endif
+static int g_fuse_conv1 = idc_env_int("IDC_FUSE_CONV1", 1) != 0;   // model1 (conv1_1 + conv1_2) as one launch on the bf16 throughput path (idc_set_option / env IDC_FUSE_CONV1=0 for A/B)
 // Split-K policy of the small-tile kernels (speed only): 0 = automatic (launches that would leave most CUs idle,
 // i.e. the batch-1 click path), 1 = never, 2 = always split as far as the cin chunks allow (tests).
 static int g_splitk_policy = 0;
@@ -524,19 +532,22 @@ static int g_splitk_policy = 0;
 static int g_wino = 1;
 static int g_wino_deconv = 1;            // 1 = small launches with Cin >= 256 only; 2 = every deconv ("winograd" = 2)
 // conv_igemm_v2 launches that qualify run as conv_igemm_v2m (16x16x32 MFMA: fewer joules per FLOP at the power cap; idc_set_option "mfma16")
-static int g_mfma16 = getenv("IDC_MFMA16") ? atoi(getenv("IDC_MFMA16")) : 1;
+static int g_mfma16 = idc_env_int("IDC_MFMA16", 1);
 // ... and so do the three deconv + shortcut launches (conv_ds_fused_m, idc_dsm.hip; idc_set_option "ds_mfma16" / env IDC_DS_M16=0 for A/B)
-static int g_ds_m16 = getenv("IDC_DS_M16") ? atoi(getenv("IDC_DS_M16")) : 1;
+static int g_ds_m16 = idc_env_int("IDC_DS_M16", 1);
 // ... and the 3x3 convs among them as conv_igemm_v2p (no address arithmetic in the K loop; idc_set_option "v2p" / env IDC_V2P=0 for A/B)
-static int g_v2p = getenv("IDC_V2P") ? atoi(getenv("IDC_V2P")) : 1;
+static int g_v2p = idc_env_int("IDC_V2P", 1);
 // throughput kernels touch their own code at entry (idc_warm_own_code, idc_kernels.h; env IDC_CODE_WARM=0 for the A/B of profiles/r04_firstuse.txt)
-static int g_code_warm = getenv("IDC_CODE_WARM") ? atoi(getenv("IDC_CODE_WARM")) : 1;
+static int g_code_warm = idc_env_int("IDC_CODE_WARM", 1);
 // bf16 click path: the 3x3 stride-1 layers and the deconvs as conv_kwave_bf16 / conv_kwave_deconv_bf16 ("kwave"; 0 = conv_click + split-K, round 2's kernels)
 static int g_kwave = 1;
 // ... and runs of consecutive same-shape 8-chunk conv_kwave_bf16 layers (the 512 -> 512 trunk at batch 1) as ONE persistent launch with a
 // grid barrier between layers ("kwave_chain" / IDC_KWAVE_CHAIN): 0 = off, 1 = hipLaunchCooperativeKernel (+24 us per launch on this runtime),
 // 2 = plain launch after an occupancy check (default; a workgroup that never sees the others gives up after ~0.3 s and the handle falls back)
-static int g_kwave_chain = getenv("IDC_KWAVE_CHAIN") ? atoi(getenv("IDC_KWAVE_CHAIN")) : 2;
+static int g_kwave_chain = idc_env_int("IDC_KWAVE_CHAIN", 2);
+static int g_spin_sync = 1;              // one- and two-image calls poll the stream instead of parking on an interrupt ("spin_sync"; 0 = the blocking wait of rounds 1-4)
+static int g_pcie_kernel = 1;            // their host <-> device transfers as copy kernels on the forward's stream ("pcie_kernel"; 0 = hipMemcpyAsync / the copy engines)
+static int g_kw_force_abort = 0;         // test hook ("kw_force_abort"): the persistent trunk launch's first grid barrier is unreachable and its give-up counter tiny
 static int g_click = -1;                 // conv_click for small launches: -1 = environment default (on), 0 off, 1 on (idc_set_option "click")
 // Shortcut fusion (conv_igemm_v2<.,.,1,true>) is correct (parity-tested under tile policy 2) but measured slower
 // than two launches on MI355X (4x re-reads of the skip tensor by the four phase workgroups, VGPR spills around
@@ -544,7 +555,7 @@ static int g_click = -1;                 // conv_click for small launches: -1 = 
 // large-tile deconv launches also run the shortcut conv they are summed with (conv_ds_fused); IDC_FUSE_SHORTCUT=0 keeps
 // the two launches apart (A/B)
 static bool fuse_shortcut_enabled() {
-    static const bool off = getenv("IDC_FUSE_SHORTCUT") != nullptr && atoi(getenv("IDC_FUSE_SHORTCUT")) == 0;
+    static const bool off = idc_env_int("IDC_FUSE_SHORTCUT", 1) == 0;
     return !off;
 }
 
@@ -553,10 +564,7 @@ static bool fuse_shortcut_enabled() {
 // not fill the 256 CUs.
 // Tuning knobs of the small-tile path (speed only), read once from the environment: tools/click_sweep.py walks them on
 // the GPU box and the defaults below are what it found best (profiles/r02_click_sweep.txt).
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
+static int env_int(const char* name, int dflt) { return idc_env_int(name, dflt); }      // (defaults only, unless built with -DIDC_AB_PARTNERS)
 struct SmallTileTuning {
     int tiles_goal = env_int("IDC_ST_TILES_GOAL", 512);         // shrink the pixel tile until this many workgroups exist
     int force_wp = env_int("IDC_ST_FORCE_WP", 0);               // 1/2/4: fixed rows-of-4 per workgroup (0 = automatic)
@@ -629,7 +637,7 @@ static void fill_taps(Layer& L) {
 
 // n_policy: the batch the kernel variant is chosen for (the handle's max_batch, so that a handle's
 // numerics do not depend on how many images a call carries); n: the batch actually launched.
-static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, int Ws) {
+static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, int Ws, bool allow_v2 = true) {
     ConvArgs& a = L.args;
     a.N = n; a.Hs = Hs; a.Ws = Ws;
     a.nkc = L.blob.nkc; a.ncg = L.blob.ncg;
@@ -653,7 +661,9 @@ static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, i
     // 128 couts x (32x16 sites); used when its grid covers at least half of the 256 CUs
     L.v2 = false;
     const bool split = is_split(precision);      // operand-split precisions: a throughput path, the large tile on every layer whatever the grid
-    if (split ? !split_island(*L.spec) : (precision == IDC_BF16 && v2_eligible(*L.spec) && g_tile_policy != 1)) {
+    // (default library: fp32-output launches -- class_logits -- stay on the small tile: conv_igemm_v2m / v2p write bf16 only)
+    const bool v2_covers = allow_v2 && (kAbPartners || !L.spec->out_f32);
+    if (split ? !split_island(*L.spec) : (precision == IDC_BF16 && v2_eligible(*L.spec) && g_tile_policy != 1 && v2_covers)) {
         ConvConfig c2 = (a.ncg % 4 == 0) ? ConvConfig{4, 2} : (a.ncg % 2 == 0) ? ConvConfig{2, 4} : ConvConfig{1, 4};   // ({1,*}: split precisions only, conv1_2)
         int tx = (Ws + 31) / 32, ty = (Hs + 4 * c2.wp - 1) / (4 * c2.wp);
         long long blocks = (long long)tx * ty * n_policy * (a.ncg / c2.wm) * a.nphase;
@@ -819,7 +829,7 @@ static int alloc_graph(idc_context* c) {
     // other runtime (torch) had already carved up the address space got some tensors on small pages, and the layers READING those
     // ran 25-35 % slower on every forward (bench.py's conv3_2 / conv5_1 / conv9_2 / conv8_1 against tools/quick_layers.py, which
     // creates the engine first).  IDC_ARENA=0 restores the per-tensor allocations for A/B.
-    static const bool use_arena = !(getenv("IDC_ARENA") && atoi(getenv("IDC_ARENA")) == 0);
+    static const bool use_arena = idc_env_int("IDC_ARENA", 1) != 0;
     if (use_arena) {
         const size_t al = (size_t)2 << 20;
         size_t total = 0;
@@ -931,11 +941,19 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             const Tensor& pin = c->tensors[P.src];
             const Tensor& to = c->tensors[L.dst];
             if (ps.kind == kConv3x3 && ps.dilation == 1 && ps.in_stride == 1 && ps.act == 0 && !ps.bnkey && !ps.resid &&
-                ps.cout == L.spec->cout && pin.H == to.H && pin.W == to.W && !pin.is_f32 && P.blob.w2_off != (size_t)-1) {
+                ps.cout == L.spec->cout && pin.H == to.H && pin.W == to.W && !pin.is_f32 && P.blob.w2_off != (size_t)-1 &&
+                (kAbPartners || (g_ds_m16 != 0 && conv_ds_m_fits(L.args.Hs, L.args.Ws, L.blob.nkc, P.blob.nkc)))) {      // (default library: conv_ds_fused_m or two launches)
                 L.fused_short = (int)j; P.skip = true;
             }
         }
     }
+    if (!kAbPartners)            // a large-tile deconv that keeps its shortcut SUM (not fused: images beyond 32-bit offsets) has no 16x16x32 kernel: small tile
+        for (auto& L : c->layers)
+            if (L.v2 && !L.split && L.resid >= 0 && L.fused_short < 0) {
+                const Tensor& ti = c->tensors[L.src];
+                const Tensor& to = c->tensors[L.dst];
+                set_geometry(L, L.lprec, n, c->max_batch, L.spec->kind == kDeconv4x4 ? ti.H : to.H, L.spec->kind == kDeconv4x4 ? ti.W : to.W, false);
+            }
     bool head_done = false;
     int chain_until = -1;                      // layers up to this index ran inside the conv_kwave_chain_bf16 launch of an earlier layer
     for (auto& L : c->layers) {
@@ -1021,7 +1039,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
         }
         // diagnostic (IDC_DOUBLE_LAUNCH=1): every launch issued twice, the event pair around the SECOND -- a layer that is slow only as
         // the first launch of its kernel after other kernels (cold instruction cache / first touch) shows its warm time here
-        static const bool double_launch = getenv("IDC_DOUBLE_LAUNCH") && atoi(getenv("IDC_DOUBLE_LAUNCH")) != 0;
+        static const bool double_launch = idc_env_int("IDC_DOUBLE_LAUNCH", 0) != 0;
         for (int rep = double_launch ? 0 : 1; rep < 2; ++rep) {
         if (rep == 1) tic();
         {
@@ -1081,9 +1099,8 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
                             ch.bar = c->d_kw_bar; ch.bar_base = c->kw_bar_count; ch.abort_flag = c->h_kw_abort;
                             // test hook (tests/test_round5_gpu.py): IDC_KW_FORCE_ABORT=1 makes the first grid barrier unreachable and the give-up
                             // counter tiny, i.e. it plays "the workgroups never become co-resident" on a healthy device
-                            static const bool force_abort = getenv("IDC_KW_FORCE_ABORT") && atoi(getenv("IDC_KW_FORCE_ABORT")) != 0;
-                            if (force_abort) { ch.bar_base += 1000; ch.spin_limit = 20u; }
-                            static const bool want_stamps = getenv("IDC_KW_STAMPS") && atoi(getenv("IDC_KW_STAMPS")) != 0;
+                            if (g_kw_force_abort) { ch.bar_base += 1000; ch.spin_limit = 20u; }
+                            static const bool want_stamps = idc_env_int("IDC_KW_STAMPS", 0) != 0;
                             if (want_stamps && !c->d_kw_stamps) HIPCHK(c, hipMalloc((void**)&c->d_kw_stamps, (size_t)4096 * kKwChainMax * 8 * 8));
                             ch.stamps = (want_stamps && blocks <= 4096) ? c->d_kw_stamps : nullptr;
                             c->kw_stamp_layers = ch.nlayers; c->kw_stamp_blocks = blocks;
@@ -1104,6 +1121,9 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
                 if (le != hipSuccess) le = launch_conv_kwave(a, s);
                 HIPCHK(c, le);
             }
+            if (!kAbPartners && le == hipErrorInvalidConfiguration && !L.split && !L.click && L.v2 && !L.m16)
+                return fail(&c->err, IDC_ERR_INTERNAL, "layer %s: planned on the large tile but no 16x16x32 kernel covers this launch (default library: no "
+                            "conv_igemm_v2 / conv_ds_fused; build with -DIDC_AB_PARTNERS)", L.spec->name);
             if (le == hipErrorInvalidConfiguration)
                 le = L.split ? (L.v2p ? launch_conv_v2ps(L.cfg, L.halo, a, s) : launch_conv_v2s(L.cfg, L.halo, a, s))
                    : L.click ? launch_conv_click(L.lprec, L.cfg.wp, L.halo, a, s)
@@ -1167,7 +1187,7 @@ static bool is_pinned(const void* p);
 // that serve ONE OR TWO images poll the stream instead (bounded: after ~4 ms of polling -- several forwards -- it blocks like everybody else).  Batches
 // keep the blocking wait: there the CPU is better spent elsewhere.  IDC_SPIN_SYNC=0 restores the blocking wait everywhere (A/B).
 static hipError_t wait_stream(idc_context* c, int n) {
-    static const bool spin = !(getenv("IDC_SPIN_SYNC") && atoi(getenv("IDC_SPIN_SYNC")) == 0);
+    const bool spin = g_spin_sync != 0;
     if (spin && n <= 2) {
         for (int i = 0; i < 4000; ++i) {
             const hipError_t e = hipStreamQuery(c->stream);
@@ -1186,7 +1206,7 @@ static hipError_t wait_stream(idc_context* c, int n) {
 // going to a copy engine: no cross-queue hand-over on either side of them.  `host` must be pinned (ours, or the caller's idc_alloc_host / hipHostMalloc /
 // mapped hipHostRegister memory); anything the device cannot address, bigger, or not 16-byte shaped takes hipMemcpyAsync.  IDC_PCIE_KERNEL=0: always (A/B).
 static hipError_t copy_h2d_or_d2h(idc_context* c, void* dev, void* host, size_t bytes, bool to_device) {
-    static const bool by_kernel = !(getenv("IDC_PCIE_KERNEL") && atoi(getenv("IDC_PCIE_KERNEL")) == 0);
+    const bool by_kernel = g_pcie_kernel != 0;
     if (by_kernel && bytes <= ((size_t)2 << 20) && bytes % 16 == 0 && (((uintptr_t)dev | (uintptr_t)host) & 15) == 0) {
         void* hv = nullptr;
         if (hipHostGetDevicePointer(&hv, host, 0) == hipSuccess && hv)
@@ -1352,10 +1372,15 @@ int idc_set_option(const char* name, int value) {
         set_wino_form(value >= 12 ? value : 0);
         return IDC_OK;
     }
+    if (!kAbPartners && ((strcmp(name, "mfma16") == 0 && value == 0) || (strcmp(name, "ds_mfma16") == 0 && value == 0)))
+        return fail(nullptr, IDC_ERR_UNSUPPORTED, "option '%s' = 0 selects a 32x32x16-MFMA partner kernel: not in the default library (build with make EXTRA=-DIDC_AB_PARTNERS)", name);
     if (strcmp(name, "mfma16") == 0) { g_mfma16 = value != 0; return IDC_OK; }
     if (strcmp(name, "v2p") == 0) { g_v2p = value != 0; return IDC_OK; }
     if (strcmp(name, "ds_mfma16") == 0) { g_ds_m16 = value != 0; set_ds_half(value != 2); return IDC_OK; }     // 2: conv_ds_fused_m, 8-wave workgroups on every grid
     if (strcmp(name, "kwave") == 0) { g_kwave = value != 0; return IDC_OK; }
+    if (strcmp(name, "spin_sync") == 0) { g_spin_sync = value != 0; return IDC_OK; }
+    if (strcmp(name, "pcie_kernel") == 0) { g_pcie_kernel = value != 0; return IDC_OK; }
+    if (strcmp(name, "kw_force_abort") == 0) { g_kw_force_abort = value != 0; return IDC_OK; }
     if (strcmp(name, "kwave_chain") == 0) { g_kwave_chain = value < 0 ? 0 : (value > 2 ? 2 : value); return IDC_OK; }
     return fail(nullptr, IDC_ERR_INVALID_ARG, "unknown option '%s'", name);
 }
@@ -2391,7 +2416,8 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     const int so = spec.kind == kDeconv4x4 ? 2 : 1;
     const int Ho = Hs * so, Wo = Ws * so;
     fill_taps(L);
-    set_geometry(L, precision, n, n, Hs, Ws);
+    // (default library: the large tile only where conv_igemm_v2m / v2p cover the launch -- no shortcut sum, no LeakyReLU without the fused head)
+    set_geometry(L, precision, n, n, Hs, Ws, kAbPartners || is_split(precision) || (resid == nullptr && spec.act != 2));
     if (L.wino && wino_dc) pack_wino_deconv_weights(wimg.data(), precision, spec, L.blob, weight);
     else if (L.wino) pack_wino_weights(wimg.data(), precision, spec, L.blob, weight);
     else {

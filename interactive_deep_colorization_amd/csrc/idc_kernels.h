@@ -1,6 +1,7 @@
 // idc_kernels.h -- launch interface of the gfx950 kernels (internal; the public ABI is
 // include/ideepcolor.h).
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -90,6 +91,14 @@ __device__ __forceinline__ void idc_warm_own_code(char* lds_scratch, int lane, i
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pc + (size_t)(j * 64 + lane) * 128),
                                              (__attribute__((address_space(3))) void*)lds_scratch, 4, 0, 0);
 }
+#endif
+
+// Tuning / A-B knobs read from the environment exist only in the -DIDC_AB_PARTNERS build (make EXTRA=-DIDC_AB_PARTNERS: tools/ab_*.sh, tools/click_sweep.py,
+// tools/probe_firstuse.sh); the default library reads ONE environment variable, IDC_RCCL_PATH (idc_engine.hip), and is steered through idc_set_option only.
+#ifdef IDC_AB_PARTNERS
+static inline int idc_env_int(const char* name, int dflt) { const char* v = getenv(name); return (v && *v) ? atoi(v) : dflt; }
+#else
+static inline int idc_env_int(const char*, int dflt) { return dflt; }
 #endif
 
 struct ConvConfig { int wm, wp; };     // waves along cout (x64) and along pixel rows (x4 rows of 16)

@@ -458,6 +458,10 @@ __device__ __forceinline__ void conv_v2m_body(const ConvArgs& a) {
             const float4 t4 = *(const float4*)(a.bn_shift + cow + g16 * 16 + mi * 4);
             bsc[mi] = f32x4{s4.x, s4.y, s4.z, s4.w};
             bsh[mi] = f32x4{t4.x, t4.y, t4.z, t4.w};
+            if (a.img_shift != nullptr) {                      // Global Hints: the per-image vector added after the BN affine (conv4_3; launches with BN only)
+                const float4 u4 = *(const float4*)(a.img_shift + (size_t)n * CoutPad + cow + g16 * 16 + mi * 4);
+                bsh[mi] += f32x4{u4.x, u4.y, u4.z, u4.w};
+            }
         }
     }
     // (one body per (BN, ReLU) combination chosen once, a row's four lines read before the first bounds check: conv_igemm_v2p's epilogue says why)
@@ -818,6 +822,10 @@ __device__ __forceinline__ void conv_v2p_body(const ConvArgs& a) {
             const float4 t4 = *(const float4*)(a.bn_shift + cow + g16 * 16 + mi * 4);
             bsc[mi] = f32x4{s4.x, s4.y, s4.z, s4.w};
             bsh[mi] = f32x4{t4.x, t4.y, t4.z, t4.w};
+            if (a.img_shift != nullptr) {                      // Global Hints: the per-image vector added after the BN affine (conv4_3; launches with BN only)
+                const float4 u4 = *(const float4*)(a.img_shift + (size_t)n * CoutPad + cow + g16 * 16 + mi * 4);
+                bsh[mi] += f32x4{u4.x, u4.y, u4.z, u4.w};
+            }
         }
     }
     // One body per (BN, ReLU) combination, chosen ONCE: written as run-time `if`s inside the element loops the compiler kept a uniform branch per packed
@@ -929,7 +937,7 @@ static constexpr size_t conv_v2m_lds_bytes_c(int wco, int wpx, int halo) {
 #define IDC_FOR_EACH_CONV_V2S(X) IDC_FOR_EACH_CONV_V2M(X) X(1, 4, 1) X(1, 2, 1)
 
 bool conv_v2m_applies(const ConvArgs& a) {
-    return a.resid == nullptr && a.in2 == nullptr && !a.out_f32 && a.img_shift == nullptr && a.pk_L == nullptr && a.ksplit <= 1 &&
+    return a.resid == nullptr && a.in2 == nullptr && !a.out_f32 && (a.img_shift == nullptr || a.bn_scale != nullptr) && a.pk_L == nullptr && a.ksplit <= 1 &&
            (a.act != 2 || a.head_w != nullptr) && (a.head_w == nullptr || a.bn_scale == nullptr) && a.zeros != nullptr;
 }
 

@@ -737,7 +737,7 @@ hipError_t launch_deconv_wino(int precision, const ConvArgs& a0, hipStream_t s) 
     return hipGetLastError();
 }
 
-int g_wino_form = getenv("IDC_WINO_FORM") ? atoi(getenv("IDC_WINO_FORM")) : 0;      // tuning: 0 automatic, 12 / 21 / 22 = force <TB,CB>
+int g_wino_form = idc_env_int("IDC_WINO_FORM", 0);      // tuning: 0 automatic, 12 / 21 / 22 = force <TB,CB>
 
 void set_wino_form(int form) { g_wino_form = form; }
 

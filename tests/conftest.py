@@ -85,3 +85,16 @@ def _close_engines_left_by_the_module():
         m = sys.modules.get(modname) or sys.modules.get("tests." + modname)
         if m is not None and hasattr(m, "_ENGINES"):
             m._ENGINES.clear()
+
+
+def has_ab_partners():
+    """True when the library was built with -DIDC_AB_PARTNERS (make EXTRA=-DIDC_AB_PARTNERS): the 32x32x16-MFMA partners conv_igemm_v2 / conv_ds_fused /
+    conv1_1_bf16_kernel exist and `mfma16` / `ds_mfma16` = 0 select them.  The default library refuses those values (IDC_ERR_UNSUPPORTED): tests that
+    compare a kernel with its partner run the partner leg only in that build (round 6)."""
+    from interactive_deep_colorization_amd import _native, engine
+    try:
+        engine.set_option("mfma16", 0)
+    except _native.IdcError:
+        return False
+    engine.set_option("mfma16", 1)
+    return True

@@ -283,7 +283,11 @@ def test_throughput_tile_in_both_mfma_shapes(golden, make_sd, name, mfma16):
     n, _, H, W = g["L_mc"].shape
     sd = make_sd(seed, style)
     outs = {}
-    for shape in (mfma16, 1 - mfma16):
+    from conftest import has_ab_partners
+    partners = has_ab_partners()
+    if not partners and mfma16 == 0:
+        pytest.skip("conv_igemm_v2 (32x32x16 MFMA) is an A/B partner: not in the default library (make EXTRA=-DIDC_AB_PARTNERS)")
+    for shape in ((mfma16, 1 - mfma16) if partners else (1,)):
         engine.set_tile_policy("large")
         engine.set_option("mfma16", shape)
         e = engine.HipColorizer(H, W, max_batch=n, precision="bf16")
@@ -299,5 +303,6 @@ def test_throughput_tile_in_both_mfma_shapes(golden, make_sd, name, mfma16):
     bound = bf16_bound(style)
     for shape, out in outs.items():
         check_bf16_ab(out - ref, style, tag="mfma16=%d" % shape)
-    d = np.abs(outs[1] - outs[0])
-    assert d.mean() <= bound[1] / 2, (d.max(), d.mean())
+    if partners:
+        d = np.abs(outs[1] - outs[0])
+        assert d.mean() <= bound[1] / 2, (d.max(), d.mean())

@@ -351,12 +351,12 @@ def test_throughput_kernels_keep_their_code_shape():
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import check_kernel_shape as chk
     csrc = os.path.join(REPO, "interactive_deep_colorization_amd", "csrc")
-    if not all(os.path.exists(os.path.join(csrc, o)) for o in ("idc_v2m.o", "idc_dsm.o", "idc_kernels.o")):
+    if not all(os.path.exists(os.path.join(csrc, o)) for o in ("idc_v2m.o", "idc_dsm.o", "idc_conv1.o")):
         pytest.skip("objects not built here")
     r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "check_kernel_shape.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 findings" in r.stdout
     old_shape = "0000 <void idc::conv_igemm_v2p<2, 2, 1>(idc::ConvArgs)>:\n" + "\tv_cvt_pk_bf16_f32 v0, v1, v2\n\ts_cbranch_vccnz 12\n" * 400 + "\tscratch_store_dwordx4 off, v[2:5], off\n"
-    stats = {"idc_v2m.o": chk.kernel_stats(old_shape), "idc_dsm.o": {}, "idc_kernels.o": {}}
+    stats = {"idc_v2m.o": chk.kernel_stats(old_shape), "idc_dsm.o": {}, "idc_conv1.o": {}}
     findings, _ = chk.check(stats)
     assert any("conditional branches" in f for f in findings) and any("scratch" in f for f in findings)

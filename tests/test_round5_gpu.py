@@ -231,8 +231,8 @@ def test_deconv_shortcut_half_workgroups_on_small_grids(make_sd, shape):
 
 def test_kwave_chain_gives_up_instead_of_hanging():
     """The safety net of the plain-launch default: a workgroup that never sees the others at the grid barrier (a partitioned / shared device; played here by
-    IDC_KW_FORCE_ABORT=1 -- unreachable barrier, tiny poll budget) sets the host-visible flag and leaves; the blocking call that waited for that forward
-    returns IDC_ERR_INTERNAL, the handle falls back to one launch per layer, and the next call gives the right answer.  Own process: the hook is read once."""
+    the test hook `kw_force_abort` = 1 -- unreachable barrier, tiny poll budget) sets the host-visible flag and leaves; the blocking call that waited for that forward
+    returns IDC_ERR_INTERNAL, the handle falls back to one launch per layer, and the next call gives the right answer.  Own process: the hook is process-wide."""
     import subprocess
     import sys
     code = r'''
@@ -241,6 +241,7 @@ sys.path.insert(0, %r)
 from interactive_deep_colorization_amd import engine, workloads, _native
 sd = workloads.random_state_dict(0, "torch")
 L, ab, m = workloads.random_batch(1, 256, seed=3)
+engine.set_option("kw_force_abort", 1)
 e = engine.HipColorizer(256, 256, max_batch=1, precision="bf16")
 e.load_state_dict(sd)
 try:
@@ -257,8 +258,7 @@ e.close()
     import tempfile
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "out.npy")
-        env = dict(os.environ); env["IDC_KW_FORCE_ABORT"] = "1"
-        p = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, env=env, timeout=300)
+        p = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=300)
         assert p.returncode == 0, p.stderr[-1500:]
         assert "ERROR:" in p.stdout and "timed" in p.stdout and "NO_ERROR" not in p.stdout, p.stdout
         assert "CHAIN_AFTER: False KW: 22" in p.stdout, p.stdout
@@ -303,14 +303,16 @@ def test_click_with_resident_l_plane_equals_click_with_l_passed(make_sd, precisi
 
 
 def test_blocking_wait_switch_gives_the_same_click():
-    """IDC_SPIN_SYNC=0 (read once at load: a fresh process) = the blocking hipStreamSynchronize of rounds 1-4 instead of the bounded poll the one-image
-    calls use since round 5; IDC_PCIE_KERNEL=0 = the copy engines instead of pcie_copy_kernel for their transfers; same bytes in every combination."""
+    """Option `spin_sync` = 0 (a fresh process each) = the blocking hipStreamSynchronize of rounds 1-4 instead of the bounded poll the one-image
+    calls use since round 5; `pcie_kernel` = 0 = the copy engines instead of pcie_copy_kernel for their transfers; same bytes in every combination.
+    (Options since round 6: the default library reads no tuning knob from the environment.)"""
     import subprocess
     import sys
     code = """
 import sys, hashlib, numpy as np
 sys.path.insert(0, %r)
 from interactive_deep_colorization_amd import engine, workloads
+engine.set_option("spin_sync", int(sys.argv[1])); engine.set_option("pcie_kernel", int(sys.argv[2]))
 e = engine.HipColorizer(64, 64, max_batch=1, precision="fp32")
 e.load_state_dict(workloads.random_state_dict(0, "torch"))
 L, ab, m = workloads.random_batch(1, 64, seed=3)
@@ -320,9 +322,8 @@ oab, lab = e.fetch_outputs(1)
 print("SUM", hashlib.sha1(out.tobytes() + rgb.tobytes() + oab.tobytes() + lab.tobytes()).hexdigest())
 """ % REPO
     sums = []
-    for spin, by_kernel in (("0", "0"), ("1", "1"), ("1", "0")):          # ... and IDC_PCIE_KERNEL=0: every transfer through hipMemcpyAsync, as before round 5
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, IDC_SPIN_SYNC=spin, IDC_PCIE_KERNEL=by_kernel), capture_output=True, text=True,
-                           timeout=300)
+    for spin, by_kernel in (("0", "0"), ("1", "1"), ("1", "0")):          # ... and pcie_kernel = 0: every transfer through hipMemcpyAsync, as before round 5
+        r = subprocess.run([sys.executable, "-c", code, spin, by_kernel], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         sums.append([l for l in r.stdout.splitlines() if l.startswith("SUM")][0])
     assert sums[0] == sums[1] == sums[2]

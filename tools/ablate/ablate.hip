@@ -6,10 +6,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
-#ifndef ABL_KERNELS
-#define ABL_KERNELS "../../interactive_deep_colorization_amd/csrc/idc_kernels.hip"
-#endif
-#include ABL_KERNELS
+#include "../../interactive_deep_colorization_amd/csrc/idc_igemm.hip"
+#include "../../interactive_deep_colorization_amd/csrc/idc_v2.hip"
+#include "../../interactive_deep_colorization_amd/csrc/idc_conv1.hip"
 #include "../../interactive_deep_colorization_amd/csrc/idc_wino.hip"
 #include "../../interactive_deep_colorization_amd/csrc/idc_v2m.hip"
 #include "../../interactive_deep_colorization_amd/csrc/idc_dsm.hip"
