@@ -74,26 +74,29 @@ int idc_version(void);
  * variant at small sizes.  No reference counterpart. */
 int idc_set_tile_policy(int policy);
 /* Process-wide switches for the parity tests and A/B measurements (speed / kernel choice only: every setting computes the same
- * function).  EIGHT names since round 5 (round 4 had fourteen):
+ * function).  Eleven names (round 6: three former environment switches became options; the library reads NO tuning knob from the environment):
  *   "fuse_conv1"  (1)  model1 = conv1_1 + conv1_2 as one launch on the bf16 path; 0 keeps the two launches apart, so that conv1_1's own
  *                      output exists and can be read with idc_get_activation.
- *   "click"       (-1 = on unless IDC_CLICK=0)  small launches (the batch-1 click path, fp32 and what "kwave" does not cover) run conv_click
+ *   "click"       (-1 = on)  small launches (the batch-1 click path, fp32 and what "kwave" does not cover) run conv_click
  *                      (weight tiles by LDS-DMA, fragments prefetched across steps); 0 keeps them on conv_igemm.
  *   "winograd"    (1)  fp32 path: 3x3 stride-1 layers as Winograd F(2x2,3x3), small deconv launches as F(2x2,2x2).  0 = direct kernels,
  *                      1 = automatic, 2 = every deconv too (tests), 12 / 21 / 22 = automatic with the 3x3 form <TB,CB> forced (tests).
- *   "mfma16"      (1)  bf16 throughput tile as conv_igemm_v2m (v_mfma_f32_16x16x32_bf16: fewer joules per FLOP at the power cap);
- *                      0 = conv_igemm_v2 (v_mfma_f32_32x32x16_bf16).
- *   "v2p"         (1)  the 3x3 convs among them as conv_igemm_v2p (column-swizzled halo tile, unrolled taps; bit-identical results).
- *   "ds_mfma16"   (1)  deconv + shortcut launches as conv_ds_fused_m (16x16x32 MFMA), grids with fewer 128-cout workgroups than CUs (model10up of ONE
- *                      256x256 image) in its 64-cout 4-wave form; 2 = 8-wave workgroups on every grid (A/B, tests); 0 = conv_ds_fused.
+ *   "mfma16"      (1)  bf16 throughput tile from v_mfma_f32_16x16x32_bf16 (conv_igemm_v2m / v2p).  0 = conv_igemm_v2 (32x32x16): A/B partner,
+ *                      exists only in the -DIDC_AB_PARTNERS build; the default library answers IDC_ERR_UNSUPPORTED.
+ *   "v2p"         (1)  the 3x3 convs among them as conv_igemm_v2p (column-swizzled halo tile, unrolled taps; bit-identical to conv_igemm_v2m).
+ *   "ds_mfma16"   (1)  deconv + shortcut launches as conv_ds_fused_m, grids with fewer 128-cout workgroups than CUs (model10up of ONE 256x256 image)
+ *                      in its 64-cout 4-wave form; 2 = 8-wave workgroups on every grid (A/B, tests); 0 = conv_ds_fused: partner build only.
  *   "kwave"       (1)  bf16 batch-1 click path: 3x3 stride-1 layers and ConvTranspose launches as conv_kwave_bf16 / conv_kwave_deconv_bf16
  *                      (direct form, K split over the waves of a workgroup); 0 = conv_click + split-K (round 2's kernels).
  *   "kwave_chain" (2)  ... and runs of consecutive same-shape 512-channel layers of that path (conv4_2 .. conv7_3 at batch 1) as ONE
  *                      persistent launch with a grid barrier between layers (conv_kwave_chain_bf16): 0 = one launch per layer,
  *                      1 = through hipLaunchCooperativeKernel, 2 = plain launch after an occupancy check; a workgroup that never sees the
  *                      others gives up after ~0.3 s, that forward fails with IDC_ERR_INTERNAL and the handle goes back to one launch per layer.
- * Retired in round 5 together with their kernels, or folded into the above: "fuse_conv1_small", "winograd_bf16", "winograd_form",
- * "winograd_deconv", "conv1_lw", "code_warm", "kwave_deconv" (IDC_ERR_INVALID_ARG now).
+ *   "spin_sync"   (1)  calls that serve one or two images wait by polling the stream (bounded) instead of parking on an interrupt; 0 = blocking wait.
+ *   "pcie_kernel" (1)  their host <-> device transfers (<= 2 MiB, pinned) run as a copy kernel on the forward's stream; 0 = hipMemcpyAsync.
+ *   "kw_force_abort" (0)  TEST HOOK: 1 makes the persistent trunk launch's first grid barrier unreachable (plays "workgroups never co-resident").
+ * Retired with their kernels, or folded into the above: "fuse_conv1_small", "winograd_bf16", "winograd_form", "winograd_deconv", "conv1_lw",
+ * "code_warm", "kwave_deconv" (IDC_ERR_INVALID_ARG).
  * Take effect on the next forward; unknown names return IDC_ERR_INVALID_ARG. */
 int idc_set_option(const char* name, int value);
 /* How a call waits for the device (no reference counterpart): calls that serve ONE OR TWO images (the click path) poll the stream instead of

@@ -80,15 +80,10 @@ SPLITK_POLICIES = {"auto": 0, "never": 1, "always": 2}
 
 
 def set_option(name, value):
-    """Process-wide switches (``idc_set_option``; speed / kernel choice only -- every setting computes the same function).  Eight names:
-    'fuse_conv1' 0/1 (model1 = conv1_1 + conv1_2 as one launch; 0 keeps conv1_1's output readable), 'click' -1/0/1 (small launches on
-    conv_click), 'winograd' 0 / 1 / 2 / 12 / 21 / 22 (fp32 path: off / automatic / every deconv too / automatic with the 3x3 form <TB,CB>
-    forced), 'mfma16' 0/1 (bf16 throughput tile from the 16x16x32 MFMA -- conv_igemm_v2m -- or the 32x32x16 one), 'v2p' 0/1 (its 3x3 form
-    without address arithmetic in the K loop), 'ds_mfma16' 0/1/2 (deconv + shortcut launches as conv_ds_fused / conv_ds_fused_m with its 64-cout 4-wave form on small grids / 8-wave workgroups everywhere), 'kwave' 0/1
-    (bf16 batch-1 click path: conv_kwave_bf16 / conv_kwave_deconv_bf16, or round 2's conv_click + split-K), 'kwave_chain' 0/1/2 (its 512 -> 512
-    trunk as one persistent launch: off / hipLaunchCooperativeKernel / plain launch after an occupancy check, the default).
-    Retired in round 5 with their kernels or folded into the above: fuse_conv1_small, winograd_bf16, winograd_form, winograd_deconv,
-    conv1_lw, code_warm, kwave_deconv."""
+    """Process-wide switches (``idc_set_option``; speed / kernel choice only -- every setting computes the same function).  Names and values are
+    documented in ``include/ideepcolor.h``: 'fuse_conv1', 'click', 'winograd', 'mfma16', 'v2p', 'ds_mfma16', 'kwave', 'kwave_chain', and since
+    round 6 'spin_sync', 'pcie_kernel' (former environment switches) and the test hook 'kw_force_abort'.  'mfma16' = 0 / 'ds_mfma16' = 0 select the
+    32x32x16-MFMA partner kernels, which exist only in a ``make EXTRA=-DIDC_AB_PARTNERS`` build: the default library raises IdcError (UNSUPPORTED)."""
     N.check(N.load().idc_set_option(name.encode(), int(value)))
 
 

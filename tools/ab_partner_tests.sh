@@ -12,9 +12,9 @@ cp $T/libideepcolor_hip.so $C/libideepcolor_hip.so
 trap 'cp $T/default.so $C/libideepcolor_hip.so' EXIT
 cd $R
 if [ "$1" = "all" ]; then
-  python -m pytest tests -m gpu -q 2>&1 | tail -5
+  python -m pytest tests -m gpu -q 2>&1 | grep -a "passed\|failed\|FAILED\|skipped" | tail -8
 else
-  python -m pytest tests/test_round3_gpu.py tests/test_round4_gpu.py tests/test_round5_gpu.py tests/test_net_gpu.py -m gpu -q 2>&1 | tail -5
+  python -m pytest tests/test_round3_gpu.py tests/test_round4_gpu.py tests/test_round5_gpu.py tests/test_net_gpu.py -m gpu -q 2>&1 | grep -a "passed\|failed\|FAILED\|skipped" | tail -8
 fi
 IDC_MFMA16=0 python -c "
 from interactive_deep_colorization_amd import engine, workloads
