@@ -50,7 +50,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=10)      # 40 ms: the clock ramp from idle ends inside the warm-up, not inside the timed region
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3", "bf16x6"],
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3", "bf16x6", "fp16x3"],
                     help="bf16x3 / bf16x6 (round 6): the fp32 contract on the bf16 matrix pipe -- fp32 operands as 2 / 3 bf16 parts, 3 / 6 bf16 MFMA products "
                          "per fp32 product, fp32 accumulation; `roofline.peak` is then the dense bf16 peak / products")
     ap.add_argument("--setup-forwards", type=int, default=0,
@@ -540,7 +540,7 @@ def main():
     conv_flops = sum(r["flops"] for r, _ in conv_rows) * nb                 # algorithmic, per launch-set
     achieved_tflops = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     # operand-split precisions: every algorithmic FLOP costs 3 (6) bf16 MFMA FLOPs, so the bound is the bf16 peak / products
-    products = {"bf16x3": 3, "bf16x6": 6}.get(args.precision, 1)
+    products = {"bf16x3": 3, "bf16x6": 6, "fp16x3": 3}.get(args.precision, 1)     # (fp16x3: three fp16 MFMA products, same dense rate as bf16)
     peak = (PEAK_BF16_DENSE_TFLOPS / products) if args.precision != "fp32" else PEAK_FP32_MFMA_TFLOPS
     ms_per_step = elapsed / args.steps * 1e3
     value = world * nb * args.steps / elapsed

@@ -44,14 +44,19 @@ typedef enum idc_status {
 
 /* Arithmetic type of the conv stack.  BF16: bf16 activations+weights, fp32 MFMA accumulation,
  * fp32 bias/BN/shortcut sums.  FP32: exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) end to end.      */
-typedef enum idc_precision { IDC_FP32 = 0, IDC_BF16 = 1, IDC_BF16X3 = 2, IDC_BF16X6 = 3 } idc_precision;
+typedef enum idc_precision { IDC_FP32 = 0, IDC_BF16 = 1, IDC_BF16X3 = 2, IDC_BF16X6 = 3, IDC_FP16X3 = 4 } idc_precision;
 /* BF16X3 / BF16X6 (round 6): the fp32 contract of colorize_image.py:263 carried on the bf16 matrix pipe.  Every fp32 operand travels as a sum of
  * bf16 values -- x = hi + lo (X3) or hi + mid + lo (X6: all 24 mantissa bits) -- and a product x*w is the sum of the bf16 products that matter:
  * hi.hi + lo.hi + hi.lo (three v_mfma_f32_16x16x32_bf16 per fragment pair, 2^-16 relative), or those + mid.hi + hi.mid + mid.mid (six, 2^-24:
  * fp32-equivalent), all into ONE fp32 accumulator set.  Activations between layers are stored split (2 or 3 bf16 planes per pixel), bias / BN /
  * shortcut sums / the tanh head stay fp32, model1 (4 -> 64 -> 64 channels, 3 % of the MACs) runs on the exact-fp32 kernels.  Throughput path:
  * every layer runs the large-tile kernels whatever the batch (the batch-1 click path keeps IDC_FP32 / IDC_BF16).  Error against the float64
- * oracle: X6 at or below IDC_FP32's, X3 <= 1e-3 on the +-110 ab map with torch-default-init weights (tests/bounds.py). */
+ * oracle: X6 at or below IDC_FP32's, X3 <= 1e-3 on the +-110 ab map with torch-default-init weights (tests/bounds.py).
+ * FP16X3 (round 6): BF16X3's planes, segments and kernels with FP16 parts -- x = hi + lo with 11-bit hi and lo (22 bits, 2^-22 relative per
+ * operand instead of 2^-16), three v_mfma_f32_16x16x32_f16 per fragment pair: at the IDC_FP32 path's distance from the float64 oracle on torch-default-init weights
+ * (2.9e-5 at N = 32) and 2.3x that distance on full-range weights (3.9e-3 against 1.7e-3; BF16X3: 2.4e-2), at BF16X3's rate.  The price is
+ * fp16's range: an activation or weight beyond +-65504 saturates (the conversions clamp; nothing becomes inf), values below 6e-5 keep 6e-8 absolute.
+ * The layers of this net are BatchNorm-ed / ReLU-ed activations of O(1..100); a checkpoint with larger activations wants BF16X6. */
 
 /* idc_create flags */
 #define IDC_FLAG_DIST_HEAD   0x1u  /* also build model_class (529-bin) head: SIGGRAPHGenerator(dist=True), model.py:105,159-160 */

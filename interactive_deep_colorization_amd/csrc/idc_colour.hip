@@ -328,11 +328,11 @@ hipError_t launch_nhwc_to_nchw(int src_is_bf16, const void* src, float* dst, int
     return hipGetLastError();
 }
 
-// ---- operand-split tensors (IDC_BF16X3 / IDC_BF16X6): a pixel is [parts][Cpad] bf16, x = part 0 + part 1 (+ part 2) ----------------
+// ---- operand-split tensors (IDC_BF16X3 / IDC_BF16X6 / IDC_FP16X3): a pixel is [parts][Cpad] bf16 (fp16), x = part 0 + part 1 (+ part 2) ----
 __device__ __forceinline__ unsigned short bf16_rne_bits(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 
 // test entry points / activation dumps only
-__global__ void split_to_nchw_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, int N, int C, int H, int W, int Cpad, int parts) {
+__global__ void split_to_nchw_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, int N, int C, int H, int W, int Cpad, int parts, int f16) {
     const long long total = (long long)N * C * H * W;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long hw = (long long)H * W;
@@ -340,19 +340,22 @@ __global__ void split_to_nchw_kernel(const unsigned short* __restrict__ src, flo
         const int c = (int)((i / hw) % C);
         const long long n = i / (hw * C);
         float v = 0.f;
-        for (int p = 0; p < parts; ++p) v += __uint_as_float((unsigned)src[((n * hw + r) * parts + p) * Cpad + c] << 16);
+        for (int p = 0; p < parts; ++p) {
+            const unsigned short q = src[((n * hw + r) * parts + p) * Cpad + c];
+            v += f16 ? (float)__builtin_bit_cast(_Float16, q) : __uint_as_float((unsigned)q << 16);
+        }
         dst[i] = v;
     }
 }
 
-hipError_t launch_split_to_nchw(const void* src, float* dst, int N, int C, int H, int W, int Cpad, int parts, hipStream_t s) {
+hipError_t launch_split_to_nchw(const void* src, float* dst, int N, int C, int H, int W, int Cpad, int parts, int f16, hipStream_t s) {
     const long long total = (long long)N * C * H * W;
     const int blocks = (int)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
-    hipLaunchKernelGGL(split_to_nchw_kernel, dim3(blocks), dim3(256), 0, s, (const unsigned short*)src, dst, N, C, H, W, Cpad, parts);
+    hipLaunchKernelGGL(split_to_nchw_kernel, dim3(blocks), dim3(256), 0, s, (const unsigned short*)src, dst, N, C, H, W, Cpad, parts, f16);
     return hipGetLastError();
 }
 
-__global__ void nchw_to_split_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int N, int C, int H, int W, int Cpad, int parts) {
+__global__ void nchw_to_split_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int N, int C, int H, int W, int Cpad, int parts, int f16) {
     const long long total = (long long)N * H * W * Cpad;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % Cpad);
@@ -361,17 +364,18 @@ __global__ void nchw_to_split_kernel(const float* __restrict__ src, unsigned sho
         const long long n = pix / hw, r = pix - n * hw;
         float v = c < C ? src[(n * C + c) * hw + r] : 0.f;
         for (int p = 0; p < parts; ++p) {
-            const unsigned short h = bf16_rne_bits(v);
-            v -= __uint_as_float((unsigned)h << 16);
+            unsigned short h;
+            if (f16) { const _Float16 q = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f); h = __builtin_bit_cast(unsigned short, q); v -= (float)q; }
+            else { h = bf16_rne_bits(v); v -= __uint_as_float((unsigned)h << 16); }
             dst[(pix * parts + p) * Cpad + c] = h;
         }
     }
 }
 
-hipError_t launch_nchw_to_split(const float* src, void* dst, int N, int C, int H, int W, int Cpad, int parts, hipStream_t s) {
+hipError_t launch_nchw_to_split(const float* src, void* dst, int N, int C, int H, int W, int Cpad, int parts, int f16, hipStream_t s) {
     const long long total = (long long)N * H * W * Cpad;
     const int blocks = (int)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
-    hipLaunchKernelGGL(nchw_to_split_kernel, dim3(blocks), dim3(256), 0, s, src, (unsigned short*)dst, N, C, H, W, Cpad, parts);
+    hipLaunchKernelGGL(nchw_to_split_kernel, dim3(blocks), dim3(256), 0, s, src, (unsigned short*)dst, N, C, H, W, Cpad, parts, f16);
     return hipGetLastError();
 }
 

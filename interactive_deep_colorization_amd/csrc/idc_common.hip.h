@@ -131,6 +131,18 @@ __device__ __forceinline__ void epilogue16(const ConvArgs& a, float (&v)[16], si
         unsigned short* o = (unsigned short*)a.out + (oidx - co0) * np + co0;
         for (int p = 0; p < np; ++p) {
             uint4 p0, p1;
+            if (a.split_f16) {                                 // IDC_FP16X3: fp16 parts (values clamped to the fp16 range first)
+                unsigned w[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const _Float16 h0 = (_Float16)fminf(fmaxf(v[2 * e], -65504.f), 65504.f), h1 = (_Float16)fminf(fmaxf(v[2 * e + 1], -65504.f), 65504.f);
+                    w[e] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+                    v[2 * e] -= (float)h0; v[2 * e + 1] -= (float)h1;
+                }
+                *(uint4*)(o + (size_t)p * CoutPad) = uint4{w[0], w[1], w[2], w[3]};
+                *(uint4*)(o + (size_t)p * CoutPad + 8) = uint4{w[4], w[5], w[6], w[7]};
+                continue;
+            }
             pack16_bf16(v, p0, p1);
             *(uint4*)(o + (size_t)p * CoutPad) = p0;
             *(uint4*)(o + (size_t)p * CoutPad + 8) = p1;

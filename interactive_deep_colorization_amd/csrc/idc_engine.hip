@@ -124,7 +124,12 @@ static inline void put_w(uint8_t* wimg, int precision, int layout, int nkc, int 
     }
     const size_t off = ((size_t)(tw * nkc + kc) * ncg + cg) * kWBlockBytes + (size_t)lam * kRowBytes +
                        (size_t)sig * kSlotBytes + (size_t)e * eb;
-    if (precision != IDC_FP32) {
+    if (split_is_f16(precision)) {                                 // IDC_FP16X3: fp16 parts (RNE; weights beyond the fp16 range saturate)
+        auto to_h = [](float x) { return (_Float16)(x > 65504.f ? 65504.f : (x < -65504.f ? -65504.f : x)); };
+        _Float16 b = to_h(v);
+        for (int q = 0; q < g_pack_part; ++q) { v -= (float)b; b = to_h(v); }
+        memcpy(wimg + off, &b, 2);
+    } else if (precision != IDC_FP32) {
         uint16_t b = f32_to_bf16_rne(v);
         for (int q = 0; q < g_pack_part; ++q) {                    // (exact: the remainder of a round-to-nearest is representable)
             uint32_t u = (uint32_t)b << 16; float hi; memcpy(&hi, &u, 4);
@@ -241,7 +246,7 @@ static int fail(std::string* err, int code, const char* fmt, ...) {
 
 static int pack_weights_impl(int precision, unsigned flags, const idc_tensor_desc* tensors, int n_tensors,
                              void* blob, size_t blob_bytes, std::string* err) {
-    if (precision < IDC_FP32 || precision > IDC_BF16X6) return fail(err, IDC_ERR_INVALID_ARG, "bad precision %d", precision);
+    if (precision < IDC_FP32 || precision > IDC_FP16X3) return fail(err, IDC_ERR_INVALID_ARG, "bad precision %d", precision);
     if (!tensors || n_tensors <= 0 || !blob) return fail(err, IDC_ERR_INVALID_ARG, "null tensors/blob");
     const BlobPlan plan = make_blob_plan(precision, flags);
     if (blob_bytes < plan.total_bytes)
@@ -967,6 +972,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
         a.in = ti.ptr; a.out = to.ptr;
         a.zeros = c->d_zeros;
         a.warm = g_code_warm;
+        a.split_f16 = split_is_f16(c->precision) ? 1 : 0;
         a.out_f32 = to.is_f32;
         a.img_shift = ((c->flags & IDC_FLAG_GLOBAL_HINTS) && L.dst == c->t_conv4_3) ? c->d_glob_vec : nullptr;
         if (L.spec->kind == kConvIm2col) {          // model.py:139-148 input pack, fused into the operand staging
@@ -1399,7 +1405,7 @@ int idc_create(int device_id, int height, int width, int max_batch, int precisio
     if (height <= 0 || width <= 0 || height % 8 || width % 8)
         return fail(nullptr, IDC_ERR_INVALID_ARG, "H and W must be positive multiples of 8 (got %dx%d)", height, width);
     if (max_batch <= 0) return fail(nullptr, IDC_ERR_INVALID_ARG, "max_batch must be positive");
-    if (precision < IDC_FP32 || precision > IDC_BF16X6) return fail(nullptr, IDC_ERR_INVALID_ARG, "bad precision %d", precision);
+    if (precision < IDC_FP32 || precision > IDC_FP16X3) return fail(nullptr, IDC_ERR_INVALID_ARG, "bad precision %d", precision);
     int rc = check_device(device_id, nullptr);
     if (rc) return rc;
     if (hipSetDevice(device_id) != hipSuccess) return fail(nullptr, IDC_ERR_HIP, "hipSetDevice(%d) failed", device_id);
@@ -1434,7 +1440,7 @@ int idc_set_io_scales(idc_handle h, float l_div, float ab_div, float mask_mul, f
 }
 
 size_t idc_weights_blob_bytes(int precision, unsigned flags) {
-    if (precision < IDC_FP32 || precision > IDC_BF16X6) return 0;
+    if (precision < IDC_FP32 || precision > IDC_FP16X3) return 0;
     return make_blob_plan(precision, flags).total_bytes;
 }
 
@@ -2366,7 +2372,7 @@ int idc_get_activation(idc_handle h, const char* name, int n, float* out, size_t
         h->scratch_bytes = need * 4;
     }
     const int src_bf16 = (!t.is_f32 && h->precision != IDC_FP32) ? 1 : 0;
-    if (t.parts > 1) HIPCHK(h, launch_split_to_nchw(t.ptr, h->d_scratch, n, t.C, t.H, t.W, t.Cpad, t.parts, h->stream));
+    if (t.parts > 1) HIPCHK(h, launch_split_to_nchw(t.ptr, h->d_scratch, n, t.C, t.H, t.W, t.Cpad, t.parts, split_is_f16(h->precision) ? 1 : 0, h->stream));
     else HIPCHK(h, launch_nhwc_to_nchw(src_bf16, t.ptr, h->d_scratch, n, t.C, t.H, t.W, t.Cpad, h->stream));
     HIPCHK(h, hipMemcpyAsync(out, h->d_scratch, need * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -2383,7 +2389,7 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
                          const float* resid, float* y) {
     int rc = check_device(device_id, nullptr);
     if (rc) return rc;
-    if (precision < IDC_FP32 || precision > IDC_BF16X6) return fail(nullptr, IDC_ERR_INVALID_ARG, "bad precision");
+    if (precision < IDC_FP32 || precision > IDC_FP16X3) return fail(nullptr, IDC_ERR_INVALID_ARG, "bad precision");
     if (!x || !weight || !bias || !y || n <= 0 || h <= 0 || w <= 0) return fail(nullptr, IDC_ERR_INVALID_ARG, "bad argument");
     const bool split = is_split(precision);
     const int parts = split_parts(precision);
@@ -2447,7 +2453,7 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     HIPCHK(nullctx, hipMemcpy(d_b.p, hb.data(), cpad * 4, hipMemcpyHostToDevice));
     HIPCHK(nullctx, hipMemcpy(d_s.p, hs.data(), cpad * 4, hipMemcpyHostToDevice));
     HIPCHK(nullctx, hipMemcpy(d_t.p, ht.data(), cpad * 4, hipMemcpyHostToDevice));
-    if (split) HIPCHK(nullctx, launch_nchw_to_split((const float*)d_x.p, d_xn.p, n, spec.cin, h, w, spec.cin, parts, nullptr));
+    if (split) HIPCHK(nullctx, launch_nchw_to_split((const float*)d_x.p, d_xn.p, n, spec.cin, h, w, spec.cin, parts, split_is_f16(precision) ? 1 : 0, nullptr));
     else HIPCHK(nullctx, launch_nchw_to_nhwc(precision, (const float*)d_x.p, d_xn.p, n, spec.cin, h, w, spec.cin, nullptr));
     // bf16 precision: the residual arrives and the output leaves in bf16, as inside the network (operand-split: fp32 residual, split output)
     const int io_bf16 = precision == IDC_BF16 ? 1 : 0;
@@ -2466,6 +2472,7 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_mul = 0.f;
     a.in2 = nullptr; a.wgt2 = nullptr; a.nkc2 = 0;
     a.warm = g_code_warm;
+    a.split_f16 = split_is_f16(precision) ? 1 : 0;
     a.out_f32 = (io_bf16 || split) ? 0 : 1;
     if (split) {
         a.in_parts = parts; a.out_parts = parts; a.nseg = split_segments(precision); a.seg_x = split_seg_x(precision); a.seg_w = split_seg_w(precision);
@@ -2492,7 +2499,7 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
                     : L.v2 ? (L.v2p ? launch_conv_v2p(L.cfg, L.halo, a, nullptr) : L.m16 ? launch_conv_v2m(L.cfg, L.halo, a, nullptr) : launch_conv_v2(L.cfg, L.halo, a, nullptr))
                            : launch_conv(precision, L.cfg, L.halo, a, nullptr));
     if (a.ksplit > 1) HIPCHK(nullctx, launch_splitk_epilogue(precision, a, nullptr));
-    if (split) HIPCHK(nullctx, launch_split_to_nchw(d_yn.p, (float*)d_y.p, n, spec.cout, Ho, Wo, cpad, parts, nullptr));
+    if (split) HIPCHK(nullctx, launch_split_to_nchw(d_yn.p, (float*)d_y.p, n, spec.cout, Ho, Wo, cpad, parts, split_is_f16(precision) ? 1 : 0, nullptr));
     else HIPCHK(nullctx, launch_nhwc_to_nchw(io_bf16, d_yn.p, (float*)d_y.p, n, spec.cout, Ho, Wo, cpad, nullptr));
     HIPCHK(nullctx, hipMemcpy(y, d_y.p, yout * 4, hipMemcpyDeviceToHost));
     HIPCHK(nullctx, hipDeviceSynchronize());

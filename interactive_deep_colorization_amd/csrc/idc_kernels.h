@@ -69,6 +69,7 @@ struct ConvArgs {
     int in_parts, out_parts, nseg;
     unsigned seg_x, seg_w;
     unsigned long long w_part_bytes;
+    int split_f16;          // IDC_FP16X3: the parts are fp16 (11-bit) instead of bf16 (8-bit) values; same planes, same segments as IDC_BF16X3
     int warm;               // != 0: the throughput kernels pull their own code into L2 at entry (idc_warm_own_code below)
     const void* zeros;      // >= 16 zero bytes in device memory: LDS-DMA source of out-of-image halo rows (conv_click)
     int dy[36], dx[36], tw[36];   // [phase*9 + t]: tap offset in sites, packed-weight tap index
@@ -252,8 +253,8 @@ hipError_t launch_nchw_to_nhwc(int precision, const float* src, void* dst, int N
 hipError_t launch_nhwc_to_nchw(int src_is_bf16, const void* src, float* dst, int N, int C, int H,
                                int W, int Cstride, hipStream_t s);
 // ... of a split tensor: dst = sum over the `parts` bf16 planes of a pixel (fp32 sum, hi first)
-hipError_t launch_split_to_nchw(const void* src, float* dst, int N, int C, int H, int W, int Cpad, int parts, hipStream_t s);
+hipError_t launch_split_to_nchw(const void* src, float* dst, int N, int C, int H, int W, int Cpad, int parts, int f16, hipStream_t s);
 // fp32 NCHW -> split NHWC (single-operator test entry points)
-hipError_t launch_nchw_to_split(const float* src, void* dst, int N, int C, int H, int W, int Cpad, int parts, hipStream_t s);
+hipError_t launch_nchw_to_split(const float* src, void* dst, int N, int C, int H, int W, int Cpad, int parts, int f16, hipStream_t s);
 
 }  // namespace idc

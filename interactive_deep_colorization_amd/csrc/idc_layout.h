@@ -51,15 +51,17 @@ __host__ __device__ inline int cg_cout_to_row2(int col) {
 
 inline int elem_bytes(int precision) { return precision == 0 ? 4 : 2; }       // IDC_FP32 == 0; IDC_BF16 and the operand-split precisions store bf16
 // operand-split precisions (IDC_BF16X3 = 2: x = hi + lo, three products; IDC_BF16X6 = 3: hi + mid + lo, six products)
-inline bool is_split(int precision) { return precision == 2 || precision == 3; }
-inline int split_parts(int precision) { return precision == 2 ? 2 : precision == 3 ? 3 : 1; }
+inline bool is_split(int precision) { return precision >= 2 && precision <= 4; }
+inline bool split_is_f16(int precision) { return precision == 4; }               // IDC_FP16X3: bf16x3's planes and segments with fp16 (11-bit) parts
+// (measured and dropped: a fourth segment lo.lo -- N = 32 he-style 3.99e-3 against 3.86e-3 without it: the 2^-23 of the two-part operands is the floor)
+inline int split_parts(int precision) { return (precision == 2 || precision == 4) ? 2 : precision == 3 ? 3 : 1; }
 // K segments (input part, weight part), 4 bits each, segment 0 in the low nibble.  SMALLEST PRODUCTS FIRST, hi.hi last, and the bias after the
 // K loop: every v_mfma rounds its result to the accumulator's magnitude, so each of the 9 x nkc x 2 accumulations of a segment costs one rounding
 // at the size the accumulator has at that moment.  hi.hi first made all 3 (6) segments round at full magnitude -- N = 32 he-style weights, bf16x6:
 // 7.1e-3 on the ab map against the exact-fp32 kernels' 1.7e-3; smallest first leaves only the hi.hi pass rounding at full size.
-inline int split_segments(int precision) { return precision == 2 ? 3 : precision == 3 ? 6 : 1; }
-inline unsigned split_seg_x(int precision) { return precision == 2 ? 0x001u : precision == 3 ? 0x001120u : 0u; }   // X3: lo, hi, hi      X6: hi, lo, mid, mid, hi, hi
-inline unsigned split_seg_w(int precision) { return precision == 2 ? 0x010u : precision == 3 ? 0x010102u : 0u; }   // X3: hi, lo, hi      X6: lo, hi, mid, hi,  mid, hi
+inline int split_segments(int precision) { return (precision == 2 || precision == 4) ? 3 : precision == 3 ? 6 : 1; }
+inline unsigned split_seg_x(int precision) { return (precision == 2 || precision == 4) ? 0x001u : precision == 3 ? 0x001120u : 0u; }   // X3: lo, hi, hi      X6: hi, lo, mid, mid, hi, hi
+inline unsigned split_seg_w(int precision) { return (precision == 2 || precision == 4) ? 0x010u : precision == 3 ? 0x010102u : 0u; }   // X3: hi, lo, hi      X6: lo, hi, mid, hi,  mid, hi
 inline int kc_elems(int precision) { return kRowBytes / elem_bytes(precision); }  // 64 or 32
 
 // fp32 -> bf16, round to nearest even (matches v_cvt_pk_bf16_f32 for finite values)

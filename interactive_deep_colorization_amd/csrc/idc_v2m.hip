@@ -58,6 +58,23 @@ __device__ __forceinline__ unsigned pack_bf16x2_m(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_pk){lo, hi}, bf16x2_pk));
 }
 
+// One 16x16x32 MFMA step on two 16-byte fragments: bf16 (every precision but IDC_FP16X3) or fp16 operands, fp32 accumulate.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_m;
+template <bool F16>
+__device__ __forceinline__ f32x4 mma_16x16x32(const u32x4& a, const u32x4& b, const f32x4& c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_m, a), __builtin_bit_cast(f16x8_m, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_m, a), __builtin_bit_cast(bf16x8_m, b), c, 0, 0, 0);
+}
+// IDC_FP16X3: two fp16 values (RNE) in one dword; inputs are clamped to the fp16 range first (a value beyond +-65504 saturates instead of becoming inf)
+__device__ __forceinline__ unsigned pack_f16x2_m(float lo, float hi) {
+    typedef float f32x2_pk __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2_pk __attribute__((ext_vector_type(2)));
+    const float a = __builtin_fminf(__builtin_fmaxf(lo, -65504.f), 65504.f), b = __builtin_fminf(__builtin_fmaxf(hi, -65504.f), 65504.f);
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_pk){a, b}, f16x2_pk));
+}
+__device__ __forceinline__ float f16_lo_to_f32(unsigned q) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(q & 0xffffu)); }
+__device__ __forceinline__ float f16_hi_to_f32(unsigned q) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(q >> 16)); }
+
 __device__ __forceinline__ void add_bias_after_k(const float* bp, f32x4 (&acc)[4][8]) {
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
@@ -72,7 +89,7 @@ __device__ __forceinline__ void add_bias_after_k(const float* bp, f32x4 (&acc)[4
 // column (pt & 1)*16 + r16) in acc[mi][pt][j].  value = BN(act(acc + fp32 shortcut sum)) + per-image shift, all fp32; then either an fp32 NHWC store
 // straight from the MFMA layout (out_parts = 0) or out_parts bf16 planes hi = rne(v), next = rne(v - hi), ... (each remainder is exact in fp32), every
 // plane through the wave-private [32 sites][64 couts] bf16 transpose tile so that stores cover whole 128-byte lines.
-template <int WCO>
+template <int WCO, bool F16 = false>
 __device__ __forceinline__ void split_epilogue(const ConvArgs& a, f32x4 (&acc)[4][8], char* smem, int n, int ty0, int tx0, int wpx, int cow, int ro, int cof) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -141,10 +158,17 @@ __device__ __forceinline__ void split_epilogue(const ConvArgs& a, f32x4 (&acc)[4
                     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
+                            if constexpr (F16) {
+                                const unsigned q = pack_f16x2_m(v[hf][mi][2 * e], v[hf][mi][2 * e + 1]);
+                                pk[mi * 2 + e] = q;
+                                v[hf][mi][2 * e] -= f16_lo_to_f32(q);                      // exact, as below (11-bit parts)
+                                v[hf][mi][2 * e + 1] -= f16_hi_to_f32(q);
+                            } else {
                             const unsigned q = pack_bf16x2_m(v[hf][mi][2 * e], v[hf][mi][2 * e + 1]);
                             pk[mi * 2 + e] = q;
                             v[hf][mi][2 * e] -= __uint_as_float(q << 16);              // exact: the remainder of a round-to-nearest fits fp32
                             v[hf][mi][2 * e + 1] -= __uint_as_float(q & 0xffff0000u);
+                            }
                         }
                     const int s0 = g16 * 2;
                     *(uint4*)(tb16 + site * 128 + ((s0 ^ (site & 7)) * 16)) = uint4{pk[0], pk[1], pk[2], pk[3]};
@@ -172,7 +196,7 @@ __device__ __forceinline__ void split_epilogue(const ConvArgs& a, f32x4 (&acc)[4
 
 // SPLIT = false: conv_igemm_v2m as described above.  SPLIT = true: conv_igemm_v2s, the operand-split form (IDC_BF16X3 / IDC_BF16X6) -- the same
 // tile and K-loop body walked over a.nseg segments of nkc chunks (input part x weight part per segment, ConvArgs), and its own epilogue.
-template <int WCO, int WPX, int HALO, bool SPLIT>
+template <int WCO, int WPX, int HALO, int SPLIT>
 __device__ __forceinline__ void conv_v2m_body(const ConvArgs& a) {
     constexpr int NT = WCO * WPX * 64;
     constexpr int TW = 32, TH = 4 * WPX;
@@ -311,9 +335,7 @@ __device__ __forceinline__ void conv_v2m_body(const ConvArgs& a) {
             auto mma4 = [&](int mi, int half, const u32x4 (&xf)[4]) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    acc[mi][half * 4 + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_m, wf[mi]),
-                                                                                    __builtin_bit_cast(bf16x8_m, xf[q]),
-                                                                                    acc[mi][half * 4 + q], 0, 0, 0);
+                    acc[mi][half * 4 + q] = mma_16x16x32<SPLIT == 2>(wf[mi], xf[q], acc[mi][half * 4 + q]);
             };
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) read_a1(0, mi);
@@ -441,7 +463,7 @@ __device__ __forceinline__ void conv_v2m_body(const ConvArgs& a) {
         return;
     }
     if constexpr (SPLIT) {
-        split_epilogue<WCO>(a, acc, smem, n, ty0, tx0, wpx, cow, ro, cof);
+        split_epilogue<WCO, SPLIT == 2>(a, acc, smem, n, ty0, tx0, wpx, cow, ro, cof);
         return;
     }
     // bf16 outputs, activation (+ eval-BN) and rounding in the MFMA layout, then a wave-private [32 sites][64 couts] bf16 tile
@@ -514,9 +536,11 @@ __device__ __forceinline__ void conv_v2m_body(const ConvArgs& a) {
 }
 
 template <int WCO, int WPX, int HALO>
-__global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2m(const ConvArgs a) { conv_v2m_body<WCO, WPX, HALO, false>(a); }
+__global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2m(const ConvArgs a) { conv_v2m_body<WCO, WPX, HALO, 0>(a); }
 template <int WCO, int WPX, int HALO>
-__global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2s(const ConvArgs a) { conv_v2m_body<WCO, WPX, HALO, true>(a); }
+__global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2s(const ConvArgs a) { conv_v2m_body<WCO, WPX, HALO, 1>(a); }
+template <int WCO, int WPX, int HALO>      // IDC_FP16X3: the same walk on fp16 parts (v_mfma_f32_16x16x32_f16)
+__global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2sh(const ConvArgs a) { conv_v2m_body<WCO, WPX, HALO, 2>(a); }
 
 // ================================================================================================
 // conv_igemm_v2p<WCO, WPX, D> -- conv_igemm_v2m for the 3x3 convolutions (dilation D = 1 | 2) with NO address arithmetic in the K loop
@@ -533,7 +557,7 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2s(const ConvArg
 // ================================================================================================
 
 // SPLIT = true: conv_igemm_v2ps, the operand-split form (as conv_igemm_v2s is conv_igemm_v2m's): a.nseg passes over the nkc chunks, split epilogue.
-template <int WCO, int WPX, int D, bool SPLIT>
+template <int WCO, int WPX, int D, int SPLIT>
 __device__ __forceinline__ void conv_v2p_body(const ConvArgs& a) {
     constexpr int NT = WCO * WPX * 64;
     constexpr int TW = 32, TH = 4 * WPX, HALO = D;
@@ -675,9 +699,7 @@ __device__ __forceinline__ void conv_v2p_body(const ConvArgs& a) {
             auto mma4 = [&](int mi, int half, const u32x4 (&xf)[4]) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    acc[mi][half * 4 + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_m, wf[mi]),
-                                                                                    __builtin_bit_cast(bf16x8_m, xf[q]),
-                                                                                    acc[mi][half * 4 + q], 0, 0, 0);
+                    acc[mi][half * 4 + q] = mma_16x16x32<SPLIT == 2>(wf[mi], xf[q], acc[mi][half * 4 + q]);
             };
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) wf[mi] = *(const u32x4*)(a0 + mi * 16 * kRowBytes);
@@ -807,7 +829,7 @@ __device__ __forceinline__ void conv_v2p_body(const ConvArgs& a) {
         return;
     }
     if constexpr (SPLIT) {
-        split_epilogue<WCO>(a, acc, smem, n, ty0, tx0, wpx, cow, 0, 0);
+        split_epilogue<WCO, SPLIT == 2>(a, acc, smem, n, ty0, tx0, wpx, cow, 0, 0);
         return;
     }
     char* const tb16 = smem + wave * 4096;
@@ -886,9 +908,11 @@ __device__ __forceinline__ void conv_v2p_body(const ConvArgs& a) {
 
 
 template <int WCO, int WPX, int D>
-__global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArgs a) { conv_v2p_body<WCO, WPX, D, false>(a); }
+__global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArgs a) { conv_v2p_body<WCO, WPX, D, 0>(a); }
 template <int WCO, int WPX, int D>
-__global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2ps(const ConvArgs a) { conv_v2p_body<WCO, WPX, D, true>(a); }
+__global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2ps(const ConvArgs a) { conv_v2p_body<WCO, WPX, D, 1>(a); }
+template <int WCO, int WPX, int D>
+__global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2psh(const ConvArgs a) { conv_v2p_body<WCO, WPX, D, 2>(a); }
 
 static constexpr size_t conv_v2p_lds_bytes_c(int wco, int wpx, int d) {            // = conv_igemm_v2m's
     const int nt = wco * wpx * 64;
@@ -972,8 +996,10 @@ hipError_t launch_conv_v2s(ConvConfig cfg, int halo, const ConvArgs& a, hipStrea
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
 #define X(WCO, WPX, HL)                                                                                                          \
     if (cfg.wm == WCO && cfg.wp == WPX && halo == HL) {                                                                          \
-        hipLaunchKernelGGL((conv_igemm_v2s<WCO, WPX, HL>), dim3((unsigned)blocks), dim3(WCO * WPX * 64),                         \
-                           conv_v2m_lds_bytes_c(WCO, WPX, HL), s, a);                                                            \
+        if (a.split_f16) hipLaunchKernelGGL((conv_igemm_v2sh<WCO, WPX, HL>), dim3((unsigned)blocks), dim3(WCO * WPX * 64),       \
+                                            conv_v2m_lds_bytes_c(WCO, WPX, HL), s, a);                                           \
+        else hipLaunchKernelGGL((conv_igemm_v2s<WCO, WPX, HL>), dim3((unsigned)blocks), dim3(WCO * WPX * 64),                    \
+                                conv_v2m_lds_bytes_c(WCO, WPX, HL), s, a);                                                       \
         return hipGetLastError();                                                                                                \
     }
     IDC_FOR_EACH_CONV_V2S(X)
@@ -997,8 +1023,10 @@ hipError_t launch_conv_v2ps(ConvConfig cfg, int halo, const ConvArgs& a, hipStre
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
 #define X(WCO, WPX, DD)                                                                                                          \
     if (cfg.wm == WCO && cfg.wp == WPX && halo == DD) {                                                                          \
-        hipLaunchKernelGGL((conv_igemm_v2ps<WCO, WPX, DD>), dim3((unsigned)blocks), dim3(WCO * WPX * 64),                        \
-                           conv_v2p_lds_bytes_c(WCO, WPX, DD), s, a);                                                            \
+        if (a.split_f16) hipLaunchKernelGGL((conv_igemm_v2psh<WCO, WPX, DD>), dim3((unsigned)blocks), dim3(WCO * WPX * 64),      \
+                                            conv_v2p_lds_bytes_c(WCO, WPX, DD), s, a);                                           \
+        else hipLaunchKernelGGL((conv_igemm_v2ps<WCO, WPX, DD>), dim3((unsigned)blocks), dim3(WCO * WPX * 64),                   \
+                                conv_v2p_lds_bytes_c(WCO, WPX, DD), s, a);                                                       \
         return hipGetLastError();                                                                                                \
     }
     IDC_FOR_EACH_CONV_V2PS(X)
@@ -1011,11 +1039,17 @@ hipError_t init_kernels_v2m() {
 #define X(WCO, WPX, DD)                                                                                                          \
     e = hipFuncSetAttribute((const void*)conv_igemm_v2ps<WCO, WPX, DD>, hipFuncAttributeMaxDynamicSharedMemorySize,              \
                             (int)conv_v2p_lds_bytes_c(WCO, WPX, DD));                                                            \
+    if (e != hipSuccess) return e;                                                                                               \
+    e = hipFuncSetAttribute((const void*)conv_igemm_v2psh<WCO, WPX, DD>, hipFuncAttributeMaxDynamicSharedMemorySize,             \
+                            (int)conv_v2p_lds_bytes_c(WCO, WPX, DD));                                                            \
     if (e != hipSuccess) return e;
     IDC_FOR_EACH_CONV_V2PS(X)
 #undef X
 #define X(WCO, WPX, HL)                                                                                                          \
     e = hipFuncSetAttribute((const void*)conv_igemm_v2s<WCO, WPX, HL>, hipFuncAttributeMaxDynamicSharedMemorySize,               \
+                            (int)conv_v2m_lds_bytes_c(WCO, WPX, HL));                                                            \
+    if (e != hipSuccess) return e;                                                                                               \
+    e = hipFuncSetAttribute((const void*)conv_igemm_v2sh<WCO, WPX, HL>, hipFuncAttributeMaxDynamicSharedMemorySize,              \
                             (int)conv_v2m_lds_bytes_c(WCO, WPX, HL));                                                            \
     if (e != hipSuccess) return e;
     IDC_FOR_EACH_CONV_V2S(X)

@@ -84,9 +84,39 @@ def test_split_blob_layout_and_parts(make_sd, precision, parts):
                 assert abs(float(total_v) - float(val)) <= 2.0 ** -16 * abs(float(val)) + 1e-30
 
 
+def test_fp16x3_blob_carries_fp16_parts(make_sd):
+    """IDC_FP16X3: bf16x3's blob layout (two layout-1 images per layer, conv1_1 an fp32 image) with FP16 parts -- part 0 = rne16(w), part 1 =
+    rne16(w - part 0): hi + lo reproduces w to 2^-22 relative (fp16 has 11 significant bits)."""
+    sd = make_sd(0, "he")
+    blob = engine.pack_weights(sd, "fp16x3")
+    plan, total = _split_plan(2)
+    assert blob.size == total == N.load().idc_weights_blob_bytes(N.IDC_FP16X3, 0) == N.load().idc_weights_blob_bytes(N.IDC_BF16X3, 0)
+    assert blob[8:12].view(np.uint32)[0] == N.IDC_FP16X3
+    rs = np.random.RandomState(2)
+    for e in plan:
+        if e["island"]:
+            continue
+        w = sd[e["wkey"] + ".weight"]
+        for _ in range(25):
+            co, ci = rs.randint(e["cout"]), rs.randint(e["cin"])
+            if e["kind"] == "c3":
+                ky, kx = rs.randint(3), rs.randint(3); tw, k, val = ky * 3 + kx, ci, w[co, ci, ky, kx]
+            elif e["kind"] == "c1":
+                tw, k, val = 0, ci, w[co, ci, 0, 0]
+            else:
+                ky, kx = rs.randint(4), rs.randint(4); tw, k, val = ky * 4 + kx, ci, w[ci, co, ky, kx]
+            val = np.float32(val)
+            hi = np.float16(val)
+            lo = np.float16(np.float32(val - np.float32(hi)))
+            got0 = _read_w(blob, e, "bf16", tw, co, k)
+            got1 = _read_w(blob, dict(e, w_off=e["w_off"] + e["w_bytes"]), "bf16", tw, co, k)
+            assert got0 == int(hi.view(np.uint16)) and got1 == int(lo.view(np.uint16)), (e["wkey"], co, ci)
+            assert abs(float(np.float32(hi) + np.float32(lo)) - float(val)) <= 2.0 ** -21 * abs(float(val)) + 1e-7
+
+
 def test_split_precisions_are_refused_where_they_do_not_apply():
     lib = N.load()
-    assert lib.idc_weights_blob_bytes(4, 0) == 0 and lib.idc_weights_blob_bytes(-1, 0) == 0
+    assert lib.idc_weights_blob_bytes(5, 0) == 0 and lib.idc_weights_blob_bytes(-1, 0) == 0
     assert lib.idc_weights_blob_bytes(N.IDC_BF16X3, 0) < lib.idc_weights_blob_bytes(N.IDC_BF16X6, 0)
     with pytest.raises(KeyError):
         engine.pack_weights({}, "bf16x9")

@@ -20,7 +20,7 @@ from interactive_deep_colorization_amd import engine, workloads
 from tests import bounds
 
 pytestmark = pytest.mark.gpu
-OP_TOL = {"bf16x6": 2e-5, "bf16x3": 1e-4}
+OP_TOL = {"bf16x6": 2e-5, "bf16x3": 1e-4, "fp16x3": 2e-5}      # fp16x3 (fp16 parts, 2^-23 relative per operand): the exact-fp32 kernels' bound
 
 
 def _ref_conv(x, w, b, dilation, in_stride, act, bn_s, bn_t, resid):
@@ -57,7 +57,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16x6"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16x6", "fp16x3"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_split_conv(case, precision):
     n, cin, cout, h, w, k, dil, stride, act, bn, has_res = case
@@ -76,7 +76,7 @@ def test_split_conv(case, precision):
 DECONV_CASES = [(1, 512, 256, 8, 8, True), (2, 256, 128, 12, 20, True), (1, 128, 128, 16, 16, False), (1, 512, 384, 8, 8, True)]
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16x6"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16x6", "fp16x3"])
 @pytest.mark.parametrize("case", DECONV_CASES)
 def test_split_deconv(case, precision):
     n, cin, cout, h, w, has_res = case
@@ -110,17 +110,17 @@ def _net_case(size, n, style, precision, maskcent=0.5, **kw):
 
 
 @pytest.mark.parametrize("style", ["torch", "he"])
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16x6"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16x6", "fp16x3"])
 def test_split_network_small(precision, style):
     """64x64, batch 2 (ragged grids for every large tile), against the float64 oracle; run-to-run identical."""
     out, again, ref = _net_case(64, 2, style, precision)
     assert np.array_equal(out, again)
     err = float(np.abs(out - ref).max())
-    tol = bounds.FP32_TOL[style] if precision == "bf16x6" else (1e-3 if style == "torch" else 5e-2)
+    tol = bounds.FP32_TOL[style] if precision in ("bf16x6", "fp16x3") else (1e-3 if style == "torch" else 5e-2)
     assert err <= tol, "%s %s: max-abs %.3e > %.1e" % (precision, style, err, tol)
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16x6"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16x6", "fp16x3"])
 def test_split_network_layer_by_layer(precision):
     """Every materialised activation of a 64x64 forward against the float64 oracle's (he-style weights: full dynamic range)."""
     from oracle import siggraph_torch
@@ -135,7 +135,7 @@ def test_split_network_layer_by_layer(precision):
     try:
         e.load_state_dict(sd)
         out = e.forward(L, ab, m, 0.0)
-        rel = 2e-4 if precision == "bf16x6" else 2e-3
+        rel = 2e-4 if precision in ("bf16x6", "fp16x3") else 2e-3
         for name in names:
             got, ref = e.activation(name, 2), acts[name]
             assert got.shape == ref.shape, name
@@ -143,7 +143,7 @@ def test_split_network_layer_by_layer(precision):
             assert err <= rel * (1 + np.abs(ref).max()), "%s %s: %.3e (max|ref| %.2f)" % (precision, name, err, np.abs(ref).max())
         with pytest.raises(Exception):
             e.activation("conv10_2", 2)
-        assert np.abs(out - ref_out).max() <= (bounds.FP32_TOL["he"] if precision == "bf16x6" else 5e-2)
+        assert np.abs(out - ref_out).max() <= (bounds.FP32_TOL["he"] if precision in ("bf16x6", "fp16x3") else 5e-2)
     finally:
         e.close()
 
