@@ -2255,7 +2255,9 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
             snprintf(out->kernel, sizeof(out->kernel), L.kw ? (L.spec->kind == kDeconv4x4 ? "conv_kwave_deconv_bf16" : "conv_kwave_bf16") : L.wino ? (L.spec->kind == kDeconv4x4 ? "conv_wino_deconv_f32" : "conv_wino_f32") : L.click ? (L.lprec == IDC_BF16 ? "conv_click<bf16,%d,%d>" : "conv_click<f32,%d,%d>")
                      : L.v2 ? "conv_igemm_v2<%d,%d>" : (L.lprec == IDC_BF16 ? "conv_igemm<bf16,%d,%d>" : "conv_igemm<f32,%d,%d>"),
                      L.cfg.wm, L.cfg.wp);
-            if (L.split) snprintf(out->kernel, sizeof(out->kernel), L.v2p ? "conv_igemm_v2ps<%d,%d>x%d" : "conv_igemm_v2s<%d,%d>x%d", L.cfg.wm, L.cfg.wp, split_segments(h->precision));
+            if (L.split) snprintf(out->kernel, sizeof(out->kernel), split_is_f16(h->precision) ? (L.v2p ? "conv_igemm_v2psh<%d,%d>x%d" : "conv_igemm_v2sh<%d,%d>x%d")
+                                                                                                    : (L.v2p ? "conv_igemm_v2ps<%d,%d>x%d" : "conv_igemm_v2s<%d,%d>x%d"),
+                                  L.cfg.wm, L.cfg.wp, split_segments(h->precision));
             else if (L.m16) strncat(out->kernel, L.v2p ? "+m16p" : "+m16", sizeof(out->kernel) - strlen(out->kernel) - 1);
             if (L.fused_head) strncat(out->kernel, "+head", sizeof(out->kernel) - strlen(out->kernel) - 1);
             if (L.args.ksplit > 1) {

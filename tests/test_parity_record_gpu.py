@@ -75,7 +75,7 @@ def test_config3_batch32_against_the_oracle(make_sd, precision, style, images, b
     if precision.startswith("bf16x") or precision.startswith("fp16x"):                        # operand-split precisions: the fp32 contract, held against the float64 oracle
         import torch
         kernels = set(r["kernel"].split("<")[0] for r in e_table if r["launches"] > 0 and r["kernel"].startswith("conv"))
-        assert kernels <= {"conv_igemm_v2ps", "conv_igemm_v2s", "conv_igemm"}, kernels
+        assert kernels <= ({"conv_igemm_v2psh", "conv_igemm_v2sh", "conv_igemm"} if precision.startswith("fp16x") else {"conv_igemm_v2ps", "conv_igemm_v2s", "conv_igemm"}), kernels
         ref = siggraph_torch.forward(sd, L[idx], ab[idx], m[idx], 0.0, dtype=torch.float64)
     else:
         ref = siggraph_torch.forward(sd, L[idx], ab[idx], m[idx], 0.0)

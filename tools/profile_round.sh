@@ -59,7 +59,7 @@ for p in stats_fp32 pmc_sq_fp32; do
   [ -n "$f" ] && python tools/rocpd_summary.py $f --family conv > $OUT/${p}_summary.txt
 done
 # operand-split precisions (round 6): bench lines, kernel stats and SQ counters of the bf16x3 command
-for p in bf16x3 bf16x6; do
+for p in bf16x3 bf16x6 fp16x3; do
   python bench.py --precision $p --no-cpu-baseline --no-end-to-end --no-peak-probe --no-latency > $OUT/bench_$p.json 2>/dev/null
 done
 cd /tmp
