@@ -462,7 +462,7 @@ def main():
 
     # ---- engine + weights (rank 0 packs, RCCL broadcast of the packed blob) --------------------------
     # bf16 throughput job: the blob without the Winograd images of the batch-1 / fp32 kernels (IDC_FLAG_THROUGHPUT_BLOB) -- the
-    # N = 32 bf16 handle never selects those kernels, and the broadcast then moves 136 MB instead of 260 MB
+    # N = 32 bf16 handle never selects those kernels, (a bf16 blob is 68 MB since round 6: one image per layer)
     tblob = args.precision == "bf16" and nb >= 8
     e = engine.HipColorizer(H, W, max_batch=nb, precision=args.precision, device=local_rank, throughput_blob=tblob)
     sc = sharded.ShardedColorizer(e, rank=rank, world_size=world)

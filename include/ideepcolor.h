@@ -68,7 +68,7 @@ typedef enum idc_precision { IDC_FP32 = 0, IDC_BF16 = 1, IDC_BF16X3 = 2, IDC_BF1
                                       501-518 (needs the glob.* tensors, see idc_set_global_hints) */
 #define IDC_FLAG_THROUGHPUT_BLOB 0x10u /* weight blob WITHOUT the Winograd images (U = G g G^T of the 3x3 layers and the deconvs).  Since
                                         * round 5 only the fp32 blob carries them (384 MB -> 136 MB with the flag; the direct fp32 kernels then run:
-                                        * same results within tolerance, slower); a bf16 blob is 136 MB with or without the flag -- the bf16 click
+                                        * same results within tolerance, slower); a bf16 blob is 68 MB with or without the flag (round 6; 136 MB in the -DIDC_AB_PARTNERS build, which also carries the layout-2 images) -- the bf16 click
                                         * path's kernels (conv_kwave_*) read the same layout-1 images as the throughput kernels. */
 
 /* ---- library ------------------------------------------------------------------------------- */
@@ -91,6 +91,8 @@ int idc_set_tile_policy(int policy);
  *   "v2p"         (1)  the 3x3 convs among them as conv_igemm_v2p (column-swizzled halo tile, unrolled taps; bit-identical to conv_igemm_v2m).
  *   "ds_mfma16"   (1)  deconv + shortcut launches as conv_ds_fused_m, grids with fewer 128-cout workgroups than CUs (model10up of ONE 256x256 image)
  *                      in its 64-cout 4-wave form; 2 = 8-wave workgroups on every grid (A/B, tests); 0 = conv_ds_fused: partner build only.
+ *   "split_ds_fuse" (1)  operand-split precisions: each ConvTranspose + the 3x3 shortcut conv it is summed with as ONE launch (conv_ds_fused_ms / _msh:
+ *                      both K loops walked per segment into one fp32 accumulator set); 0 = shortcut conv (fp32 sums through HBM) + deconv launch.
  *   "kwave"       (1)  bf16 batch-1 click path: 3x3 stride-1 layers and ConvTranspose launches as conv_kwave_bf16 / conv_kwave_deconv_bf16
  *                      (direct form, K split over the waves of a workgroup); 0 = conv_click + split-K (round 2's kernels).
  *   "kwave_chain" (2)  ... and runs of consecutive same-shape 512-channel layers of that path (conv4_2 .. conv7_3 at batch 1) as ONE

@@ -24,12 +24,11 @@
 #include "idc_kernels.h"
 
 #include "idc_layout.h"
+#include "idc_split.hip.h"
 
 namespace idc {
 
-typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_d;
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 #ifdef IDC_TIMING
 extern __device__ long long* g_idc_dbg;
@@ -59,8 +58,16 @@ __device__ __forceinline__ unsigned pack_bf16x2_d(float lo, float hi) {
 // for the skip tensor's chunk (84 KiB), so that chunk goes to LDS by LDS-DMA (buffer loads: bounds check = zero padding; de-interleave and swizzle in the
 // per-lane SOURCE address) -- once, in the prologue: the form is only launched for ONE shortcut chunk (64 skip channels: model1short10), which is the
 // only deconv + shortcut launch the click path hands to this kernel.
-template <int NCW>
-__global__ __launch_bounds__(NCW * 256, 2) void conv_ds_fused_m(const ConvArgs a) {
+//
+// SPLIT (round 6, the operand-split precisions IDC_BF16X3 / IDC_BF16X6 / IDC_FP16X3; 1 = bf16 parts, 2 = fp16 parts): both inputs are split tensors (a pixel
+// is [part][chunk] x 128 bytes), a.wgt / a.wgt2 the layout-1 images of the weight parts (w_part_bytes / w_part_bytes2 apart).  The S part and then the D part
+// are walked a.nseg times -- segment s multiplies input part seg_x[s] with weight part seg_w[s], smallest products first, as conv_igemm_v2ps does -- into the
+// ONE fp32 accumulator set, which starts at zero; the summed bias joins after the K loops and the epilogue is split_epilogue (fp32 activation, 2 / 3 planes).
+// A segment is to the loops what a further halo chunk is: the flat chunk index q = seg * nkc + kc selects the pixel's chunk slot seg_x[seg] * nkc + kc and the
+// weight image seg_w[seg]; a chunk change whose slot does not change (one-chunk tensors: hi.lo -> hi.hi) keeps the halo in LDS.  The fp32 shortcut sums of
+// the two-launch form (1.07 GB written and read at conv10_1's shape) never exist.
+template <int NCW, int SPLIT>
+__device__ __forceinline__ void conv_ds_fused_m_body(const ConvArgs& a) {
     constexpr int NT = NCW * 256;
     constexpr int SW = 66, SROWS = 10 * SW, S_ITEMS = (SROWS * kSlots + NT - 1) / NT, S_HALO_BYTES = S_ITEMS * NT * kSlotBytes;
     constexpr int DW = 34, DROWS = 6 * DW, D_ITEMS = (DROWS * kSlots + NT - 1) / NT, D_HALO_BYTES = D_ITEMS * NT * kSlotBytes;
@@ -87,7 +94,11 @@ __global__ __launch_bounds__(NCW * 256, 2) void conv_ds_fused_m(const ConvArgs a
     const int y0 = tyi * 4, x0 = txi * 32;
     const int ro = a.ro[ph], cof = a.co[ph];
     const int nkc = a.nkc, nkc2 = a.nkc2, ncg = a.ncg;
-    const int pixD = nkc * kRowBytes, pixS = nkc2 * kRowBytes;
+    const int nseg = SPLIT ? a.nseg : 1;
+    const int pixD = (SPLIT ? a.in_parts * nkc : nkc) * kRowBytes, pixS = (SPLIT ? a.in_parts * nkc2 : nkc2) * kRowBytes;
+    // SPLIT: input part / weight part of segment s
+    auto seg_xp = [&](int sg) { return SPLIT ? (int)((a.seg_x >> (4 * sg)) & 15u) : 0; };
+    auto seg_wp = [&](int sg) { return SPLIT ? (size_t)((a.seg_w >> (4 * sg)) & 15u) : (size_t)0; };
     const char* const imgD = (const char*)a.in + (size_t)n * Hs * Ws * pixD;
     const char* const imgS = (const char*)a.in2 + (size_t)n * (4 * (size_t)Hs * Ws) * pixS;
     const int cg0 = ct * NCW;
@@ -103,7 +114,7 @@ __global__ __launch_bounds__(NCW * 256, 2) void conv_ds_fused_m(const ConvArgs a
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             const float4 bq = *(const float4*)(bp + mi * 4);
-            const f32x4 b4 = f32x4{bq.x, bq.y, bq.z, bq.w};
+            const f32x4 b4 = SPLIT ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{bq.x, bq.y, bq.z, bq.w};     // (SPLIT: the bias joins after the K loops)
 #pragma unroll
             for (int pt = 0; pt < 8; ++pt) acc[mi][pt] = b4;
         }
@@ -161,7 +172,7 @@ __global__ __launch_bounds__(NCW * 256, 2) void conv_ds_fused_m(const ConvArgs a
         for (int j = D_ITEMS; j < H_ITEMS; ++j) hreg[j] = u32x4{0u, 0u, 0u, 0u};   // (one definition per path for every halo register)
     };
     auto dma_S = [&](int tap, int kc2, int buf) {              // 128 couts x 64 cin, shared: every wave brings 2 KiB
-        const char* src = (const char*)a.wgt2 + (((size_t)tap * nkc2 + kc2) * ncg + cg0) * kWBlockBytes + (size_t)tid * kSlotBytes;
+        const char* src = (const char*)a.wgt2 + seg_wp(0) * (size_t)a.w_part_bytes2 + (((size_t)tap * nkc2 + kc2) * ncg + cg0) * kWBlockBytes + (size_t)tid * kSlotBytes;
         char* dst = ringS + buf * S_WB + wave * 64 * kSlotBytes;
 #pragma unroll
         for (int j = 0; j < 2; ++j)                            // S_WB = 2 x NT x 16 bytes in both forms
@@ -172,7 +183,7 @@ __global__ __launch_bounds__(NCW * 256, 2) void conv_ds_fused_m(const ConvArgs a
     auto dma_D = [&](int tw, int kc, int buf) {                // this wave's 64 couts x 64 cin of its phase's tap
         int lane_ = lane;
         asm volatile("" : "+v"(lane_));
-        const char* src = (const char*)a.wgt + (((size_t)tw * nkc + kc) * ncg + cg0 + wco) * kWBlockBytes + (size_t)lane_ * kSlotBytes;
+        const char* src = (const char*)a.wgt + seg_wp(0) * (size_t)a.w_part_bytes + (((size_t)tw * nkc + kc) * ncg + cg0 + wco) * kWBlockBytes + (size_t)lane_ * kSlotBytes;
         char* dst = ringD + buf * D_WB;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
@@ -194,9 +205,7 @@ __global__ __launch_bounds__(NCW * 256, 2) void conv_ds_fused_m(const ConvArgs a
     auto mma4 = [&](int mi, int half, const u32x4 (&xf)[4]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            acc[mi][half * 4 + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_d, wf[mi]),
-                                                                            __builtin_bit_cast(bf16x8_d, xf[q]),
-                                                                            acc[mi][half * 4 + q], 0, 0, 0);
+            acc[mi][half * 4 + q] = mma_16x16x32<SPLIT == 2>(wf[mi], xf[q], acc[mi][half * 4 + q]);
     };
     // stage A: 16 MFMAs (all cout blocks x pixel rows 0-1) over the 4 reads of rows 2-3
 #define IDC_DSM_STAGE_A()                                                             \
@@ -217,15 +226,16 @@ __global__ __launch_bounds__(NCW * 256, 2) void conv_ds_fused_m(const ConvArgs a
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 
     // ---------------------------------------------------------------- S part: 3x3 conv of the skip tensor
-    load_halo_S(0);
+    load_halo_S(seg_xp(0) * nkc2);
     dma_S(0, 0, 0);
     dma_S(1, 0, 1);
     if (a.warm && wave == 0) idc_warm_own_code(halo + SROWS * kRowBytes, lane, NCW == 2 ? 100 : 96);   // 12.5 of this kernel's 13.8 KB (<2> is the last kernel of its code object: stay inside -- tools/check_code_warm.py holds the count against the build); scratch: the halo area's unread tail
     static_assert(S_HALO_BYTES - SROWS * kRowBytes >= 256, "scratch for the code warm-up");
-    int rt = 2, rkc = 0;                                       // request cursor: (tap, chunk) of tile s+2
+    int rt = 2, rkc = 0, rseg = 0;                             // request cursor: (tap, chunk, segment) of tile s+2
+    size_t rwp = seg_wp(0) * (size_t)a.w_part_bytes2;          // ... and its weight part's offset
     auto dma_S_req = [&](int slot_off) {
-        const bool real = rkc < nkc2;
-        const char* src = real ? (const char*)a.wgt2 + (((size_t)rt * nkc2 + rkc) * ncg + cg0) * kWBlockBytes + (size_t)tid * kSlotBytes
+        const bool real = SPLIT ? rseg < nseg : rkc < nkc2;
+        const char* src = real ? (const char*)a.wgt2 + rwp + (((size_t)rt * nkc2 + rkc) * ncg + cg0) * kWBlockBytes + (size_t)tid * kSlotBytes
                                : (const char*)a.zeros + (tid & 15) * kSlotBytes;
         const size_t jstep = real ? (size_t)NT * kSlotBytes : 0;
         char* dst = ringS + slot_off + wave * 64 * kSlotBytes;
@@ -258,16 +268,21 @@ __global__ __launch_bounds__(NCW * 256, 2) void conv_ds_fused_m(const ConvArgs a
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) read_a1(ringS, wrowS, 0, mi);
     read_b(xs, 0, 0, xlo);
-    for (int kc2 = 0; kc2 < nkc2; ++kc2) {
-        const bool last_kc = kc2 + 1 == nkc2;
+    int sseg = 0, skc = 0, sslot = seg_xp(0) * nkc2;           // the S loop's segment, chunk and the chunk's slot inside a pixel
+    for (int q = 0, nq = nseg * nkc2; q < nq; ++q) {
+        const bool last_kc = q + 1 == nq;
+        int sseg_n = sseg, skc_n = skc + 1;
+        if (skc_n == nkc2) { skc_n = 0; ++sseg_n; }
+        const int sslot_n = SPLIT ? (last_kc ? sslot : seg_xp(sseg_n) * nkc2 + skc_n) : q + 1;
+        const bool reloadS = SPLIT ? (!last_kc && sslot_n != sslot) : !last_kc;      // (a segment change on a one-chunk tensor may keep the halo: hi.lo -> hi.hi)
         auto tap_body = [&](int t, auto last_tag) {
             constexpr bool LAST = decltype(last_tag)::value;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // my pieces of the next step's tile
             __syncthreads();                                    // ... everybody's: published; everybody left slot off_free
             dma_S_req(off_free);
             if constexpr (LAST) {
-                if (NCW == 2 && !last_kc) load_halo_S(kc2 + 1);
-                else load_halo_D(0);                            // the deconv input's first chunk: rows wait in registers (4-wave form: ONE shortcut chunk)
+                if (NCW == 2 && !last_kc) { if (reloadS && SPLIT == 0) load_halo_S(sslot_n); }   // (SPLIT: after the barrier below -- a chunk is nseg x longer there, its 44 halo registers would cost spills in every step)
+                else load_halo_D(seg_xp(0) * nkc);              // the deconv input's first chunk: rows wait in registers (4-wave form: ONE shortcut chunk)
             }
             __builtin_amdgcn_sched_barrier(0);
             const char* const wcur = ringS + off_cur;
@@ -289,7 +304,12 @@ __global__ __launch_bounds__(NCW * 256, 2) void conv_ds_fused_m(const ConvArgs a
             for (int mi = 0; mi < 4; ++mi) mma4(mi, 0, xlo);
             IDC_DSM_STAGE_A()
             set_xs(LAST ? 0 : t + 1, 0, 4);
-            if (++rt == 9) { rt = 0; ++rkc; }
+            if (++rt == 9) {
+                rt = 0; ++rkc;
+                if constexpr (SPLIT != 0) {
+                    if (rkc == nkc2) { rkc = 0; ++rseg; rwp = seg_wp(rseg < nseg ? rseg : 0) * (size_t)a.w_part_bytes2; }
+                }
+            }
             read_b(xs, 0, 0, xlo);
             mma4(0, 1, xhi); read_a1(wnxt, wrowS, 0, 0);
             mma4(1, 1, xhi); read_a1(wnxt, wrowS, 0, 1);
@@ -298,8 +318,9 @@ __global__ __launch_bounds__(NCW * 256, 2) void conv_ds_fused_m(const ConvArgs a
             IDC_DSM_STAGE_B()
             if constexpr (LAST) {
                 if constexpr (NCW == 2) {
-                    if (!last_kc) {
+                    if (reloadS) {
                         __syncthreads();                        // everybody is done with halo chunk kc2
+                        if constexpr (SPLIT != 0) load_halo_S(sslot_n);
 #pragma unroll
                         for (int j = 0; j < S_ITEMS; ++j) *(u32x4*)(halo + (tid + j * NT) * kSlotBytes) = hreg[j];
                         __syncthreads();
@@ -311,6 +332,7 @@ __global__ __launch_bounds__(NCW * 256, 2) void conv_ds_fused_m(const ConvArgs a
         };
         for (int t = 0; t < 8; ++t) tap_body(t, std::false_type{});
         tap_body(8, std::true_type{});
+        if constexpr (SPLIT != 0) { sseg = sseg_n; skc = skc_n; sslot = sslot_n; }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the trailing zero-page requests target LDS the D part reuses
     // ---------------------------------------------------------------- hand-over: the D part reuses the whole LDS
@@ -329,7 +351,7 @@ __global__ __launch_bounds__(NCW * 256, 2) void conv_ds_fused_m(const ConvArgs a
     dma_D(__builtin_amdgcn_readlane(v_tw, 1), 0, 1);
     // ---------------------------------------------------------------- D part: the wave's deconv phase, 2x2 taps, wave-private weight ring
     const int wrowD = r16 * kRowBytes;
-    const int nsteps = 4 * nkc;
+    const int nsteps = 4 * nkc * nseg;
     int xa[4];
     auto set_xa = [&](int xo) {
 #pragma unroll
@@ -345,12 +367,26 @@ __global__ __launch_bounds__(NCW * 256, 2) void conv_ds_fused_m(const ConvArgs a
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) read_a1(ringD, wrowD, 0, mi);
     read_b(xa, 0, 0, xlo);
+    int dkc = 0, dseg = 0, dslot = seg_xp(0) * nkc;             // the D loop's chunk, segment and the chunk's slot inside a pixel
+    int qkc = 0, qseg = 0;                                     // request cursor: (chunk, segment) of step st + 2 (steps 0 and 1 are in flight)
+    size_t qwp = seg_wp(0) * (size_t)a.w_part_bytes;
     for (int st = 0; st < nsteps; ++st) {
-        const int t = st & 3, kc = st >> 2;
+        const int t = st & 3;
         const char* const wcur = ringD + (st & 1) * D_WB;
         const char* const wnext = ringD + ((st + 1) & 1) * D_WB;
-        const bool swap = t == 3 && st + 1 < nsteps;
-        if (swap) load_halo_D(kc + 1);                         // next chunk's rows wait in registers
+        bool swap_ = t == 3 && st + 1 < nsteps;
+        if constexpr (SPLIT != 0) {
+            if (t == 3) {
+                if (++dkc == nkc) { dkc = 0; ++dseg; }
+                const int dslot_n = swap_ ? seg_xp(dseg) * nkc + dkc : dslot;
+                swap_ = swap_ && dslot_n != dslot;
+                dslot = dslot_n;
+            }
+        } else {
+            dslot = (st >> 2) + 1;
+        }
+        const bool swap = swap_;
+        if (swap) load_halo_D(dslot);                          // next chunk's rows wait in registers
         read_b(xa, 0, 1, xhi);
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) mma4(mi, 0, xlo);
@@ -369,10 +405,17 @@ __global__ __launch_bounds__(NCW * 256, 2) void conv_ds_fused_m(const ConvArgs a
         {
             const int s2 = st + 2;
             const bool real = s2 < nsteps;
+            if constexpr (SPLIT != 0) {
+                if ((s2 & 3) == 0) {                            // step s2 opens a chunk: advance the request cursor
+                    if (++qkc == nkc) { qkc = 0; ++qseg; qwp = seg_wp(qseg < nseg ? qseg : 0) * (size_t)a.w_part_bytes; }
+                }
+            } else {
+                qkc = s2 >> 2;
+            }
             const int tw2 = __builtin_amdgcn_readlane(v_tw, s2 & 3);
             int lane_ = lane;
             asm volatile("" : "+v"(lane_));
-            const char* src = real ? (const char*)a.wgt + (((size_t)tw2 * nkc + (s2 >> 2)) * ncg + cg0 + wco) * kWBlockBytes + (size_t)lane_ * kSlotBytes
+            const char* src = real ? (const char*)a.wgt + qwp + (((size_t)tw2 * nkc + qkc) * ncg + cg0 + wco) * kWBlockBytes + (size_t)lane_ * kSlotBytes
                                    : (const char*)a.zeros + (lane_ & 15) * kSlotBytes;
             const int jstep = real ? 64 * kSlotBytes : 0;
             char* dst = ringD + (st & 1) * D_WB;
@@ -402,6 +445,12 @@ __global__ __launch_bounds__(NCW * 256, 2) void conv_ds_fused_m(const ConvArgs a
     // ---------------------------------------------------------------- epilogue: (ReLU,) round, transpose, whole-line stores
     IDC_DSTAMP(2);
     __syncthreads();
+    if constexpr (SPLIT != 0) {
+        add_bias_after_k(a.bias + (cg0 + wco) * kCoutGroup + g16 * 16, acc);
+        split_epilogue<NCW, SPLIT == 2>(a, acc, smem, n, y0, x0, 0, (cg0 + wco) * kCoutGroup, ro, cof);
+        IDC_DSTAMP(3);
+        return;
+    }
     char* const tb16 = smem + wave * 4096;                     // wave-private [32 sites][64 couts] bf16, 128-byte rows, slot ^ (site & 7)
     typedef short s16x2 __attribute__((ext_vector_type(2)));
     const int rr = lane >> 3, cc = lane & 7;
@@ -451,6 +500,12 @@ __global__ __launch_bounds__(NCW * 256, 2) void conv_ds_fused_m(const ConvArgs a
 #endif
 }
 
+template <int NCW>
+__global__ __launch_bounds__(NCW * 256, 2) void conv_ds_fused_m(const ConvArgs a) { conv_ds_fused_m_body<NCW, 0>(a); }
+// the operand-split forms: bf16 parts (IDC_BF16X3 / IDC_BF16X6) and fp16 parts (IDC_FP16X3); 8-wave workgroups only
+__global__ __launch_bounds__(512, 2) void conv_ds_fused_ms(const ConvArgs a) { conv_ds_fused_m_body<2, 1>(a); }
+__global__ __launch_bounds__(512, 2) void conv_ds_fused_msh(const ConvArgs a) { conv_ds_fused_m_body<2, 2>(a); }
+
 // deconv 4x4 s2 + its 3x3 shortcut conv in one launch, 16x16x32 MFMA: bf16, Cout a multiple of 128, (ReLU | none), no BN.
 // a.wgt / a.wgt2 = the LAYOUT-1 images of the deconv / the shortcut conv.
 // buffer loads address ONE image with 32-bit offsets (out-of-image rows: offset 2^31)
@@ -478,8 +533,26 @@ hipError_t launch_conv_ds_m(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ... its operand-split form: a.in / a.in2 / a.out split tensors of a.in_parts (= a.out_parts) planes, a.wgt / a.wgt2 the weight parts' layout-1 images
+hipError_t launch_conv_ds_ms(const ConvArgs& a, hipStream_t s) {
+    if (a.in2 == nullptr || a.wgt2 == nullptr || a.zeros == nullptr || a.nphase != 4 || a.so != 2 || a.si != 1 || (a.ncg & 1) || a.out_f32 ||
+        a.img_shift != nullptr || a.resid != nullptr || a.head_w != nullptr || a.in_parts < 2 || a.in_parts > 3 || a.out_parts != a.in_parts ||
+        a.nseg < 1 || a.nseg > 6 || a.w_part_bytes == 0 || a.w_part_bytes2 == 0 ||
+        !conv_ds_m_fits(a.Hs, a.Ws, a.nkc * a.in_parts, a.nkc2 * a.in_parts))
+        return hipErrorInvalidConfiguration;
+    const long long blocks = (long long)((a.Ws + 31) / 32) * ((a.Hs + 3) / 4) * a.N * (a.ncg / 2);
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (a.split_f16) hipLaunchKernelGGL(conv_ds_fused_msh, dim3((unsigned)blocks), dim3(512), 160 * 1024, s, a);
+    else hipLaunchKernelGGL(conv_ds_fused_ms, dim3((unsigned)blocks), dim3(512), 160 * 1024, s, a);
+    return hipGetLastError();
+}
+
 hipError_t init_kernels_dsm() {
     hipError_t e = hipFuncSetAttribute((const void*)conv_ds_fused_m<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)conv_ds_fused_ms, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)conv_ds_fused_msh, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void*)conv_ds_fused_m<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }

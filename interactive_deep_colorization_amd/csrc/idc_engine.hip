@@ -15,6 +15,9 @@
 #include <string>
 #include <algorithm>
 #include <vector>
+#include <atomic>
+#include <functional>
+#include <thread>
 
 #include "../../include/ideepcolor.h"
 #include "idc_kernels.h"
@@ -25,6 +28,15 @@ namespace idc {
 
 static thread_local std::string g_last_error;
 
+// The 32x32x16-MFMA partners of the throughput kernels (conv_igemm_v2, conv_ds_fused, conv1_1_bf16_kernel: idc_v2.hip, idc_conv1.hip) exist only in the
+// -DIDC_AB_PARTNERS build (round 6).  The default library plans every launch on conv_igemm_v2p / conv_igemm_v2m / conv_ds_fused_m / conv1_block_fused_t or
+// the small-tile kernels, and refuses the option values that ask for a partner.
+#ifdef IDC_AB_PARTNERS
+static constexpr bool kAbPartners = true;
+#else
+static constexpr bool kAbPartners = false;
+#endif
+
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 BlobPlan make_blob_plan(int precision, unsigned flags) {
@@ -32,7 +44,8 @@ BlobPlan make_blob_plan(int precision, unsigned flags) {
     p.precision = precision;
     p.flags = flags & (IDC_FLAG_DIST_HEAD | IDC_FLAG_GLOBAL_HINTS | IDC_FLAG_DIST313 | IDC_FLAG_THROUGHPUT_BLOB);
     // Winograd U images: the fp32 path only (round 5: the bf16 click path's Winograd kernels were retired -- conv_kwave_* read the layout-1
-    // images -- so a bf16 blob is 136 MB whatever the flag says; fp32: 384 MB, 136 MB with IDC_FLAG_THROUGHPUT_BLOB)
+    // images -- so a bf16 blob is 70 MB (136 MB with the partner build's layout-2 images) whatever the flag says; fp32: 384 MB, 136 MB with
+    // IDC_FLAG_THROUGHPUT_BLOB)
     const bool wino_images = !(flags & IDC_FLAG_THROUGHPUT_BLOB) && precision == IDC_FP32;
     const auto& specs = layer_specs();
     size_t off = sizeof(BlobHeader);
@@ -54,7 +67,8 @@ BlobPlan make_blob_plan(int precision, unsigned flags) {
         lb.w_bytes = (size_t)weight_taps(s.kind) * lb.nkc * lb.ncg * kWBlockBytes;
         off = align_up(off, 256); lb.w_off = off; off += lb.w_bytes * lb.parts;
         lb.w2_off = (size_t)-1;
-        if (precision == IDC_BF16 && v2_eligible(s)) { off = align_up(off, 256); lb.w2_off = off; off += lb.w_bytes; }
+        // (layout 2 = the 32x32x16-MFMA kernels' image: partner build only; the default library's bf16 blob is 70 MB instead of 136)
+        if (kAbPartners && precision == IDC_BF16 && v2_eligible(s)) { off = align_up(off, 256); lb.w2_off = off; off += lb.w_bytes; }
         lb.w3_off = (size_t)-1; lb.w3_bytes = 0;
         if (wino_l && wino_eligible(s) && s.cin % kc == 0) {                            // fp32: every batch size; bf16: the batch-1 click path
             lb.w3_bytes = (size_t)s.cin * cout_pad(s.cout) * 16 * elem_bytes(lprec);   // 16 transformed values per (cin, cout)
@@ -106,8 +120,8 @@ static bool dims_are(const TensorView& t, std::initializer_list<int64_t> d) {
 }
 
 // Write one element of the packed weight image (layout 1: small-tile kernels, layout 2: conv_igemm_v2).
-static int g_pack_part = 0;      // operand-split precisions: which bf16 part of the weight put_w stores (0 = hi: rne(v); 1: rne(v - hi); 2: rne(v - hi - mid))
-static inline void put_w(uint8_t* wimg, int precision, int layout, int nkc, int ncg, int tw, int co, int k, float v) {
+// part: operand-split precisions -- which part of the weight is stored (0 = hi: rne(v); 1: rne(v - hi); 2: rne(v - hi - mid))
+static inline void put_w(uint8_t* wimg, int precision, int layout, int nkc, int ncg, int tw, int co, int k, float v, int part) {
     const int kc_e = kc_elems(precision), eb = elem_bytes(precision), eps = kSlotBytes / eb;
     const int kc = k / kc_e, kin = k % kc_e;
     const int s = kin / eps, e = kin % eps;
@@ -127,11 +141,11 @@ static inline void put_w(uint8_t* wimg, int precision, int layout, int nkc, int 
     if (split_is_f16(precision)) {                                 // IDC_FP16X3: fp16 parts (RNE; weights beyond the fp16 range saturate)
         auto to_h = [](float x) { return (_Float16)(x > 65504.f ? 65504.f : (x < -65504.f ? -65504.f : x)); };
         _Float16 b = to_h(v);
-        for (int q = 0; q < g_pack_part; ++q) { v -= (float)b; b = to_h(v); }
+        for (int q = 0; q < part; ++q) { v -= (float)b; b = to_h(v); }
         memcpy(wimg + off, &b, 2);
     } else if (precision != IDC_FP32) {
         uint16_t b = f32_to_bf16_rne(v);
-        for (int q = 0; q < g_pack_part; ++q) {                    // (exact: the remainder of a round-to-nearest is representable)
+        for (int q = 0; q < part; ++q) {                           // (exact: the remainder of a round-to-nearest is representable)
             uint32_t u = (uint32_t)b << 16; float hi; memcpy(&hi, &u, 4);
             v -= hi;
             b = f32_to_bf16_rne(v);
@@ -144,28 +158,28 @@ static inline void put_w(uint8_t* wimg, int precision, int layout, int nkc, int 
 
 // Pack one conv-like layer: weights in torch layout -> MFMA-tiled, swizzled image.
 static void pack_layer_weights(uint8_t* wimg, int precision, int layout, const LayerSpec& s, const LayerBlob& lb,
-                               const float* w) {
+                               const float* w, int part = 0) {
     memset(wimg, 0, lb.w_bytes);
     const int cin = s.cin, cout = s.cout;
     if (s.kind == kConv3x3) {
         for (int co = 0; co < cout; ++co)
             for (int ci = 0; ci < cin; ++ci)
                 for (int t = 0; t < 9; ++t)
-                    put_w(wimg, precision, layout, lb.nkc, lb.ncg, t, co, ci, w[((size_t)co * cin + ci) * 9 + t]);
+                    put_w(wimg, precision, layout, lb.nkc, lb.ncg, t, co, ci, w[((size_t)co * cin + ci) * 9 + t], part);
     } else if (s.kind == kConvIm2col) {          // K index = tap*4 + c  (the order conv1_1's fused input pack builds)
         for (int co = 0; co < cout; ++co)
             for (int ci = 0; ci < cin; ++ci)
                 for (int t = 0; t < 9; ++t)
-                    put_w(wimg, precision, layout, lb.nkc, lb.ncg, 0, co, t * 4 + ci, w[((size_t)co * cin + ci) * 9 + t]);
+                    put_w(wimg, precision, layout, lb.nkc, lb.ncg, 0, co, t * 4 + ci, w[((size_t)co * cin + ci) * 9 + t], part);
     } else if (s.kind == kConv1x1) {
         for (int co = 0; co < cout; ++co)
             for (int ci = 0; ci < cin; ++ci)
-                put_w(wimg, precision, layout, lb.nkc, lb.ncg, 0, co, ci, w[(size_t)co * cin + ci]);
+                put_w(wimg, precision, layout, lb.nkc, lb.ncg, 0, co, ci, w[(size_t)co * cin + ci], part);
     } else {                                      // ConvTranspose2d weight is (Cin, Cout, 4, 4)
         for (int ci = 0; ci < cin; ++ci)
             for (int co = 0; co < cout; ++co)
                 for (int t = 0; t < 16; ++t)
-                    put_w(wimg, precision, layout, lb.nkc, lb.ncg, t, co, ci, w[((size_t)ci * cout + co) * 16 + t]);
+                    put_w(wimg, precision, layout, lb.nkc, lb.ncg, t, co, ci, w[((size_t)ci * cout + co) * 16 + t], part);
     }
 }
 
@@ -244,6 +258,21 @@ static int fail(std::string* err, int code, const char* fmt, ...) {
     return code;
 }
 
+// the queued image packers on up to 16 host threads (each writes its own image: no sharing)
+static void run_pack_tasks(std::vector<std::function<void()>>& t) {
+    if (t.empty()) return;
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt == 0 ? 4 : (nt > 16 ? 16 : nt);
+    if (nt > t.size()) nt = (unsigned)t.size();
+    std::atomic<size_t> next{0};
+    auto work = [&]() { for (size_t i; (i = next.fetch_add(1)) < t.size();) t[i](); };
+    std::vector<std::thread> th;
+    for (unsigned k = 1; k < nt; ++k) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+    t.clear();
+}
+
 static int pack_weights_impl(int precision, unsigned flags, const idc_tensor_desc* tensors, int n_tensors,
                              void* blob, size_t blob_bytes, std::string* err) {
     if (precision < IDC_FP32 || precision > IDC_FP16X3) return fail(err, IDC_ERR_INVALID_ARG, "bad precision %d", precision);
@@ -266,9 +295,10 @@ static int pack_weights_impl(int precision, unsigned flags, const idc_tensor_des
         *out = &it->second;
         return true;
     };
-    uint8_t* base = (uint8_t*)blob;
+    uint8_t* const base = (uint8_t*)blob;
     memset(base, 0, plan.total_bytes);
     const auto& specs = layer_specs();
+    std::vector<std::function<void()>> tasks;
     for (size_t li = 0; li < plan.active.size(); ++li) {
         const LayerSpec& s = specs[plan.active[li]];
         const LayerBlob& lb = plan.layers[li];
@@ -283,15 +313,14 @@ static int pack_weights_impl(int precision, unsigned flags, const idc_tensor_des
         if (!ok) return fail(err, IDC_ERR_MISSING_KEY, "key '%s' has the wrong shape", wk.c_str());
         if (!dims_are(*b, {s.cout})) return fail(err, IDC_ERR_MISSING_KEY, "key '%s' has the wrong shape", bk.c_str());
         const int lprec = lb.f32 ? (int)IDC_FP32 : precision;        // (operand-split precisions: model1's fp32 island)
-        for (int part = 0; part < lb.parts; ++part) {
-            g_pack_part = part;
-            pack_layer_weights(base + lb.w_off + (size_t)part * lb.w_bytes, lprec, 1, s, lb, w->data);
-        }
-        g_pack_part = 0;
-        if (lb.w2_off != (size_t)-1) pack_layer_weights(base + lb.w2_off, lprec, 2, s, lb, w->data);
+        // the weight images are independent of each other: queued here, packed by the worker threads below (round 6: 1.4 s -> 0.2 s for a bf16 blob)
+        const LayerSpec* sp = &s; const LayerBlob* lbp = &lb; const float* wd = w->data;
+        for (int part = 0; part < lb.parts; ++part)
+            tasks.push_back([=]() { pack_layer_weights(base + lbp->w_off + (size_t)part * lbp->w_bytes, lprec, 1, *sp, *lbp, wd, part); });
+        if (lb.w2_off != (size_t)-1) tasks.push_back([=]() { pack_layer_weights(base + lbp->w2_off, lprec, 2, *sp, *lbp, wd); });
         if (lb.w3_off != (size_t)-1) {
-            if (s.kind == kDeconv4x4) pack_wino_deconv_weights(base + lb.w3_off, lprec, s, lb, w->data);
-            else pack_wino_weights(base + lb.w3_off, lprec, s, lb, w->data);
+            if (s.kind == kDeconv4x4) tasks.push_back([=]() { pack_wino_deconv_weights(base + lbp->w3_off, lprec, *sp, *lbp, wd); });
+            else tasks.push_back([=]() { pack_wino_weights(base + lbp->w3_off, lprec, *sp, *lbp, wd); });
         }
         float* bias = (float*)(base + lb.bias_off);
         for (int c = 0; c < s.cout; ++c) bias[c] = b->data[c];
@@ -313,6 +342,7 @@ static int pack_weights_impl(int precision, unsigned flags, const idc_tensor_des
             }
         }
     }
+    run_pack_tasks(tasks);
     // layers that sum a shortcut branch: bias of the fused launch = own bias + the shortcut conv's bias
     for (size_t li = 0; li < plan.active.size(); ++li) {
         const LayerSpec& s = specs[plan.active[li]];
@@ -519,14 +549,6 @@ static int find_tensor(idc_context* c, const char* name) {
 // Tile policy (speed only; every choice computes the same result): 0 = automatic, 1 = always the
 // small-tile kernels (conv_igemm), 2 = the large-tile bf16 kernel (conv_igemm_v2) wherever it applies.
 static int g_tile_policy = 0;
-// The 32x32x16-MFMA partners of the throughput kernels (conv_igemm_v2, conv_ds_fused, conv1_1_bf16_kernel: idc_v2.hip, idc_conv1.hip) exist only in the
-// -DIDC_AB_PARTNERS build (round 6).  The default library plans every launch on conv_igemm_v2p / conv_igemm_v2m / conv_ds_fused_m / conv1_block_fused_t or
-// the small-tile kernels, and refuses the option values that ask for a partner.
-#ifdef IDC_AB_PARTNERS
-static constexpr bool kAbPartners = true;
-#else
-static constexpr bool kAbPartners = false;
-#endif
 static int g_fuse_conv1 = idc_env_int("IDC_FUSE_CONV1", 1) != 0;   // model1 (conv1_1 + conv1_2) as one launch on the bf16 throughput path (idc_set_option / env IDC_FUSE_CONV1=0 for A/B)
 // Split-K policy of the small-tile kernels (speed only): 0 = automatic (launches that would leave most CUs idle,
 // i.e. the batch-1 click path), 1 = never, 2 = always split as far as the cin chunks allow (tests).
@@ -540,6 +562,9 @@ static int g_wino_deconv = 1;            // 1 = small launches with Cin >= 256 o
 static int g_mfma16 = idc_env_int("IDC_MFMA16", 1);
 // ... and so do the three deconv + shortcut launches (conv_ds_fused_m, idc_dsm.hip; idc_set_option "ds_mfma16" / env IDC_DS_M16=0 for A/B)
 static int g_ds_m16 = idc_env_int("IDC_DS_M16", 1);
+// operand-split precisions: the deconv + shortcut pairs as ONE launch (conv_ds_fused_ms / _msh) instead of shortcut conv (fp32 sums to HBM) + deconv
+// (idc_set_option "split_ds_fuse", 0 for A/B)
+static int g_split_ds_fuse = 1;
 // ... and the 3x3 convs among them as conv_igemm_v2p (no address arithmetic in the K loop; idc_set_option "v2p" / env IDC_V2P=0 for A/B)
 static int g_v2p = idc_env_int("IDC_V2P", 1);
 // throughput kernels touch their own code at entry (idc_warm_own_code, idc_kernels.h; env IDC_CODE_WARM=0 for the A/B of profiles/r04_firstuse.txt)
@@ -937,7 +962,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
         }
     }
     for (auto& L : c->layers) {
-        if (L.spec->kind != kDeconv4x4 || L.resid < 0 || !L.v2 || !fuse_shortcut_enabled() || L.split) continue;   // (split: two launches, fp32 shortcut sum)
+        if (L.spec->kind != kDeconv4x4 || L.resid < 0 || !L.v2 || !fuse_shortcut_enabled() || (L.split && !g_split_ds_fuse)) continue;
         if (L.spec->cout % 128 != 0 || L.spec->bnkey || L.spec->act == 2 || c->tensors[L.dst].is_f32) continue;   // conv_ds_fused's domain
         for (size_t j = 0; j < c->layers.size(); ++j) {
             Layer& P = c->layers[j];
@@ -945,8 +970,17 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             if (P.dst != L.resid) continue;
             const Tensor& pin = c->tensors[P.src];
             const Tensor& to = c->tensors[L.dst];
+            if (L.split) {      // operand-split: conv_ds_fused_ms (split tensors in and out, both of the same part count) or two launches
+                if (ps.kind == kConv3x3 && ps.dilation == 1 && ps.in_stride == 1 && ps.act == 0 && !ps.bnkey && !ps.resid && P.split &&
+                    ps.cout == L.spec->cout && pin.H == to.H && pin.W == to.W && !pin.is_f32 && pin.parts == to.parts &&
+                    c->tensors[L.src].parts == to.parts && !c->tensors[L.src].is_f32 &&
+                    conv_ds_m_fits(L.args.Hs, L.args.Ws, L.blob.nkc * to.parts, P.blob.nkc * to.parts)) {
+                    L.fused_short = (int)j; P.skip = true;
+                }
+                continue;
+            }
             if (ps.kind == kConv3x3 && ps.dilation == 1 && ps.in_stride == 1 && ps.act == 0 && !ps.bnkey && !ps.resid &&
-                ps.cout == L.spec->cout && pin.H == to.H && pin.W == to.W && !pin.is_f32 && P.blob.w2_off != (size_t)-1 &&
+                ps.cout == L.spec->cout && pin.H == to.H && pin.W == to.W && !pin.is_f32 && (!kAbPartners || P.blob.w2_off != (size_t)-1) &&
                 (kAbPartners || (g_ds_m16 != 0 && conv_ds_m_fits(L.args.Hs, L.args.Ws, L.blob.nkc, P.blob.nkc)))) {      // (default library: conv_ds_fused_m or two launches)
                 L.fused_short = (int)j; P.skip = true;
             }
@@ -981,17 +1015,18 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
         } else {
             a.pk_L = nullptr;
         }
-        a.wgt = c->d_blob + (L.wino ? L.blob.w3_off : L.v2 ? L.blob.w2_off : L.blob.w_off);
+        a.wgt = c->d_blob + (L.wino ? L.blob.w3_off : (L.v2 && L.blob.w2_off != (size_t)-1) ? L.blob.w2_off : L.blob.w_off);
         a.bias = (const float*)(c->d_blob + L.blob.bias_off);
         a.bn_scale = L.blob.bn_scale_off != (size_t)-1 ? (const float*)(c->d_blob + L.blob.bn_scale_off) : nullptr;
         a.bn_shift = L.blob.bn_shift_off != (size_t)-1 ? (const float*)(c->d_blob + L.blob.bn_shift_off) : nullptr;
         if (L.fused_short >= 0) {            // model8up(.) + model3short8(.) in one K loop (model.py:156,170,172)
             const Layer& P = c->layers[L.fused_short];
             a.resid = nullptr; a.resid_bf16 = 0;
-            a.in2 = c->tensors[P.src].ptr; a.wgt2 = c->d_blob + P.blob.w2_off; a.nkc2 = P.blob.nkc;
+            a.in2 = c->tensors[P.src].ptr; a.wgt2 = c->d_blob + (P.blob.w2_off != (size_t)-1 ? P.blob.w2_off : P.blob.w_off); a.nkc2 = P.blob.nkc;
             a.bias = (const float*)(c->d_blob + L.blob.fbias_off);
             L.m16 = g_ds_m16 != 0 && conv_ds_m_fits(a.Hs, a.Ws, a.nkc, P.blob.nkc);   // (huge images: conv_ds_fused, 64-bit addressing)
             if (L.m16) { a.wgt = c->d_blob + L.blob.w_off; a.wgt2 = c->d_blob + P.blob.w_off; }   // conv_ds_fused_m reads the layout-1 images
+            if (L.split) { L.m16 = true; a.wgt = c->d_blob + L.blob.w_off; a.wgt2 = c->d_blob + P.blob.w_off; a.w_part_bytes2 = P.blob.w_bytes; }
         } else {
             a.resid = L.resid >= 0 ? c->tensors[L.resid].ptr : nullptr;
             a.resid_bf16 = (L.resid >= 0 && !c->tensors[L.resid].is_f32) ? 1 : 0;
@@ -1034,10 +1069,10 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             a.in_parts = ti.parts; a.out_parts = (to.is_f32 || L.fused_head) ? 0 : to.parts;
             a.nseg = split_segments(c->precision); a.seg_x = split_seg_x(c->precision); a.seg_w = split_seg_w(c->precision);
             a.w_part_bytes = L.blob.w_bytes;
-            if (!L.v2 || !conv_v2s_applies(a))
+            if (L.fused_short < 0 && (!L.v2 || !conv_v2s_applies(a)))
                 return fail(&c->err, IDC_ERR_INTERNAL, "layer %s: no operand-split kernel covers this launch", L.spec->name);
             L.m16 = true;
-            L.v2p = g_v2p && conv_v2ps_applies(L.cfg, L.halo, a);
+            L.v2p = L.fused_short < 0 && g_v2p && conv_v2ps_applies(L.cfg, L.halo, a);
         } else if (L.fused_short < 0) {
             L.m16 = L.v2 && g_mfma16 && L.fused_next < 0 && !L.wino && !L.click && conv_v2m_applies(a);
             if (L.m16) a.wgt = c->d_blob + L.blob.w_off;            // the layout-1 image (the one conv_igemm / conv_click read)
@@ -1057,7 +1092,9 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             else if (L.spec->kind == kConvIm2col && L.lprec == IDC_BF16 && a.ksplit <= 1 &&
                 (long long)((a.Ws + 31) / 32) * ((a.Hs + 31) / 32) * c->max_batch >= 128)
                 le = launch_conv1_1_bf16(a, s);
-            if (L.fused_short >= 0) le = L.m16 ? launch_conv_ds_m(a, s) : launch_conv_ds(a, s);
+            if (L.fused_short >= 0) le = L.split ? launch_conv_ds_ms(a, s) : L.m16 ? launch_conv_ds_m(a, s) : launch_conv_ds(a, s);
+            if (L.fused_short >= 0 && L.split && le == hipErrorInvalidConfiguration)
+                return fail(&c->err, IDC_ERR_INTERNAL, "layer %s: conv_ds_fused_ms planned for a launch it does not cover", L.spec->name);
     // deconv + its shortcut conv in one K loop
             if (L.wino) {
                 // a.wgt points at the Winograd U image and L.cfg / tiles were never set for this layer: a refused launch must not fall
@@ -1383,6 +1420,7 @@ int idc_set_option(const char* name, int value) {
     if (strcmp(name, "mfma16") == 0) { g_mfma16 = value != 0; return IDC_OK; }
     if (strcmp(name, "v2p") == 0) { g_v2p = value != 0; return IDC_OK; }
     if (strcmp(name, "ds_mfma16") == 0) { g_ds_m16 = value != 0; set_ds_half(value != 2); return IDC_OK; }     // 2: conv_ds_fused_m, 8-wave workgroups on every grid
+    if (strcmp(name, "split_ds_fuse") == 0) { g_split_ds_fuse = value != 0; return IDC_OK; }
     if (strcmp(name, "kwave") == 0) { g_kwave = value != 0; return IDC_OK; }
     if (strcmp(name, "spin_sync") == 0) { g_spin_sync = value != 0; return IDC_OK; }
     if (strcmp(name, "pcie_kernel") == 0) { g_pcie_kernel = value != 0; return IDC_OK; }
@@ -2274,7 +2312,8 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
             if (L.fused_short >= 0) {
                 const Layer& P = h->layers[L.fused_short];
                 // the name rocprofv3 shows for this launch (the deconv and its 3x3 shortcut conv in one K loop)
-                snprintf(out->kernel, sizeof(out->kernel), L.m16 ? "conv_ds_fused_m+shortcut" : "conv_ds_fused+shortcut");
+                if (L.split) snprintf(out->kernel, sizeof(out->kernel), split_is_f16(h->precision) ? "conv_ds_fused_msh+shortcut x%d" : "conv_ds_fused_ms+shortcut x%d", L.args.nseg);
+                else snprintf(out->kernel, sizeof(out->kernel), L.m16 ? "conv_ds_fused_m+shortcut" : "conv_ds_fused+shortcut");
                 out->flops += P.flops;
                 out->min_bytes += P.min_bytes - 2.0 * (double)h->tensors[P.dst].H * h->tensors[P.dst].W * h->tensors[P.dst].Cpad * eb;
             }
@@ -2431,11 +2470,8 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     else {
         if (wino_ok) L.blob.w_bytes = (size_t)weight_taps(spec.kind) * L.blob.nkc * L.blob.ncg * kWBlockBytes;
         L.m16 = split || (L.v2 && g_mfma16 && resid == nullptr && spec.act != 2);       // as in the network: conv_igemm_v2m where it applies
-        for (int part = 0; part < parts; ++part) {
-            g_pack_part = part;
-            pack_layer_weights(wimg.data() + (size_t)part * L.blob.w_bytes, precision, (L.v2 && !L.m16) ? 2 : 1, spec, L.blob, weight);
-        }
-        g_pack_part = 0;
+        for (int part = 0; part < parts; ++part)
+            pack_layer_weights(wimg.data() + (size_t)part * L.blob.w_bytes, precision, (L.v2 && !L.m16) ? 2 : 1, spec, L.blob, weight, part);
     }
     std::vector<float> hb(cpad, 0.f), hs(cpad, 1.f), ht(cpad, 0.f);
     for (int c = 0; c < spec.cout; ++c) {

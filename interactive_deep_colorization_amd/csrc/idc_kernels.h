@@ -69,6 +69,7 @@ struct ConvArgs {
     int in_parts, out_parts, nseg;
     unsigned seg_x, seg_w;
     unsigned long long w_part_bytes;
+    unsigned long long w_part_bytes2;   // ... of the fused shortcut conv's images (a.wgt2; conv_ds_fused_m's split form)
     int split_f16;          // IDC_FP16X3: the parts are fp16 (11-bit) instead of bf16 (8-bit) values; same planes, same segments as IDC_BF16X3
     int warm;               // != 0: the throughput kernels pull their own code into L2 at entry (idc_warm_own_code below)
     const void* zeros;      // >= 16 zero bytes in device memory: LDS-DMA source of out-of-image halo rows (conv_click)
@@ -133,6 +134,8 @@ bool conv_v2ps_applies(ConvConfig cfg, int halo, const ConvArgs& a);
 hipError_t launch_conv_ds(const ConvArgs& a, hipStream_t s);
 // The same launch from v_mfma_f32_16x16x32_bf16 (idc_dsm.hip: conv_ds_fused_m); a.wgt / a.wgt2 = the LAYOUT-1 images
 hipError_t launch_conv_ds_m(const ConvArgs& a, hipStream_t s);
+// ... and its operand-split form (conv_ds_fused_ms / _msh: split tensors in and out, fp32 accumulation of both K loops, split epilogue)
+hipError_t launch_conv_ds_ms(const ConvArgs& a, hipStream_t s);
 bool conv_ds_m_fits(int Hs, int Ws, int nkc, int nkc2);   // (else conv_ds_fused, which addresses with 64-bit pointers)
 hipError_t init_kernels_dsm();
 void set_ds_half(int v);              // 1 (default): grids with fewer 128-cout workgroups than CUs run the 64-cout, 4-wave form of conv_ds_fused_m

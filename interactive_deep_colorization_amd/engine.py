@@ -83,7 +83,7 @@ SPLITK_POLICIES = {"auto": 0, "never": 1, "always": 2}
 def set_option(name, value):
     """Process-wide switches (``idc_set_option``; speed / kernel choice only -- every setting computes the same function).  Names and values are
     documented in ``include/ideepcolor.h``: 'fuse_conv1', 'click', 'winograd', 'mfma16', 'v2p', 'ds_mfma16', 'kwave', 'kwave_chain', and since
-    round 6 'spin_sync', 'pcie_kernel' (former environment switches) and the test hook 'kw_force_abort'.  'mfma16' = 0 / 'ds_mfma16' = 0 select the
+    round 6 'split_ds_fuse', 'spin_sync', 'pcie_kernel' (former environment switches) and the test hook 'kw_force_abort'.  'mfma16' = 0 / 'ds_mfma16' = 0 select the
     32x32x16-MFMA partner kernels, which exist only in a ``make EXTRA=-DIDC_AB_PARTNERS`` build: the default library raises IdcError (UNSUPPORTED)."""
     N.check(N.load().idc_set_option(name.encode(), int(value)))
 
@@ -96,7 +96,7 @@ def set_splitk_policy(policy="auto"):
 def pack_weights(sd, precision="bf16", dist=False, global_hints=False, dist313=False, throughput_blob=False):
     """Host-only: reference ``state_dict`` -> packed device-ready blob (uint8 ndarray).
     Needs no GPU (used by rank 0 before the RCCL broadcast).  ``throughput_blob``: without the Winograd images of the
-    batch-1 / fp32 kernels (IDC_FLAG_THROUGHPUT_BLOB: 136 MB instead of 260 MB in bf16) -- must match the handle's."""
+    batch-1 / fp32 kernels (IDC_FLAG_THROUGHPUT_BLOB: fp32 136 MB instead of 384 MB; a bf16 blob is 68 MB either way) -- must match the handle's."""
     lib = N.load()
     prec = _PREC[precision]
     flags = _flags(dist, global_hints, dist313, throughput_blob)

@@ -5,9 +5,9 @@ eval-mode BatchNorm uses fixed statistics (``data/colorize_image.py:232``) and n
 So:
 
 * images are split into contiguous shards, one per rank -- no data-path collective;
-* the ONLY collective is a one-time broadcast of the packed weight blob from rank 0 (bf16: 136 MB for a throughput
-  handle -- ``throughput_blob=True``, both MFMA layouts of every layer -- or 260 MB with the Winograd images of the
-  batch-1 click path; fp32: 136 / 384 MB; ``engine.blob_bytes()`` is the exact figure): RCCL over xGMI when the process group is ``nccl``, ``gloo`` in the CPU tests.
+* the ONLY collective is a one-time broadcast of the packed weight blob from rank 0 (bf16: 68 MB -- one MFMA-tiled
+  image per layer, read by the throughput and the batch-1 click kernels alike; fp32: 136 MB for a throughput handle --
+  ``throughput_blob=True`` -- or 384 MB with the Winograd images; ``engine.blob_bytes()`` is the exact figure): RCCL over xGMI when the process group is ``nccl``, ``gloo`` in the CPU tests.
   Rank 0 packs once on the host; every other rank receives device-ready bytes straight into the
   memory its engine then adopts (no re-packing, no host copy on the receivers);
 * results stay on the rank that produced them unless ``gather_to_rank0`` is asked for.

@@ -83,6 +83,8 @@ def _al(v, a=256):
 
 
 def _plan(precision, dist):
+    from conftest import has_ab_partners
+    partners = has_ab_partners()          # round 6: the layout-2 images (conv_igemm_v2's) exist only in the -DIDC_AB_PARTNERS build; default bf16 blob 68 MB
     kc = 64 if precision == "bf16" else 32
     off, plan = 64, []
     for wkey, bnkey, kind, cin, cout in LAYERS:
@@ -93,10 +95,10 @@ def _plan(precision, dist):
         ntap = {"c3": 9, "dc": 16, "c1": 1, "im2col": 1}[kind]
         e = dict(wkey=wkey, bnkey=bnkey, kind=kind, cin=cin, cout=cout, cpad=cpad, nkc=nkc, ncg=cpad // 64, ntap=ntap)
         off = _al(off); e["w_off"] = off; off += ntap * nkc * e["ncg"] * 8192
-        if precision == "bf16" and kind != "im2col" and cpad >= 128:   # second image: layout 2 (conv_igemm_v2)
+        if partners and precision == "bf16" and kind != "im2col" and cpad >= 128:   # second image: layout 2 (conv_igemm_v2)
             off = _al(off); e["w2_off"] = off; off += ntap * nkc * e["ncg"] * 8192
         if kind == "c3" and precision == "fp32":
-            # third image, fp32 blob only (round 5: the bf16 click path's Winograd kernels were retired, a bf16 blob is 136 MB):
+            # third image, fp32 blob only (round 5: the bf16 click path's Winograd kernels were retired, a bf16 blob is 68 MB, 136 MB in the partner build):
             # Winograd F(2x2,3x3) weights U = G g G^T of the 3x3 stride-1 layers (idc_wino.hip)
             off = _al(off); e["w3_off"] = off; off += cin * cpad * 16 * 4
         if kind == "dc" and precision == "fp32":     # deconvs: Winograd F(2x2,2x2) over the four phases, 36 values per (cin, cout)

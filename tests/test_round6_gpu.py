@@ -120,9 +120,11 @@ def test_split_network_small(precision, style):
     assert err <= tol, "%s %s: max-abs %.3e > %.1e" % (precision, style, err, tol)
 
 
+@pytest.mark.parametrize("fuse", [1, 0])
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16x6", "fp16x3"])
-def test_split_network_layer_by_layer(precision):
-    """Every materialised activation of a 64x64 forward against the float64 oracle's (he-style weights: full dynamic range)."""
+def test_split_network_layer_by_layer(precision, fuse):
+    """Every materialised activation of a 64x64 forward against the float64 oracle's (he-style weights: full dynamic range).
+    fuse = 1 (default): the deconv + shortcut pairs are conv_ds_fused_ms launches and the shortcut sums are never stored; fuse = 0: two launches each."""
     from oracle import siggraph_torch
     from tests.conftest import state_dict_for
     sd = state_dict_for(0, "he")
@@ -131,6 +133,9 @@ def test_split_network_layer_by_layer(precision):
     names = ["conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3", "conv4_1", "conv4_2", "conv4_3", "conv5_1", "conv5_2", "conv5_3",
              "conv6_1", "conv6_2", "conv6_3", "conv7_1", "conv7_2", "conv7_3", "conv3_3_short", "conv8_1", "conv8_2", "conv8_3", "conv2_2_short", "conv9_1",
              "conv9_2", "conv1_2_short", "conv10_1"]            # (conv10_2 is consumed by the tanh head inside its own launch: never stored)
+    if fuse:
+        names = [n_ for n_ in names if not n_.endswith("_short")]
+    engine.set_option("split_ds_fuse", fuse)
     e = engine.HipColorizer(64, 64, max_batch=2, precision=precision)
     try:
         e.load_state_dict(sd)
@@ -144,8 +149,44 @@ def test_split_network_layer_by_layer(precision):
         with pytest.raises(Exception):
             e.activation("conv10_2", 2)
         assert np.abs(out - ref_out).max() <= (bounds.FP32_TOL["he"] if precision in ("bf16x6", "fp16x3") else 5e-2)
+        kernels = {r["name"]: r["kernel"] for r in e.layer_table()}
+        assert ("conv_ds_fused_ms" in kernels["conv10_1"]) == bool(fuse), kernels["conv10_1"]
     finally:
         e.close()
+        engine.set_option("split_ds_fuse", 1)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16x6", "fp16x3"])
+def test_split_ds_fused_against_two_launches(precision):
+    """conv_ds_fused_ms / _msh (deconv 4x4 s2 + the 3x3 shortcut conv in one launch, models/pytorch/model.py:156,170,172) on a ragged size (72 x 104: partial
+    64 x 8 output tiles on both axes), batch 3: within the fp32 bounds of the float64 oracle, and as close to it as the two-launch form (same fp32 sums in
+    another order)."""
+    from oracle import siggraph_torch
+    from tests.conftest import state_dict_for
+    sd = state_dict_for(1, "torch")
+    H, W = 72, 104
+    rs = np.random.RandomState(11)
+    L = (rs.rand(3, 1, H, W) * 100).astype(np.float32)
+    ab = np.zeros((3, 2, H, W), np.float32); m = np.zeros((3, 1, H, W), np.float32)
+    ab[:, :, 10:16, 20:26] = rs.uniform(-60, 60, (3, 2, 1, 1)); m[:, :, 10:16, 20:26] = 1
+    ref = siggraph_torch.forward(sd, L, ab, m, 0.5, dtype=torch.float64)
+    outs = {}
+    try:
+        for fuse in (1, 0):
+            engine.set_option("split_ds_fuse", fuse)
+            e = engine.HipColorizer(H, W, max_batch=3, precision=precision)
+            try:
+                e.load_state_dict(sd)
+                outs[fuse] = e.forward(L, ab, m, 0.5)
+                assert np.array_equal(outs[fuse], e.forward(L, ab, m, 0.5))
+            finally:
+                e.close()
+    finally:
+        engine.set_option("split_ds_fuse", 1)
+    tol = 1e-3
+    e1, e0 = float(np.abs(outs[1] - ref).max()), float(np.abs(outs[0] - ref).max())
+    assert e1 <= tol and e0 <= tol, (precision, e1, e0)
+    assert e1 <= 2.0 * e0 + 1e-5, (precision, e1, e0)
 
 
 def test_split_dist_head_and_global_hints_build():
