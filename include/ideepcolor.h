@@ -93,6 +93,7 @@ int idc_set_tile_policy(int policy);
  *                      in its 64-cout 4-wave form; 2 = 8-wave workgroups on every grid (A/B, tests); 0 = conv_ds_fused: partner build only.
  *   "split_ds_fuse" (1)  operand-split precisions: each ConvTranspose + the 3x3 shortcut conv it is summed with as ONE launch (conv_ds_fused_ms / _msh:
  *                      both K loops walked per segment into one fp32 accumulator set); 0 = shortcut conv (fp32 sums through HBM) + deconv launch.
+ *   "conv1_1_split" (1)  operand-split precisions: conv1_1 (their exact-fp32 island) on conv1_1_split_kernel where the grid is throughput-sized; 0 = conv_igemm<float>.
  *   "kwave"       (1)  bf16 batch-1 click path: 3x3 stride-1 layers and ConvTranspose launches as conv_kwave_bf16 / conv_kwave_deconv_bf16
  *                      (direct form, K split over the waves of a workgroup); 0 = conv_click + split-K (round 2's kernels).
  *   "kwave_chain" (2)  ... and runs of consecutive same-shape 512-channel layers of that path (conv4_2 .. conv7_3 at batch 1) as ONE

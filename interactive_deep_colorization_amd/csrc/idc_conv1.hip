@@ -8,6 +8,7 @@
 #include "idc_layout.h"
 
 #include "idc_common.hip.h"
+#include "idc_split.hip.h"
 
 namespace idc {
 
@@ -533,6 +534,103 @@ hipError_t launch_conv1_block(const ConvArgs& a, hipStream_t s) {
     if (!big) hipLaunchKernelGGL((conv1_block_fused_t<4, 2, true>), dim3((unsigned)blocks), dim3(256), conv1_block_lds(4, 2, true), s, a);
     else if (g_c1_lw) hipLaunchKernelGGL((conv1_block_fused_t<4, 3, true>), dim3((unsigned)blocks), dim3(256), conv1_block_lds(4, 3, true), s, a);
     else hipLaunchKernelGGL((conv1_block_fused_t<8, 4, false>), dim3((unsigned)blocks), dim3(512), conv1_block_lds(8, 4, false), s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv1_1_split_kernel (round 6): model1.0 (4 -> 64, 3x3, ReLU; model.py:13,139-148) as the EXACT-FP32 ISLAND of the operand-split precisions at throughput
+// size.  conv1_1 is 0.2 % of the network's MACs and stays fp32 (K = 36 products of normalised inputs; splitting them would cost more than it saves), but its
+// output is the largest tensor of the forward: conv_igemm<float> -- a generic small tile that pads K to 64, stages im2col rows through LDS and stores 32-byte
+// pieces -- took 0.48 ms at N = 32 for 9.7 GFLOP and 537 MB.  Here: workgroup = 32 x 16 pixels x 64 couts, 4 waves x 4 pixel rows; the 34 x 18 input patch is
+// normalised once into LDS as float4 (L, a, b, mask); v_mfma_f32_16x16x4_f32 with k = the four channels of ONE tap (K index = tap*4 + channel, as the packed
+// image orders it): the B operand of a (site tile, tap) is one ds_read_b32 per lane straight from the patch -- no im2col rows -- reused by the four cout
+// blocks, the A operands (36 floats per lane) sit in registers for the whole tile; accumulators in conv_igemm_v2m's layout (lane (site r16, group g16)
+// register j of acc[mi][pt] = cout g16*16 + mi*4 + j), so the epilogue IS split_epilogue: bias, ReLU, hi = rne(v), next = rne(v - hi) ..., every plane
+// through the wave-private transpose tile, whole 128-byte line stores.  Nine taps in ascending order into zero accumulators, bias after: fp32 throughout.
+template <bool F16>
+__global__ __launch_bounds__(256, 2) void conv1_1_split_kernel(const ConvArgs a) {
+    constexpr int PW = 34, PH = 18;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [4 x 4096 B transpose tiles][34 x 18 float4 patch]
+    float* const patch = (float*)(smem + 4 * 4096);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g16 = lane >> 4;
+    const int Hs = a.Hs, Ws = a.Ws;
+    const int ntx = (Ws + 31) >> 5, nty = (Hs + 15) >> 4;
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int txi = b % ntx; b /= ntx;
+    const int tyi = b % nty;
+    const int n = b / nty;
+    const int ty0 = tyi * 16, tx0 = txi * 32;
+    {
+        const size_t hw = (size_t)Hs * Ws;
+        const float* const pL = a.pk_L + (size_t)n * hw;
+        const float* const pA = a.pk_ab + (size_t)n * 2 * hw;
+        const float* const pM = a.pk_mask + (size_t)n * hw;
+        constexpr int P_ITEMS = (PW * PH + 255) / 256;
+        float vl[P_ITEMS], va[P_ITEMS], vb[P_ITEMS], vm[P_ITEMS];
+        bool ok[P_ITEMS];
+#pragma unroll
+        for (int j = 0; j < P_ITEMS; ++j) {                          // all plane reads in flight before the first is used
+            const int idx = tid + j * 256;
+            const int py = idx / PW, pxx = idx - py * PW;
+            const int yy = ty0 - 1 + py, xx = tx0 - 1 + pxx;
+            ok[j] = idx < PW * PH && (unsigned)yy < (unsigned)Hs && (unsigned)xx < (unsigned)Ws;
+            const size_t p = ok[j] ? (size_t)yy * Ws + xx : 0;
+            vl[j] = pL[p]; va[j] = pA[p]; vb[j] = pA[hw + p]; vm[j] = pM[p];
+        }
+#pragma unroll
+        for (int j = 0; j < P_ITEMS; ++j) {
+            const int idx = tid + j * 256;
+            float4 c = float4{0.f, 0.f, 0.f, 0.f};                  // outside the image: conv1_1's zero padding
+            if (ok[j]) c = float4{vl[j] / a.pk_ldiv, va[j] / a.pk_abdiv, vb[j] / a.pk_abdiv, vm[j] * a.pk_mmul - a.pk_mcent};
+            if (idx < PW * PH) ((float4*)patch)[idx] = c;
+        }
+    }
+    // A operands from the packed fp32 layout-1 image (idc_layout.h; two chunks of 32 K values, K = tap*4 + channel): MFMA row m of block mi is image row
+    // lam = mi*16 + m (= cout (m>>2)*16 + mi*4 + (m&3)), tap t is slot t & 7 of chunk t >> 3, channel g16 its element
+    float wa[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int lam = mi * 16 + r16;
+            wa[t][mi] = *(const float*)((const char*)a.wgt + (size_t)(t >> 3) * kWBlockBytes + lam * kRowBytes + (((t & 7) ^ swz(lam)) * kSlotBytes) + g16 * 4);
+        }
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int pt = 0; pt < 8; ++pt) acc[mi][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();                                                 // patch complete
+#pragma unroll
+    for (int pt = 0; pt < 8; ++pt) {
+        const int pbase = ((wave * 4 + (pt >> 1)) * PW + (pt & 1) * 16 + r16) * 4 + g16;      // float index of tap (0,0)'s channel g16 for this lane's site
+        float bv[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) bv[t] = patch[pbase + ((t / 3) * PW + t % 3) * 4];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                acc[mi][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t][mi], bv[t], acc[mi][pt], 0, 0, 0);
+    }
+    add_bias_after_k(a.bias + g16 * 16, acc);
+    split_epilogue<1, F16>(a, acc, smem, n, ty0, tx0, wave, 0, 0, 0);
+}
+
+// conv1_1 of an operand-split handle at throughput size: fp32 planes in, a.out_parts (2 | 3) planes out; hipErrorInvalidConfiguration if the launch does not
+// qualify (the caller keeps conv_igemm<float>)
+hipError_t launch_conv1_1_split(const ConvArgs& a, hipStream_t s) {
+    if (a.pk_L == nullptr || a.bn_scale != nullptr || a.resid != nullptr || a.img_shift != nullptr || a.ncg != 1 || a.nkc != 2 || a.so != 1 ||
+        a.out_parts < 2 || a.out_parts > 3 || a.in2 != nullptr)
+        return hipErrorInvalidConfiguration;
+    const long long blocks = (long long)((a.Ws + 31) / 32) * ((a.Hs + 15) / 16) * a.N;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    const int lds = 4 * 4096 + 34 * 18 * 16;
+    if (a.split_f16) hipLaunchKernelGGL(conv1_1_split_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(conv1_1_split_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 

@@ -565,6 +565,8 @@ static int g_ds_m16 = idc_env_int("IDC_DS_M16", 1);
 // operand-split precisions: the deconv + shortcut pairs as ONE launch (conv_ds_fused_ms / _msh) instead of shortcut conv (fp32 sums to HBM) + deconv
 // (idc_set_option "split_ds_fuse", 0 for A/B)
 static int g_split_ds_fuse = 1;
+// ... and conv1_1, their exact-fp32 island, on conv1_1_split_kernel where the grid is throughput-sized (>= 128 tiles of 32 x 16; "conv1_1_split", 0 = conv_igemm<float>)
+static int g_conv1_1_split = 1;
 // ... and the 3x3 convs among them as conv_igemm_v2p (no address arithmetic in the K loop; idc_set_option "v2p" / env IDC_V2P=0 for A/B)
 static int g_v2p = idc_env_int("IDC_V2P", 1);
 // throughput kernels touch their own code at entry (idc_warm_own_code, idc_kernels.h; env IDC_CODE_WARM=0 for the A/B of profiles/r04_firstuse.txt)
@@ -1092,6 +1094,9 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             else if (L.spec->kind == kConvIm2col && L.lprec == IDC_BF16 && a.ksplit <= 1 &&
                 (long long)((a.Ws + 31) / 32) * ((a.Hs + 31) / 32) * c->max_batch >= 128)
                 le = launch_conv1_1_bf16(a, s);
+            if (is_split(c->precision) && !L.split && L.spec->kind == kConvIm2col && g_conv1_1_split && a.out_parts >= 2 &&
+                (long long)((a.Ws + 31) / 32) * ((a.Hs + 15) / 16) * c->max_batch >= 128)
+                le = launch_conv1_1_split(a, s);
             if (L.fused_short >= 0) le = L.split ? launch_conv_ds_ms(a, s) : L.m16 ? launch_conv_ds_m(a, s) : launch_conv_ds(a, s);
             if (L.fused_short >= 0 && L.split && le == hipErrorInvalidConfiguration)
                 return fail(&c->err, IDC_ERR_INTERNAL, "layer %s: conv_ds_fused_ms planned for a launch it does not cover", L.spec->name);
@@ -1421,6 +1426,7 @@ int idc_set_option(const char* name, int value) {
     if (strcmp(name, "v2p") == 0) { g_v2p = value != 0; return IDC_OK; }
     if (strcmp(name, "ds_mfma16") == 0) { g_ds_m16 = value != 0; set_ds_half(value != 2); return IDC_OK; }     // 2: conv_ds_fused_m, 8-wave workgroups on every grid
     if (strcmp(name, "split_ds_fuse") == 0) { g_split_ds_fuse = value != 0; return IDC_OK; }
+    if (strcmp(name, "conv1_1_split") == 0) { g_conv1_1_split = value != 0; return IDC_OK; }
     if (strcmp(name, "kwave") == 0) { g_kwave = value != 0; return IDC_OK; }
     if (strcmp(name, "spin_sync") == 0) { g_spin_sync = value != 0; return IDC_OK; }
     if (strcmp(name, "pcie_kernel") == 0) { g_pcie_kernel = value != 0; return IDC_OK; }
@@ -2297,6 +2303,9 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
                                                                                                     : (L.v2p ? "conv_igemm_v2ps<%d,%d>x%d" : "conv_igemm_v2s<%d,%d>x%d"),
                                   L.cfg.wm, L.cfg.wp, split_segments(h->precision));
             else if (L.m16) strncat(out->kernel, L.v2p ? "+m16p" : "+m16", sizeof(out->kernel) - strlen(out->kernel) - 1);
+            if (is_split(h->precision) && !L.split && L.spec->kind == kConvIm2col && g_conv1_1_split && h->tensors[L.dst].parts >= 2 && !h->tensors[L.dst].is_f32 &&
+                (long long)((h->W + 31) / 32) * ((h->H + 15) / 16) * h->max_batch >= 128)
+                snprintf(out->kernel, sizeof(out->kernel), "conv1_1_split_kernel");
             if (L.fused_head) strncat(out->kernel, "+head", sizeof(out->kernel) - strlen(out->kernel) - 1);
             if (L.args.ksplit > 1) {
                 char sk[16]; snprintf(sk, sizeof(sk), " splitK%d", L.args.ksplit);

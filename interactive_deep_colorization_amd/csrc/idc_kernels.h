@@ -142,6 +142,8 @@ void set_ds_half(int v);              // 1 (default): grids with fewer 128-cout 
 // model1 = conv1_1 + conv1_2 of a 32x32 tile in one workgroup (conv1_block_fused): `a` = conv1_1's arguments with conv1_2's
 // riding in (wgt2 = its layout-1 weights, head_b = its bias, bn_scale/bn_shift, out = its output)
 hipError_t launch_conv1_block(const ConvArgs& a, hipStream_t s);
+// conv1_1 as the exact-fp32 island of an operand-split handle (conv1_1_split_kernel: fp32 MFMA straight from the input patch, a.out_parts planes out)
+hipError_t launch_conv1_1_split(const ConvArgs& a, hipStream_t s);
 // conv1_1 (4 -> 64, input pack fused) as one 32x32 tile per workgroup, bf16; hipErrorInvalidConfiguration if the
 // launch does not qualify (the caller then uses launch_conv)
 hipError_t launch_conv1_1_bf16(const ConvArgs& a, hipStream_t s);
