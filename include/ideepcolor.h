@@ -53,9 +53,11 @@ typedef enum idc_precision { IDC_FP32 = 0, IDC_BF16 = 1, IDC_BF16X3 = 2, IDC_BF1
  * every layer runs the large-tile kernels whatever the batch (the batch-1 click path keeps IDC_FP32 / IDC_BF16).  Error against the float64
  * oracle: X6 at or below IDC_FP32's, X3 <= 1e-3 on the +-110 ab map with torch-default-init weights (tests/bounds.py).
  * FP16X3 (round 6): BF16X3's planes, segments and kernels with FP16 parts -- x = hi + lo with 11-bit hi and lo (22 bits, 2^-22 relative per
- * operand instead of 2^-16), three v_mfma_f32_16x16x32_f16 per fragment pair: at the IDC_FP32 path's distance from the float64 oracle on torch-default-init weights
- * (2.9e-5 at N = 32) and 2.3x that distance on full-range weights (3.9e-3 against 1.7e-3; BF16X3: 2.4e-2), at BF16X3's rate.  The price is
- * fp16's range: an activation or weight beyond +-65504 saturates (the conversions clamp; nothing becomes inf), values below 6e-5 keep 6e-8 absolute.
+ * operand instead of 2^-16), three v_mfma_f32_16x16x32_f16 per fragment pair.  A layer's weight parts hold w * 2^s, s the power of two that brings
+ * the layer's largest weight into [8192, 16384) (exact; the accumulators are multiplied by 2^-s when the bias joins), so that the lo part of a small
+ * weight is a normal fp16 number: at the IDC_FP32 path's distance from the float64 oracle on BOTH weight styles (N = 32: 2.2e-5 torch-default-init,
+ * 1.9e-3 full-range, against 2.3e-5 / 1.7e-3; without the scale full-range weights ~0.02 had subnormal lo parts and 3.9e-3), at BF16X3's rate.
+ * The price is fp16's range for ACTIVATIONS: beyond +-65504 they saturate (the conversions clamp; nothing becomes inf), below 6e-5 they keep 6e-8 absolute.
  * The layers of this net are BatchNorm-ed / ReLU-ed activations of O(1..100); a checkpoint with larger activations wants BF16X6. */
 
 /* idc_create flags */

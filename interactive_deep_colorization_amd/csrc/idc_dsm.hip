@@ -446,7 +446,7 @@ __device__ __forceinline__ void conv_ds_fused_m_body(const ConvArgs& a) {
     IDC_DSTAMP(2);
     __syncthreads();
     if constexpr (SPLIT != 0) {
-        add_bias_after_k(a.bias + (cg0 + wco) * kCoutGroup + g16 * 16, acc);
+        add_bias_after_k(a.bias + (cg0 + wco) * kCoutGroup + g16 * 16, acc, a.acc_scale);
         split_epilogue<NCW, SPLIT == 2>(a, acc, smem, n, y0, x0, 0, (cg0 + wco) * kCoutGroup, ro, cof);
         IDC_DSTAMP(3);
         return;

@@ -87,6 +87,7 @@ BlobPlan make_blob_plan(int precision, unsigned flags) {
         }
         lb.fbias_off = (size_t)-1;
         if (s.resid) { off = align_up(off, 256); lb.fbias_off = off; off += (size_t)cout_pad(s.cout) * 4; }
+        if (is_split(precision) && !lb.f32) { off = align_up(off, 256); lb.wscale_off = off; off += 4; }     // 2^-s of weights packed as w * 2^s (IDC_FP16X3; else 1.0)
         p.layers.push_back(lb);
         p.active.push_back(i);
     }
@@ -121,7 +122,8 @@ static bool dims_are(const TensorView& t, std::initializer_list<int64_t> d) {
 
 // Write one element of the packed weight image (layout 1: small-tile kernels, layout 2: conv_igemm_v2).
 // part: operand-split precisions -- which part of the weight is stored (0 = hi: rne(v); 1: rne(v - hi); 2: rne(v - hi - mid))
-static inline void put_w(uint8_t* wimg, int precision, int layout, int nkc, int ncg, int tw, int co, int k, float v, int part) {
+static inline void put_w(uint8_t* wimg, int precision, int layout, int nkc, int ncg, int tw, int co, int k, float v, int part, float wmul = 1.f) {
+    v *= wmul;                                                     // (a power of two: exact)
     const int kc_e = kc_elems(precision), eb = elem_bytes(precision), eps = kSlotBytes / eb;
     const int kc = k / kc_e, kin = k % kc_e;
     const int s = kin / eps, e = kin % eps;
@@ -157,29 +159,41 @@ static inline void put_w(uint8_t* wimg, int precision, int layout, int nkc, int 
 }
 
 // Pack one conv-like layer: weights in torch layout -> MFMA-tiled, swizzled image.
+// IDC_FP16X3: the power of two s that brings max|w| into [8192, 16384) -- hi = rne16(w 2^s) uses fp16's top binades, lo = rne16(w 2^s - hi) is a NORMAL fp16
+// number down to weights 2^-17 of the largest; unscaled, he-style weights (~0.02) have lo parts ~1e-5, below fp16's smallest normal 6.1e-5, and keep only
+// 6e-8 absolute = 2^-18 of the weight (measured, oracle/emulate.py + tools/split_study.py: N = 1 he-style 2.7e-3 -> 9.5e-4 on the ab map, fp32 arithmetic 1.2e-3)
+static int f16_weight_exponent(const float* w, size_t n) {
+    float mx = 0.f;
+    for (size_t i = 0; i < n; ++i) { const float a = fabsf(w[i]); if (a > mx && a < INFINITY) mx = a; }
+    if (mx == 0.f) return 0;
+    int e; (void)frexpf(mx, &e);                                   // mx = m 2^e, m in [0.5, 1)
+    int s = 14 - e;                                                // mx 2^s in [8192, 16384)
+    return s < -10 ? -10 : (s > 40 ? 40 : s);
+}
+
 static void pack_layer_weights(uint8_t* wimg, int precision, int layout, const LayerSpec& s, const LayerBlob& lb,
-                               const float* w, int part = 0) {
+                               const float* w, int part = 0, float wmul = 1.f) {
     memset(wimg, 0, lb.w_bytes);
     const int cin = s.cin, cout = s.cout;
     if (s.kind == kConv3x3) {
         for (int co = 0; co < cout; ++co)
             for (int ci = 0; ci < cin; ++ci)
                 for (int t = 0; t < 9; ++t)
-                    put_w(wimg, precision, layout, lb.nkc, lb.ncg, t, co, ci, w[((size_t)co * cin + ci) * 9 + t], part);
+                    put_w(wimg, precision, layout, lb.nkc, lb.ncg, t, co, ci, w[((size_t)co * cin + ci) * 9 + t], part, wmul);
     } else if (s.kind == kConvIm2col) {          // K index = tap*4 + c  (the order conv1_1's fused input pack builds)
         for (int co = 0; co < cout; ++co)
             for (int ci = 0; ci < cin; ++ci)
                 for (int t = 0; t < 9; ++t)
-                    put_w(wimg, precision, layout, lb.nkc, lb.ncg, 0, co, t * 4 + ci, w[((size_t)co * cin + ci) * 9 + t], part);
+                    put_w(wimg, precision, layout, lb.nkc, lb.ncg, 0, co, t * 4 + ci, w[((size_t)co * cin + ci) * 9 + t], part, wmul);
     } else if (s.kind == kConv1x1) {
         for (int co = 0; co < cout; ++co)
             for (int ci = 0; ci < cin; ++ci)
-                put_w(wimg, precision, layout, lb.nkc, lb.ncg, 0, co, ci, w[(size_t)co * cin + ci], part);
+                put_w(wimg, precision, layout, lb.nkc, lb.ncg, 0, co, ci, w[(size_t)co * cin + ci], part, wmul);
     } else {                                      // ConvTranspose2d weight is (Cin, Cout, 4, 4)
         for (int ci = 0; ci < cin; ++ci)
             for (int co = 0; co < cout; ++co)
                 for (int t = 0; t < 16; ++t)
-                    put_w(wimg, precision, layout, lb.nkc, lb.ncg, t, co, ci, w[((size_t)ci * cout + co) * 16 + t], part);
+                    put_w(wimg, precision, layout, lb.nkc, lb.ncg, t, co, ci, w[((size_t)ci * cout + co) * 16 + t], part, wmul);
     }
 }
 
@@ -299,6 +313,27 @@ static int pack_weights_impl(int precision, unsigned flags, const idc_tensor_des
     memset(base, 0, plan.total_bytes);
     const auto& specs = layer_specs();
     std::vector<std::function<void()>> tasks;
+    // IDC_FP16X3: per-layer power-of-two weight scale (f16_weight_exponent); a deconv and the shortcut conv it is summed with share ONE (the smaller
+    // exponent): conv_ds_fused_ms accumulates both K loops into one accumulator set.  Every other precision: exponent 0.
+    std::vector<int> wexp(plan.active.size(), 0);
+    if (split_is_f16(precision)) {
+        for (size_t li = 0; li < plan.active.size(); ++li) {
+            const LayerSpec& s = specs[plan.active[li]];
+            if (plan.layers[li].f32) continue;
+            const TensorView* w = nullptr;
+            if (!need(std::string(s.wkey) + ".weight", &w)) continue;      // (reported by the loop below)
+            size_t cnt = 1;
+            for (int d = 0; d < w->ndim; ++d) cnt *= (size_t)w->dims[d];
+            wexp[li] = f16_weight_exponent(w->data, cnt);
+        }
+        for (size_t li = 0; li < plan.active.size(); ++li) {
+            const LayerSpec& s = specs[plan.active[li]];
+            if (!s.resid) continue;
+            for (size_t lj = 0; lj < plan.active.size(); ++lj)
+                if (strcmp(specs[plan.active[lj]].name, s.resid) == 0 && !plan.layers[lj].f32 && !plan.layers[li].f32)
+                    wexp[li] = wexp[lj] = std::min(wexp[li], wexp[lj]);
+        }
+    }
     for (size_t li = 0; li < plan.active.size(); ++li) {
         const LayerSpec& s = specs[plan.active[li]];
         const LayerBlob& lb = plan.layers[li];
@@ -315,8 +350,10 @@ static int pack_weights_impl(int precision, unsigned flags, const idc_tensor_des
         const int lprec = lb.f32 ? (int)IDC_FP32 : precision;        // (operand-split precisions: model1's fp32 island)
         // the weight images are independent of each other: queued here, packed by the worker threads below (round 6: 1.4 s -> 0.2 s for a bf16 blob)
         const LayerSpec* sp = &s; const LayerBlob* lbp = &lb; const float* wd = w->data;
+        const float wmul = ldexpf(1.f, wexp[li]);
+        if (lb.wscale_off != (size_t)-1) *(float*)(base + lb.wscale_off) = ldexpf(1.f, -wexp[li]);
         for (int part = 0; part < lb.parts; ++part)
-            tasks.push_back([=]() { pack_layer_weights(base + lbp->w_off + (size_t)part * lbp->w_bytes, lprec, 1, *sp, *lbp, wd, part); });
+            tasks.push_back([=]() { pack_layer_weights(base + lbp->w_off + (size_t)part * lbp->w_bytes, lprec, 1, *sp, *lbp, wd, part, wmul); });
         if (lb.w2_off != (size_t)-1) tasks.push_back([=]() { pack_layer_weights(base + lbp->w2_off, lprec, 2, *sp, *lbp, wd); });
         if (lb.w3_off != (size_t)-1) {
             if (s.kind == kDeconv4x4) tasks.push_back([=]() { pack_wino_deconv_weights(base + lbp->w3_off, lprec, *sp, *lbp, wd); });
@@ -1009,6 +1046,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
         a.zeros = c->d_zeros;
         a.warm = g_code_warm;
         a.split_f16 = split_is_f16(c->precision) ? 1 : 0;
+        a.acc_scale = (L.split && a.split_f16 && L.blob.wscale_off != (size_t)-1) ? (const float*)(c->d_blob + L.blob.wscale_off) : nullptr;
         a.out_f32 = to.is_f32;
         a.img_shift = ((c->flags & IDC_FLAG_GLOBAL_HINTS) && L.dst == c->t_conv4_3) ? c->d_glob_vec : nullptr;
         if (L.spec->kind == kConvIm2col) {          // model.py:139-148 input pack, fused into the operand staging
@@ -2474,13 +2512,16 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
     fill_taps(L);
     // (default library: the large tile only where conv_igemm_v2m / v2p cover the launch -- no shortcut sum, no LeakyReLU without the fused head)
     set_geometry(L, precision, n, n, Hs, Ws, kAbPartners || is_split(precision) || (resid == nullptr && spec.act != 2));
+    int op_wexp = 0;
     if (L.wino && wino_dc) pack_wino_deconv_weights(wimg.data(), precision, spec, L.blob, weight);
     else if (L.wino) pack_wino_weights(wimg.data(), precision, spec, L.blob, weight);
     else {
         if (wino_ok) L.blob.w_bytes = (size_t)weight_taps(spec.kind) * L.blob.nkc * L.blob.ncg * kWBlockBytes;
         L.m16 = split || (L.v2 && g_mfma16 && resid == nullptr && spec.act != 2);       // as in the network: conv_igemm_v2m where it applies
+        const size_t wcount = (size_t)spec.cin * spec.cout * (spec.kind == kDeconv4x4 ? 16 : spec.kind == kConv1x1 ? 1 : 9);
+        op_wexp = split_is_f16(precision) ? f16_weight_exponent(weight, wcount) : 0;      // as the blob packer does per layer
         for (int part = 0; part < parts; ++part)
-            pack_layer_weights(wimg.data() + (size_t)part * L.blob.w_bytes, precision, (L.v2 && !L.m16) ? 2 : 1, spec, L.blob, weight, part);
+            pack_layer_weights(wimg.data() + (size_t)part * L.blob.w_bytes, precision, (L.v2 && !L.m16) ? 2 : 1, spec, L.blob, weight, part, ldexpf(1.f, op_wexp));
     }
     std::vector<float> hb(cpad, 0.f), hs(cpad, 1.f), ht(cpad, 0.f);
     for (int c = 0; c < spec.cout; ++c) {
@@ -2525,7 +2566,14 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
         a.in_parts = parts; a.out_parts = parts; a.nseg = split_segments(precision); a.seg_x = split_seg_x(precision); a.seg_w = split_seg_w(precision);
         a.w_part_bytes = L.blob.w_bytes;
     }
-    DevBuf d_part, d_zero;
+    DevBuf d_part, d_zero, d_wsc;
+    a.acc_scale = nullptr;
+    if (split && split_is_f16(precision)) {
+        const float sc = ldexpf(1.f, -op_wexp);
+        HIPCHK(nullctx, d_wsc.alloc(256));
+        HIPCHK(nullctx, hipMemcpy(d_wsc.p, &sc, 4, hipMemcpyHostToDevice));
+        a.acc_scale = (const float*)d_wsc.p;
+    }
     if (a.ksplit > 1) {
         HIPCHK(nullctx, d_part.alloc((size_t)a.ksplit * n * Ho * Wo * cpad * 4));
         a.partial = (float*)d_part.p;

@@ -70,6 +70,9 @@ struct ConvArgs {
     unsigned seg_x, seg_w;
     unsigned long long w_part_bytes;
     unsigned long long w_part_bytes2;   // ... of the fused shortcut conv's images (a.wgt2; conv_ds_fused_m's split form)
+    const float* acc_scale; // IDC_FP16X3: one fp32 in device memory, 2^-s -- the layer's weight parts hold w * 2^s (a power of two: exact) so that the lo parts
+                            // of small weights are NORMAL fp16 numbers (he-style weights ~0.02: lo ~1e-5 is subnormal, 6e-8 absolute = 2^-18 of the weight);
+                            // the accumulators are multiplied by it when the bias joins.  nullptr = 1.0
     int split_f16;          // IDC_FP16X3: the parts are fp16 (11-bit) instead of bf16 (8-bit) values; same planes, same segments as IDC_BF16X3
     int warm;               // != 0: the throughput kernels pull their own code into L2 at entry (idc_warm_own_code below)
     const void* zeros;      // >= 16 zero bytes in device memory: LDS-DMA source of out-of-image halo rows (conv_click)

@@ -53,7 +53,9 @@ inline int elem_bytes(int precision) { return precision == 0 ? 4 : 2; }       //
 // operand-split precisions (IDC_BF16X3 = 2: x = hi + lo, three products; IDC_BF16X6 = 3: hi + mid + lo, six products)
 inline bool is_split(int precision) { return precision >= 2 && precision <= 4; }
 inline bool split_is_f16(int precision) { return precision == 4; }               // IDC_FP16X3: bf16x3's planes and segments with fp16 (11-bit) parts
-// (measured and dropped: a fourth segment lo.lo -- N = 32 he-style 3.99e-3 against 3.86e-3 without it: the 2^-23 of the two-part operands is the floor)
+// (measured and dropped: a fourth segment lo.lo -- N = 32 he-style 3.99e-3 against 3.86e-3 without it.  What that error was: fp16 lo parts of ~0.02
+//  weights are SUBNORMAL (6e-8 absolute = 2^-18 of the weight); with the weight parts holding w * 2^s per layer -- LayerBlob::wscale_off, ConvArgs::acc_scale --
+//  it is 1.9e-3, the fp32 arithmetic's own distance; oracle/emulate.py 'splitf2_fp32' / 'splitf2s_fp32' reproduce both figures on the CPU)
 inline int split_parts(int precision) { return (precision == 2 || precision == 4) ? 2 : precision == 3 ? 3 : 1; }
 // K segments (input part, weight part), 4 bits each, segment 0 in the low nibble.  SMALLEST PRODUCTS FIRST, hi.hi last, and the bias after the
 // K loop: every v_mfma rounds its result to the accumulator's magnitude, so each of the 9 x nkc x 2 accumulations of a segment costs one rounding

@@ -101,6 +101,8 @@ struct LayerBlob {
     size_t bn_scale_off, bn_shift_off;   // fp32 [cout_pad] or (size_t)-1
     size_t fbias_off;             // layers with a shortcut sum: fp32 [cout_pad] = bias + the shortcut conv's bias, or (size_t)-1
     int nkc, ncg;
+    size_t wscale_off = (size_t)-1;   // operand-split precisions (not the fp32 island): ONE fp32 = 2^-s, the factor that takes this layer's accumulators back
+                                  // from weights packed as w * 2^s (IDC_FP16X3: s chosen so that max|w| * 2^s is in [8192, 16384); bf16 parts: s = 0, 1.0)
     int parts = 1;                // operand-split precisions: weight parts (hi, [mid,] lo), each w_bytes long, contiguous from w_off
     int f32 = 0;                  // operand-split precisions: this layer belongs to the fp32 island (fp32 images, fp32 chunk size)
 };

@@ -39,13 +39,17 @@ __device__ __forceinline__ unsigned pack_f16x2_m(float lo, float hi) {
 __device__ __forceinline__ float f16_lo_to_f32(unsigned q) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(q & 0xffffu)); }
 __device__ __forceinline__ float f16_hi_to_f32(unsigned q) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(q >> 16)); }
 
-__device__ __forceinline__ void add_bias_after_k(const float* bp, f32x4 (&acc)[4][8]) {
+// acc = acc * sc + bias: sc = *acc_scale (2^-s of weights packed as w * 2^s, IDC_FP16X3) or 1 -- fma(x, 1, b) is x + b rounded once, the bf16 parts' sum
+__device__ __forceinline__ void add_bias_after_k(const float* bp, f32x4 (&acc)[4][8], const float* acc_scale = nullptr) {
+    const float sc = acc_scale != nullptr ? *acc_scale : 1.f;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const float4 bq = *(const float4*)(bp + mi * 4);
-        const f32x4 b4 = f32x4{bq.x, bq.y, bq.z, bq.w};
 #pragma unroll
-        for (int pt = 0; pt < 8; ++pt) acc[mi][pt] += b4;
+        for (int pt = 0; pt < 8; ++pt) {
+            acc[mi][pt][0] = fmaf(acc[mi][pt][0], sc, bq.x); acc[mi][pt][1] = fmaf(acc[mi][pt][1], sc, bq.y);
+            acc[mi][pt][2] = fmaf(acc[mi][pt][2], sc, bq.z); acc[mi][pt][3] = fmaf(acc[mi][pt][3], sc, bq.w);
+        }
     }
 }
 

@@ -259,7 +259,7 @@ __device__ __forceinline__ void conv_v2m_body(const ConvArgs& a) {
     }
 
     // ---- epilogue: lane (site r16, group g16) owns couts g16*16 + mi*4 + j of its wave's 64 -------------------------------------
-    if constexpr (SPLIT) add_bias_after_k(a.bias + (ct * WCO + wco) * kCoutGroup + g16 * 16, acc);
+    if constexpr (SPLIT) add_bias_after_k(a.bias + (ct * WCO + wco) * kCoutGroup + g16 * 16, acc, a.acc_scale);
     const int CoutPad = a.ncg * kCoutGroup;
     const bool has_bn = a.bn_scale != nullptr;
     const int so = a.so, Wout = Ws * so, Hout = Hs * so;
@@ -619,7 +619,7 @@ __device__ __forceinline__ void conv_v2p_body(const ConvArgs& a) {
 
     // ---- epilogue (conv_igemm_v2m's): lane (site r16, group g16) owns couts g16*16 + mi*4 + j of its wave's 64 ----------------------
     IDC_MSTAMP(2);
-    if constexpr (SPLIT) add_bias_after_k(a.bias + (ct * WCO + wco) * kCoutGroup + g16 * 16, acc);
+    if constexpr (SPLIT) add_bias_after_k(a.bias + (ct * WCO + wco) * kCoutGroup + g16 * 16, acc, a.acc_scale);
     const int CoutPad = a.ncg * kCoutGroup;
     const bool has_bn = a.bn_scale != nullptr;
     const int cow = (ct * WCO + wco) * kCoutGroup;

@@ -137,6 +137,38 @@ def split_bf16(x, terms):
     return parts
 
 
+def split_f16(x, terms, scale_exp=0):
+    """x (fp32) * 2^scale_exp as a sum of `terms` fp16 values (RNE, clamped to +-65504; subnormals as the hardware keeps them), each divided back by
+    2^scale_exp (powers of two: exact).  IDC_FP16X3 (round 6): activations unscaled, a layer's weights with the power of two that brings max|w| into
+    [8192, 16384) -- ``f16_weight_exponent`` below, csrc/idc_engine.hip's packer -- so that the lo part of a small weight is a NORMAL fp16 number."""
+    s = 2.0 ** scale_exp
+    parts, r = [], x * s
+    for _ in range(terms):
+        p = r.clamp(-65504., 65504.).to(torch.float16).to(torch.float32)
+        parts.append(p / s)
+        r = r - p
+    return parts
+
+
+def f16_weight_exponent(*ws):
+    """the power of two shared by the given weight tensors (a deconv and the shortcut conv summed with it share one: one accumulator set)"""
+    mx = max(float(w.abs().max()) for w in ws)
+    if mx == 0.0:
+        return 0
+    return min(40, max(-10, 14 - int(np.frexp(np.float32(mx))[1])))
+
+
+def _splits(mode, x, w, *more_w):
+    """operand parts of one layer in a split mode: 'split2_fp32' / 'split3_fp32' (bf16 parts), 'splitf2_fp32' (fp16 parts, unscaled weights: what round 6
+    first shipped), 'splitf2s_fp32' (fp16 parts, per-layer weight scale: IDC_FP16X3 as shipped)"""
+    if mode.startswith("splitf"):
+        terms = int(mode[6])
+        e = f16_weight_exponent(w, *more_w) if mode[7:8] == "s" else 0
+        return split_f16(x, terms), split_f16(w, terms, e), e
+    terms = int(mode[5])
+    return split_bf16(x, terms), split_bf16(w, terms), 0
+
+
 def _split_products(xs, ws, op):
     """sum over the operand-term pairs (i, j) with i + j < terms of op(x_i, w_j), every product exact in fp32 (bf16 x bf16), accumulated in fp32
     smallest terms first: terms = 3 -> six bf16 products per fp32 product (hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi), terms = 2 -> three."""
@@ -150,9 +182,9 @@ def _split_products(xs, ws, op):
 
 
 def _conv3(x, w, b, dilation, mode):
-    if mode.startswith("split"):                         # 'split3_fp32' / 'split2_fp32': an fp32 conv from bf16 MFMAs on split operands (study)
-        terms = int(mode[5])
-        y = _split_products(split_bf16(x, terms), split_bf16(w, terms), lambda a, c: F.conv2d(a, c, None, padding=dilation, dilation=dilation))
+    if mode.startswith("split"):                         # 'split3_fp32' / 'split2_fp32' / 'splitf2[s]_fp32': an fp32 conv from 16-bit MFMAs on split operands
+        xs, ws, _ = _splits(mode, x, w)
+        y = _split_products(xs, ws, lambda a, c: F.conv2d(a, c, None, padding=dilation, dilation=dilation))
         return y + b[None, :, None, None]
     if mode in ("fp32", "bf16"):
         ww = q(w) if mode == "bf16" else w
@@ -199,9 +231,10 @@ def forward(sd, L_mc, ab, mask, maskcent=0.0, modes=None, default="bf16", l_div=
             w, b = _w(sd, key)
             ws, bs = _w(sd, SHORT_OF[name])
             if md(name).startswith("split"):
-                terms = int(md(name)[5])
-                y = _split_products(split_bf16(x, terms), split_bf16(w, terms), lambda a, c: F.conv_transpose2d(a, c, None, stride=2, padding=1)) + b[None, :, None, None]
-                y = y + _split_products(split_bf16(skip, terms), split_bf16(ws, terms), lambda a, c: F.conv2d(a, c, None, padding=1)) + bs[None, :, None, None]
+                xs_, wd_, _ = _splits(md(name), x, w, ws)               # (the deconv and its shortcut conv share the weight exponent)
+                sk_, wsh_, _ = _splits(md(name), skip, ws, w)
+                y = _split_products(xs_, wd_, lambda a, c: F.conv_transpose2d(a, c, None, stride=2, padding=1)) + b[None, :, None, None]
+                y = y + _split_products(sk_, wsh_, lambda a, c: F.conv2d(a, c, None, padding=1)) + bs[None, :, None, None]
             elif md(name).startswith("wino"):                   # deconv as F(2x2,2x2), shortcut conv as F(2x2,3x3)
                 ro = not md(name).endswith("_fp32")
                 xin, sk = (q(x), q(skip)) if ro else (x, skip)

@@ -58,7 +58,8 @@ def record(config, precision, style, images, out, ref):
     ("bf16x3", "torch", (0, 31), (1e-3, None)),
     ("bf16x3", "he", (5,), (5e-2, None)),
     ("fp16x3", "torch", (0, 31), (2e-4, None)),              # fp16 parts (22 bits per operand): the fp32 path's bounds on both weight styles
-    ("fp16x3", "he", (5,), (5e-3, None)),                    # measured 3.9e-3 = 2.3x the fp32 path's distance: two 11-bit parts carry 2^-23 per operand (a fourth product lo.lo: 3.99e-3, dropped)
+    ("fp16x3", "he", (5,), (3e-3, None)),                    # the fp32 path's bound: since the weight parts hold w * 2^s (per-layer power of two, lo parts normal fp16 numbers) the he-style error
+                                                             # is the fp32 arithmetic's own; unscaled it was 3.9e-3 (lo parts of ~0.02 weights subnormal: 2^-18 of the weight)
 ])
 def test_config3_batch32_against_the_oracle(make_sd, precision, style, images, bound):
     sd = make_sd(0, style)
@@ -74,8 +75,9 @@ def test_config3_batch32_against_the_oracle(make_sd, precision, style, images, b
     idx = list(images)
     if precision.startswith("bf16x") or precision.startswith("fp16x"):                        # operand-split precisions: the fp32 contract, held against the float64 oracle
         import torch
-        kernels = set(r["kernel"].split("<")[0] for r in e_table if r["launches"] > 0 and r["kernel"].startswith("conv"))
-        assert kernels <= ({"conv_igemm_v2psh", "conv_igemm_v2sh", "conv_igemm"} if precision.startswith("fp16x") else {"conv_igemm_v2ps", "conv_igemm_v2s", "conv_igemm"}), kernels
+        kernels = set(r["kernel"].split("<")[0].split("+")[0] for r in e_table if r["launches"] > 0 and r["kernel"].startswith("conv"))
+        assert kernels == ({"conv_igemm_v2psh", "conv_ds_fused_msh", "conv1_1_split_kernel"} if precision.startswith("fp16x")
+                           else {"conv_igemm_v2ps", "conv_ds_fused_ms", "conv1_1_split_kernel"}), kernels      # (the N = 32 forward: 3x3 tile, fused deconv pairs, the fp32 island)
         ref = siggraph_torch.forward(sd, L[idx], ab[idx], m[idx], 0.0, dtype=torch.float64)
     else:
         ref = siggraph_torch.forward(sd, L[idx], ab[idx], m[idx], 0.0)

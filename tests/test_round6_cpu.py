@@ -35,6 +35,8 @@ def _split_plan(parts, dist=False):
             off = _al(off); off += cpad * 4
         if kind == "dc":
             off = _al(off); off += cpad * 4
+        if not island:                      # one fp32 = 2^-s: the layer's weight parts hold w * 2^s (IDC_FP16X3; 1.0 for bf16 parts)
+            off = _al(off); e["ws_off"] = off; off += 4
         plan.append(e)
     off = _al(off); off += 1024
     off = _al(off); off += 8
@@ -56,6 +58,8 @@ def test_split_blob_layout_and_parts(make_sd, precision, parts):
     rs = np.random.RandomState(1)
     for e in plan:
         w = sd[e["wkey"] + ".weight"]
+        if not e["island"]:
+            assert blob[e["ws_off"]:e["ws_off"] + 4].view(np.float32)[0] == 1.0       # bf16 parts keep fp32's exponent range: no weight scale
         for _ in range(25):
             co, ci = rs.randint(e["cout"]), rs.randint(e["cin"])
             if e["kind"] == "c3":
@@ -84,19 +88,42 @@ def test_split_blob_layout_and_parts(make_sd, precision, parts):
                 assert abs(float(total_v) - float(val)) <= 2.0 ** -16 * abs(float(val)) + 1e-30
 
 
-def test_fp16x3_blob_carries_fp16_parts(make_sd):
-    """IDC_FP16X3: bf16x3's blob layout (two layout-1 images per layer, conv1_1 an fp32 image) with FP16 parts -- part 0 = rne16(w), part 1 =
-    rne16(w - part 0): hi + lo reproduces w to 2^-22 relative (fp16 has 11 significant bits)."""
-    sd = make_sd(0, "he")
+FUSED_PAIRS = {"model8up.0": "model3short8.0", "model9up.0": "model2short9.0", "model10up.0": "model1short10.0"}     # deconv -> the shortcut conv it is summed with
+
+
+def _f16_exponents(sd, plan):
+    """the packer's per-layer power of two: max|w| * 2^s in [8192, 16384); a deconv and its shortcut conv share the smaller one (one accumulator set)"""
+    ex = {}
+    for e in plan:
+        if e["island"]:
+            continue
+        mx = float(np.abs(sd[e["wkey"] + ".weight"]).max())
+        ex[e["wkey"]] = 14 - int(np.frexp(np.float32(mx))[1]) if mx > 0 else 0
+    for d, c in FUSED_PAIRS.items():
+        ex[d] = ex[c] = min(ex[d], ex[c])
+    return ex
+
+
+@pytest.mark.parametrize("style", ["he", "torch"])
+def test_fp16x3_blob_carries_fp16_parts(make_sd, style):
+    """IDC_FP16X3: bf16x3's blob layout (two layout-1 images per layer, conv1_1 an fp32 image) with FP16 parts of w * 2^s -- part 0 = rne16(w 2^s), part 1 =
+    rne16(w 2^s - part 0), s the layer's power of two (stored as 2^-s beside the bias): hi + lo reproduces w 2^s to 2^-22 relative (fp16 has 11 significant
+    bits) for every weight down to 2^-13 of the layer's largest -- unscaled, he-style weights (~0.02) had SUBNORMAL lo parts (6e-8 absolute)."""
+    sd = make_sd(0, style)
     blob = engine.pack_weights(sd, "fp16x3")
     plan, total = _split_plan(2)
     assert blob.size == total == N.load().idc_weights_blob_bytes(N.IDC_FP16X3, 0) == N.load().idc_weights_blob_bytes(N.IDC_BF16X3, 0)
     assert blob[8:12].view(np.uint32)[0] == N.IDC_FP16X3
     rs = np.random.RandomState(2)
+    ex = _f16_exponents(sd, plan)
     for e in plan:
         if e["island"]:
             continue
         w = sd[e["wkey"] + ".weight"]
+        sexp = ex[e["wkey"]]
+        assert blob[e["ws_off"]:e["ws_off"] + 4].view(np.float32)[0] == np.float32(2.0 ** -sexp), e["wkey"]
+        assert 8192 <= float(np.abs(w).max()) * 2.0 ** sexp or e["wkey"] in FUSED_PAIRS or e["wkey"] in FUSED_PAIRS.values()
+        assert float(np.abs(w).max()) * 2.0 ** sexp < 16384
         for _ in range(25):
             co, ci = rs.randint(e["cout"]), rs.randint(e["cin"])
             if e["kind"] == "c3":
@@ -105,13 +132,15 @@ def test_fp16x3_blob_carries_fp16_parts(make_sd):
                 tw, k, val = 0, ci, w[co, ci, 0, 0]
             else:
                 ky, kx = rs.randint(4), rs.randint(4); tw, k, val = ky * 4 + kx, ci, w[ci, co, ky, kx]
-            val = np.float32(val)
+            val = np.float32(np.float32(val) * np.float32(2.0 ** sexp))          # exact: a power of two
             hi = np.float16(val)
             lo = np.float16(np.float32(val - np.float32(hi)))
             got0 = _read_w(blob, e, "bf16", tw, co, k)
             got1 = _read_w(blob, dict(e, w_off=e["w_off"] + e["w_bytes"]), "bf16", tw, co, k)
             assert got0 == int(hi.view(np.uint16)) and got1 == int(lo.view(np.uint16)), (e["wkey"], co, ci)
             assert abs(float(np.float32(hi) + np.float32(lo)) - float(val)) <= 2.0 ** -21 * abs(float(val)) + 1e-7
+            if abs(float(val)) >= 2.0:                       # i.e. |w| >= 2^-13 of the layer's largest: the lo part is a normal fp16 number
+                assert abs(float(np.float32(hi) + np.float32(lo)) - float(val)) <= 2.0 ** -22 * abs(float(val))
 
 
 def test_split_precisions_are_refused_where_they_do_not_apply():

@@ -30,8 +30,10 @@ for style in ("torch", "he"):
     hab, hm = workloads.hints_config2(size, 5, 3, 0)
     ab, m = hab[None].astype(np.float32), hm[None].astype(np.float32)
     ref = siggraph_torch.forward(sd, L, ab, m, 0.0, dtype=torch.float64)
-    for mode in ("fp32", "split3_fp32", "split2_fp32", "bf16"):
+    # round 6: 'splitf2' = fp16 parts (IDC_FP16X3 as first shipped), 'splitf2s' = with the per-layer power-of-two weight scale (as shipped now);
+    # conv1_1 is an exact-fp32 island in every split mode, as on the GPU
+    for mode in ("fp32", "split3_fp32", "split2_fp32", "splitf2_fp32", "splitf2s_fp32", "bf16"):
         t0 = time.time()
-        out = emulate.forward(sd, L, ab, m, 0.0, default=mode)
+        out = emulate.forward(sd, L, ab, m, 0.0, default=mode, modes={"conv1_1": "fp32"} if mode.startswith("split") else None)
         st = emulate.error_stats(out, ref)
         print("%-8s %-14s %12.3e %12.3e %12.3e %12.3e   (%.0f s)" % (style, mode, st["max_abs"], st["mean_abs"], st["q999"], st["rel_rms"], time.time() - t0))
