@@ -53,7 +53,7 @@ def parse_args():
     ap.add_argument("--no-contract-leg", action="store_true",
                     help="skip `fp32_contract_path`: the same N = 32 workload on precision fp16x3 (the fastest path inside the 1e-3 contract of "
                          "data/colorize_image.py:263) and the distance of both precisions' outputs from the CPU baseline's own fp32 outputs")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3", "bf16x6", "fp16x3"],
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3", "bf16x6", "fp16x3", "fp16"],
                     help="bf16x3 / bf16x6 (round 6): the fp32 contract on the bf16 matrix pipe -- fp32 operands as 2 / 3 bf16 parts, 3 / 6 bf16 MFMA products "
                          "per fp32 product, fp32 accumulation; `roofline.peak` is then the dense bf16 peak / products")
     ap.add_argument("--setup-forwards", type=int, default=0,

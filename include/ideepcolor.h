@@ -44,7 +44,7 @@ typedef enum idc_status {
 
 /* Arithmetic type of the conv stack.  BF16: bf16 activations+weights, fp32 MFMA accumulation,
  * fp32 bias/BN/shortcut sums.  FP32: exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) end to end.      */
-typedef enum idc_precision { IDC_FP32 = 0, IDC_BF16 = 1, IDC_BF16X3 = 2, IDC_BF16X6 = 3, IDC_FP16X3 = 4 } idc_precision;
+typedef enum idc_precision { IDC_FP32 = 0, IDC_BF16 = 1, IDC_BF16X3 = 2, IDC_BF16X6 = 3, IDC_FP16X3 = 4, IDC_FP16 = 5 } idc_precision;
 /* BF16X3 / BF16X6 (round 6): the fp32 contract of colorize_image.py:263 carried on the bf16 matrix pipe.  Every fp32 operand travels as a sum of
  * bf16 values -- x = hi + lo (X3) or hi + mid + lo (X6: all 24 mantissa bits) -- and a product x*w is the sum of the bf16 products that matter:
  * hi.hi + lo.hi + hi.lo (three v_mfma_f32_16x16x32_bf16 per fragment pair, 2^-16 relative), or those + mid.hi + hi.mid + mid.mid (six, 2^-24:
@@ -58,6 +58,8 @@ typedef enum idc_precision { IDC_FP32 = 0, IDC_BF16 = 1, IDC_BF16X3 = 2, IDC_BF1
  * weight is a normal fp16 number: at the IDC_FP32 path's distance from the float64 oracle on BOTH weight styles (N = 32: 2.2e-5 torch-default-init,
  * 1.9e-3 full-range, against 2.3e-5 / 1.7e-3; without the scale full-range weights ~0.02 had subnormal lo parts and 3.9e-3), at BF16X3's rate.
  * The price is fp16's range for ACTIVATIONS: beyond +-65504 they saturate (the conversions clamp; nothing becomes inf), below 6e-5 they keep 6e-8 absolute.
+ * FP16 (round 6): FP16X3's machinery with ONE part and ONE product -- plain fp16 operands (11 significant bits against bf16's 8; weights scaled per layer
+ * as above), fp32 accumulation, every layer on the throughput tiles: 1 / 8 of IDC_BF16's rounding error at ~0.9 of its N = 32 rate.  Not a 1e-3 path.
  * The layers of this net are BatchNorm-ed / ReLU-ed activations of O(1..100); a checkpoint with larger activations wants BF16X6. */
 
 /* idc_create flags */

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libideepcolor_hip.so")
 
-IDC_FP32, IDC_BF16, IDC_BF16X3, IDC_BF16X6, IDC_FP16X3 = 0, 1, 2, 3, 4
+IDC_FP32, IDC_BF16, IDC_BF16X3, IDC_BF16X6, IDC_FP16X3, IDC_FP16 = 0, 1, 2, 3, 4, 5
 IDC_FLAG_DIST_HEAD, IDC_FLAG_GLOBAL_HINTS, IDC_FLAG_DIST313, IDC_FLAG_THROUGHPUT_BLOB = 0x1, 0x4, 0x8, 0x10
 IDC_OK = 0
 STATUS_NAMES = {0: "IDC_OK", -1: "IDC_ERR_INVALID_ARG", -2: "IDC_ERR_NO_DEVICE", -3: "IDC_ERR_HIP",

@@ -624,7 +624,7 @@ __global__ __launch_bounds__(256, 2) void conv1_1_split_kernel(const ConvArgs a)
 // qualify (the caller keeps conv_igemm<float>)
 hipError_t launch_conv1_1_split(const ConvArgs& a, hipStream_t s) {
     if (a.pk_L == nullptr || a.bn_scale != nullptr || a.resid != nullptr || a.img_shift != nullptr || a.ncg != 1 || a.nkc != 2 || a.so != 1 ||
-        a.out_parts < 2 || a.out_parts > 3 || a.in2 != nullptr)
+        a.out_parts < 1 || a.out_parts > 3 || a.in2 != nullptr)
         return hipErrorInvalidConfiguration;
     const long long blocks = (long long)((a.Ws + 31) / 32) * ((a.Hs + 15) / 16) * a.N;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;

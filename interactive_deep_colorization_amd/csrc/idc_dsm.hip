@@ -536,7 +536,7 @@ hipError_t launch_conv_ds_m(const ConvArgs& a, hipStream_t s) {
 // ... its operand-split form: a.in / a.in2 / a.out split tensors of a.in_parts (= a.out_parts) planes, a.wgt / a.wgt2 the weight parts' layout-1 images
 hipError_t launch_conv_ds_ms(const ConvArgs& a, hipStream_t s) {
     if (a.in2 == nullptr || a.wgt2 == nullptr || a.zeros == nullptr || a.nphase != 4 || a.so != 2 || a.si != 1 || (a.ncg & 1) || a.out_f32 ||
-        a.img_shift != nullptr || a.resid != nullptr || a.head_w != nullptr || a.in_parts < 2 || a.in_parts > 3 || a.out_parts != a.in_parts ||
+        a.img_shift != nullptr || a.resid != nullptr || a.head_w != nullptr || a.in_parts < 1 || a.in_parts > 3 || a.out_parts != a.in_parts ||
         a.nseg < 1 || a.nseg > 6 || a.w_part_bytes == 0 || a.w_part_bytes2 == 0 ||
         !conv_ds_m_fits(a.Hs, a.Ws, a.nkc * a.in_parts, a.nkc2 * a.in_parts))
         return hipErrorInvalidConfiguration;

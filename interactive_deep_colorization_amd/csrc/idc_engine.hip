@@ -289,7 +289,7 @@ static void run_pack_tasks(std::vector<std::function<void()>>& t) {
 
 static int pack_weights_impl(int precision, unsigned flags, const idc_tensor_desc* tensors, int n_tensors,
                              void* blob, size_t blob_bytes, std::string* err) {
-    if (precision < IDC_FP32 || precision > IDC_FP16X3) return fail(err, IDC_ERR_INVALID_ARG, "bad precision %d", precision);
+    if (precision < IDC_FP32 || precision > IDC_FP16) return fail(err, IDC_ERR_INVALID_ARG, "bad precision %d", precision);
     if (!tensors || n_tensors <= 0 || !blob) return fail(err, IDC_ERR_INVALID_ARG, "null tensors/blob");
     const BlobPlan plan = make_blob_plan(precision, flags);
     if (blob_bytes < plan.total_bytes)
@@ -1132,7 +1132,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             else if (L.spec->kind == kConvIm2col && L.lprec == IDC_BF16 && a.ksplit <= 1 &&
                 (long long)((a.Ws + 31) / 32) * ((a.Hs + 31) / 32) * c->max_batch >= 128)
                 le = launch_conv1_1_bf16(a, s);
-            if (is_split(c->precision) && !L.split && L.spec->kind == kConvIm2col && g_conv1_1_split && a.out_parts >= 2 &&
+            if (is_split(c->precision) && !L.split && L.spec->kind == kConvIm2col && g_conv1_1_split && a.out_parts >= 1 &&
                 (long long)((a.Ws + 31) / 32) * ((a.Hs + 15) / 16) * c->max_batch >= 128)
                 le = launch_conv1_1_split(a, s);
             if (L.fused_short >= 0) le = L.split ? launch_conv_ds_ms(a, s) : L.m16 ? launch_conv_ds_m(a, s) : launch_conv_ds(a, s);
@@ -1487,7 +1487,7 @@ int idc_create(int device_id, int height, int width, int max_batch, int precisio
     if (height <= 0 || width <= 0 || height % 8 || width % 8)
         return fail(nullptr, IDC_ERR_INVALID_ARG, "H and W must be positive multiples of 8 (got %dx%d)", height, width);
     if (max_batch <= 0) return fail(nullptr, IDC_ERR_INVALID_ARG, "max_batch must be positive");
-    if (precision < IDC_FP32 || precision > IDC_FP16X3) return fail(nullptr, IDC_ERR_INVALID_ARG, "bad precision %d", precision);
+    if (precision < IDC_FP32 || precision > IDC_FP16) return fail(nullptr, IDC_ERR_INVALID_ARG, "bad precision %d", precision);
     int rc = check_device(device_id, nullptr);
     if (rc) return rc;
     if (hipSetDevice(device_id) != hipSuccess) return fail(nullptr, IDC_ERR_HIP, "hipSetDevice(%d) failed", device_id);
@@ -1522,7 +1522,7 @@ int idc_set_io_scales(idc_handle h, float l_div, float ab_div, float mask_mul, f
 }
 
 size_t idc_weights_blob_bytes(int precision, unsigned flags) {
-    if (precision < IDC_FP32 || precision > IDC_FP16X3) return 0;
+    if (precision < IDC_FP32 || precision > IDC_FP16) return 0;
     return make_blob_plan(precision, flags).total_bytes;
 }
 
@@ -2341,7 +2341,7 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
                                                                                                     : (L.v2p ? "conv_igemm_v2ps<%d,%d>x%d" : "conv_igemm_v2s<%d,%d>x%d"),
                                   L.cfg.wm, L.cfg.wp, split_segments(h->precision));
             else if (L.m16) strncat(out->kernel, L.v2p ? "+m16p" : "+m16", sizeof(out->kernel) - strlen(out->kernel) - 1);
-            if (is_split(h->precision) && !L.split && L.spec->kind == kConvIm2col && g_conv1_1_split && h->tensors[L.dst].parts >= 2 && !h->tensors[L.dst].is_f32 &&
+            if (is_split(h->precision) && !L.split && L.spec->kind == kConvIm2col && g_conv1_1_split && !h->tensors[L.dst].is_f32 &&
                 (long long)((h->W + 31) / 32) * ((h->H + 15) / 16) * h->max_batch >= 128)
                 snprintf(out->kernel, sizeof(out->kernel), "conv1_1_split_kernel");
             if (L.fused_head) strncat(out->kernel, "+head", sizeof(out->kernel) - strlen(out->kernel) - 1);
@@ -2477,7 +2477,7 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
                          const float* resid, float* y) {
     int rc = check_device(device_id, nullptr);
     if (rc) return rc;
-    if (precision < IDC_FP32 || precision > IDC_FP16X3) return fail(nullptr, IDC_ERR_INVALID_ARG, "bad precision");
+    if (precision < IDC_FP32 || precision > IDC_FP16) return fail(nullptr, IDC_ERR_INVALID_ARG, "bad precision");
     if (!x || !weight || !bias || !y || n <= 0 || h <= 0 || w <= 0) return fail(nullptr, IDC_ERR_INVALID_ARG, "bad argument");
     const bool split = is_split(precision);
     const int parts = split_parts(precision);

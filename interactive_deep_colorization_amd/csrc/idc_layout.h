@@ -51,17 +51,19 @@ __host__ __device__ inline int cg_cout_to_row2(int col) {
 
 inline int elem_bytes(int precision) { return precision == 0 ? 4 : 2; }       // IDC_FP32 == 0; IDC_BF16 and the operand-split precisions store bf16
 // operand-split precisions (IDC_BF16X3 = 2: x = hi + lo, three products; IDC_BF16X6 = 3: hi + mid + lo, six products)
-inline bool is_split(int precision) { return precision >= 2 && precision <= 4; }
-inline bool split_is_f16(int precision) { return precision == 4; }               // IDC_FP16X3: bf16x3's planes and segments with fp16 (11-bit) parts
+inline bool is_split(int precision) { return precision >= 2 && precision <= 5; }
+inline bool split_is_f16(int precision) { return precision == 4 || precision == 5; }   // IDC_FP16X3: bf16x3's planes and segments with fp16 (11-bit) parts
+// IDC_FP16 (= 5, round 6): the operand-split machinery with ONE fp16 part and ONE segment -- plain fp16 operands (11 significant bits against bf16's 8),
+// fp32 accumulation, per-layer power-of-two weight scale, conv1_1 exact fp32: the throughput tiles at 1 / 8 of the bf16 path's rounding error
 // (measured and dropped: a fourth segment lo.lo -- N = 32 he-style 3.99e-3 against 3.86e-3 without it.  What that error was: fp16 lo parts of ~0.02
 //  weights are SUBNORMAL (6e-8 absolute = 2^-18 of the weight); with the weight parts holding w * 2^s per layer -- LayerBlob::wscale_off, ConvArgs::acc_scale --
 //  it is 1.9e-3, the fp32 arithmetic's own distance; oracle/emulate.py 'splitf2_fp32' / 'splitf2s_fp32' reproduce both figures on the CPU)
-inline int split_parts(int precision) { return (precision == 2 || precision == 4) ? 2 : precision == 3 ? 3 : 1; }
+inline int split_parts(int precision) { return (precision == 2 || precision == 4) ? 2 : precision == 3 ? 3 : 1; }      // (IDC_FP16: 1)
 // K segments (input part, weight part), 4 bits each, segment 0 in the low nibble.  SMALLEST PRODUCTS FIRST, hi.hi last, and the bias after the
 // K loop: every v_mfma rounds its result to the accumulator's magnitude, so each of the 9 x nkc x 2 accumulations of a segment costs one rounding
 // at the size the accumulator has at that moment.  hi.hi first made all 3 (6) segments round at full magnitude -- N = 32 he-style weights, bf16x6:
 // 7.1e-3 on the ab map against the exact-fp32 kernels' 1.7e-3; smallest first leaves only the hi.hi pass rounding at full size.
-inline int split_segments(int precision) { return (precision == 2 || precision == 4) ? 3 : precision == 3 ? 6 : 1; }
+inline int split_segments(int precision) { return (precision == 2 || precision == 4) ? 3 : precision == 3 ? 6 : 1; }      // (IDC_FP16: 1 = hi.hi)
 inline unsigned split_seg_x(int precision) { return (precision == 2 || precision == 4) ? 0x001u : precision == 3 ? 0x001120u : 0u; }   // X3: lo, hi, hi      X6: hi, lo, mid, mid, hi, hi
 inline unsigned split_seg_w(int precision) { return (precision == 2 || precision == 4) ? 0x010u : precision == 3 ? 0x010102u : 0u; }   // X3: hi, lo, hi      X6: lo, hi, mid, hi,  mid, hi
 inline int kc_elems(int precision) { return kRowBytes / elem_bytes(precision); }  // 64 or 32

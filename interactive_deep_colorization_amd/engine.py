@@ -17,7 +17,7 @@ _PREC = {"fp32": N.IDC_FP32, "f32": N.IDC_FP32, "float32": N.IDC_FP32, 0: N.IDC_
          "bf16": N.IDC_BF16, "bfloat16": N.IDC_BF16, 1: N.IDC_BF16,
          # operand-split precisions (round 6): fp32 values carried as 2 / 3 bf16 parts, 3 / 6 bf16 MFMA products per fp32 product
          "bf16x3": N.IDC_BF16X3, 2: N.IDC_BF16X3, "bf16x6": N.IDC_BF16X6, 3: N.IDC_BF16X6,
-         "fp16x3": N.IDC_FP16X3, 4: N.IDC_FP16X3}
+         "fp16x3": N.IDC_FP16X3, 4: N.IDC_FP16X3, "fp16": N.IDC_FP16, 5: N.IDC_FP16}
 
 
 def _fptr(a):

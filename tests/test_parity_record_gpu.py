@@ -60,6 +60,8 @@ def record(config, precision, style, images, out, ref):
     ("fp16x3", "torch", (0, 31), (2e-4, None)),              # fp16 parts (22 bits per operand): the fp32 path's bounds on both weight styles
     ("fp16x3", "he", (5,), (3e-3, None)),                    # the fp32 path's bound: since the weight parts hold w * 2^s (per-layer power of two, lo parts normal fp16 numbers) the he-style error
                                                              # is the fp32 arithmetic's own; unscaled it was 3.9e-3 (lo parts of ~0.02 weights subnormal: 2^-18 of the weight)
+    ("fp16", "torch", (0, 31), (0.05, 0.008)),               # plain fp16 operands (11 bits against bf16's 8): ~1 / 8 of the bf16 path's error, not a 1e-3 path
+    ("fp16", "he", (7,), (4.0, 0.4)),
 ])
 def test_config3_batch32_against_the_oracle(make_sd, precision, style, images, bound):
     sd = make_sd(0, style)
@@ -89,7 +91,7 @@ def test_config3_batch32_against_the_oracle(make_sd, precision, style, images, b
         assert row["q999"] <= bound[2], row
 
 
-@pytest.mark.parametrize("precision,style", [("fp32", "torch"), ("fp32", "he"), ("bf16", "he"), ("bf16x6", "torch")])
+@pytest.mark.parametrize("precision,style", [("fp32", "torch"), ("fp32", "he"), ("bf16", "he"), ("bf16x6", "torch"), ("fp16x3", "torch"), ("fp16x3", "he")])
 def test_config5_512_global_hints_against_the_oracle(precision, style):
     """fp32: torch-init weights at the BASELINE bound 1e-3 against the fp32 oracle; he-style weights (full tanh range, the
     stress case) against the FLOAT64 oracle at 3e-3 -- at 512x512 two fp32 implementations of this 30-layer net sit ~2e-3
@@ -108,10 +110,10 @@ def test_config5_512_global_hints_against_the_oracle(precision, style):
     idx = [1] if precision == "fp32" else [3]
     ref = siggraph_torch.forward(sd, L[idx], ab[idx], m[idx], 0.0, glob=glob[idx], sat=sat[idx])
     row = record("configs[4] 512x512 global hints N=%d" % nb, precision, style, idx, out[idx], ref)
-    if precision == "bf16x6":                                # the fp32 contract through the Global Hints fusion (per-image shift in conv4_3's split epilogue)
+    if precision in ("bf16x6", "fp16x3"):                    # the fp32 contract through the Global Hints fusion (per-image shift in conv4_3's split epilogue)
         ref64 = siggraph_torch.forward(sd, L[idx], ab[idx], m[idx], 0.0, glob=glob[idx], sat=sat[idx], dtype=torch.float64)
         row64 = record("configs[4] 512x512 global hints N=%d vs float64 oracle" % nb, precision, style, idx, out[idx], ref64)
-        assert row64["max_abs"] <= 1e-3, row64
+        assert row64["max_abs"] <= (1e-3 if style == "torch" else 4e-3), row64      # (he-style at 512^2: the fp32 path's own bound below)
     elif precision == "fp32" and style == "torch":
         assert row["max_abs"] <= 1e-3, row
     elif precision == "fp32":

@@ -145,7 +145,7 @@ def test_fp16x3_blob_carries_fp16_parts(make_sd, style):
 
 def test_split_precisions_are_refused_where_they_do_not_apply():
     lib = N.load()
-    assert lib.idc_weights_blob_bytes(5, 0) == 0 and lib.idc_weights_blob_bytes(-1, 0) == 0
+    assert lib.idc_weights_blob_bytes(6, 0) == 0 and lib.idc_weights_blob_bytes(-1, 0) == 0        # (5 = IDC_FP16 since the one-part form exists)
     assert lib.idc_weights_blob_bytes(N.IDC_BF16X3, 0) < lib.idc_weights_blob_bytes(N.IDC_BF16X6, 0)
     with pytest.raises(KeyError):
         engine.pack_weights({}, "bf16x9")
@@ -212,3 +212,23 @@ def test_cpu_baseline_times_the_reference_module_where_it_exists():
     assert np.array_equal(out, siggraph_torch.forward(sd, L, ab, m, 0.0)[0])
     wh = bench.cpu_whole_host(2, 4, 1.0, "torch")              # fewer than two workers fit: says so instead of inventing a number
     assert wh["value"] is None and "whole host" in wh["note"]
+
+
+def test_fp16_blob_is_one_fp16_image_per_layer(make_sd):
+    """IDC_FP16: the split plan with ONE part -- an fp16 image of w * 2^s per layer (s as IDC_FP16X3's), conv1_1 an fp32 image."""
+    sd = make_sd(0, "he")
+    blob = engine.pack_weights(sd, "fp16")
+    plan, total = _split_plan(1)
+    assert blob.size == total == N.load().idc_weights_blob_bytes(N.IDC_FP16, 0)
+    assert blob[8:12].view(np.uint32)[0] == N.IDC_FP16
+    ex = _f16_exponents(sd, plan)
+    rs = np.random.RandomState(3)
+    for e in plan:
+        if e["island"] or e["kind"] != "c3":
+            continue
+        w = sd[e["wkey"] + ".weight"]
+        assert blob[e["ws_off"]:e["ws_off"] + 4].view(np.float32)[0] == np.float32(2.0 ** -ex[e["wkey"]])
+        for _ in range(10):
+            co, ci, ky, kx = rs.randint(e["cout"]), rs.randint(e["cin"]), rs.randint(3), rs.randint(3)
+            val = np.float32(np.float32(w[co, ci, ky, kx]) * np.float32(2.0 ** ex[e["wkey"]]))
+            assert _read_w(blob, e, "bf16", ky * 3 + kx, co, ci) == int(np.float16(val).view(np.uint16)), (e["wkey"], co, ci)
