@@ -516,8 +516,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || LW) ? 2 : 3) void conv1_block_
 static const int g_c1_lw = idc_env_int("IDC_C1_LW", 3);
 
 // the fused block uses more than the default 64 KiB of dynamic LDS (set per device: this runs for every handle)
+static hipError_t init_kernels_conv1_split();      // (conv1_2_split_kernel, defined below)
 hipError_t init_kernels_conv1() {
-    hipError_t e = hipFuncSetAttribute((const void*)conv1_block_fused_t<4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv1_block_lds(4, 2, true));
+    hipError_t e = init_kernels_conv1_split();
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)conv1_block_fused_t<4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv1_block_lds(4, 2, true));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)conv1_block_fused_t<4, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv1_block_lds(4, 3, true));
     if (e != hipSuccess) return e;
@@ -631,6 +634,228 @@ hipError_t launch_conv1_1_split(const ConvArgs& a, hipStream_t s) {
     const int lds = 4 * 4096 + 34 * 18 * 16;
     if (a.split_f16) hipLaunchKernelGGL(conv1_1_split_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, s, a);
     else hipLaunchKernelGGL(conv1_1_split_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv1_2_split_kernel (round 6): model1.2 (64 -> 64, 3x3, ReLU, eval-BN; model.py:15-17) of the operand-split precisions.  The generic 64-cout tile
+// (conv_igemm_v2ps<1,4,1>: 98 KiB of LDS per 4-wave workgroup) leaves ONE wave per SIMD -- every tap's barrier and LDS-DMA wait is exposed: MFMA-busy 0.25,
+// 0.86 ms for fp16x3 at N = 32.  This is conv1_block_fused_t<4,3,true>'s conv1_2 phase (32 x 12 pixel tile, 4 waves x 3 rows, v_mfma_f32_32x32x16, the
+// tap's 8 KiB weight tile re-laid for the 32x32 A operand on its way into a two-slot LDS ring, static halo tile: 76 KiB, TWO workgroups per CU) with the
+// halo coming from the split tensor instead of an in-kernel conv1_1, walked a.nseg times: segment s stages input part seg_x[s] (buffer loads straight to
+// LDS, bounds check = zero padding, the source address carries the swizzle; a segment that keeps the part keeps the halo) and streams weight part
+// seg_w[s]; the accumulators start at zero, and the epilogue is fp32 throughout: x 2^-s + bias, ReLU, BN, hi = rne(v), next = rne(v - hi), ... every plane
+// through the wave-private transpose tile, whole 128-byte lines.
+template <bool F16>
+__global__ __launch_bounds__(256, 2) void conv1_2_split_kernel(const ConvArgs a) {
+    constexpr int NW = 4, RPW = 3, NT = NW * 64, TH = NW * RPW;
+    constexpr int HW_ = 34, HH_ = TH + 2, NSITE = HW_ * HH_;
+    constexpr int H_ITEMS = (NSITE * kSlots + NT - 1) / NT;            // 15 LDS-DMA instructions per thread and halo
+    constexpr int HALO_BYTES = H_ITEMS * NT * kSlotBytes;              // 61,440
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const halo = smem;
+    char* const wring = smem + HALO_BYTES;                             // 2 x 8 KiB
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 31, h = lane >> 5;
+    const int Hs = a.Hs, Ws = a.Ws;
+    const int ntx = (Ws + 31) >> 5, nty = (Hs + TH - 1) / TH;
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int txi = b % ntx; b /= ntx;
+    const int tyi = b % nty;
+    const int n = b / nty;
+    const int ty0 = tyi * TH, tx0 = txi * 32;
+    const int np = a.in_parts, pix_bytes = np * kRowBytes;             // a pixel of the split input: [part][64 channels]
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.in + (size_t)n * Hs * Ws * pix_bytes), 0, Hs * Ws * pix_bytes, 0x00020000);
+    auto seg_xp = [&](int sg) { return (int)((a.seg_x >> (4 * sg)) & 15u); };
+    auto seg_wp = [&](int sg) { return (size_t)((a.seg_w >> (4 * sg)) & 15u) * (size_t)a.w_part_bytes; };
+    // weight tile -> ring slot, re-laid for the 32x32 A fragment (as conv1_block_fused_t: LDS row rho = the MFMA row, slot ^ swz2(rho))
+    constexpr int W2_ITEMS = kWBlockBytes / (NT * kSlotBytes);
+    int w2_src[W2_ITEMS];
+#pragma unroll
+    for (int j = 0; j < W2_ITEMS; ++j) {
+        const int i = tid + j * NT, rho = i >> 3, sphys = i & 7, px_ = rho & 31, mi_ = rho >> 5;
+        const int c = ((px_ >> 2) & 1) * 32 + mi_ * 16 + (px_ >> 3) * 4 + (px_ & 3);
+        const int lr = ((c >> 2) & 3) * 16 + (c >> 4) * 4 + (c & 3);
+        w2_src[j] = lr * kRowBytes + (((sphys ^ swz2(rho)) ^ swz(lr)) * kSlotBytes);
+    }
+    auto dma_w = [&](int sg, int t, int slot) {
+        const char* const src = (const char*)a.wgt + seg_wp(sg) + (size_t)t * kWBlockBytes;
+        char* dst = wring + slot * kWBlockBytes + wave * 64 * kSlotBytes;
+#pragma unroll
+        for (int j = 0; j < W2_ITEMS; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + w2_src[j]),
+                                             (__attribute__((address_space(3))) void*)(dst + j * NT * kSlotBytes), 16, 0, 0);
+    };
+    auto load_halo = [&](int xp) {
+#pragma unroll
+        for (int j = 0; j < H_ITEMS; ++j) {
+            const int item = tid + j * NT;
+            const int row = item >> 3, phys = item & 7;                // halo site, physical slot
+            const int hy = row / HW_, hx = row - hy * HW_;
+            const int Y = ty0 - 1 + hy, X = tx0 - 1 + hx;
+            const bool inside = row < NSITE && (unsigned)Y < (unsigned)Hs && (unsigned)X < (unsigned)Ws;
+            const int off = (Y * Ws + X) * pix_bytes + xp * kRowBytes + ((phys ^ swz2(row)) * kSlotBytes);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(halo + (j * NT + wave * 64) * kSlotBytes), 16,
+                                                     inside ? off : (int)0x80000000, 0, 0, 0);
+        }
+    };
+    const int nseg = a.nseg, total = nseg * 9;
+    dma_w(0, 0, 0);
+    load_halo(seg_xp(0));
+
+    f32x16 acc[2][RPW];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int pj = 0; pj < RPW; ++pj)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][pj][e] = 0.f;
+    const int wlam0 = px * kRowBytes + ((h ^ swz2(px)) * kSlotBytes), wlam1 = wlam0 + 32 * kRowBytes;
+    int sg = 0, t = 0;
+#pragma unroll 1
+    for (int s = 0; s < total; ++s) {
+        const char* const wcur_ = wring + (s & 1) * kWBlockBytes;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // my pieces of this step's weight tile (and of a halo just asked for)
+        __syncthreads();                                        // everybody's; everybody left the other ring slot
+        int sg_n = sg, t_n = t + 1;
+        if (t_n == 9) { t_n = 0; ++sg_n; }
+        if (s + 1 < total) dma_w(sg_n, t_n, (s + 1) & 1);
+        const int dy = t / 3 - 1, dx = t - (t / 3) * 3 - 1;
+        int xaddr[RPW];
+#pragma unroll
+        for (int pj = 0; pj < RPW; ++pj) {
+            const int xr = (wave * RPW + pj + 1 + dy) * HW_ + (px + 1 + dx);
+            xaddr[pj] = xr * kRowBytes + ((h ^ swz2(xr)) * kSlotBytes);
+        }
+        u32x4 xfA[RPW], xfB[RPW], wA[2], wB[2];
+        auto read_f = [&](int kk, u32x4 (&xf)[RPW], u32x4 (&wf)[2]) {
+            wf[0] = *(const u32x4*)(wcur_ + (wlam0 ^ (kk * 2 * kSlotBytes)));
+            wf[1] = *(const u32x4*)(wcur_ + (wlam1 ^ (kk * 2 * kSlotBytes)));
+#pragma unroll
+            for (int pj = 0; pj < RPW; ++pj) xf[pj] = *(const u32x4*)(halo + (xaddr[pj] ^ (kk * 2 * kSlotBytes)));
+        };
+        auto mmaL = [&](const u32x4 (&wf)[2], const u32x4 (&xf)[RPW]) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int pj = 0; pj < RPW; ++pj) {
+                    if constexpr (F16) acc[mi][pj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_m, wf[mi]), __builtin_bit_cast(f16x8_m, xf[pj]), acc[mi][pj], 0, 0, 0);
+                    else acc[mi][pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[mi]), __builtin_bit_cast(bf16x8, xf[pj]), acc[mi][pj], 0, 0, 0);
+                }
+        };
+#define IDC_C12_INTERLEAVE()                                                          \
+    _Pragma("unroll") for (int q_ = 0; q_ < RPW + 2; ++q_) {                         \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
+    }                                                                                 \
+    __builtin_amdgcn_sched_group_barrier(0x008, RPW - 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_f(0, xfA, wA);
+        __builtin_amdgcn_sched_group_barrier(0x100, RPW + 2, 0);
+        read_f(1, xfB, wB);
+        mmaL(wA, xfA);
+        IDC_C12_INTERLEAVE()
+        read_f(2, xfA, wA);
+        mmaL(wB, xfB);
+        IDC_C12_INTERLEAVE()
+        read_f(3, xfB, wB);
+        mmaL(wA, xfA);
+        IDC_C12_INTERLEAVE()
+        mmaL(wB, xfB);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * RPW, 0);
+#undef IDC_C12_INTERLEAVE
+        if (t == 8 && s + 1 < total && seg_xp(sg_n) != seg_xp(sg)) {   // the next segment reads another input part (uniform)
+            __syncthreads();                                    // everybody is done with this halo
+            load_halo(seg_xp(sg_n));                            // lands before the next step's vmcnt(0) + barrier
+        }
+        sg = sg_n; t = t_n;
+    }
+    __syncthreads();                                            // every wave left the halo tile: the transpose tiles live there
+    // ---- epilogue: v = BN(ReLU(acc * 2^-s + bias)) in fp32, then the planes -------------------------------------------------------------
+    const float sc = a.acc_scale != nullptr ? *a.acc_scale : 1.f;
+    const bool has_bn = a.bn_scale != nullptr;
+    f32x16 bia[2], bsc[2], bsh[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 bq = *(const float4*)(a.bias + h * 32 + mi * 16 + q * 4);
+            bia[mi][q * 4 + 0] = bq.x; bia[mi][q * 4 + 1] = bq.y; bia[mi][q * 4 + 2] = bq.z; bia[mi][q * 4 + 3] = bq.w;
+            float4 s4 = float4{1.f, 1.f, 1.f, 1.f}, t4 = float4{0.f, 0.f, 0.f, 0.f};
+            if (has_bn) { s4 = *(const float4*)(a.bn_scale + h * 32 + mi * 16 + q * 4); t4 = *(const float4*)(a.bn_shift + h * 32 + mi * 16 + q * 4); }
+            bsc[mi][q * 4 + 0] = s4.x; bsc[mi][q * 4 + 1] = s4.y; bsc[mi][q * 4 + 2] = s4.z; bsc[mi][q * 4 + 3] = s4.w;
+            bsh[mi][q * 4 + 0] = t4.x; bsh[mi][q * 4 + 1] = t4.y; bsh[mi][q * 4 + 2] = t4.z; bsh[mi][q * 4 + 3] = t4.w;
+        }
+    char* const tb16 = smem + wave * 4096;
+    const int rr = lane >> 3, cc = lane & 7;
+    const int onp = a.out_parts, CoutPad = a.ncg * kCoutGroup;
+    const bool relu = a.act == 1;
+#pragma unroll
+    for (int pj = 0; pj < RPW; ++pj) {
+        const int sy = ty0 + wave * RPW + pj;
+        float v[2][16];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float x = fmaf(acc[mi][pj][e], sc, bia[mi][e]);
+                if (relu) x = fmaxf(x, 0.f);
+                v[mi][e] = fmaf(x, bsc[mi][e], bsh[mi][e]);
+            }
+        for (int p = 0; p < onp; ++p) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                unsigned pk[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if constexpr (F16) {
+                        const unsigned q = pack_f16x2_m(v[mi][2 * e], v[mi][2 * e + 1]);
+                        pk[e] = q;
+                        v[mi][2 * e] -= f16_lo_to_f32(q); v[mi][2 * e + 1] -= f16_hi_to_f32(q);
+                    } else {
+                        const unsigned q = pack_bf16x2(v[mi][2 * e], v[mi][2 * e + 1]);
+                        pk[e] = q;
+                        v[mi][2 * e] -= __uint_as_float(q << 16); v[mi][2 * e + 1] -= __uint_as_float(q & 0xffff0000u);
+                    }
+                }
+                const int s0 = h * 4 + mi * 2;
+                *(uint4*)(tb16 + px * 128 + ((s0 ^ (px & 7)) * 16)) = uint4{pk[0], pk[1], pk[2], pk[3]};
+                *(uint4*)(tb16 + px * 128 + (((s0 + 1) ^ (px & 7)) * 16)) = uint4{pk[4], pk[5], pk[6], pk[7]};
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            auto line = [&](int i) { const int row = i * 8 + rr; return *(const uint4*)(tb16 + row * 128 + ((cc ^ (row & 7)) * 16)); };
+            const uint4 o0 = line(0), o1 = line(1), o2 = line(2), o3 = line(3);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            auto put = [&](int i, const uint4& o) {
+                const int sx = tx0 + i * 8 + rr;
+                if (sy < Hs && sx < Ws)
+                    *(uint4*)((unsigned short*)a.out + ((((size_t)n * Hs + sy) * Ws + sx) * onp + p) * CoutPad + cc * 8) = o;
+            };
+            put(0, o0); put(1, o1); put(2, o2); put(3, o3);
+        }
+    }
+}
+
+static hipError_t init_kernels_conv1_split() {
+    hipError_t e = hipFuncSetAttribute((const void*)conv1_2_split_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)conv1_2_split_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+}
+
+constexpr int kConv12SplitLds = ((34 * 14 * kSlots + 255) / 256) * 256 * kSlotBytes + 2 * kWBlockBytes;      // 77,824
+
+// conv1_2 of an operand-split handle (64 -> 64, 3x3 stride 1, ReLU, optional BN; split tensors in and out); hipErrorInvalidConfiguration otherwise
+hipError_t launch_conv1_2_split(const ConvArgs& a, hipStream_t s) {
+    if (a.ncg != 1 || a.nkc != 1 || a.nphase != 1 || a.ntaps != 9 || a.si != 1 || a.so != 1 || a.dy[8] != 1 || a.act != 1 || a.resid != nullptr ||
+        a.img_shift != nullptr || a.in2 != nullptr || a.pk_L != nullptr || a.head_w != nullptr || a.out_f32 || a.in_parts < 1 || a.in_parts > 3 ||
+        a.out_parts != a.in_parts || a.nseg < 1 || a.nseg > 6 || a.w_part_bytes == 0 || (long long)a.Hs * a.Ws * a.in_parts * kRowBytes >= 0x7fffffffLL)
+        return hipErrorInvalidConfiguration;
+    const long long blocks = (long long)((a.Ws + 31) / 32) * ((a.Hs + 11) / 12) * a.N;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (a.split_f16) hipLaunchKernelGGL(conv1_2_split_kernel<true>, dim3((unsigned)blocks), dim3(256), kConv12SplitLds, s, a);
+    else hipLaunchKernelGGL(conv1_2_split_kernel<false>, dim3((unsigned)blocks), dim3(256), kConv12SplitLds, s, a);
     return hipGetLastError();
 }
 

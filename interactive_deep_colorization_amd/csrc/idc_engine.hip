@@ -604,6 +604,11 @@ static int g_ds_m16 = idc_env_int("IDC_DS_M16", 1);
 static int g_split_ds_fuse = 1;
 // ... and conv1_1, their exact-fp32 island, on conv1_1_split_kernel where the grid is throughput-sized (>= 128 tiles of 32 x 16; "conv1_1_split", 0 = conv_igemm<float>)
 static int g_conv1_1_split = 1;
+// ... and conv1_2 (64 -> 64 at full resolution) on conv1_2_split_kernel instead of the generic 64-cout tile ("conv1_2_split", 0 = conv_igemm_v2ps<1,4,1>)
+static int g_conv1_2_split = 1;
+static bool conv1_2_split_layer(const LayerSpec& s) {
+    return s.kind == kConv3x3 && s.cin == 64 && s.cout == 64 && s.dilation == 1 && s.in_stride == 1 && s.act == 1 && !s.resid;
+}
 // ... and the 3x3 convs among them as conv_igemm_v2p (no address arithmetic in the K loop; idc_set_option "v2p" / env IDC_V2P=0 for A/B)
 static int g_v2p = idc_env_int("IDC_V2P", 1);
 // throughput kernels touch their own code at entry (idc_warm_own_code, idc_kernels.h; env IDC_CODE_WARM=0 for the A/B of profiles/r04_firstuse.txt)
@@ -1135,6 +1140,9 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             if (is_split(c->precision) && !L.split && L.spec->kind == kConvIm2col && g_conv1_1_split && a.out_parts >= 1 &&
                 (long long)((a.Ws + 31) / 32) * ((a.Hs + 15) / 16) * c->max_batch >= 128)
                 le = launch_conv1_1_split(a, s);
+            if (L.split && L.fused_short < 0 && g_conv1_2_split && conv1_2_split_layer(*L.spec) && !to.is_f32 &&
+                (long long)((a.Ws + 31) / 32) * ((a.Hs + 11) / 12) * c->max_batch >= 256)
+                le = launch_conv1_2_split(a, s);
             if (L.fused_short >= 0) le = L.split ? launch_conv_ds_ms(a, s) : L.m16 ? launch_conv_ds_m(a, s) : launch_conv_ds(a, s);
             if (L.fused_short >= 0 && L.split && le == hipErrorInvalidConfiguration)
                 return fail(&c->err, IDC_ERR_INTERNAL, "layer %s: conv_ds_fused_ms planned for a launch it does not cover", L.spec->name);
@@ -1465,6 +1473,7 @@ int idc_set_option(const char* name, int value) {
     if (strcmp(name, "ds_mfma16") == 0) { g_ds_m16 = value != 0; set_ds_half(value != 2); return IDC_OK; }     // 2: conv_ds_fused_m, 8-wave workgroups on every grid
     if (strcmp(name, "split_ds_fuse") == 0) { g_split_ds_fuse = value != 0; return IDC_OK; }
     if (strcmp(name, "conv1_1_split") == 0) { g_conv1_1_split = value != 0; return IDC_OK; }
+    if (strcmp(name, "conv1_2_split") == 0) { g_conv1_2_split = value != 0; return IDC_OK; }
     if (strcmp(name, "kwave") == 0) { g_kwave = value != 0; return IDC_OK; }
     if (strcmp(name, "spin_sync") == 0) { g_spin_sync = value != 0; return IDC_OK; }
     if (strcmp(name, "pcie_kernel") == 0) { g_pcie_kernel = value != 0; return IDC_OK; }
@@ -2344,6 +2353,9 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
             if (is_split(h->precision) && !L.split && L.spec->kind == kConvIm2col && g_conv1_1_split && !h->tensors[L.dst].is_f32 &&
                 (long long)((h->W + 31) / 32) * ((h->H + 15) / 16) * h->max_batch >= 128)
                 snprintf(out->kernel, sizeof(out->kernel), "conv1_1_split_kernel");
+            if (L.split && L.fused_short < 0 && g_conv1_2_split && conv1_2_split_layer(*L.spec) && !h->tensors[L.dst].is_f32 &&
+                (long long)((h->W + 31) / 32) * ((h->H + 11) / 12) * h->max_batch >= 256)
+                snprintf(out->kernel, sizeof(out->kernel), "conv1_2_split_kernel x%d", split_segments(h->precision));
             if (L.fused_head) strncat(out->kernel, "+head", sizeof(out->kernel) - strlen(out->kernel) - 1);
             if (L.args.ksplit > 1) {
                 char sk[16]; snprintf(sk, sizeof(sk), " splitK%d", L.args.ksplit);
@@ -2362,7 +2374,8 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
                 if (L.split) snprintf(out->kernel, sizeof(out->kernel), split_is_f16(h->precision) ? "conv_ds_fused_msh+shortcut x%d" : "conv_ds_fused_ms+shortcut x%d", L.args.nseg);
                 else snprintf(out->kernel, sizeof(out->kernel), L.m16 ? "conv_ds_fused_m+shortcut" : "conv_ds_fused+shortcut");
                 out->flops += P.flops;
-                out->min_bytes += P.min_bytes - 2.0 * (double)h->tensors[P.dst].H * h->tensors[P.dst].W * h->tensors[P.dst].Cpad * eb;
+                // (the shortcut sums are neither written nor read: fp32 in the operand-split graph, bf16 otherwise)
+                out->min_bytes += P.min_bytes - 2.0 * (double)h->tensors[P.dst].H * h->tensors[P.dst].W * h->tensors[P.dst].Cpad * (h->tensors[P.dst].is_f32 ? 4 : eb);
             }
         }
     } else if (layer == nl + 1) {
@@ -2460,7 +2473,8 @@ int idc_get_activation(idc_handle h, const char* name, int n, float* out, size_t
         h->scratch_bytes = need * 4;
     }
     const int src_bf16 = (!t.is_f32 && h->precision != IDC_FP32) ? 1 : 0;
-    if (t.parts > 1) HIPCHK(h, launch_split_to_nchw(t.ptr, h->d_scratch, n, t.C, t.H, t.W, t.Cpad, t.parts, split_is_f16(h->precision) ? 1 : 0, h->stream));
+    if (t.parts > 1 || (is_split(h->precision) && !t.is_f32)) HIPCHK(h, launch_split_to_nchw(      // (IDC_FP16: one fp16 plane)
+        t.ptr, h->d_scratch, n, t.C, t.H, t.W, t.Cpad, t.parts, split_is_f16(h->precision) ? 1 : 0, h->stream));
     else HIPCHK(h, launch_nhwc_to_nchw(src_bf16, t.ptr, h->d_scratch, n, t.C, t.H, t.W, t.Cpad, h->stream));
     HIPCHK(h, hipMemcpyAsync(out, h->d_scratch, need * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -147,6 +147,8 @@ void set_ds_half(int v);              // 1 (default): grids with fewer 128-cout 
 hipError_t launch_conv1_block(const ConvArgs& a, hipStream_t s);
 // conv1_1 as the exact-fp32 island of an operand-split handle (conv1_1_split_kernel: fp32 MFMA straight from the input patch, a.out_parts planes out)
 hipError_t launch_conv1_1_split(const ConvArgs& a, hipStream_t s);
+// conv1_2 of an operand-split handle on conv1_block_fused_t's conv1_2 tile (conv1_2_split_kernel: 32 x 12 pixels, two workgroups per CU, segments over a static halo)
+hipError_t launch_conv1_2_split(const ConvArgs& a, hipStream_t s);
 // conv1_1 (4 -> 64, input pack fused) as one 32x32 tile per workgroup, bf16; hipErrorInvalidConfiguration if the
 // launch does not qualify (the caller then uses launch_conv)
 hipError_t launch_conv1_1_bf16(const ConvArgs& a, hipStream_t s);

@@ -83,7 +83,7 @@ SPLITK_POLICIES = {"auto": 0, "never": 1, "always": 2}
 def set_option(name, value):
     """Process-wide switches (``idc_set_option``; speed / kernel choice only -- every setting computes the same function).  Names and values are
     documented in ``include/ideepcolor.h``: 'fuse_conv1', 'click', 'winograd', 'mfma16', 'v2p', 'ds_mfma16', 'kwave', 'kwave_chain', and since
-    round 6 'split_ds_fuse', 'spin_sync', 'pcie_kernel' (former environment switches) and the test hook 'kw_force_abort'.  'mfma16' = 0 / 'ds_mfma16' = 0 select the
+    round 6 'split_ds_fuse', 'conv1_1_split', 'conv1_2_split', 'spin_sync', 'pcie_kernel' (former environment switches) and the test hook 'kw_force_abort'.  'mfma16' = 0 / 'ds_mfma16' = 0 select the
     32x32x16-MFMA partner kernels, which exist only in a ``make EXTRA=-DIDC_AB_PARTNERS`` build: the default library raises IdcError (UNSUPPORTED)."""
     N.check(N.load().idc_set_option(name.encode(), int(value)))
 

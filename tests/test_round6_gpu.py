@@ -272,3 +272,41 @@ def test_fp16_precision_is_the_split_machinery_with_one_part(style):
         errs[precision] = float(np.abs(out - ref).max())
     assert errs["fp16"] <= (0.05 if style == "torch" else 4.0), errs
     assert errs["fp16"] <= 0.4 * errs["bf16"], errs
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16x6", "fp16x3", "fp16"])
+def test_conv1_2_split_kernel_against_the_generic_tile(precision):
+    """conv1_2 (64 -> 64 at full resolution, ReLU + eval-BN, models/pytorch/model.py:15-17) of the operand-split precisions on conv1_2_split_kernel (>= 256
+    tiles of 32 x 12: batch 8 of 104 x 104, ragged on both axes) against conv_igemm_v2ps<1,4,1> (option conv1_2_split = 0) and the float64 oracle's conv1_2."""
+    from oracle import siggraph_torch
+    from tests.conftest import state_dict_for
+    sd = state_dict_for(3, "he")
+    H, W, n = 104, 104, 8                     # (multiples of 8 for the net; 104 / 12 and 104 / 32 leave partial tiles)
+    rs = np.random.RandomState(6)
+    L = (rs.rand(n, 1, H, W) * 100).astype(np.float32)
+    ab = (rs.uniform(-80, 80, (n, 2, H, W)) * (rs.rand(n, 1, H, W) < 0.05)).astype(np.float32)
+    m = (np.abs(ab).sum(1, keepdims=True) > 0).astype(np.float32)
+    ref_out, _, acts = siggraph_torch.forward(sd, L, ab, m, 0.5, dtype=torch.float64, return_acts=True)
+    got, outs = {}, {}
+    try:
+        for v in (1, 0):
+            engine.set_option("conv1_2_split", v)
+            e = engine.HipColorizer(H, W, max_batch=n, precision=precision)
+            try:
+                e.load_state_dict(sd)
+                outs[v] = e.forward(L, ab, m, 0.5)
+                assert np.array_equal(outs[v], e.forward(L, ab, m, 0.5))
+                got[v] = e.activation("conv1_2", n)
+                kernels = {r["name"]: r["kernel"] for r in e.layer_table()}
+                assert ("conv1_2_split_kernel" in kernels["conv1_2"]) == bool(v), kernels["conv1_2"]
+            finally:
+                e.close()
+    finally:
+        engine.set_option("conv1_2_split", 1)
+    ref = acts["conv1_2"]
+    scale = 1 + np.abs(ref).max()
+    rel = {"bf16x3": 2e-3, "bf16x6": 2e-4, "fp16x3": 2e-4, "fp16": 4e-3}[precision]      # (test_split_network_layer_by_layer's per-layer bounds; fp16: one 11-bit part)
+    for v in (1, 0):
+        assert np.abs(got[v] - ref).max() <= rel * scale, (precision, v, float(np.abs(got[v] - ref).max()), scale)
+    e1, e0 = float(np.abs(outs[1] - ref_out).max()), float(np.abs(outs[0] - ref_out).max())
+    assert e1 <= 1.5 * e0 + 1e-5, (precision, e1, e0)
