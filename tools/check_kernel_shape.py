@@ -40,7 +40,10 @@ def _llvm_bin():
 LLVM = _llvm_bin()
 # kernel name prefix -> (object, max conditional branches, max scratch instructions); measured at the round-5 HEAD: v2p 92-109, v2m 119-198, ds 63-66, conv1 block 36-47; scratch 0 (v2p<4,2,*>: 6 = three spilled epilogue constants)
 BUDGET = [("conv_igemm_v2p<2, 2,", "idc_v2m.o", 165, 0), ("conv_igemm_v2p<4, 2,", "idc_v2m.o", 140, 12), ("conv_igemm_v2m<", "idc_v2m.o", 300, 0),
-          ("conv_ds_fused_m<", "idc_dsm.o", 100, 0), ("conv1_block_fused_t<4,", "idc_conv1.o", 70, 0)]
+          ("conv_ds_fused_m<", "idc_dsm.o", 100, 0), ("conv1_block_fused_t<4,", "idc_conv1.o", 70, 0),
+          # round 6, the operand-split forms: their K loops are spill-free (the scratch instructions are split_epilogue's fp32 constants: 49-56 measured);
+          # conv_ds_fused_ms once had 21 of them INSIDE its K loops (the S halo's 44 prefetch registers) -- that build counted 102
+          ("conv_ds_fused_ms", "idc_dsm.o", 460, 75), ("conv1_2_split_kernel<", "idc_conv1.o", 65, 0), ("conv1_1_split_kernel<", "idc_conv1.o", 420, 85)]
 
 
 def disassemble(obj):
