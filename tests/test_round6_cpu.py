@@ -232,3 +232,22 @@ def test_fp16_blob_is_one_fp16_image_per_layer(make_sd):
             co, ci, ky, kx = rs.randint(e["cout"]), rs.randint(e["cin"]), rs.randint(3), rs.randint(3)
             val = np.float32(np.float32(w[co, ci, ky, kx]) * np.float32(2.0 ** ex[e["wkey"]]))
             assert _read_w(blob, e, "bf16", ky * 3 + kx, co, ci) == int(np.float16(val).view(np.uint16)), (e["wkey"], co, ci)
+
+
+def test_fp16_weight_scale_is_what_closes_the_gap_to_fp32(make_sd):
+    """Why IDC_FP16X3's weight parts hold w * 2^s: on he-style weights (~0.02) the lo part of an UNSCALED weight is a subnormal fp16 number (6e-8 absolute =
+    2^-18 of the weight).  oracle/emulate.py restates both arithmetics on the CPU (fp16 parts, three products, fp32 accumulation; conv1_1 exact fp32 as on
+    the GPU): the scaled form must sit at the fp32 arithmetic's own distance from the float64 oracle, the unscaled one well above it (GPU, N = 32 256^2:
+    3.9e-3 unscaled, 1.9e-3 scaled, 1.7e-3 fp32 -- profiles/parity_r06_gpu.json, profiles/r06_fp16_wscale_study.txt)."""
+    import torch
+    from interactive_deep_colorization_amd import workloads
+    from oracle import emulate, siggraph_torch
+    sd = make_sd(0, "he")
+    L, ab, m = workloads.random_batch(1, 64, seed=4, max_points=4, max_p=2)
+    ref = siggraph_torch.forward(sd, L, ab, m, 0.0, dtype=torch.float64)
+    err = {}
+    for mode in ("fp32", "splitf2_fp32", "splitf2s_fp32"):
+        out = emulate.forward(sd, L, ab, m, 0.0, default=mode, modes={"conv1_1": "fp32"})
+        err[mode] = emulate.error_stats(out, ref)["mean_abs"]
+    assert err["splitf2s_fp32"] <= 1.5 * err["fp32"], err
+    assert err["splitf2_fp32"] >= 1.8 * err["splitf2s_fp32"], err

@@ -11,7 +11,7 @@ cd $R
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -1 $OUT/bench.json | cut -c1-300
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 5 --warmup 2 --no-latency --no-cpu-baseline --no-end-to-end --no-peak-probe"
+CMD="python $R/bench.py --steps 5 --warmup 2 --no-latency --no-cpu-baseline --no-end-to-end --no-peak-probe --no-contract-leg"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o x -- $CMD > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o x -- $CMD > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o x -- $CMD > $OUT/pmc_write.log 2>&1
