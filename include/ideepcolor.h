@@ -100,6 +100,8 @@ int idc_set_tile_policy(int policy);
  *   "conv1_1_split" (1)  operand-split precisions: conv1_1 (their exact-fp32 island) on conv1_1_split_kernel where the grid is throughput-sized; 0 = conv_igemm<float>.
  *   "conv1_2_split" (1)  ... and conv1_2 (64 -> 64 at full resolution) on conv1_2_split_kernel (conv1_block_fused_t's conv1_2 tile walked per segment); 0 = the generic
  *                      64-cout tile conv_igemm_v2ps<1,4,1>.
+ *   "fp16_fast"   (1)  IDC_FP16: launches the bf16 throughput kernels cover run their fp16 twins (conv_igemm_v2ph, conv_ds_fused_mh); 0 = the one-segment
+ *                      operand-split kernels everywhere.
  *   "kwave"       (1)  bf16 batch-1 click path: 3x3 stride-1 layers and ConvTranspose launches as conv_kwave_bf16 / conv_kwave_deconv_bf16
  *                      (direct form, K split over the waves of a workgroup); 0 = conv_click + split-K (round 2's kernels).
  *   "kwave_chain" (2)  ... and runs of consecutive same-shape 512-channel layers of that path (conv4_2 .. conv7_3 at batch 1) as ONE

@@ -66,8 +66,11 @@ __device__ __forceinline__ unsigned pack_bf16x2_d(float lo, float hi) {
 // A segment is to the loops what a further halo chunk is: the flat chunk index q = seg * nkc + kc selects the pixel's chunk slot seg_x[seg] * nkc + kc and the
 // weight image seg_w[seg]; a chunk change whose slot does not change (one-chunk tensors: hi.lo -> hi.hi) keeps the halo in LDS.  The fp32 shortcut sums of
 // the two-launch form (1.07 GB written and read at conv10_1's shape) never exist.
-template <int NCW, int SPLIT>
+// MODE: 0 = conv_ds_fused_m (bf16), 1 / 2 = the split forms above, 4 = MODE 0's body on fp16 operands (IDC_FP16's fast path)
+template <int NCW, int MODE>
 __device__ __forceinline__ void conv_ds_fused_m_body(const ConvArgs& a) {
+    constexpr int SPLIT = MODE == 4 ? 0 : MODE;
+    constexpr bool F16 = MODE == 2 || MODE == 4;
     constexpr int NT = NCW * 256;
     constexpr int SW = 66, SROWS = 10 * SW, S_ITEMS = (SROWS * kSlots + NT - 1) / NT, S_HALO_BYTES = S_ITEMS * NT * kSlotBytes;
     constexpr int DW = 34, DROWS = 6 * DW, D_ITEMS = (DROWS * kSlots + NT - 1) / NT, D_HALO_BYTES = D_ITEMS * NT * kSlotBytes;
@@ -205,7 +208,7 @@ __device__ __forceinline__ void conv_ds_fused_m_body(const ConvArgs& a) {
     auto mma4 = [&](int mi, int half, const u32x4 (&xf)[4]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            acc[mi][half * 4 + q] = mma_16x16x32<SPLIT == 2>(wf[mi], xf[q], acc[mi][half * 4 + q]);
+            acc[mi][half * 4 + q] = mma_16x16x32<F16>(wf[mi], xf[q], acc[mi][half * 4 + q]);
     };
     // stage A: 16 MFMAs (all cout blocks x pixel rows 0-1) over the 4 reads of rows 2-3
 #define IDC_DSM_STAGE_A()                                                             \
@@ -472,7 +475,7 @@ __device__ __forceinline__ void conv_ds_fused_m_body(const ConvArgs& a) {
                 for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        unsigned p = pack_bf16x2_d(acc[mi][pt][2 * e], acc[mi][pt][2 * e + 1]);
+                        unsigned p = pack16x2_m<F16>(acc[mi][pt][2 * e], acc[mi][pt][2 * e + 1]);
                         if constexpr (RELU) p = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), s16x2{0, 0}));
                         pk[mi * 2 + e] = p;
                     }
@@ -502,6 +505,8 @@ __device__ __forceinline__ void conv_ds_fused_m_body(const ConvArgs& a) {
 
 template <int NCW>
 __global__ __launch_bounds__(NCW * 256, 2) void conv_ds_fused_m(const ConvArgs a) { conv_ds_fused_m_body<NCW, 0>(a); }
+template <int NCW>      // IDC_FP16: conv_ds_fused_m on fp16 operands
+__global__ __launch_bounds__(NCW * 256, 2) void conv_ds_fused_mh(const ConvArgs a) { conv_ds_fused_m_body<NCW, 4>(a); }
 // the operand-split forms: bf16 parts (IDC_BF16X3 / IDC_BF16X6) and fp16 parts (IDC_FP16X3); 8-wave workgroups only
 __global__ __launch_bounds__(512, 2) void conv_ds_fused_ms(const ConvArgs a) { conv_ds_fused_m_body<2, 1>(a); }
 __global__ __launch_bounds__(512, 2) void conv_ds_fused_msh(const ConvArgs a) { conv_ds_fused_m_body<2, 2>(a); }
@@ -526,7 +531,11 @@ hipError_t launch_conv_ds_m(const ConvArgs& a, hipStream_t s) {
     // fewer 128-cout workgroups than CUs (model10up + shortcut of ONE 256x256 image: 128) and a single shortcut chunk: the 64-cout, 4-wave form
     static int n_cu = 0;
     if (n_cu == 0) { int dev = 0; hipDeviceProp_t pr; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : -1; }
-    if (g_ds_half && a.nkc2 == 1 && n_cu > 0 && blocks < n_cu)
+    const bool half = g_ds_half && a.nkc2 == 1 && n_cu > 0 && blocks < n_cu;
+    if (a.split_f16) {                                           // IDC_FP16's fast path
+        if (half) hipLaunchKernelGGL(conv_ds_fused_mh<1>, dim3((unsigned)(2 * blocks)), dim3(256), 160 * 1024, s, a);
+        else hipLaunchKernelGGL(conv_ds_fused_mh<2>, dim3((unsigned)blocks), dim3(512), 160 * 1024, s, a);
+    } else if (half)
         hipLaunchKernelGGL(conv_ds_fused_m<1>, dim3((unsigned)(2 * blocks)), dim3(256), 160 * 1024, s, a);
     else
         hipLaunchKernelGGL(conv_ds_fused_m<2>, dim3((unsigned)blocks), dim3(512), 160 * 1024, s, a);
@@ -549,6 +558,10 @@ hipError_t launch_conv_ds_ms(const ConvArgs& a, hipStream_t s) {
 
 hipError_t init_kernels_dsm() {
     hipError_t e = hipFuncSetAttribute((const void*)conv_ds_fused_m<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)conv_ds_fused_mh<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)conv_ds_fused_mh<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)conv_ds_fused_ms, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;

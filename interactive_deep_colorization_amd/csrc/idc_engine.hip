@@ -316,7 +316,7 @@ static int pack_weights_impl(int precision, unsigned flags, const idc_tensor_des
     // IDC_FP16X3: per-layer power-of-two weight scale (f16_weight_exponent); a deconv and the shortcut conv it is summed with share ONE (the smaller
     // exponent): conv_ds_fused_ms accumulates both K loops into one accumulator set.  Every other precision: exponent 0.
     std::vector<int> wexp(plan.active.size(), 0);
-    if (split_is_f16(precision)) {
+    if (split_is_f16(precision) && split_parts(precision) > 1) {       // (IDC_FP16, one part: a weight keeps its 11 bits down to 6e-5 unscaled)
         for (size_t li = 0; li < plan.active.size(); ++li) {
             const LayerSpec& s = specs[plan.active[li]];
             if (plan.layers[li].f32) continue;
@@ -482,6 +482,7 @@ struct Layer {
     bool v2 = false;                     // bf16 large-tile kernel (layout-2 weights)
     bool m16 = false;                    // ... its 16x16x32-MFMA build (conv_igemm_v2m, layout-1 weights): set per launch in run_graph
     bool v2p = false;                    // ... conv_igemm_v2p (padded halo rows, unrolled taps): set per launch in run_graph
+    bool f16fast = false;                // IDC_FP16: this launch runs the bf16 throughput kernel's fp16 twin (conv_igemm_v2ph / conv_ds_fused_mh): set per launch in run_graph
     bool click = false;                  // batch-1 click-path kernel (conv_click: whole K slice by LDS-DMA)
     bool wino = false;                   // fp32 Winograd F(2x2,3x3) kernel (conv_wino_f32, idc_wino.hip)
     bool kw = false;                     // bf16 click path: conv_kwave_bf16 (idc_kw.hip: K split over the waves of a workgroup, layout-1 weights)
@@ -606,6 +607,9 @@ static int g_split_ds_fuse = 1;
 static int g_conv1_1_split = 1;
 // ... and conv1_2 (64 -> 64 at full resolution) on conv1_2_split_kernel instead of the generic 64-cout tile ("conv1_2_split", 0 = conv_igemm_v2ps<1,4,1>)
 static int g_conv1_2_split = 1;
+// IDC_FP16 (one fp16 part, one segment): launches the bf16 throughput kernels cover run their fp16 twins (conv_igemm_v2ph, conv_ds_fused_mh: bias in the
+// accumulators, packed-pair epilogue) instead of the one-segment split kernels ("fp16_fast", 0 = the split kernels everywhere)
+static int g_fp16_fast = 1;
 static bool conv1_2_split_layer(const LayerSpec& s) {
     return s.kind == kConv3x3 && s.cin == 64 && s.cout == 64 && s.dilation == 1 && s.in_stride == 1 && s.act == 1 && !s.resid;
 }
@@ -1118,6 +1122,9 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
                 return fail(&c->err, IDC_ERR_INTERNAL, "layer %s: no operand-split kernel covers this launch", L.spec->name);
             L.m16 = true;
             L.v2p = L.fused_short < 0 && g_v2p && conv_v2ps_applies(L.cfg, L.halo, a);
+            // IDC_FP16: where the bf16 forward's own kernels cover the launch, their fp16 twins (same tile, bias in the accumulators, packed-pair epilogue)
+            L.f16fast = c->precision == IDC_FP16 && g_fp16_fast && !to.is_f32 &&
+                        (L.fused_short >= 0 ? (L.spec->act != 2 && !L.spec->bnkey && (a.ncg & 1) == 0) : (L.v2 && g_v2p && conv_v2p_applies(L.cfg, L.halo, a)));
         } else if (L.fused_short < 0) {
             L.m16 = L.v2 && g_mfma16 && L.fused_next < 0 && !L.wino && !L.click && conv_v2m_applies(a);
             if (L.m16) a.wgt = c->d_blob + L.blob.w_off;            // the layout-1 image (the one conv_igemm / conv_click read)
@@ -1140,10 +1147,12 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             if (is_split(c->precision) && !L.split && L.spec->kind == kConvIm2col && g_conv1_1_split && a.out_parts >= 1 &&
                 (long long)((a.Ws + 31) / 32) * ((a.Hs + 15) / 16) * c->max_batch >= 128)
                 le = launch_conv1_1_split(a, s);
+            if (L.split && L.f16fast) le = L.fused_short >= 0 ? launch_conv_ds_m(a, s) : launch_conv_v2p(L.cfg, L.halo, a, s);
+            else
             if (L.split && L.fused_short < 0 && g_conv1_2_split && conv1_2_split_layer(*L.spec) && !to.is_f32 &&
                 (long long)((a.Ws + 31) / 32) * ((a.Hs + 11) / 12) * c->max_batch >= 256)
                 le = launch_conv1_2_split(a, s);
-            if (L.fused_short >= 0) le = L.split ? launch_conv_ds_ms(a, s) : L.m16 ? launch_conv_ds_m(a, s) : launch_conv_ds(a, s);
+            if (L.fused_short >= 0 && !(L.split && L.f16fast)) le = L.split ? launch_conv_ds_ms(a, s) : L.m16 ? launch_conv_ds_m(a, s) : launch_conv_ds(a, s);
             if (L.fused_short >= 0 && L.split && le == hipErrorInvalidConfiguration)
                 return fail(&c->err, IDC_ERR_INTERNAL, "layer %s: conv_ds_fused_ms planned for a launch it does not cover", L.spec->name);
     // deconv + its shortcut conv in one K loop
@@ -1474,6 +1483,7 @@ int idc_set_option(const char* name, int value) {
     if (strcmp(name, "split_ds_fuse") == 0) { g_split_ds_fuse = value != 0; return IDC_OK; }
     if (strcmp(name, "conv1_1_split") == 0) { g_conv1_1_split = value != 0; return IDC_OK; }
     if (strcmp(name, "conv1_2_split") == 0) { g_conv1_2_split = value != 0; return IDC_OK; }
+    if (strcmp(name, "fp16_fast") == 0) { g_fp16_fast = value != 0; return IDC_OK; }
     if (strcmp(name, "kwave") == 0) { g_kwave = value != 0; return IDC_OK; }
     if (strcmp(name, "spin_sync") == 0) { g_spin_sync = value != 0; return IDC_OK; }
     if (strcmp(name, "pcie_kernel") == 0) { g_pcie_kernel = value != 0; return IDC_OK; }
@@ -2350,6 +2360,7 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
                                                                                                     : (L.v2p ? "conv_igemm_v2ps<%d,%d>x%d" : "conv_igemm_v2s<%d,%d>x%d"),
                                   L.cfg.wm, L.cfg.wp, split_segments(h->precision));
             else if (L.m16) strncat(out->kernel, L.v2p ? "+m16p" : "+m16", sizeof(out->kernel) - strlen(out->kernel) - 1);
+            if (L.split && L.f16fast) snprintf(out->kernel, sizeof(out->kernel), "conv_igemm_v2ph<%d,%d>", L.cfg.wm, L.cfg.wp);
             if (is_split(h->precision) && !L.split && L.spec->kind == kConvIm2col && g_conv1_1_split && !h->tensors[L.dst].is_f32 &&
                 (long long)((h->W + 31) / 32) * ((h->H + 15) / 16) * h->max_batch >= 128)
                 snprintf(out->kernel, sizeof(out->kernel), "conv1_1_split_kernel");
@@ -2371,7 +2382,8 @@ int idc_layer_info_get(idc_handle h, int layer, idc_layer_info* out) {
             if (L.fused_short >= 0) {
                 const Layer& P = h->layers[L.fused_short];
                 // the name rocprofv3 shows for this launch (the deconv and its 3x3 shortcut conv in one K loop)
-                if (L.split) snprintf(out->kernel, sizeof(out->kernel), split_is_f16(h->precision) ? "conv_ds_fused_msh+shortcut x%d" : "conv_ds_fused_ms+shortcut x%d", L.args.nseg);
+                if (L.split && L.f16fast) snprintf(out->kernel, sizeof(out->kernel), "conv_ds_fused_mh+shortcut");
+                else if (L.split) snprintf(out->kernel, sizeof(out->kernel), split_is_f16(h->precision) ? "conv_ds_fused_msh+shortcut x%d" : "conv_ds_fused_ms+shortcut x%d", L.args.nseg);
                 else snprintf(out->kernel, sizeof(out->kernel), L.m16 ? "conv_ds_fused_m+shortcut" : "conv_ds_fused+shortcut");
                 out->flops += P.flops;
                 // (the shortcut sums are neither written nor read: fp32 in the operand-split graph, bf16 otherwise)
@@ -2533,7 +2545,7 @@ static int run_single_op(int device_id, int precision, LayerSpec spec, int n, in
         if (wino_ok) L.blob.w_bytes = (size_t)weight_taps(spec.kind) * L.blob.nkc * L.blob.ncg * kWBlockBytes;
         L.m16 = split || (L.v2 && g_mfma16 && resid == nullptr && spec.act != 2);       // as in the network: conv_igemm_v2m where it applies
         const size_t wcount = (size_t)spec.cin * spec.cout * (spec.kind == kDeconv4x4 ? 16 : spec.kind == kConv1x1 ? 1 : 9);
-        op_wexp = split_is_f16(precision) ? f16_weight_exponent(weight, wcount) : 0;      // as the blob packer does per layer
+        op_wexp = (split_is_f16(precision) && parts > 1) ? f16_weight_exponent(weight, wcount) : 0;      // as the blob packer does per layer
         for (int part = 0; part < parts; ++part)
             pack_layer_weights(wimg.data() + (size_t)part * L.blob.w_bytes, precision, (L.v2 && !L.m16) ? 2 : 1, spec, L.blob, weight, part, ldexpf(1.f, op_wexp));
     }

@@ -36,6 +36,10 @@ __device__ __forceinline__ unsigned pack_f16x2_m(float lo, float hi) {
     const float a = __builtin_fminf(__builtin_fmaxf(lo, -65504.f), 65504.f), b = __builtin_fminf(__builtin_fmaxf(hi, -65504.f), 65504.f);
     return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_pk){a, b}, f16x2_pk));
 }
+// two fp32 -> one dword of 16-bit values: bf16 (RNE) or fp16 (RNE, clamped)
+template <bool F16> __device__ __forceinline__ unsigned pack16x2_m(float lo, float hi) {
+    if constexpr (F16) return pack_f16x2_m(lo, hi); else return pack_bf16x2_m(lo, hi);
+}
 __device__ __forceinline__ float f16_lo_to_f32(unsigned q) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(q & 0xffffu)); }
 __device__ __forceinline__ float f16_hi_to_f32(unsigned q) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(q >> 16)); }
 

@@ -411,8 +411,12 @@ __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2sh(const ConvAr
 // ================================================================================================
 
 // SPLIT = true: conv_igemm_v2ps, the operand-split form (as conv_igemm_v2s is conv_igemm_v2m's): a.nseg passes over the nkc chunks, split epilogue.
-template <int WCO, int WPX, int D, int SPLIT>
+// MODE: 0 = conv_igemm_v2p (bf16), 1 / 2 = the operand-split forms on bf16 / fp16 parts, 4 = conv_igemm_v2ph: MODE 0's body on fp16 operands (IDC_FP16's
+// fast path: v_mfma_f32_16x16x32_f16, fp16 stores clamped to the fp16 range; everything else textually MODE 0)
+template <int WCO, int WPX, int D, int MODE>
 __device__ __forceinline__ void conv_v2p_body(const ConvArgs& a) {
+    constexpr int SPLIT = MODE == 4 ? 0 : MODE;
+    constexpr bool F16 = MODE == 2 || MODE == 4;
     constexpr int NT = WCO * WPX * 64;
     constexpr int TW = 32, TH = 4 * WPX, HALO = D;
     constexpr int HWP = TW + 2 * HALO, HHP = TH + 2 * HALO, HROWS = HWP * HHP, HP = kRowBytes;
@@ -553,7 +557,7 @@ __device__ __forceinline__ void conv_v2p_body(const ConvArgs& a) {
             auto mma4 = [&](int mi, int half, const u32x4 (&xf)[4]) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    acc[mi][half * 4 + q] = mma_16x16x32<SPLIT == 2>(wf[mi], xf[q], acc[mi][half * 4 + q]);
+                    acc[mi][half * 4 + q] = mma_16x16x32<F16>(wf[mi], xf[q], acc[mi][half * 4 + q]);
             };
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) wf[mi] = *(const u32x4*)(a0 + mi * 16 * kRowBytes);
@@ -723,9 +727,9 @@ __device__ __forceinline__ void conv_v2p_body(const ConvArgs& a) {
                         float v0 = acc[mi][pt][2 * e], v1 = acc[mi][pt][2 * e + 1];
                         if constexpr (BN) {
                             if constexpr (RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-                            pk[mi * 2 + e] = pack_bf16x2_m(fmaf(v0, bsc[mi][2 * e], bsh[mi][2 * e]), fmaf(v1, bsc[mi][2 * e + 1], bsh[mi][2 * e + 1]));
+                            pk[mi * 2 + e] = pack16x2_m<F16>(fmaf(v0, bsc[mi][2 * e], bsh[mi][2 * e]), fmaf(v1, bsc[mi][2 * e + 1], bsh[mi][2 * e + 1]));
                         } else {
-                            unsigned p = pack_bf16x2_m(v0, v1);
+                            unsigned p = pack16x2_m<F16>(v0, v1);
                             if constexpr (RELU) p = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), s16x2{0, 0}));
                             pk[mi * 2 + e] = p;
                         }
@@ -763,6 +767,8 @@ __device__ __forceinline__ void conv_v2p_body(const ConvArgs& a) {
 
 template <int WCO, int WPX, int D>
 __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2p(const ConvArgs a) { conv_v2p_body<WCO, WPX, D, 0>(a); }
+template <int WCO, int WPX, int D>      // IDC_FP16: conv_igemm_v2p on fp16 operands
+__global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2ph(const ConvArgs a) { conv_v2p_body<WCO, WPX, D, 4>(a); }
 template <int WCO, int WPX, int D>
 __global__ __launch_bounds__(WCO* WPX * 64, 2) void conv_igemm_v2ps(const ConvArgs a) { conv_v2p_body<WCO, WPX, D, 1>(a); }
 template <int WCO, int WPX, int D>
@@ -795,8 +801,10 @@ hipError_t launch_conv_v2p(ConvConfig cfg, int halo, const ConvArgs& a, hipStrea
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
 #define X(WCO, WPX, DD)                                                                                                          \
     if (cfg.wm == WCO && cfg.wp == WPX && halo == DD) {                                                                          \
-        hipLaunchKernelGGL((conv_igemm_v2p<WCO, WPX, DD>), dim3((unsigned)blocks), dim3(WCO * WPX * 64),                         \
-                           conv_v2p_lds_bytes_c(WCO, WPX, DD), s, a);                                                            \
+        if (a.split_f16) hipLaunchKernelGGL((conv_igemm_v2ph<WCO, WPX, DD>), dim3((unsigned)blocks), dim3(WCO * WPX * 64),       \
+                                            conv_v2p_lds_bytes_c(WCO, WPX, DD), s, a);          /* IDC_FP16's fast path */           \
+        else hipLaunchKernelGGL((conv_igemm_v2p<WCO, WPX, DD>), dim3((unsigned)blocks), dim3(WCO * WPX * 64),                    \
+                                conv_v2p_lds_bytes_c(WCO, WPX, DD), s, a);                                                       \
         return hipGetLastError();                                                                                                \
     }
     IDC_FOR_EACH_CONV_V2P(X)
@@ -910,6 +918,9 @@ hipError_t init_kernels_v2m() {
 #undef X
 #define X(WCO, WPX, DD)                                                                                                          \
     e = hipFuncSetAttribute((const void*)conv_igemm_v2p<WCO, WPX, DD>, hipFuncAttributeMaxDynamicSharedMemorySize,               \
+                            (int)conv_v2p_lds_bytes_c(WCO, WPX, DD));                                                            \
+    if (e != hipSuccess) return e;                                                                                               \
+    e = hipFuncSetAttribute((const void*)conv_igemm_v2ph<WCO, WPX, DD>, hipFuncAttributeMaxDynamicSharedMemorySize,              \
                             (int)conv_v2p_lds_bytes_c(WCO, WPX, DD));                                                            \
     if (e != hipSuccess) return e;
     IDC_FOR_EACH_CONV_V2P(X)

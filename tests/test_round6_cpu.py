@@ -215,23 +215,22 @@ def test_cpu_baseline_times_the_reference_module_where_it_exists():
 
 
 def test_fp16_blob_is_one_fp16_image_per_layer(make_sd):
-    """IDC_FP16: the split plan with ONE part -- an fp16 image of w * 2^s per layer (s as IDC_FP16X3's), conv1_1 an fp32 image."""
+    """IDC_FP16: the split plan with ONE part -- an fp16 image of w per layer, UNSCALED (one part keeps its 11 bits down to |w| = 6e-5, and the fp16 twins of
+    the bf16 throughput kernels start their accumulators at the bias: no factor to take back), the scale slot 1.0, conv1_1 an fp32 image."""
     sd = make_sd(0, "he")
     blob = engine.pack_weights(sd, "fp16")
     plan, total = _split_plan(1)
     assert blob.size == total == N.load().idc_weights_blob_bytes(N.IDC_FP16, 0)
     assert blob[8:12].view(np.uint32)[0] == N.IDC_FP16
-    ex = _f16_exponents(sd, plan)
     rs = np.random.RandomState(3)
     for e in plan:
         if e["island"] or e["kind"] != "c3":
             continue
         w = sd[e["wkey"] + ".weight"]
-        assert blob[e["ws_off"]:e["ws_off"] + 4].view(np.float32)[0] == np.float32(2.0 ** -ex[e["wkey"]])
+        assert blob[e["ws_off"]:e["ws_off"] + 4].view(np.float32)[0] == 1.0
         for _ in range(10):
             co, ci, ky, kx = rs.randint(e["cout"]), rs.randint(e["cin"]), rs.randint(3), rs.randint(3)
-            val = np.float32(np.float32(w[co, ci, ky, kx]) * np.float32(2.0 ** ex[e["wkey"]]))
-            assert _read_w(blob, e, "bf16", ky * 3 + kx, co, ci) == int(np.float16(val).view(np.uint16)), (e["wkey"], co, ci)
+            assert _read_w(blob, e, "bf16", ky * 3 + kx, co, ci) == int(np.float16(np.float32(w[co, ci, ky, kx])).view(np.uint16)), (e["wkey"], co, ci)
 
 
 def test_fp16_weight_scale_is_what_closes_the_gap_to_fp32(make_sd):

@@ -249,29 +249,40 @@ def test_conv1_1_split_kernel_against_the_generic_island(precision):
 
 @pytest.mark.parametrize("style", ["torch", "he"])
 def test_fp16_precision_is_the_split_machinery_with_one_part(style):
-    """precision="fp16" (IDC_FP16): plain fp16 operands (11 significant bits against bf16's 8), fp32 accumulation, per-layer power-of-two weight scale,
-    conv1_1 exact fp32 -- every layer on the operand-split kernels with one part and one segment.  Against the float64 oracle it must sit well inside the
-    bf16 path's bounds (tests/bounds.py: 0.3 torch-init / 16 he-style at 256^2; measured here ~1 / 8 of bf16's error) and run to run identical."""
+    """precision="fp16" (IDC_FP16): plain fp16 operands (11 significant bits against bf16's 8), fp32 accumulation, conv1_1 exact fp32 -- the operand-split
+    graph with one part and one segment, its launches on the fp16 twins of the bf16 throughput kernels (conv_igemm_v2ph, conv_ds_fused_mh; option fp16_fast,
+    0 = the one-segment split kernels).  Against the float64 oracle it must sit well inside the bf16 path's bounds (measured ~1 / 8 of bf16's error), run
+    to run identical, and the two kernel sets must agree to fp16's own rounding."""
     from oracle import siggraph_torch
     from tests.conftest import state_dict_for
     sd = state_dict_for(0, style)
     L, ab, m = workloads.random_batch(2, 64, seed=3, max_points=6, max_p=3)
     ref = siggraph_torch.forward(sd, L, ab, m, 0.5, dtype=torch.float64)
-    errs = {}
-    for precision in ("fp16", "bf16"):
-        e = engine.HipColorizer(64, 64, max_batch=2, precision=precision)
-        try:
-            e.load_state_dict(sd)
-            out = e.forward(L, ab, m, 0.5)
-            assert np.array_equal(out, e.forward(L, ab, m, 0.5))
-            if precision == "fp16":
+    errs, outs = {}, {}
+    try:
+        for precision, fast in (("fp16", 1), ("fp16", 0), ("bf16", 1)):
+            engine.set_option("fp16_fast", fast)
+            e = engine.HipColorizer(64, 64, max_batch=2, precision=precision)
+            try:
+                e.load_state_dict(sd)
+                out = e.forward(L, ab, m, 0.5)
+                assert np.array_equal(out, e.forward(L, ab, m, 0.5))
                 kernels = set(r["kernel"].split("<")[0].split("+")[0].split(" ")[0] for r in e.layer_table() if r["launches"] > 0 and r["kernel"].startswith("conv"))
-                assert kernels <= {"conv_igemm_v2psh", "conv_igemm_v2sh", "conv_ds_fused_msh", "conv1_1_split_kernel", "conv_igemm"}, kernels
-        finally:
-            e.close()
-        errs[precision] = float(np.abs(out - ref).max())
-    assert errs["fp16"] <= (0.05 if style == "torch" else 4.0), errs
-    assert errs["fp16"] <= 0.4 * errs["bf16"], errs
+                if precision == "fp16" and fast:
+                    assert {"conv_igemm_v2ph", "conv_ds_fused_mh"} <= kernels <= {"conv_igemm_v2ph", "conv_ds_fused_mh", "conv_igemm_v2psh", "conv_igemm_v2sh",
+                                                                                  "conv1_1_split_kernel", "conv1_2_split_kernel", "conv_igemm"}, kernels
+                elif precision == "fp16":
+                    assert kernels <= {"conv_igemm_v2psh", "conv_igemm_v2sh", "conv_ds_fused_msh", "conv1_1_split_kernel", "conv1_2_split_kernel", "conv_igemm"}, kernels
+            finally:
+                e.close()
+            errs[(precision, fast)] = float(np.abs(out - ref).max())
+            outs[(precision, fast)] = out
+    finally:
+        engine.set_option("fp16_fast", 1)
+    for key in (("fp16", 1), ("fp16", 0)):
+        assert errs[key] <= (0.05 if style == "torch" else 4.0), errs
+        assert errs[key] <= 0.4 * errs[("bf16", 1)], errs
+    assert np.abs(outs[("fp16", 1)] - outs[("fp16", 0)]).max() <= 2.0 * max(errs[("fp16", 1)], errs[("fp16", 0)])
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16x6", "fp16x3", "fp16"])
