@@ -58,8 +58,9 @@ typedef enum idc_precision { IDC_FP32 = 0, IDC_BF16 = 1, IDC_BF16X3 = 2, IDC_BF1
  * weight is a normal fp16 number: at the IDC_FP32 path's distance from the float64 oracle on BOTH weight styles (N = 32: 2.2e-5 torch-default-init,
  * 1.9e-3 full-range, against 2.3e-5 / 1.7e-3; without the scale full-range weights ~0.02 had subnormal lo parts and 3.9e-3), at BF16X3's rate.
  * The price is fp16's range for ACTIVATIONS: beyond +-65504 they saturate (the conversions clamp; nothing becomes inf), below 6e-5 they keep 6e-8 absolute.
- * FP16 (round 6): FP16X3's machinery with ONE part and ONE product -- plain fp16 operands (11 significant bits against bf16's 8; weights scaled per layer
- * as above), fp32 accumulation, every layer on the throughput tiles: 1 / 8 of IDC_BF16's rounding error at ~0.9 of its N = 32 rate.  Not a 1e-3 path.
+ * FP16 (round 6): FP16X3's graph with ONE part and ONE product -- plain fp16 operands (11 significant bits against bf16's 8; unscaled weights), fp32
+ * accumulation, every layer on the throughput tiles, the launches on the fp16 twins of the bf16 kernels: 1 / 9 ... 1 / 7 of IDC_BF16's rounding error at
+ * 0.96 of its N = 32 rate.  Not a 1e-3 path.
  * The layers of this net are BatchNorm-ed / ReLU-ed activations of O(1..100); a checkpoint with larger activations wants BF16X6. */
 
 /* idc_create flags */

@@ -12,6 +12,13 @@
 
 namespace idc {
 
+// one 32x32x16 MFMA step on two 16-byte fragments: bf16 or fp16 operands, fp32 accumulate
+template <bool F16>
+__device__ __forceinline__ f32x16 mma_32x32x16(const u32x4& w, const u32x4& x, const f32x16& c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_m, w), __builtin_bit_cast(f16x8_m, x), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
+}
+
 constexpr int conv1_block_lds(int nw, int rpw, bool lw) { return 34 * (nw * rpw + 2) * 128 + 36 * (nw * rpw + 4) * 8 + (lw ? 2 * kWBlockBytes : 0); }
 
 #ifdef IDC_AB_PARTNERS      // conv1_1 alone at throughput size: "fuse_conv1" = 0 A/B only (the default library keeps it on conv_igemm)
@@ -166,8 +173,10 @@ hipError_t launch_conv1_1_bf16(const ConvArgs&, hipStream_t) { return hipErrorIn
 // waves, requested one tap ahead, one barrier per tap) instead of global -> registers per wave: the L2 -> CU stream of the phase drops
 // by the number of waves, which is what kept the small tiles from paying (profiles/r03_conv1_tile8.txt); <4,3,true> = 32x12 tile at
 // exactly 80 KiB and <4,2,true> = 32x8 at 62 KiB: two workgroups per CU.
-template <int NW, int RPW, bool LW>
-__global__ __launch_bounds__(NW * 64, (NW == 8 || LW) ? 2 : 3) void conv1_block_fused_t(const ConvArgs a) {
+// F16 (round 6, IDC_FP16's fast path): the same block on fp16 operands -- v_mfma_f32_32x32x16_f16, the patch / the conv1_1 tile / the output as fp16 (clamped
+// to the fp16 range); a.wgt / a.wgt2 = the fp16 layout-1 images.  Everything else textually the bf16 block.
+template <int NW, int RPW, bool LW, bool F16>
+__device__ __forceinline__ void conv1_block_body(const ConvArgs& a) {
     constexpr int NT = NW * 64, TH = NW * RPW;
     constexpr int HW_ = 34, HH_ = TH + 2, PW = 36, PH = TH + 4, NSITE = HW_ * HH_;
     constexpr int HALO_BYTES = NSITE * kRowBytes;              // 147,968
@@ -238,7 +247,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || LW) ? 2 : 3) void conv1_block_
             const int idx = tid + j * NT;
             uint2 c = uint2{0u, 0u};
             if (ok[j])
-                c = uint2{pack_bf16x2(vl[j] / a.pk_ldiv, va[j] / a.pk_abdiv), pack_bf16x2(vb[j] / a.pk_abdiv, vm[j] * a.pk_mmul - a.pk_mcent)};
+                c = uint2{pack16x2_m<F16>(vl[j] / a.pk_ldiv, va[j] / a.pk_abdiv), pack16x2_m<F16>(vb[j] / a.pk_abdiv, vm[j] * a.pk_mmul - a.pk_mcent)};
             if (idx < PW * PH) patch[idx] = c;
         }
     }
@@ -287,8 +296,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || LW) ? 2 : 3) void conv1_block_
                 const u32x4 xf = u32x4{q0.x, q0.y, q1.x, q1.y};
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
-                    c1[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[kk][mi]),
-                                                                     __builtin_bit_cast(bf16x8, xf), c1[mi], 0, 0, 0);
+                    c1[mi] = mma_32x32x16<F16>(wf[kk][mi], xf, c1[mi]);
             }
             if (live) {
 #pragma unroll
@@ -296,7 +304,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || LW) ? 2 : 3) void conv1_block_
                     unsigned pk[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        pk[e] = pack_bf16x2(c1[mi][2 * e], c1[mi][2 * e + 1]);
+                        pk[e] = pack16x2_m<F16>(c1[mi][2 * e], c1[mi][2 * e + 1]);
                         if (a.act == 1)
                             pk[e] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk[e]), s16x2{0, 0}));
                         if (!inimg) pk[e] = 0u;
@@ -355,8 +363,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || LW) ? 2 : 3) void conv1_block_
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int pj = 0; pj < RPW; ++pj)
-                    acc[mi][pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wcur[kk][mi]),
-                                                                          __builtin_bit_cast(bf16x8, xf[pj]), acc[mi][pj], 0, 0, 0);
+                    acc[mi][pj] = mma_32x32x16<F16>(wcur[kk][mi], xf[pj], acc[mi][pj]);
         };
 #define IDC_C1_INTERLEAVE()                                                           \
     _Pragma("unroll") for (int q_ = 0; q_ < RPW; ++q_) {                             \
@@ -419,8 +426,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || LW) ? 2 : 3) void conv1_block_
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int pj = 0; pj < RPW; ++pj)
-                    acc[mi][pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[mi]),
-                                                                          __builtin_bit_cast(bf16x8, xf[pj]), acc[mi][pj], 0, 0, 0);
+                    acc[mi][pj] = mma_32x32x16<F16>(wf[mi], xf[pj], acc[mi][pj]);
         };
 #define IDC_C1L_INTERLEAVE()                                                          \
     _Pragma("unroll") for (int q_ = 0; q_ < RPW + 2; ++q_) {                         \
@@ -479,7 +485,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || LW) ? 2 : 3) void conv1_block_
                 for (int e = 0; e < 8; ++e) {
                     float v0 = fmaxf(acc[mi][pj][2 * e], 0.f), v1 = fmaxf(acc[mi][pj][2 * e + 1], 0.f);
                     if constexpr (BN) { v0 = fmaf(v0, bsc[mi][2 * e], bsh[mi][2 * e]); v1 = fmaf(v1, bsc[mi][2 * e + 1], bsh[mi][2 * e + 1]); }
-                    pk[e] = pack_bf16x2(v0, v1);
+                    pk[e] = pack16x2_m<F16>(v0, v1);
                 }
                 const int s0 = h * 4 + mi * 2;
                 *(uint4*)(tb16 + px * 128 + ((s0 ^ (px & 7)) * 16)) = uint4{pk[0], pk[1], pk[2], pk[3]};
@@ -506,6 +512,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || LW) ? 2 : 3) void conv1_block_
 #endif
 }
 
+template <int NW, int RPW, bool LW>
+__global__ __launch_bounds__(NW * 64, (NW == 8 || LW) ? 2 : 3) void conv1_block_fused_t(const ConvArgs a) { conv1_block_body<NW, RPW, LW, false>(a); }
+template <int NW, int RPW, bool LW>      // IDC_FP16: the block on fp16 operands
+__global__ __launch_bounds__(NW * 64, (NW == 8 || LW) ? 2 : 3) void conv1_block_fused_th(const ConvArgs a) { conv1_block_body<NW, RPW, LW, true>(a); }
+
 // model1 (conv1_1 + conv1_2) in one launch.  `a` = conv1_1's arguments (fused-pack planes, layout-1 weights, bias, act)
 // with conv1_2's riding in: wgt2 = its layout-1 weights (9 taps x 8 KiB), head_b = its bias, bn_scale/bn_shift = its
 // eval-BN affine, out = its output.  conv1_2 is ReLU + (optional) BN, 64 -> 64.
@@ -524,6 +535,10 @@ hipError_t init_kernels_conv1() {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)conv1_block_fused_t<4, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv1_block_lds(4, 3, true));
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)conv1_block_fused_th<4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv1_block_lds(4, 2, true));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)conv1_block_fused_th<4, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv1_block_lds(4, 3, true));
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void*)conv1_block_fused_t<8, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, conv1_block_lds(8, 4, false));
 }
 
@@ -534,6 +549,12 @@ hipError_t launch_conv1_block(const ConvArgs& a, hipStream_t s) {
     const int th = !big ? 8 : g_c1_lw ? 12 : 32;
     const long long blocks = (long long)((a.Ws + 31) / 32) * ((a.Hs + th - 1) / th) * a.N;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (a.split_f16) {                                       // IDC_FP16's fast path: the ring forms only
+        if (!big) hipLaunchKernelGGL((conv1_block_fused_th<4, 2, true>), dim3((unsigned)blocks), dim3(256), conv1_block_lds(4, 2, true), s, a);
+        else hipLaunchKernelGGL((conv1_block_fused_th<4, 3, true>), dim3((unsigned)((long long)((a.Ws + 31) / 32) * ((a.Hs + 11) / 12) * a.N)), dim3(256),
+                                conv1_block_lds(4, 3, true), s, a);
+        return hipGetLastError();
+    }
     if (!big) hipLaunchKernelGGL((conv1_block_fused_t<4, 2, true>), dim3((unsigned)blocks), dim3(256), conv1_block_lds(4, 2, true), s, a);
     else if (g_c1_lw) hipLaunchKernelGGL((conv1_block_fused_t<4, 3, true>), dim3((unsigned)blocks), dim3(256), conv1_block_lds(4, 3, true), s, a);
     else hipLaunchKernelGGL((conv1_block_fused_t<8, 4, false>), dim3((unsigned)blocks), dim3(512), conv1_block_lds(8, 4, false), s, a);

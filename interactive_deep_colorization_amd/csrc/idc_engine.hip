@@ -69,6 +69,9 @@ BlobPlan make_blob_plan(int precision, unsigned flags) {
         lb.w2_off = (size_t)-1;
         // (layout 2 = the 32x32x16-MFMA kernels' image: partner build only; the default library's bf16 blob is 70 MB instead of 136)
         if (kAbPartners && precision == IDC_BF16 && v2_eligible(s)) { off = align_up(off, 256); lb.w2_off = off; off += lb.w_bytes; }
+        // IDC_FP16: conv1_1 also as ONE fp16 layout-1 block (K = 36 in a 64-wide chunk) -- what conv1_block_fused_th reads; the fp32 island image above stays
+        // for the launches the block does not take
+        if (precision == IDC_FP16 && s.kind == kConvIm2col) { off = align_up(off, 256); lb.w2_off = off; off += kWBlockBytes; }
         lb.w3_off = (size_t)-1; lb.w3_bytes = 0;
         if (wino_l && wino_eligible(s) && s.cin % kc == 0) {                            // fp32: every batch size; bf16: the batch-1 click path
             lb.w3_bytes = (size_t)s.cin * cout_pad(s.cout) * 16 * elem_bytes(lprec);   // 16 transformed values per (cin, cout)
@@ -354,7 +357,10 @@ static int pack_weights_impl(int precision, unsigned flags, const idc_tensor_des
         if (lb.wscale_off != (size_t)-1) *(float*)(base + lb.wscale_off) = ldexpf(1.f, -wexp[li]);
         for (int part = 0; part < lb.parts; ++part)
             tasks.push_back([=]() { pack_layer_weights(base + lbp->w_off + (size_t)part * lbp->w_bytes, lprec, 1, *sp, *lbp, wd, part, wmul); });
-        if (lb.w2_off != (size_t)-1) tasks.push_back([=]() { pack_layer_weights(base + lbp->w2_off, lprec, 2, *sp, *lbp, wd); });
+        if (precision == IDC_FP16 && s.kind == kConvIm2col && lb.w2_off != (size_t)-1) {
+            LayerBlob lbc = lb; lbc.nkc = 1; lbc.w_bytes = kWBlockBytes;           // one 64-wide fp16 chunk
+            tasks.push_back([=]() { pack_layer_weights(base + lbc.w2_off, (int)IDC_FP16, 1, *sp, lbc, wd, 0, 1.f); });
+        } else if (lb.w2_off != (size_t)-1) tasks.push_back([=]() { pack_layer_weights(base + lbp->w2_off, lprec, 2, *sp, *lbp, wd); });
         if (lb.w3_off != (size_t)-1) {
             if (s.kind == kDeconv4x4) tasks.push_back([=]() { pack_wino_deconv_weights(base + lbp->w3_off, lprec, *sp, *lbp, wd); });
             else tasks.push_back([=]() { pack_wino_weights(base + lbp->w3_off, lprec, *sp, *lbp, wd); });
@@ -992,7 +998,8 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
     // model1 in one launch: conv1_1 (input pack fused) followed by conv1_2 on the small-tile bf16 path, >= 128 big tiles
     for (size_t i = 0; i + 1 < c->layers.size(); ++i) {
         Layer& L = c->layers[i];
-        if (L.spec->kind != kConvIm2col || c->precision != IDC_BF16 || !g_fuse_conv1 || L.spec->act != 1 || L.spec->bnkey) continue;
+        const bool f16blk = c->precision == IDC_FP16 && g_fp16_fast && L.blob.w2_off != (size_t)-1;      // IDC_FP16: conv1_block_fused_th
+        if (L.spec->kind != kConvIm2col || (c->precision != IDC_BF16 && !f16blk) || !g_fuse_conv1 || L.spec->act != 1 || L.spec->bnkey) continue;
         // 32x32 tiles when there are >= 128 of them (N = 32); else the 32x8 tile (conv1_block_fused_t<4,2>) when THAT gives >= 128
         // workgroups -- the batch-1 click path: one launch instead of conv1_1 + conv1_2 and no 8 MB intermediate
         const long long t32 = (long long)((c->W + 31) / 32) * ((c->H + 31) / 32) * c->max_batch;
@@ -1002,7 +1009,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
         for (size_t j = 0; j < c->layers.size(); ++j) {
             Layer& P = c->layers[j];
             const LayerSpec& ps = *P.spec;
-            if (P.src != L.dst || P.v2 || ps.kind != kConv3x3 || ps.cin != 64 || ps.cout != 64 || ps.dilation != 1 ||
+            if (P.src != L.dst || (P.v2 && !f16blk) || ps.kind != kConv3x3 || ps.cin != 64 || ps.cout != 64 || ps.dilation != 1 ||
                 ps.in_stride != 1 || ps.act != 1 || ps.resid || c->tensors[P.dst].is_f32 || P.args.ksplit > 1 || P.click || P.wino) continue;
             bool only_consumer = true;
             for (const Layer& Q : c->layers) if (&Q != &P && (Q.src == L.dst || Q.resid == L.dst)) only_consumer = false;
@@ -1107,6 +1114,10 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             }
             a.partial = c->d_partial;
         }
+        if (L.fused_next >= 0 && c->precision == IDC_FP16) {
+            a.wgt = c->d_blob + L.blob.w2_off;               // conv1_1's fp16 block (conv1_block_fused_th)
+            a.out_parts = 0; a.ksplit = 1; a.kc_per = a.nkc;
+        } else
         if (is_split(c->precision) && !L.split) {        // fp32 island: conv_igemm<f32> with a split store (no split-K: its epilogue kernel writes fp32)
             a.out_parts = to.is_f32 ? 0 : to.parts;
             a.out_f32 = 1; a.ksplit = 1; a.kc_per = a.nkc;
@@ -1144,7 +1155,7 @@ static int run_graph(idc_context* c, int n, const float* dL, const float* dab, c
             else if (L.spec->kind == kConvIm2col && L.lprec == IDC_BF16 && a.ksplit <= 1 &&
                 (long long)((a.Ws + 31) / 32) * ((a.Hs + 31) / 32) * c->max_batch >= 128)
                 le = launch_conv1_1_bf16(a, s);
-            if (is_split(c->precision) && !L.split && L.spec->kind == kConvIm2col && g_conv1_1_split && a.out_parts >= 1 &&
+            if (is_split(c->precision) && !L.split && L.fused_next < 0 && L.spec->kind == kConvIm2col && g_conv1_1_split && a.out_parts >= 1 &&
                 (long long)((a.Ws + 31) / 32) * ((a.Hs + 15) / 16) * c->max_batch >= 128)
                 le = launch_conv1_1_split(a, s);
             if (L.split && L.f16fast) le = L.fused_short >= 0 ? launch_conv_ds_m(a, s) : launch_conv_v2p(L.cfg, L.halo, a, s);

@@ -16,7 +16,7 @@ from interactive_deep_colorization_amd import engine
 from test_abi_cpu import LAYERS, _al, _bf16_bits, _read_w
 
 
-def _split_plan(parts, dist=False):
+def _split_plan(parts, dist=False, fp16_block=False):
     off, plan = 64, []
     for wkey, bnkey, kind, cin, cout in LAYERS:
         if wkey == "model_class.0" and not dist:
@@ -29,6 +29,8 @@ def _split_plan(parts, dist=False):
         e = dict(wkey=wkey, bnkey=bnkey, kind=kind, cin=cin, cout=cout, cpad=cpad, nkc=nkc, ncg=cpad // 64, ntap=ntap, island=island)
         e["w_bytes"] = ntap * nkc * e["ncg"] * 8192
         off = _al(off); e["w_off"] = off; off += e["w_bytes"] * (1 if island else parts)
+        if island and fp16_block:           # IDC_FP16: conv1_1 also as one fp16 layout-1 block (conv1_block_fused_th's operand)
+            off = _al(off); e["w2_off"] = off; off += 8192
         off = _al(off); e["b_off"] = off; off += cpad * 4
         if bnkey:
             off = _al(off); off += cpad * 4
@@ -219,12 +221,20 @@ def test_fp16_blob_is_one_fp16_image_per_layer(make_sd):
     the bf16 throughput kernels start their accumulators at the bias: no factor to take back), the scale slot 1.0, conv1_1 an fp32 image."""
     sd = make_sd(0, "he")
     blob = engine.pack_weights(sd, "fp16")
-    plan, total = _split_plan(1)
+    plan, total = _split_plan(1, fp16_block=True)
     assert blob.size == total == N.load().idc_weights_blob_bytes(N.IDC_FP16, 0)
     assert blob[8:12].view(np.uint32)[0] == N.IDC_FP16
     rs = np.random.RandomState(3)
     for e in plan:
-        if e["island"] or e["kind"] != "c3":
+        if e["island"]:                      # conv1_1: the fp32 island image AND one fp16 block with K = tap * 4 + channel (nkc = 1)
+            w = sd[e["wkey"] + ".weight"]
+            for _ in range(20):
+                co, ci, ky, kx = rs.randint(e["cout"]), rs.randint(e["cin"]), rs.randint(3), rs.randint(3)
+                k = (ky * 3 + kx) * 4 + ci
+                assert _read_w(blob, e, "fp32", 0, co, k) == float(np.float32(w[co, ci, ky, kx]))
+                assert _read_w(blob, dict(e, w_off=e["w2_off"], nkc=1), "bf16", 0, co, k) == int(np.float16(np.float32(w[co, ci, ky, kx])).view(np.uint16))
+            continue
+        if e["kind"] != "c3":
             continue
         w = sd[e["wkey"] + ".weight"]
         assert blob[e["ws_off"]:e["ws_off"] + 4].view(np.float32)[0] == 1.0

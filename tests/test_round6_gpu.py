@@ -270,7 +270,7 @@ def test_fp16_precision_is_the_split_machinery_with_one_part(style):
                 kernels = set(r["kernel"].split("<")[0].split("+")[0].split(" ")[0] for r in e.layer_table() if r["launches"] > 0 and r["kernel"].startswith("conv"))
                 if precision == "fp16" and fast:
                     assert {"conv_igemm_v2ph", "conv_ds_fused_mh"} <= kernels <= {"conv_igemm_v2ph", "conv_ds_fused_mh", "conv_igemm_v2psh", "conv_igemm_v2sh",
-                                                                                  "conv1_1_split_kernel", "conv1_2_split_kernel", "conv_igemm"}, kernels
+                                                                                  "conv1_1_split_kernel", "conv1_2_split_kernel", "conv_igemm", "conv1_block_fused"}, kernels
                 elif precision == "fp16":
                     assert kernels <= {"conv_igemm_v2psh", "conv_igemm_v2sh", "conv_ds_fused_msh", "conv1_1_split_kernel", "conv1_2_split_kernel", "conv_igemm"}, kernels
             finally:
@@ -300,6 +300,7 @@ def test_conv1_2_split_kernel_against_the_generic_tile(precision):
     ref_out, _, acts = siggraph_torch.forward(sd, L, ab, m, 0.5, dtype=torch.float64, return_acts=True)
     got, outs = {}, {}
     try:
+        engine.set_option("fp16_fast", 0)            # (precision "fp16": model1 would otherwise run conv1_block_fused_th, conv1_2 inside it)
         for v in (1, 0):
             engine.set_option("conv1_2_split", v)
             e = engine.HipColorizer(H, W, max_batch=n, precision=precision)
@@ -314,6 +315,7 @@ def test_conv1_2_split_kernel_against_the_generic_tile(precision):
                 e.close()
     finally:
         engine.set_option("conv1_2_split", 1)
+        engine.set_option("fp16_fast", 1)
     ref = acts["conv1_2"]
     scale = 1 + np.abs(ref).max()
     rel = {"bf16x3": 2e-3, "bf16x6": 2e-4, "fp16x3": 2e-4, "fp16": 4e-3}[precision]      # (test_split_network_layer_by_layer's per-layer bounds; fp16: one 11-bit part)
@@ -321,3 +323,35 @@ def test_conv1_2_split_kernel_against_the_generic_tile(precision):
         assert np.abs(got[v] - ref).max() <= rel * scale, (precision, v, float(np.abs(got[v] - ref).max()), scale)
     e1, e0 = float(np.abs(outs[1] - ref_out).max()), float(np.abs(outs[0] - ref_out).max())
     assert e1 <= 1.5 * e0 + 1e-5, (precision, e1, e0)
+
+
+def test_fp16_conv1_block_twin():
+    """IDC_FP16 at throughput size (>= 128 tiles: batch 16 of 64 x 64 gives 128 tiles of 32 x 8): model1 runs conv1_block_fused_th -- conv1_1 on ITS fp16 block of
+    the blob, conv1_2's fp16 image, fp16 tile in LDS -- against fp16_fast = 0 (conv1_1's exact-fp32 island + conv1_2 on the split kernels) and the float64 oracle."""
+    from oracle import siggraph_torch
+    from tests.conftest import state_dict_for
+    sd = state_dict_for(4, "he")
+    n = 16
+    L, ab, m = workloads.random_batch(n, 64, seed=8, max_points=5, max_p=3)
+    ref_out, _, acts = siggraph_torch.forward(sd, L[:4], ab[:4], m[:4], 0.5, dtype=torch.float64, return_acts=True)
+    got, outs = {}, {}
+    try:
+        for fast in (1, 0):
+            engine.set_option("fp16_fast", fast)
+            e = engine.HipColorizer(64, 64, max_batch=n, precision="fp16")
+            try:
+                e.load_state_dict(sd)
+                outs[fast] = e.forward(L, ab, m, 0.5)
+                got[fast] = e.activation("conv1_2", 4)
+                kernels = {r["name"]: r["kernel"] for r in e.layer_table()}
+                assert ("conv1_block_fused" in kernels["conv1_1"]) == bool(fast), kernels["conv1_1"]
+            finally:
+                e.close()
+    finally:
+        engine.set_option("fp16_fast", 1)
+    ref = acts["conv1_2"]
+    scale = 1 + np.abs(ref).max()
+    for fast in (1, 0):
+        assert np.abs(got[fast] - ref).max() <= 4e-3 * scale, (fast, float(np.abs(got[fast] - ref).max()), scale)
+    e1, e0 = float(np.abs(outs[1][:4] - ref_out).max()), float(np.abs(outs[0][:4] - ref_out).max())
+    assert e1 <= 4.0 and e0 <= 4.0 and e1 <= 2.0 * e0 + 1e-3, (e1, e0)
