@@ -16,6 +16,7 @@ CONFIGS = [  # (label, H, N, precision, kwargs, max_batch)
     ("bf16 N=4 256", 256, 4, "bf16", {}, 4), ("bf16 N=8 256", 256, 8, "bf16", {}, 8), ("bf16 N=1 64", 64, 1, "bf16", {}, 1), ("bf16 N=3 40x72", (40, 72), 3, "bf16", {}, 3),
     ("fp32 N=1 256 (click)", 256, 1, "fp32", {}, 1), ("fp32 N=8 256", 256, 8, "fp32", {}, 8), ("fp32 N=1 64", 64, 1, "fp32", {}, 1),
     ("bf16x3 N=8 256", 256, 8, "bf16x3", {}, 8), ("bf16x6 N=1 256", 256, 1, "bf16x6", {}, 1), ("fp16x3 N=8 256", 256, 8, "fp16x3", {}, 8),
+    ("fp16x3 N=32 256", 256, 32, "fp16x3", {}, 32), ("fp16 N=32 256", 256, 32, "fp16", {}, 32), ("fp16 N=1 256", 256, 1, "fp16", {}, 1),
     ("bf16 N=8 512 global", 512, 8, "bf16", {"global_hints": True}, 8), ("fp32 N=1 512 global", 512, 1, "fp32", {"global_hints": True}, 1),
     ("bf16 N=1 256 global", 256, 1, "bf16", {"global_hints": True}, 1),
     ("bf16 N=1 256 dist", 256, 1, "bf16", {"dist": True}, 1), ("fp32 N=1 256 dist", 256, 1, "fp32", {"dist": True}, 1), ("bf16 N=8 256 dist", 256, 8, "bf16", {"dist": True}, 8),
