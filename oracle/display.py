@@ -4,8 +4,11 @@
 * ``resize_cubic_cv2``: ``cv2.resize(src, (ow, oh), interpolation=cv2.INTER_CUBIC)`` on float64 data as OpenCV's
   ``resize.cpp`` computes it (``ui/gui_draw.py:281``): half-pixel centres, ``fx = (float)((dx + .5) * scale - .5)``,
   four taps ``sx-1 .. sx+2`` clamped to the image (replicated border), float32 Keys coefficients with A = -0.75
-  (``interpolateCubic``), horizontal pass then vertical pass, sums in double.  **Parity unpinned**: cv2 is not
-  installable here, so this follows the published algorithm, not a run of cv2 itself.
+  (``interpolateCubic``), horizontal pass then vertical pass, sums in double.  cv2 is not installable here, so this follows
+  the published algorithm, not a run of cv2 itself (**unpinned against cv2**); since round 6 it is held against an INDEPENDENT
+  library implementation of the same algorithm -- ``torch.nn.functional.interpolate(mode="bicubic", align_corners=False)``:
+  Keys kernel at A = -0.75, half-pixel centres, clamped indices -- to rounding at exact phases and to 2e-5 of the data range
+  elsewhere (OpenCV's float32 coefficient arithmetic, which this file keeps): ``tests/test_round2_cpu.py``.
 * ``zoom_linear`` / ``zoom_nearest``: ``scipy.ndimage.zoom(x, (1, fh, fw), order=1 | 0)`` of
   ``data/colorize_image.py:123-158`` -- **pinned**: scipy is present, the tests compare these with scipy itself.
 * ``display_rgb``: the four lines of ``GUIDraw.compute_result`` (``ui/gui_draw.py:280-283``).

@@ -66,6 +66,39 @@ def test_cubic_restatement_properties():
     np.testing.assert_allclose(c, [-0.09375, 0.59375, 0.59375, -0.09375], atol=1e-7)
 
 
+def test_cubic_restatement_against_an_independent_library():
+    """Round 6: cv2 itself cannot be installed here, but torch ships an independent implementation of the SAME published algorithm -- bicubic interpolation
+    with the Keys kernel at A = -0.75, half-pixel centres (align_corners=False) and indices clamped to the image, which is OpenCV's INTER_CUBIC convention
+    (ui/gui_draw.py:281 calls cv2.resize(..., interpolation=cv2.INTER_CUBIC)).  oracle/display.py must agree with it: to rounding where the sampling
+    phases are exact in float32 (2x), and to the precision of OpenCV's FLOAT32 coordinate / coefficient arithmetic -- which the restatement follows and
+    torch's float64 path does not -- everywhere else (measured 2e-5 of the data range)."""
+    import torch
+    import torch.nn.functional as F
+    rs = np.random.RandomState(4)
+    for (H, W, oh, ow) in ((64, 64, 200, 150), (256, 256, 500, 333), (48, 40, 96, 80), (100, 120, 70, 90), (256, 256, 531, 400)):
+        x = rs.uniform(-100, 100, (H, W))
+        ours = display.resize_cubic_cv2(x, oh, ow)
+        lib = F.interpolate(torch.from_numpy(x)[None, None].double(), size=(oh, ow), mode="bicubic", align_corners=False)[0, 0].numpy()
+        tol = 1e-11 if (oh, ow) == (2 * H, 2 * W) else 5e-5 * 200
+        assert np.abs(ours - lib).max() <= tol, ((H, W, oh, ow), float(np.abs(ours - lib).max()))
+
+
+def test_global_stats_saturation_against_an_independent_library():
+    """Round 6: the saturation half of models/global_model/global_stats.prototxt (caffe_files/caffe_traininglayers.py:78 calls skimage.color.rgb2hsv, not
+    installable here) held against matplotlib's rgb_to_hsv -- an independent implementation of the same HSV definition S = (max - min) / max, 0 for black --
+    on random, black, white and grey pixels: the checker's global mean saturation must equal the library's to rounding."""
+    mc = pytest.importorskip("matplotlib.colors")
+    from interactive_deep_colorization_amd import color_bins
+    from oracle import colorspace
+    rs = np.random.RandomState(0)
+    rgb = rs.randint(0, 256, (64, 64, 3)).astype(np.uint8)
+    rgb[:8] = 0; rgb[8:16] = 255
+    rgb[16:20, :, 1] = rgb[16:20, :, 0]; rgb[16:20, :, 2] = rgb[16:20, :, 0]
+    _, s_avg = colorspace.global_stats(rgb, color_bins.pts_in_hull())
+    lib = float(mc.rgb_to_hsv(rgb.astype(np.float64) / 255.0)[..., 1].mean())
+    assert abs(s_avg - lib) <= 1e-12, (s_avg, lib)
+
+
 class _Stub(object):
     closed = False
 
