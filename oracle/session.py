@@ -12,8 +12,10 @@
   on the drawn colours with greedy k-means++ seeding.  Bit-exact restatement of the kernel for bin centres with
   integer coordinates (all sums are then exact in float64).
 
-PARITY UNPINNED for the rasteriser (cv2 is absent here; ``cv2.rectangle`` semantics -- inclusive corners, either
-corner order, clipping -- are restated from its documentation) and statistical only for the suggestions (the
+PARITY UNPINNED AGAINST cv2 for the rasteriser (cv2 is absent here; ``cv2.rectangle`` semantics -- inclusive corners, either
+corner order, clipping -- are restated from its documentation; since round 6 the restatement is held against PIL's
+``ImageDraw.rectangle``, an independent filled-rectangle rasteriser with the same inclusive / clipped / last-wins convention:
+``tests/test_session_cpu.py``) and statistical only for the suggestions (the
 reference is stochastic): ``tests/test_session_cpu.py`` checks that ``suggest_colors`` and
 ``get_ab_reccs_reference`` agree on well-separated mixtures.
 """

@@ -92,3 +92,33 @@ def test_suggest_colors_degenerate_inputs():
     pdf = np.full(529, 1.0 / 529, np.float32)                   # flat: K clusters, all populated
     cen, conf = session.suggest_colors(pdf, c, K=5, N=25000, seed=1)
     assert (conf > 0.05).all() and abs(conf.sum() - 1) < 1e-12
+
+
+def test_rectangle_rasteriser_against_an_independent_library():
+    """Round 6: cv2.rectangle(img, p0, p1, colour, -1) (ui/ui_control.py:52-63) cannot be run here; PIL's ImageDraw.rectangle(fill=...) is an independent
+    filled-rectangle rasteriser with the same convention -- both corners INCLUSIVE, clipped to the canvas, later edits painted over earlier ones.
+    oracle/session.py's raster_hints must produce PIL's mask and PIL's canvas (through the same rgb2lab) for overlapping, clipped and one-pixel edits.
+    (Corner ORDER is normalised before the PIL call: recent PIL refuses x1 < x0, cv2 accepts either order -- that part stays documentation-only.)"""
+    pytest = __import__("pytest")
+    ImageDraw = pytest.importorskip("PIL.ImageDraw")
+    Image = pytest.importorskip("PIL.Image")
+    from oracle import colorspace, session
+    H, W = 48, 64
+    rs = np.random.RandomState(5)
+    hints = []
+    for _ in range(12):
+        y, x, p = rs.randint(-4, H + 4), rs.randint(-4, W + 4), rs.randint(0, 6)
+        hints.append((y - p, x - p, y + p, x + p) + tuple(int(v) for v in rs.randint(0, 256, 3)))
+    hints.append((5, 60, 5, 70, 10, 200, 30))            # clipped on the right, one row high
+    hints.append((47, 0, 47, 0, 255, 0, 0))              # a single corner pixel
+    ab, mask = session.raster_hints(hints, H, W, mode="rgb")
+    canvas = Image.new("RGB", (W, H), (0, 0, 0))
+    mimg = Image.new("L", (W, H), 0)
+    dc, dm = ImageDraw.Draw(canvas), ImageDraw.Draw(mimg)
+    for (y0, x0, y1, x1, r, g, b) in hints:
+        box = [min(x0, x1), min(y0, y1), max(x0, x1), max(y0, y1)]
+        dc.rectangle(box, fill=(r, g, b)); dm.rectangle(box, fill=255)
+    lib_mask = (np.asarray(mimg) > 0).astype(np.float32)
+    assert np.array_equal(mask[0], lib_mask)
+    lib_ab = colorspace.rgb2lab(np.asarray(canvas))[..., 1:].transpose(2, 0, 1) * lib_mask[None]
+    assert np.abs(ab - lib_ab).max() <= 1e-4
