@@ -4,7 +4,8 @@ The reference's default backend builds ``caffe.Net(prototxt_path, caffemodel_pat
 (``data/colorize_image.py:392-403``; ``ideepcolor.py:60-66`` passes ``./models/reference_model/model.caffemodel``).  A
 ``.caffemodel`` is a serialised ``caffe.NetParameter`` protobuf; the subset needed to get the learned blobs out is small
 (BVLC Caffe ``src/caffe/proto/caffe.proto``, restated here -- Caffe is not in this image, so this follows the published
-schema; PARITY UNPINNED against a real checkpoint, ``models/fetch_models.sh`` needs the network):
+schema; PARITY UNPINNED against a real checkpoint, ``models/fetch_models.sh`` needs the network; the wire-format code itself is held
+against Google's protobuf runtime serialising / parsing that subset, ``tests/test_round6_cpu.py``):
 
     NetParameter      1 name (string)   100 layer (LayerParameter, repeated)   2 layers (V1LayerParameter, repeated, legacy)
     LayerParameter    1 name   2 type (string)   3 bottom   4 top   7 blobs (BlobProto, repeated)

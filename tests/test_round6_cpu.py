@@ -260,3 +260,85 @@ def test_fp16_weight_scale_is_what_closes_the_gap_to_fp32(make_sd):
         err[mode] = emulate.error_stats(out, ref)["mean_abs"]
     assert err["splitf2s_fp32"] <= 1.5 * err["fp32"], err
     assert err["splitf2_fp32"] >= 1.8 * err["splitf2s_fp32"], err
+
+
+def _caffe_subset_messages():
+    """caffe.proto's NetParameter / LayerParameter / V1LayerParameter / BlobProto / BlobShape subset built with Google's protobuf runtime (descriptor_pb2 ->
+    message classes): the reference implementation of the wire format, independent of caffe_io's hand-written reader and writer."""
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    F = descriptor_pb2.FieldDescriptorProto
+    fd = descriptor_pb2.FileDescriptorProto(name="caffe_subset_test.proto", package="caffe_subset_test", syntax="proto2")
+
+    def msg(name, fields):
+        m = fd.message_type.add(name=name)
+        for fname, num, ftype, label, extra in fields:
+            f = m.field.add(name=fname, number=num, type=ftype, label=label)
+            if extra.get("type_name"):
+                f.type_name = ".caffe_subset_test." + extra["type_name"]
+            if extra.get("packed"):
+                f.options.packed = True
+    R, O = F.LABEL_REPEATED, F.LABEL_OPTIONAL
+    msg("BlobShape", [("dim", 1, F.TYPE_INT64, R, {"packed": True})])
+    msg("BlobProto", [("shape", 7, F.TYPE_MESSAGE, O, {"type_name": "BlobShape"}), ("data", 5, F.TYPE_FLOAT, R, {"packed": True}),
+                      ("double_data", 8, F.TYPE_DOUBLE, R, {"packed": True}), ("num", 1, F.TYPE_INT32, O, {}), ("channels", 2, F.TYPE_INT32, O, {}),
+                      ("height", 3, F.TYPE_INT32, O, {}), ("width", 4, F.TYPE_INT32, O, {})])
+    msg("BlobProtoUnpacked", [("shape", 7, F.TYPE_MESSAGE, O, {"type_name": "BlobShape"}), ("data", 5, F.TYPE_FLOAT, R, {})])
+    msg("LayerParameter", [("name", 1, F.TYPE_STRING, O, {}), ("type", 2, F.TYPE_STRING, O, {}), ("bottom", 3, F.TYPE_STRING, R, {}),
+                           ("top", 4, F.TYPE_STRING, R, {}), ("phase", 10, F.TYPE_INT32, O, {}), ("blobs", 7, F.TYPE_MESSAGE, R, {"type_name": "BlobProto"})])
+    msg("LayerParameterU", [("name", 1, F.TYPE_STRING, O, {}), ("type", 2, F.TYPE_STRING, O, {}), ("blobs", 7, F.TYPE_MESSAGE, R, {"type_name": "BlobProtoUnpacked"})])
+    msg("V1LayerParameter", [("bottom", 2, F.TYPE_STRING, R, {}), ("top", 3, F.TYPE_STRING, R, {}), ("name", 4, F.TYPE_STRING, O, {}),
+                             ("type", 5, F.TYPE_INT32, O, {}), ("blobs", 6, F.TYPE_MESSAGE, R, {"type_name": "BlobProto"})])
+    msg("NetParameter", [("name", 1, F.TYPE_STRING, O, {}), ("layers", 2, F.TYPE_MESSAGE, R, {"type_name": "V1LayerParameter"}),
+                         ("force_backward", 5, F.TYPE_BOOL, O, {}), ("layer", 100, F.TYPE_MESSAGE, R, {"type_name": "LayerParameter"})])
+    msg("NetParameterU", [("name", 1, F.TYPE_STRING, O, {}), ("layer", 100, F.TYPE_MESSAGE, R, {"type_name": "LayerParameterU"})])
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    get = lambda n: message_factory.GetMessageClass(pool.FindMessageTypeByName("caffe_subset_test." + n))
+    return {n: get(n) for n in ("NetParameter", "NetParameterU")}
+
+
+def test_caffemodel_wire_format_against_googles_protobuf_runtime():
+    """Round 6: caffe_io.py reads and writes the protobuf wire format by hand (Caffe is absent).  Google's protobuf runtime IS in the image: files it
+    serialises from the published caffe.proto subset -- packed and unpacked float data, BlobShape and the legacy num/channels/height/width, V2 `layer` and
+    V1 `layers` records, unknown fields in between, double_data -- must come back from read_caffemodel value for value, and what write_caffemodel emits
+    must parse in the runtime to the same layers.  (Pins the wire-format code to the format's reference implementation; a real checkpoint stays absent.)"""
+    pytest.importorskip("google.protobuf")
+    from interactive_deep_colorization_amd import caffe_io
+    M = _caffe_subset_messages()
+    rs = np.random.RandomState(0)
+    w = rs.randn(5, 3, 3, 3).astype(np.float32); b = rs.randn(5).astype(np.float32); legacy = rs.randn(2, 3, 1, 1).astype(np.float32)
+    dd = rs.randn(4).astype(np.float64)
+    net = M["NetParameter"](name="n", force_backward=True)
+    L = net.layer.add(name="conv1_2", type="Convolution", phase=1); L.bottom.append("x"); L.top.append("y")
+    for arr in (w, b):
+        bl = L.blobs.add(); bl.shape.dim.extend(arr.shape); bl.data.extend(arr.ravel().tolist())
+    L2 = net.layer.add(name="relu", type="ReLU"); L2.bottom.append("y"); L2.top.append("y")
+    L3 = net.layer.add(name="legacy_dims", type="Convolution")
+    bl = L3.blobs.add(num=2, channels=3, height=1, width=1); bl.data.extend(legacy.ravel().tolist())
+    L4 = net.layer.add(name="doubles", type="Scale")
+    bl = L4.blobs.add(); bl.shape.dim.append(4); bl.double_data.extend(dd.tolist())
+    V1 = net.layers.add(name="old_conv", type=4); V1.bottom.append("a"); V1.top.append("b")
+    bl = V1.blobs.add(); bl.shape.dim.extend(b.shape); bl.data.extend(b.tolist())
+    got = caffe_io.read_caffemodel(net.SerializeToString())
+    by = {g["name"]: g for g in got}
+    assert set(by) == {"conv1_2", "relu", "legacy_dims", "doubles", "old_conv"}
+    assert by["conv1_2"]["type"] == "Convolution" and by["conv1_2"]["bottom"] == ["x"] and by["conv1_2"]["top"] == ["y"]
+    assert np.array_equal(by["conv1_2"]["blobs"][0], w) and np.array_equal(by["conv1_2"]["blobs"][1], b)
+    assert by["relu"]["blobs"] == [] and np.array_equal(by["legacy_dims"]["blobs"][0], legacy)
+    assert np.array_equal(by["doubles"]["blobs"][0], dd.astype(np.float32))
+    assert by["old_conv"]["type"] == "Convolution" and np.array_equal(by["old_conv"]["blobs"][0], b)
+    # unpacked repeated floats (a writer may emit one 32-bit record per value)
+    netu = M["NetParameterU"](name="u")
+    Lu = netu.layer.add(name="conv1_2", type="Convolution")
+    bl = Lu.blobs.add(); bl.shape.dim.extend(w.shape); bl.data.extend(w.ravel().tolist())
+    gotu = caffe_io.read_caffemodel(netu.SerializeToString())
+    assert np.array_equal(gotu[0]["blobs"][0], w)
+    # our writer -> Google's parser
+    raw = caffe_io.write_caffemodel(None, [{"name": "conv1_2", "type": "Convolution", "bottom": ["x"], "top": ["y"], "blobs": [w, b]},
+                                           {"name": "relu", "type": "ReLU", "bottom": ["y"], "top": ["y"], "blobs": []}])
+    back = M["NetParameter"]()
+    back.ParseFromString(raw)
+    assert [l.name for l in back.layer] == ["conv1_2", "relu"] and back.layer[0].type == "Convolution"
+    assert list(back.layer[0].blobs[0].shape.dim) == list(w.shape)
+    assert np.array_equal(np.array(back.layer[0].blobs[0].data, np.float32).reshape(w.shape), w)
+    assert np.array_equal(np.array(back.layer[0].blobs[1].data, np.float32), b)
