@@ -355,3 +355,27 @@ def test_fp16_conv1_block_twin():
         assert np.abs(got[fast] - ref).max() <= 4e-3 * scale, (fast, float(np.abs(got[fast] - ref).max()), scale)
     e1, e0 = float(np.abs(outs[1][:4] - ref_out).max()), float(np.abs(outs[0][:4] - ref_out).max())
     assert e1 <= 4.0 and e0 <= 4.0 and e1 <= 2.0 * e0 + 1e-3, (e1, e0)
+
+
+@pytest.mark.parametrize("precision", ["fp16x3", "bf16x6"])
+def test_split_precisions_through_the_caffe_only_heads(precision):
+    """The operand-split handles also carry the Caffe-only branches (models/reference_model/deploy_nopred.prototxt:650-850 -- the 313-bin hyper-column head and
+    its soft decode -- and models/global_model/deploy_nodist.prototxt:37-172,501-518 -- Global Hints): the ab map within 1e-3 of the float64 oracle, and the three
+    outputs of forward_dist313 (decoded ab at two temperatures, the 313-bin distribution) within 1e-3 of the fp32 engine's."""
+    from oracle import siggraph_torch, weights
+    L, ab, m = workloads.random_batch(2, 64, seed=3, max_points=5, max_p=3)
+    sd = weights.add_pred313_head(weights.add_global_branch(weights.make_state_dict(1, "torch"), 5), 7)
+    g, s = workloads.global_hint_config5(2, seed=2)
+    ref = siggraph_torch.forward(sd, L, ab, m, 0.0, dtype=torch.float64, glob=g, sat=s)
+    res = {}
+    for prec in ("fp32", precision):
+        e = engine.HipColorizer(64, 64, max_batch=2, precision=prec, global_hints=True, dist313=True)
+        try:
+            e.load_state_dict(sd)
+            e.set_global_hints(g, s)
+            res[prec] = (e.forward(L, ab, m, 0.0), e.forward_dist313(L, ab, m, 0.0))
+        finally:
+            e.close()
+    assert np.abs(res[precision][0] - ref).max() <= 1e-3
+    for x32, xs in zip(res["fp32"][1], res[precision][1]):
+        assert np.isfinite(xs).all() and np.abs(np.asarray(xs) - np.asarray(x32)).max() <= 1e-3 * (1 + np.abs(x32).max())
