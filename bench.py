@@ -14,10 +14,13 @@ With N ranks every rank runs its own 32 images (weak scaling, no data-path colle
 weights are packed on rank 0 and broadcast once over RCCL before the timed region.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      : the conv stack (kernels conv_igemm_v2m / conv_igemm_v2 / conv_ds_fused / conv_igemm / conv1_1_bf16) against the dense bf16 MFMA peak,
+  roofline      : the conv stack (kernels conv_igemm_v2p / conv_ds_fused_m / conv1_block_fused_t; --precision: their split / fp16 forms) against the dense bf16 MFMA peak,
                   from per-layer HIP events recorded on the engine's stream inside the timed region;
   cpu_baseline  : the torch-CPU oracle (same ATen kernels as the reference's PyTorch backend)
                   timed on this box's host cores on a bounded sample (rank 0, N=1 only);
+  fp32_contract_path : (N = 1 GPU, default run) the same batch, weights and step count on precision fp16x3 -- the fastest path inside the reference's
+                  1e-3 contract (data/colorize_image.py:263) -- and `parity.max_abs_err`: the distance of the bf16 and fp16x3 outputs of images 0, 1 from the
+                  CPU baseline's own fp32 outputs of those images; never `value`;
   latency       : p50 per-click recolor latency, BASELINE.json configs[1] (one 256x256 image,
                   5 hint points), fp32 and bf16: kernels only (device-resident), the blocking C-ABI call with
                   host buffers, and the whole reference-API net_forward (forward + Lab->RGB + refresh).
