@@ -761,7 +761,10 @@ static void set_geometry(Layer& L, int precision, int n, int n_policy, int Hs, i
         const int force22 = tuning().v2_force22;     // experiment switch: 0 = rule above, 1 = never, 2 = everywhere
         // (the 64-cout tile of the split precisions keeps 32 x 16 sites: conv1_2 0.84 ms as {1,4}, 1.01 ms as {1,2} at N = 32, bf16x3)
         const bool rule22 = force22 == 2 || (force22 == 0 && (c2.wm == 2 || (c2.wm == 4 && a.nkc <= tuning().v2_22_nkc)) && blocks >= 256);
-        if (a.nphase == 1 && c2.wm != 1 && ((blocks >= tuning().v2_min_blocks && blocks < 256 && tuning().v2_half_tiles) || rule22)) {
+        // operand-split precisions have no batch-1 kernels: a grid that leaves most of the chip idle (fp16x3 at 1..8 images: the 512 -> 512 trunk is 8 x N
+        // workgroups of the 8-wave tile) at least takes the 4-wave 128-cout tile -- twice the workgroups, half the K-loop time each (round 6, tools/batch_sweep.py)
+        const bool split_small = split && blocks < 128;         // (at 128 workgroups -- the trunk at N = 16 -- the 8-wave tile is still the faster one: 2546 against 2475 img/s)
+        if (a.nphase == 1 && c2.wm != 1 && ((blocks >= tuning().v2_min_blocks && blocks < 256 && tuning().v2_half_tiles) || rule22 || split_small)) {
             c2 = ConvConfig{2, 2};
             ty = (Hs + 4 * c2.wp - 1) / (4 * c2.wp);
             blocks = (long long)tx * ty * n_policy * (a.ncg / c2.wm) * a.nphase;
